@@ -1,0 +1,87 @@
+"""ctypes binding of libhyperpri_hip.so (the C ABI declared in include/hyperpri_hip.h).
+
+The argument types are read from the header itself, so the header stays the single source of
+truth for the boundary.  There is NO fallback: if the library is missing or a call fails, a
+RuntimeError is raised -- the product path never routes through PyTorch ops or the CPU oracle.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import re
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libhyperpri_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "hyperpri_hip.h")
+
+_lock = threading.Lock()
+_lib = None
+_decls = None
+
+
+def _ctype(decl: str):
+    d = decl.strip()
+    if "*" in d or "hipStream_t" in d:
+        return ctypes.c_void_p
+    if "unsigned long long" in d:
+        return ctypes.c_ulonglong
+    if "long long" in d:
+        return ctypes.c_longlong
+    if "size_t" in d:
+        return ctypes.c_size_t
+    if re.search(r"\bfloat\b", d):
+        return ctypes.c_float
+    if re.search(r"\bint\b", d):
+        return ctypes.c_int
+    raise ValueError(f"unhandled C type in header: {decl!r}")
+
+
+def parse_header(path: str = HEADER_PATH):
+    """{name: (restype, [argtypes])} for every ``hpri_*`` function the header declares."""
+    src = open(path).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    out = {}
+    for m in re.finditer(r"([A-Za-z_][\w\s\*]*?)\b(hpri_\w+)\s*\(([^;{]*?)\)\s*;", src):
+        ret, name, args = m.group(1).strip(), m.group(2), m.group(3).strip()
+        if ret.endswith("*"):
+            restype = ctypes.c_char_p
+        elif "size_t" in ret:
+            restype = ctypes.c_size_t
+        else:
+            restype = ctypes.c_int
+        argtypes = [] if args in ("", "void") else [_ctype(a) for a in args.split(",")]
+        out[name] = (restype, argtypes)
+    return out
+
+
+def load():
+    """Load (once) and return the ctypes library; raises if it has not been built."""
+    global _lib, _decls
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"hyperpri_amd: HIP extension not built ({LIB_PATH} missing). Run "
+                "`python -m hyperpri_amd.build` (needs hipcc, --offload-arch=gfx950). "
+                "There is no CPU/PyTorch fallback for the hot path.")
+        lib = ctypes.CDLL(LIB_PATH)
+        _decls = parse_header()
+        for name, (restype, argtypes) in _decls.items():
+            fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _lib = lib
+    return _lib
+
+
+def call(name: str, *args) -> None:
+    """Call an int-returning launcher; raise RuntimeError with the library's message on failure."""
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        msg = lib.hpri_last_error()
+        raise RuntimeError(f"{name} failed (code {rc}): {msg.decode() if msg else ''}")

@@ -1,0 +1,366 @@
+// BatchNorm{1,2,3}d (+ fused ReLU) over NHWC fp32 activations: training-mode statistics from the conv
+// epilogue's per-tile partials, normalise+ReLU, and the backward pass.  Reference semantics:
+// torch.nn.BatchNorm2d/3d/1d as used at model_parts.py:23,26 and models.py:113,172,178 -- biased batch
+// variance (eps 1e-5) for normalisation, running stats updated with momentum and the UNBIASED variance,
+// running stats in eval mode.  "Groups" (G) are independent statistic sets: G = 1 for the conv nets,
+// G = N images for SpectralUNET whose per-image loop (models.py:132) makes every image its own batch.
+// All cross-workgroup reductions are two-stage and fixed-order (bitwise reproducible; no float atomics).
+#include "common.h"
+
+// -------------------------------------------------------------------------------------------------
+// forward statistics: combine per-tile (mean, M2, count) partials -> mean, invstd, scale, shift
+// -------------------------------------------------------------------------------------------------
+__global__ void bn_finalize_kernel(const float4* __restrict__ part, int tiles_per_group, int Cp, int C,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                   float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ var_unbiased,
+                                   float* __restrict__ scale, float* __restrict__ shift) {
+  // block = 8 slices x 32 channels; grid = (ceil(C/32), G)
+  __shared__ double s1[8][32], s2[8][32], sn[8][32];
+  const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl, g = blockIdx.y;
+  double a1 = 0.0, a2 = 0.0, an = 0.0;
+  if (c < C) {
+    const float4* p = part + (size_t)g * tiles_per_group * Cp + c;
+    for (int t = sl; t < tiles_per_group; t += 8) {
+      const float4 v = p[(size_t)t * Cp];
+      const double m = v.x, n = v.z;
+      a1 += n * m;
+      a2 += (double)v.y + n * m * m;
+      an += n;
+    }
+  }
+  s1[sl][cl] = a1; s2[sl][cl] = a2; sn[sl][cl] = an;
+  __syncthreads();
+  if (sl == 0 && c < C) {
+    double t1 = 0.0, t2 = 0.0, tn = 0.0;
+    for (int k = 0; k < 8; ++k) { t1 += s1[k][cl]; t2 += s2[k][cl]; tn += sn[k][cl]; }
+    const double mu = t1 / tn;
+    double var = t2 / tn - mu * mu;
+    if (var < 0.0) var = 0.0;
+    const double is = 1.0 / sqrt(var + (double)eps);
+    const int o = g * C + c;
+    mean[o] = (float)mu;
+    invstd[o] = (float)is;
+    var_unbiased[o] = (float)(tn > 1.0 ? var * tn / (tn - 1.0) : var);
+    const float sc = gamma[c] * (float)is;
+    scale[o] = sc;
+    shift[o] = beta[c] - (float)mu * sc;
+  }
+}
+
+// running = (1-m)*running + m*stat, applied for g = 0..G-1 in order (SpectralUNET advances N times per call)
+__global__ void bn_update_running_kernel(const float* __restrict__ mean, const float* __restrict__ var_unbiased,
+                                         int G, int C, float momentum, float* __restrict__ rm, float* __restrict__ rv,
+                                         long long* __restrict__ nbt) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) {
+    float m = rm[c], v = rv[c];
+    for (int g = 0; g < G; ++g) {
+      m = (1.f - momentum) * m + momentum * mean[g * C + c];
+      v = (1.f - momentum) * v + momentum * var_unbiased[g * C + c];
+    }
+    rm[c] = m; rv[c] = v;
+  }
+  if (c == 0 && nbt != nullptr) *nbt += G;
+}
+
+__global__ void bn_eval_prepare_kernel(const float* __restrict__ rm, const float* __restrict__ rv,
+                                       const float* __restrict__ gamma, const float* __restrict__ beta, float eps, int C,
+                                       float* __restrict__ mean, float* __restrict__ invstd,
+                                       float* __restrict__ scale, float* __restrict__ shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) {
+    const float is = 1.f / sqrtf(rv[c] + eps);
+    mean[c] = rm[c]; invstd[c] = is;
+    const float sc = gamma[c] * is;
+    scale[c] = sc; shift[c] = beta[c] - rm[c] * sc;
+  }
+}
+
+// -------------------------------------------------------------------------------------------------
+// y = relu(x*scale + shift)  (float4 over channels; pad channels C..Cw are written as zeros)
+// -------------------------------------------------------------------------------------------------
+__global__ void bn_apply_relu_kernel(const float* __restrict__ x, int x_cs, int x_coff, float* __restrict__ y,
+                                     int y_cs, int y_coff, const float* __restrict__ scale,
+                                     const float* __restrict__ shift, long long P, long long pix_per_group, int C,
+                                     int Cw, int relu) {
+  const int c4n = Cw >> 2;
+  const long long total = P * c4n;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long p = i / c4n;
+    const int c = (int)(i - p * c4n) * 4;
+    const int g = (int)(p / pix_per_group);
+    const float4 v = *reinterpret_cast<const float4*>(x + p * x_cs + x_coff + c);
+    float in[4] = {v.x, v.y, v.z, v.w}, out[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float r = 0.f;
+      if (c + j < C) {
+        r = in[j] * scale[g * C + c + j] + shift[g * C + c + j];
+        if (relu) r = fmaxf(r, 0.f);
+      }
+      out[j] = r;
+    }
+    *reinterpret_cast<float4*>(y + p * y_cs + y_coff + c) = make_float4(out[0], out[1], out[2], out[3]);
+  }
+}
+
+// -------------------------------------------------------------------------------------------------
+// backward, stage 1: per-channel partial sums of g = dy * [y > 0] and g * xhat over pixel ranges
+// -------------------------------------------------------------------------------------------------
+// grid = (nblk, ceil(C4/CQ), G); block = 256 = ROWS x CQ; partial layout [G][nblk][2][Cq4*4]
+template <int MODE>  // 0: BN+ReLU backward sums (s1 = sum g, s2 = sum g*xhat); 1: plain column sum of dy
+__global__ void col_reduce_kernel(const float* __restrict__ dy, int dy_cs, int dy_coff, const float* __restrict__ x,
+                                  int x_cs, int x_coff, const float* __restrict__ mean,
+                                  const float* __restrict__ invstd, const float* __restrict__ scale,
+                                  const float* __restrict__ shift, long long pix_per_group, int C, int CQ,
+                                  int relu, float* __restrict__ part, int Cpart) {
+  __shared__ float4 red[2][256];
+  const int rows = 256 / CQ;
+  const int cq = threadIdx.x % CQ, pr = threadIdx.x / CQ;
+  const int c = (blockIdx.y * CQ + cq) * 4;
+  const int g = blockIdx.z;
+  const long long per = (pix_per_group + gridDim.x - 1) / gridDim.x;
+  const long long p0 = g * pix_per_group + (long long)blockIdx.x * per;
+  long long p1 = p0 + per;
+  const long long pend = (long long)(g + 1) * pix_per_group;
+  if (p1 > pend) p1 = pend;
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+  if (c < C) {
+    float mu[4], is[4], sc[4], sh[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bool ok = (c + j < C) && MODE == 0;
+      mu[j] = ok ? mean[g * C + c + j] : 0.f;
+      is[j] = ok ? invstd[g * C + c + j] : 0.f;
+      sc[j] = ok ? scale[g * C + c + j] : 0.f;
+      sh[j] = ok ? shift[g * C + c + j] : 0.f;
+    }
+    for (long long p = p0 + pr; p < p1; p += rows) {
+      const float4 dv = *reinterpret_cast<const float4*>(dy + p * dy_cs + dy_coff + c);
+      const float d[4] = {dv.x, dv.y, dv.z, dv.w};
+      if (MODE == 0) {
+        const float4 xv = *reinterpret_cast<const float4*>(x + p * x_cs + x_coff + c);
+        const float xx[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float gj = (!relu || (xx[j] * sc[j] + sh[j] > 0.f)) ? d[j] : 0.f;
+          s1[j] += gj;
+          s2[j] += gj * ((xx[j] - mu[j]) * is[j]);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s1[j] += d[j];
+      }
+    }
+  }
+  red[0][threadIdx.x] = make_float4(s1[0], s1[1], s1[2], s1[3]);
+  red[1][threadIdx.x] = make_float4(s2[0], s2[1], s2[2], s2[3]);
+  __syncthreads();
+  if (pr == 0 && c < Cpart) {
+    float4 t1 = make_float4(0.f, 0.f, 0.f, 0.f), t2 = t1;
+    for (int r = 0; r < rows; ++r) {
+      const float4 a = red[0][r * CQ + cq], b = red[1][r * CQ + cq];
+      t1.x += a.x; t1.y += a.y; t1.z += a.z; t1.w += a.w;
+      t2.x += b.x; t2.y += b.y; t2.z += b.z; t2.w += b.w;
+    }
+    float* o = part + ((size_t)(g * gridDim.x + blockIdx.x) * 2) * Cpart + c;
+    *reinterpret_cast<float4*>(o) = t1;
+    *reinterpret_cast<float4*>(o + Cpart) = t2;
+  }
+}
+
+// stage 2: sums[g][k][c] = sum over blocks (double accumulation, fixed order); k in {0,1}
+__global__ void col_finalize_kernel(const float* __restrict__ part, int nblk, int Cpart, int C, float* __restrict__ sums) {
+  __shared__ double s[2][8][32];
+  const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl, g = blockIdx.y;
+  double a1 = 0.0, a2 = 0.0;
+  if (c < C) {
+    const float* p = part + (size_t)g * nblk * 2 * Cpart + c;
+    for (int b = sl; b < nblk; b += 8) { a1 += p[(size_t)b * 2 * Cpart]; a2 += p[(size_t)b * 2 * Cpart + Cpart]; }
+  }
+  s[0][sl][cl] = a1; s[1][sl][cl] = a2;
+  __syncthreads();
+  if (sl == 0 && c < C) {
+    double t1 = 0.0, t2 = 0.0;
+    for (int k = 0; k < 8; ++k) { t1 += s[0][k][cl]; t2 += s[1][k][cl]; }
+    sums[((size_t)g * 2) * C + c] = (float)t1;
+    sums[((size_t)g * 2 + 1) * C + c] = (float)t2;
+  }
+}
+
+// dgamma[c] (+)= sum_g s2[g][c], dbeta[c] (+)= sum_g s1[g][c]
+__global__ void bn_param_grad_kernel(const float* __restrict__ sums, int G, int C, float* __restrict__ dgamma,
+                                     float* __restrict__ dbeta, int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float a = 0.f, b = 0.f;
+  for (int g = 0; g < G; ++g) { b += sums[((size_t)g * 2) * C + c]; a += sums[((size_t)g * 2 + 1) * C + c]; }
+  dgamma[c] = accumulate ? dgamma[c] + a : a;
+  dbeta[c] = accumulate ? dbeta[c] + b : b;
+}
+
+// dx = scale * (g - s1/Np - xhat * s2/Np)   (training) ;  dx = scale * g  (eval: use_batch_stats = 0)
+__global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, int dy_cs, int dy_coff, const float* __restrict__ x,
+                                    int x_cs, int x_coff, float* __restrict__ dx, int dx_cs, int dx_coff,
+                                    const float* __restrict__ mean, const float* __restrict__ invstd,
+                                    const float* __restrict__ scale, const float* __restrict__ shift,
+                                    const float* __restrict__ sums, long long P, long long pix_per_group, int C, int Cw,
+                                    int relu, int use_batch_stats) {
+  const int c4n = Cw >> 2;
+  const long long total = P * c4n;
+  const float inv_np = 1.f / (float)pix_per_group;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long p = i / c4n;
+    const int c = (int)(i - p * c4n) * 4;
+    const int g = (int)(p / pix_per_group);
+    const float4 dv = *reinterpret_cast<const float4*>(dy + p * dy_cs + dy_coff + c);
+    const float4 xv = *reinterpret_cast<const float4*>(x + p * x_cs + x_coff + c);
+    const float d[4] = {dv.x, dv.y, dv.z, dv.w}, xx[4] = {xv.x, xv.y, xv.z, xv.w};
+    float o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float r = 0.f;
+      if (c + j < C) {
+        const int k = g * C + c + j;
+        const float sc = scale[k];
+        const float gj = (!relu || (xx[j] * sc + shift[k] > 0.f)) ? d[j] : 0.f;
+        if (use_batch_stats) {
+          const float xh = (xx[j] - mean[k]) * invstd[k];
+          r = sc * (gj - sums[((size_t)g * 2) * C + c + j] * inv_np - xh * sums[((size_t)g * 2 + 1) * C + c + j] * inv_np);
+        } else {
+          r = sc * gj;
+        }
+      }
+      o[j] = r;
+    }
+    *reinterpret_cast<float4*>(dx + p * dx_cs + dx_coff + c) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+// ------------------------------------------- C ABI ---------------------------------------------
+static inline int ew_blocks(long long total) {
+  long long b = (total + 255) / 256;
+  if (b > 8192) b = 8192;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+extern "C" int hpri_bn_finalize(const float* partials, int tiles_per_group, int G, int Cp, int C,
+                                const float* gamma, const float* beta, float eps, float momentum,
+                                float* mean, float* invstd, float* var_unbiased, float* scale, float* shift,
+                                float* running_mean, float* running_var, long long* num_batches_tracked,
+                                hipStream_t stream) {
+  HPRI_REQUIRE(partials && gamma && beta && mean && invstd && var_unbiased && scale && shift, "bn_finalize: null pointer");
+  HPRI_REQUIRE(tiles_per_group > 0 && G > 0 && C > 0 && Cp >= C, "bn_finalize: bad sizes");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(hpri_cdiv(C, 32), G), dim3(256), 0, stream,
+                     reinterpret_cast<const float4*>(partials), tiles_per_group, Cp, C, gamma, beta, eps, mean, invstd,
+                     var_unbiased, scale, shift);
+  HPRI_CHECK_LAUNCH();
+  if (running_mean != nullptr && running_var != nullptr) {
+    hipLaunchKernelGGL(bn_update_running_kernel, dim3(hpri_cdiv(C, 256)), dim3(256), 0, stream, mean, var_unbiased, G, C,
+                       momentum, running_mean, running_var, num_batches_tracked);
+    HPRI_CHECK_LAUNCH();
+  }
+  return HPRI_OK;
+}
+
+extern "C" int hpri_bn_eval_prepare(const float* running_mean, const float* running_var, const float* gamma,
+                                    const float* beta, float eps, int C, float* mean, float* invstd, float* scale,
+                                    float* shift, hipStream_t stream) {
+  HPRI_REQUIRE(running_mean && running_var && gamma && beta && mean && invstd && scale && shift, "bn_eval_prepare: null pointer");
+  hipLaunchKernelGGL(bn_eval_prepare_kernel, dim3(hpri_cdiv(C, 256)), dim3(256), 0, stream, running_mean, running_var,
+                     gamma, beta, eps, C, mean, invstd, scale, shift);
+  HPRI_CHECK_LAUNCH();
+  return HPRI_OK;
+}
+
+extern "C" int hpri_bn_apply_relu(const float* x, int x_cs, int x_coff, float* y, int y_cs, int y_coff,
+                                  const float* scale, const float* shift, long long P, long long pix_per_group,
+                                  int C, int Cw, int relu, hipStream_t stream) {
+  HPRI_REQUIRE(x && y && scale && shift, "bn_apply_relu: null pointer");
+  HPRI_REQUIRE(Cw % 4 == 0 && Cw >= C && x_cs % 4 == 0 && y_cs % 4 == 0 && x_coff % 4 == 0 && y_coff % 4 == 0 &&
+                   Cw + x_coff <= x_cs && Cw + y_coff <= y_cs,
+               "bn_apply_relu: channel layout must be float4-aligned and fit the strides");
+  HPRI_REQUIRE(P > 0 && pix_per_group > 0 && P % pix_per_group == 0, "bn_apply_relu: bad pixel counts");
+  hipLaunchKernelGGL(bn_apply_relu_kernel, dim3(ew_blocks(P * (Cw >> 2))), dim3(256), 0, stream, x, x_cs, x_coff, y, y_cs,
+                     y_coff, scale, shift, P, pix_per_group, C, Cw, relu);
+  HPRI_CHECK_LAUNCH();
+  return HPRI_OK;
+}
+
+static inline int pick_cq(int c4) { int q = 1; while (q < c4 && q < 64) q <<= 1; return q; }
+
+extern "C" int hpri_col_reduce_plan(long long pix_per_group, int G, int C, int* nblk, int* Cpart) {
+  const int c4 = hpri_cdiv(C, 4), cq = pick_cq(c4), rows = 256 / cq;
+  const int ycols = hpri_cdiv(c4, cq);
+  long long nb = 2048 / ((long long)ycols * G);
+  const long long maxb = (pix_per_group + rows * 8 - 1) / (rows * 8);
+  if (nb > maxb) nb = maxb;
+  if (nb < 1) nb = 1;
+  *nblk = (int)nb;
+  *Cpart = ycols * cq * 4;
+  return HPRI_OK;
+}
+
+// BN(+ReLU) backward: reduce -> finalize -> parameter grads -> dx.  workspace = partials
+// (G*nblk*2*Cpart floats, hpri_col_reduce_plan) followed by sums (G*2*C floats).
+extern "C" int hpri_bn_relu_bwd(const float* dy, int dy_cs, int dy_coff, const float* x, int x_cs, int x_coff,
+                                float* dx, int dx_cs, int dx_coff, const float* mean, const float* invstd,
+                                const float* scale, const float* shift, float* dgamma, float* dbeta,
+                                int accumulate_param_grads, float* workspace, size_t ws_floats, long long P,
+                                long long pix_per_group, int C, int Cw, int relu, int use_batch_stats,
+                                hipStream_t stream) {
+  HPRI_REQUIRE(dy && x && dx && mean && invstd && scale && shift && workspace, "bn_relu_bwd: null pointer");
+  HPRI_REQUIRE(Cw % 4 == 0 && Cw >= C && dy_cs % 4 == 0 && x_cs % 4 == 0 && dx_cs % 4 == 0 && dy_coff % 4 == 0 &&
+                   x_coff % 4 == 0 && dx_coff % 4 == 0, "bn_relu_bwd: channel layout must be float4-aligned");
+  HPRI_REQUIRE(P > 0 && pix_per_group > 0 && P % pix_per_group == 0, "bn_relu_bwd: bad pixel counts");
+  const int G = (int)(P / pix_per_group);
+  int nblk, Cpart;
+  hpri_col_reduce_plan(pix_per_group, G, C, &nblk, &Cpart);
+  const size_t need = (size_t)G * nblk * 2 * Cpart + (size_t)G * 2 * C;
+  if (need > ws_floats) return hpri_set_error(HPRI_ERR_WORKSPACE, "bn_relu_bwd: workspace too small");
+  float* part = workspace;
+  float* sums = workspace + (size_t)G * nblk * 2 * Cpart;
+  const int c4 = hpri_cdiv(C, 4), cq = pick_cq(c4);
+  hipLaunchKernelGGL((col_reduce_kernel<0>), dim3(nblk, hpri_cdiv(c4, cq), G), dim3(256), 0, stream, dy, dy_cs, dy_coff, x,
+                     x_cs, x_coff, mean, invstd, scale, shift, pix_per_group, C, cq, relu, part, Cpart);
+  HPRI_CHECK_LAUNCH();
+  hipLaunchKernelGGL(col_finalize_kernel, dim3(hpri_cdiv(C, 32), G), dim3(256), 0, stream, part, nblk, Cpart, C, sums);
+  HPRI_CHECK_LAUNCH();
+  if (dgamma != nullptr && dbeta != nullptr) {
+    hipLaunchKernelGGL(bn_param_grad_kernel, dim3(hpri_cdiv(C, 256)), dim3(256), 0, stream, sums, G, C, dgamma, dbeta,
+                       accumulate_param_grads);
+    HPRI_CHECK_LAUNCH();
+  }
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(P * (Cw >> 2))), dim3(256), 0, stream, dy, dy_cs, dy_coff, x, x_cs,
+                     x_coff, dx, dx_cs, dx_coff, mean, invstd, scale, shift, sums, P, pix_per_group, C, Cw, relu,
+                     use_batch_stats);
+  HPRI_CHECK_LAUNCH();
+  return HPRI_OK;
+}
+
+// out[c] (+)= sum over all P pixels of src[p][coff + c]   (conv / linear bias gradients)
+extern "C" int hpri_col_sum(const float* src, int cs, int coff, float* out, int accumulate, float* workspace,
+                            size_t ws_floats, long long P, int C, hipStream_t stream) {
+  HPRI_REQUIRE(src && out && workspace, "col_sum: null pointer");
+  HPRI_REQUIRE(cs % 4 == 0 && coff % 4 == 0 && P > 0 && C > 0, "col_sum: bad layout");
+  int nblk, Cpart;
+  hpri_col_reduce_plan(P, 1, C, &nblk, &Cpart);
+  const size_t need = (size_t)nblk * 2 * Cpart + 2 * (size_t)C;
+  if (need > ws_floats) return hpri_set_error(HPRI_ERR_WORKSPACE, "col_sum: workspace too small");
+  float* part = workspace;
+  float* sums = workspace + (size_t)nblk * 2 * Cpart;
+  const int c4 = hpri_cdiv(C, 4), cq = pick_cq(c4);
+  // note: reading float4 at channel c..c+3 needs c+3 < cs - coff; callers keep cs a multiple of 4 >= C
+  hipLaunchKernelGGL((col_reduce_kernel<1>), dim3(nblk, hpri_cdiv(c4, cq), 1), dim3(256), 0, stream, src, cs, coff, nullptr, 0,
+                     0, nullptr, nullptr, nullptr, nullptr, P, C, cq, 0, part, Cpart);
+  HPRI_CHECK_LAUNCH();
+  hipLaunchKernelGGL(col_finalize_kernel, dim3(hpri_cdiv(C, 32), 1), dim3(256), 0, stream, part, nblk, Cpart, C, sums);
+  HPRI_CHECK_LAUNCH();
+  // sums[0][c] holds the column sums; reuse the param-grad kernel's "dbeta" path
+  hipLaunchKernelGGL(bn_param_grad_kernel, dim3(hpri_cdiv(C, 256)), dim3(256), 0, stream, sums, 1, C, sums + C, out, accumulate);
+  HPRI_CHECK_LAUNCH();
+  return HPRI_OK;
+}

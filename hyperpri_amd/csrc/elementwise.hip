@@ -1,0 +1,422 @@
+// Bandwidth-bound companions of the conv kernels, all on NHWC fp32 with float4 channel vectors:
+// layout changes at the module boundary (the reference hands NC(D)HW tensors, dataset.py:267-271),
+// MaxPool2d(2) forward/backward (model_parts.py:40), the skip-concat copy and zero padding of
+// Up.forward (model_parts.py:77-87), the 1x1 OutConv / final Linear (model_parts.py:96; models.py:103),
+// and the counter-based synthetic generator used by bench.py.
+#include "common.h"
+
+static inline int ew_blocks(long long total) {
+  long long b = (total + 255) / 256;
+  if (b > 8192) b = 8192;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+// ---------------------------------- NCHW <-> NHWC ----------------------------------------------
+// src [N][C][P] -> dst [N][P][cs] at channel offset coff; channels C..Cw are zero-filled.
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, float* __restrict__ dst, int C, long long P,
+                                    int cs, int coff, int Cw) {
+  __shared__ float tile[32][65];
+  const int n = blockIdx.z;
+  const long long p0 = (long long)blockIdx.x * 64;
+  const int c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;   // 64 x 4
+  for (int r = ty; r < 32; r += 4) {
+    const int c = c0 + r;
+    const long long p = p0 + tx;
+    tile[r][tx] = (c < C && p < P) ? src[((long long)n * C + c) * P + p] : 0.f;
+  }
+  __syncthreads();
+  const int cx = threadIdx.x & 31, py = threadIdx.x >> 5;   // 32 x 8
+  for (int r = py; r < 64; r += 8) {
+    const long long p = p0 + r;
+    const int c = c0 + cx;
+    if (p < P && c < Cw) dst[((long long)n * P + p) * cs + coff + c] = tile[cx][r];
+  }
+}
+
+// src [N][P][cs]+coff -> dst [N][C][P]
+__global__ void nhwc_to_nchw_kernel(const float* __restrict__ src, float* __restrict__ dst, int C, long long P,
+                                    int cs, int coff, int accumulate) {
+  __shared__ float tile[64][33];
+  const int n = blockIdx.z;
+  const long long p0 = (long long)blockIdx.x * 64;
+  const int c0 = blockIdx.y * 32;
+  const int cx = threadIdx.x & 31, py = threadIdx.x >> 5;
+  for (int r = py; r < 64; r += 8) {
+    const long long p = p0 + r;
+    const int c = c0 + cx;
+    tile[r][cx] = (p < P && c < C) ? src[((long long)n * P + p) * cs + coff + c] : 0.f;
+  }
+  __syncthreads();
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int r = ty; r < 32; r += 4) {
+    const int c = c0 + r;
+    const long long p = p0 + tx;
+    if (c < C && p < P) {
+      float* o = dst + ((long long)n * C + c) * P + p;
+      *o = accumulate ? *o + tile[tx][r] : tile[tx][r];
+    }
+  }
+}
+
+// ---------------------------------- MaxPool2d(2) ------------------------------------------------
+__global__ void maxpool2_fwd_kernel(const float* __restrict__ x, int x_cs, int x_coff, float* __restrict__ y, int y_cs,
+                                    int y_coff, int N, int H, int W, int OH, int OW, int C4) {
+  const long long total = (long long)N * OH * OW * C4;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4) * 4;
+    long long r = i / C4;
+    const int ox = (int)(r % OW); r /= OW;
+    const int oy = (int)(r % OH);
+    const int n = (int)(r / OH);
+    const float* b = x + (((long long)n * H + 2 * oy) * W + 2 * ox) * x_cs + x_coff + c;
+    const float4 v00 = *reinterpret_cast<const float4*>(b);
+    const float4 v01 = *reinterpret_cast<const float4*>(b + x_cs);
+    const float4 v10 = *reinterpret_cast<const float4*>(b + (long long)W * x_cs);
+    const float4 v11 = *reinterpret_cast<const float4*>(b + (long long)W * x_cs + x_cs);
+    float4 m;
+    m.x = fmaxf(fmaxf(v00.x, v01.x), fmaxf(v10.x, v11.x));
+    m.y = fmaxf(fmaxf(v00.y, v01.y), fmaxf(v10.y, v11.y));
+    m.z = fmaxf(fmaxf(v00.z, v01.z), fmaxf(v10.z, v11.z));
+    m.w = fmaxf(fmaxf(v00.w, v01.w), fmaxf(v10.w, v11.w));
+    *reinterpret_cast<float4*>(y + (((long long)n * OH + oy) * OW + ox) * y_cs + y_coff + c) = m;
+  }
+}
+
+// dx[iy][ix] (+)= dy[iy/2][ix/2] if (iy,ix) is the FIRST maximum of its window in scan order
+// (ATen's max_pool2d keeps the first element that compares greater), else 0; rows/cols dropped by the
+// floor get 0.
+__device__ __forceinline__ int first_argmax4(float a, float b, float c, float d) {
+  int k = 0; float m = a;
+  if (b > m) { m = b; k = 1; }
+  if (c > m) { m = c; k = 2; }
+  if (d > m) { k = 3; }
+  return k;
+}
+
+__global__ void maxpool2_bwd_kernel(const float* __restrict__ x, int x_cs, int x_coff, const float* __restrict__ dy,
+                                    int dy_cs, int dy_coff, float* __restrict__ dx, int dx_cs, int dx_coff, int N, int H,
+                                    int W, int OH, int OW, int C4, int accumulate) {
+  const long long total = (long long)N * H * W * C4;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4) * 4;
+    long long r = i / C4;
+    const int ix = (int)(r % W); r /= W;
+    const int iy = (int)(r % H);
+    const int n = (int)(r / H);
+    const int oy = iy >> 1, ox = ix >> 1;
+    float o[4] = {0.f, 0.f, 0.f, 0.f};
+    if (oy < OH && ox < OW) {
+      const float* b = x + (((long long)n * H + 2 * oy) * W + 2 * ox) * x_cs + x_coff + c;
+      const float4 v00 = *reinterpret_cast<const float4*>(b);
+      const float4 v01 = *reinterpret_cast<const float4*>(b + x_cs);
+      const float4 v10 = *reinterpret_cast<const float4*>(b + (long long)W * x_cs);
+      const float4 v11 = *reinterpret_cast<const float4*>(b + (long long)W * x_cs + x_cs);
+      const float4 g = *reinterpret_cast<const float4*>(dy + (((long long)n * OH + oy) * OW + ox) * dy_cs + dy_coff + c);
+      const int me = (iy & 1) * 2 + (ix & 1);
+      if (first_argmax4(v00.x, v01.x, v10.x, v11.x) == me) o[0] = g.x;
+      if (first_argmax4(v00.y, v01.y, v10.y, v11.y) == me) o[1] = g.y;
+      if (first_argmax4(v00.z, v01.z, v10.z, v11.z) == me) o[2] = g.z;
+      if (first_argmax4(v00.w, v01.w, v10.w, v11.w) == me) o[3] = g.w;
+    }
+    float* p = dx + (((long long)n * H + iy) * W + ix) * dx_cs + dx_coff + c;
+    if (accumulate) {
+      const float4 old = *reinterpret_cast<const float4*>(p);
+      o[0] += old.x; o[1] += old.y; o[2] += old.z; o[3] += old.w;
+    }
+    *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+// ---------------------------------- slice copy / pad fill / add ---------------------------------
+__global__ void copy_slice_kernel(const float* __restrict__ s, int s_cs, int s_coff, float* __restrict__ d, int d_cs,
+                                  int d_coff, long long P, int C4, int accumulate) {
+  const long long total = P * C4;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long p = i / C4;
+    const int c = (int)(i - p * C4) * 4;
+    float4 v = *reinterpret_cast<const float4*>(s + p * s_cs + s_coff + c);
+    float* o = d + p * d_cs + d_coff + c;
+    if (accumulate) {
+      const float4 w = *reinterpret_cast<const float4*>(o);
+      v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+    }
+    *reinterpret_cast<float4*>(o) = v;
+  }
+}
+
+// zero channels [coff, coff+4*C4) of every pixel outside the rectangle [y0,y1) x [x0,x1)
+__global__ void fill_pad_kernel(float* __restrict__ d, int cs, int coff, int N, int H, int W, int C4, int y0, int y1,
+                                int x0, int x1) {
+  const long long total = (long long)N * H * W * C4;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4) * 4;
+    long long r = i / C4;
+    const int ix = (int)(r % W); r /= W;
+    const int iy = (int)(r % H);
+    if (iy >= y0 && iy < y1 && ix >= x0 && ix < x1) continue;
+    *reinterpret_cast<float4*>(d + (i / C4) * cs + coff + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+
+__global__ void fill_kernel(float* __restrict__ d, long long n, float v) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) d[i] = v;
+}
+
+// ---------------------------------- 1x1 output conv ---------------------------------------------
+// logits[n][k][p] = sum_c x[n][p][c] * w[k][c] + b[k]   (NHWC in, NCHW out).  One 16-lane group per pixel.
+__global__ void outconv_fwd_kernel(const float* __restrict__ x, int x_cs, int x_coff, const float* __restrict__ w,
+                                   const float* __restrict__ b, float* __restrict__ y, int N, long long P, int C, int K) {
+  const int gl = threadIdx.x & 15;
+  const long long grp = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+  const long long ngrp = ((long long)gridDim.x * blockDim.x) >> 4;
+  const int C4 = (C + 3) >> 2;
+  for (long long pg = grp; pg < (long long)N * P; pg += ngrp) {
+    const float* xp = x + pg * x_cs + x_coff;
+    for (int k = 0; k < K; ++k) {
+      float s = 0.f;
+      for (int q = gl; q < C4; q += 16) {
+        const float4 v = *reinterpret_cast<const float4*>(xp + q * 4);
+        const float* wk = w + (long long)k * C + q * 4;
+        s += v.x * wk[0];
+        if (q * 4 + 1 < C) s += v.y * wk[1];
+        if (q * 4 + 2 < C) s += v.z * wk[2];
+        if (q * 4 + 3 < C) s += v.w * wk[3];
+      }
+      s += __shfl_xor(s, 8, 16); s += __shfl_xor(s, 4, 16); s += __shfl_xor(s, 2, 16); s += __shfl_xor(s, 1, 16);
+      if (gl == 0) {
+        const long long n = pg / P, p = pg - n * P;
+        y[(n * K + k) * P + p] = s + (b ? b[k] : 0.f);
+      }
+    }
+  }
+}
+
+// dx[n][p][c] = sum_k dy[n][k][p] * w[k][c]  (written, or accumulated into dx)
+__global__ void outconv_bwd_data_kernel(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx,
+                                        int dx_cs, int dx_coff, int N, long long P, int C, int Cw, int K, int accumulate) {
+  const int C4 = Cw >> 2;
+  const long long total = (long long)N * P * C4;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long pg = i / C4;
+    const int c = (int)(i - pg * C4) * 4;
+    const long long n = pg / P, p = pg - n * P;
+    float o[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < K; ++k) {
+      const float g = dy[(n * K + k) * P + p];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (c + j < C) o[j] += g * w[(long long)k * C + c + j];
+    }
+    float* q = dx + pg * dx_cs + dx_coff + c;
+    if (accumulate) {
+      const float4 old = *reinterpret_cast<const float4*>(q);
+      o[0] += old.x; o[1] += old.y; o[2] += old.z; o[3] += old.w;
+    }
+    *reinterpret_cast<float4*>(q) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+// partial[blk][k][c] = sum over the block's pixels of dy[k][p] * x[p][c]; partial_b[blk][k] = sum dy[k][p]
+// grid = (nblk, ceil(C4/CQ), K); block = 256 = ROWS x CQ
+__global__ void outconv_bwd_weight_kernel(const float* __restrict__ dy, const float* __restrict__ x, int x_cs, int x_coff,
+                                          int N, long long P, int C, int K, int CQ, float* __restrict__ part, int Cpart) {
+  __shared__ float4 red[256];
+  __shared__ float redb[256];
+  const int rows = 256 / CQ;
+  const int cq = threadIdx.x % CQ, pr = threadIdx.x / CQ;
+  const int c = (blockIdx.y * CQ + cq) * 4;
+  const int k = blockIdx.z;
+  const long long NP = (long long)N * P;
+  const long long per = (NP + gridDim.x - 1) / gridDim.x;
+  const long long p0 = (long long)blockIdx.x * per;
+  const long long p1 = (p0 + per < NP) ? p0 + per : NP;
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  float sb = 0.f;
+  for (long long pg = p0 + pr; pg < p1; pg += rows) {
+    const long long n = pg / P, p = pg - n * P;
+    const float g = dy[(n * K + k) * P + p];
+    sb += g;
+    if (c < C) {
+      const float4 v = *reinterpret_cast<const float4*>(x + pg * x_cs + x_coff + c);
+      s[0] += g * v.x; s[1] += g * v.y; s[2] += g * v.z; s[3] += g * v.w;
+    }
+  }
+  red[threadIdx.x] = make_float4(s[0], s[1], s[2], s[3]);
+  redb[threadIdx.x] = sb;
+  __syncthreads();
+  if (pr == 0) {
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+    float tb = 0.f;
+    for (int r = 0; r < rows; ++r) {
+      const float4 a = red[r * CQ + cq];
+      t.x += a.x; t.y += a.y; t.z += a.z; t.w += a.w;
+      tb += redb[r * CQ + cq];
+    }
+    // layout [blk][K][2][Cpart]: row 0 = weight partials, row 1 (element 0 only) = bias partial
+    float* o = part + (((size_t)blockIdx.x * K + k) * 2) * Cpart;
+    *reinterpret_cast<float4*>(o + c) = t;
+    if (blockIdx.y == 0 && cq == 0) o[Cpart] = tb;
+  }
+}
+
+__global__ void outconv_bwd_weight_finalize_kernel(const float* __restrict__ part, int nblk, int K, int Cpart, int C,
+                                                   float* __restrict__ dw, float* __restrict__ db, int accumulate) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= K * (C + 1)) return;
+  const int k = idx / (C + 1), c = idx - k * (C + 1);
+  double s = 0.0;
+  if (c < C) {
+    for (int b = 0; b < nblk; ++b) s += part[(((size_t)b * K + k) * 2) * Cpart + c];
+    float* o = dw + (size_t)k * C + c;
+    *o = accumulate ? *o + (float)s : (float)s;
+  } else if (db != nullptr) {
+    for (int b = 0; b < nblk; ++b) s += part[(((size_t)b * K + k) * 2 + 1) * Cpart];
+    db[k] = accumulate ? db[k] + (float)s : (float)s;
+  }
+}
+
+// ---------------------------------- synthetic generator -----------------------------------------
+__device__ __forceinline__ float synth_u(unsigned long long seed, unsigned long long idx) {
+  unsigned long long z = seed * 0x9E3779B97F4A7C15ull + idx;
+  z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull;
+  z ^= z >> 27; z *= 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+
+// mode 0: u ; mode 1: (u > thr) ? 1 : 0 ; mode 2: (2u - 1) * scale
+__global__ void synth_kernel(float* __restrict__ d, long long n, unsigned long long seed, int mode, float thr, float scale) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float u = synth_u(seed, (unsigned long long)i);
+    d[i] = mode == 0 ? u : (mode == 1 ? (u > thr ? 1.f : 0.f) : (2.f * u - 1.f) * scale);
+  }
+}
+
+// ------------------------------------------- C ABI ---------------------------------------------
+extern "C" int hpri_nchw_to_nhwc(const float* src, float* dst, int N, int C, long long P, int cs, int coff, int Cw,
+                                 hipStream_t stream) {
+  HPRI_REQUIRE(src && dst && N > 0 && C > 0 && P > 0 && Cw >= C && Cw + coff <= cs, "nchw_to_nhwc: bad arguments");
+  dim3 grid((unsigned)hpri_cdiv64(P, 64), (unsigned)hpri_cdiv(Cw, 32), (unsigned)N);
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, grid, dim3(256), 0, stream, src, dst, C, P, cs, coff, Cw);
+  HPRI_CHECK_LAUNCH();
+  return HPRI_OK;
+}
+
+extern "C" int hpri_nhwc_to_nchw(const float* src, float* dst, int N, int C, long long P, int cs, int coff,
+                                 int accumulate, hipStream_t stream) {
+  HPRI_REQUIRE(src && dst && N > 0 && C > 0 && P > 0 && C + coff <= cs, "nhwc_to_nchw: bad arguments");
+  dim3 grid((unsigned)hpri_cdiv64(P, 64), (unsigned)hpri_cdiv(C, 32), (unsigned)N);
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, grid, dim3(256), 0, stream, src, dst, C, P, cs, coff, accumulate);
+  HPRI_CHECK_LAUNCH();
+  return HPRI_OK;
+}
+
+#define HPRI_REQ_V4(cs, coff) HPRI_REQUIRE((cs) % 4 == 0 && (coff) % 4 == 0, "channel stride/offset must be multiples of 4")
+
+extern "C" int hpri_maxpool2_fwd(const float* x, int x_cs, int x_coff, float* y, int y_cs, int y_coff, int N, int H,
+                                 int W, int C, hipStream_t stream) {
+  HPRI_REQUIRE(x && y && N > 0 && H >= 2 && W >= 2 && C > 0 && C % 4 == 0, "maxpool2_fwd: bad arguments");
+  HPRI_REQ_V4(x_cs, x_coff); HPRI_REQ_V4(y_cs, y_coff);
+  const int OH = H / 2, OW = W / 2;
+  hipLaunchKernelGGL(maxpool2_fwd_kernel, dim3(ew_blocks((long long)N * OH * OW * (C / 4))), dim3(256), 0, stream, x, x_cs,
+                     x_coff, y, y_cs, y_coff, N, H, W, OH, OW, C / 4);
+  HPRI_CHECK_LAUNCH();
+  return HPRI_OK;
+}
+
+extern "C" int hpri_maxpool2_bwd(const float* x, int x_cs, int x_coff, const float* dy, int dy_cs, int dy_coff, float* dx,
+                                 int dx_cs, int dx_coff, int N, int H, int W, int C, int accumulate, hipStream_t stream) {
+  HPRI_REQUIRE(x && dy && dx && N > 0 && H >= 2 && W >= 2 && C > 0 && C % 4 == 0, "maxpool2_bwd: bad arguments");
+  HPRI_REQ_V4(x_cs, x_coff); HPRI_REQ_V4(dy_cs, dy_coff); HPRI_REQ_V4(dx_cs, dx_coff);
+  hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(ew_blocks((long long)N * H * W * (C / 4))), dim3(256), 0, stream, x, x_cs,
+                     x_coff, dy, dy_cs, dy_coff, dx, dx_cs, dx_coff, N, H, W, H / 2, W / 2, C / 4, accumulate);
+  HPRI_CHECK_LAUNCH();
+  return HPRI_OK;
+}
+
+extern "C" int hpri_copy_slice(const float* src, int s_cs, int s_coff, float* dst, int d_cs, int d_coff, long long P,
+                               int C, int accumulate, hipStream_t stream) {
+  HPRI_REQUIRE(src && dst && P > 0 && C > 0 && C % 4 == 0, "copy_slice: bad arguments");
+  HPRI_REQ_V4(s_cs, s_coff); HPRI_REQ_V4(d_cs, d_coff);
+  hipLaunchKernelGGL(copy_slice_kernel, dim3(ew_blocks(P * (C / 4))), dim3(256), 0, stream, src, s_cs, s_coff, dst, d_cs,
+                     d_coff, P, C / 4, accumulate);
+  HPRI_CHECK_LAUNCH();
+  return HPRI_OK;
+}
+
+extern "C" int hpri_fill_pad(float* dst, int cs, int coff, int N, int H, int W, int C, int y0, int y1, int x0, int x1,
+                             hipStream_t stream) {
+  HPRI_REQUIRE(dst && N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "fill_pad: bad arguments");
+  HPRI_REQ_V4(cs, coff);
+  hipLaunchKernelGGL(fill_pad_kernel, dim3(ew_blocks((long long)N * H * W * (C / 4))), dim3(256), 0, stream, dst, cs, coff, N,
+                     H, W, C / 4, y0, y1, x0, x1);
+  HPRI_CHECK_LAUNCH();
+  return HPRI_OK;
+}
+
+extern "C" int hpri_fill(float* dst, long long n, float value, hipStream_t stream) {
+  HPRI_REQUIRE(dst && n > 0, "fill: bad arguments");
+  hipLaunchKernelGGL(fill_kernel, dim3(ew_blocks(n)), dim3(256), 0, stream, dst, n, value);
+  HPRI_CHECK_LAUNCH();
+  return HPRI_OK;
+}
+
+extern "C" int hpri_outconv_fwd(const float* x, int x_cs, int x_coff, const float* w, const float* b, float* y, int N,
+                                long long P, int C, int K, hipStream_t stream) {
+  HPRI_REQUIRE(x && w && y && N > 0 && P > 0 && C > 0 && K > 0, "outconv_fwd: bad arguments");
+  HPRI_REQ_V4(x_cs, x_coff);
+  HPRI_REQUIRE(((C + 3) / 4) * 4 + x_coff <= x_cs, "outconv_fwd: channel stride too small for float4 reads");
+  hipLaunchKernelGGL(outconv_fwd_kernel, dim3(ew_blocks((long long)N * P * 16)), dim3(256), 0, stream, x, x_cs, x_coff, w, b,
+                     y, N, P, C, K);
+  HPRI_CHECK_LAUNCH();
+  return HPRI_OK;
+}
+
+static inline int pick_cq(int c4) { int q = 1; while (q < c4 && q < 64) q <<= 1; return q; }
+
+extern "C" int hpri_outconv_bwd_plan(int N, long long P, int C, int K, int* nblk, int* Cpart) {
+  const int c4 = hpri_cdiv(C, 4), cq = pick_cq(c4), rows = 256 / cq, ycols = hpri_cdiv(c4, cq);
+  long long nb = 1024 / ((long long)ycols * K);
+  const long long maxb = ((long long)N * P + rows * 8 - 1) / (rows * 8);
+  if (nb > maxb) nb = maxb;
+  if (nb < 1) nb = 1;
+  *nblk = (int)nb; *Cpart = ycols * cq * 4;
+  return HPRI_OK;
+}
+
+// dx (optional), dw, db of the 1x1 output conv.  workspace: nblk*K*2*Cpart floats (hpri_outconv_bwd_plan)
+extern "C" int hpri_outconv_bwd(const float* dy, const float* x, int x_cs, int x_coff, const float* w, float* dx,
+                                int dx_cs, int dx_coff, int dx_cw, int dx_accumulate, float* dw, float* db,
+                                int accumulate_param_grads, float* workspace, size_t ws_floats, int N, long long P, int C,
+                                int K, hipStream_t stream) {
+  HPRI_REQUIRE(dy && x && w && dw && workspace && N > 0 && P > 0 && C > 0 && K > 0, "outconv_bwd: bad arguments");
+  HPRI_REQ_V4(x_cs, x_coff);
+  if (dx != nullptr) {
+    HPRI_REQ_V4(dx_cs, dx_coff);
+    HPRI_REQUIRE(dx_cw % 4 == 0 && dx_cw >= C && dx_cw + dx_coff <= dx_cs, "outconv_bwd: dx channel layout");
+    hipLaunchKernelGGL(outconv_bwd_data_kernel, dim3(ew_blocks((long long)N * P * (dx_cw / 4))), dim3(256), 0, stream, dy, w,
+                       dx, dx_cs, dx_coff, N, P, C, dx_cw, K, dx_accumulate);
+    HPRI_CHECK_LAUNCH();
+  }
+  int nblk, Cpart;
+  hpri_outconv_bwd_plan(N, P, C, K, &nblk, &Cpart);
+  if ((size_t)nblk * K * 2 * Cpart > ws_floats) return hpri_set_error(HPRI_ERR_WORKSPACE, "outconv_bwd: workspace too small");
+  const int c4 = hpri_cdiv(C, 4), cq = pick_cq(c4);
+  hipLaunchKernelGGL(outconv_bwd_weight_kernel, dim3(nblk, hpri_cdiv(c4, cq), K), dim3(256), 0, stream, dy, x, x_cs, x_coff,
+                     N, P, C, K, cq, workspace, Cpart);
+  HPRI_CHECK_LAUNCH();
+  hipLaunchKernelGGL(outconv_bwd_weight_finalize_kernel, dim3(hpri_cdiv(K * (C + 1), 256)), dim3(256), 0, stream, workspace,
+                     nblk, K, Cpart, C, dw, db, accumulate_param_grads);
+  HPRI_CHECK_LAUNCH();
+  return HPRI_OK;
+}
+
+extern "C" int hpri_synth_fill(float* dst, long long n, unsigned long long seed, int mode, float thr, float scale,
+                               hipStream_t stream) {
+  HPRI_REQUIRE(dst && n > 0 && mode >= 0 && mode <= 2, "synth_fill: bad arguments");
+  hipLaunchKernelGGL(synth_kernel, dim3(ew_blocks(n)), dim3(256), 0, stream, dst, n, seed, mode, thr, scale);
+  HPRI_CHECK_LAUNCH();
+  return HPRI_OK;
+}

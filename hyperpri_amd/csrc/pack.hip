@@ -1,0 +1,51 @@
+// Weight re-layout kernels: PyTorch parameter layouts (OIHW conv, (Cin,Cout,2,2) transposed conv,
+// (out,in) linear) -> the [chunk][tap][32 k][Cout_pad] panels conv_fwd.hip streams through LDS.
+// The packed copies are derived caches; the nn.Parameter stays the source of truth.
+#include "common.h"
+
+// mode 0: conv forward      wp[t][k=c][n]        = W[n][c][t]                 (W: [Cout][Cin][T])
+// mode 1: conv data-grad    wp[t][k=n][col=c]    = W[n][c][T-1-t]             (K = Cout, cols = Cin)
+// mode 2: convT forward     wp[0][k=ci][n=tap*Cup+co] = Wt[ci][co][tap]       (Wt: [Cin][Cup][4])
+// mode 3: convT data-grad   wp[0][k=tap*Cup+co][col=ci] = Wt[ci][co][tap]
+__global__ void pack_weight_kernel(const float* __restrict__ w, float* __restrict__ wp, int mode,
+                                   int K, int Ncols, int Ncols_pad, int T, int chunks, int Cup,
+                                   int src_d0, int src_d1) {
+  // one thread per packed element; layout [chunk][t][kk(32)][Ncols_pad]
+  const size_t total = (size_t)chunks * T * 32 * Ncols_pad;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int col = (int)(idx % Ncols_pad);
+    size_t r = idx / Ncols_pad;
+    const int kk = (int)(r % 32); r /= 32;
+    const int t = (int)(r % T);
+    const int chunk = (int)(r / T);
+    const int k = chunk * 32 + kk;
+    float v = 0.f;
+    if (k < K && col < Ncols) {
+      if (mode == 0) v = w[((size_t)col * src_d1 + k) * T + t];                  // W[n=col][c=k][t]
+      else if (mode == 1) v = w[((size_t)k * src_d1 + col) * T + (T - 1 - t)];   // W[n=k][c=col][flip t]
+      else if (mode == 2) { const int tap = col / Cup, co = col - tap * Cup; v = w[((size_t)k * Cup + co) * 4 + tap]; }
+      else { const int tap = k / Cup, co = k - tap * Cup; v = w[((size_t)col * Cup + co) * 4 + tap]; }
+    }
+    wp[idx] = v;
+  }
+}
+
+extern "C" size_t hpri_packed_weight_floats(int K, int Ncols_pad, int T) {
+  return (size_t)hpri_cdiv(K, 32) * T * 32 * Ncols_pad;
+}
+
+// K = GEMM reduction length per tap (before padding), Ncols = GEMM output columns.
+extern "C" int hpri_pack_weight(const float* w, float* wp, int mode, int K, int Ncols, int Ncols_pad,
+                                int T, int Cup, int src_d0, int src_d1, hipStream_t stream) {
+  HPRI_REQUIRE(w && wp, "pack_weight: null pointer");
+  HPRI_REQUIRE(mode >= 0 && mode <= 3 && K > 0 && Ncols > 0 && Ncols_pad >= Ncols && Ncols_pad % 64 == 0,
+               "pack_weight: bad arguments");
+  const int chunks = hpri_cdiv(K, 32);
+  const size_t total = (size_t)chunks * T * 32 * Ncols_pad;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, stream, w, wp, mode, K, Ncols, Ncols_pad, T,
+                     chunks, Cup, src_d0, src_d1);
+  HPRI_CHECK_LAUNCH();
+  return HPRI_OK;
+}

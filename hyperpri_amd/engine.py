@@ -1,0 +1,425 @@
+"""Host-side engine: NHWC activation views, a reverse-mode tape, and one Python wrapper per HIP op.
+
+Everything numeric happens in libhyperpri_hip.so (see include/hyperpri_hip.h); PyTorch is used for
+device memory (caching allocator), the current HIP stream and autograd plumbing only.  The op
+wrappers mirror what the reference's layers do (file:line cited per op) and record a backward
+closure on the tape; ``model_parts.py`` / ``models.py`` compose them into the reference's modules.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Callable, Dict, List, Optional, Tuple
+
+import torch
+
+from . import _lib
+
+A_DIRECT, A_S2D = 0, 1
+E_DIRECT, E_D2S = 0, 1
+
+
+def _rup(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+def _stream() -> ctypes.c_void_p:
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t: Optional[torch.Tensor]) -> ctypes.c_void_p:
+    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _require_cuda(t: torch.Tensor, what: str) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"hyperpri_amd: {what} is on {t.device}; the hot path exists only as HIP kernels for "
+            "MI355X (no CPU fallback). Move the module and its inputs to a ROCm device.")
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"hyperpri_amd: {what} must be float32, got {t.dtype}")
+
+
+class Act:
+    """fp32 NHWC activation view: element (n,h,w,c) at buf[((n*H+h)*W+w)*cs + coff + c].
+
+    Invariant: channels [C, cw) (cw = C rounded up to 8) exist inside the stride and hold zeros, so
+    consumers may run their K loop over ``cw`` channels."""
+    __slots__ = ("buf", "N", "H", "W", "C", "cs", "coff")
+
+    def __init__(self, buf: torch.Tensor, N: int, H: int, W: int, C: int, cs: int, coff: int = 0):
+        self.buf, self.N, self.H, self.W, self.C, self.cs, self.coff = buf, N, H, W, C, cs, coff
+
+    @property
+    def cw(self) -> int:
+        return _rup(self.C, 8)
+
+    @property
+    def P(self) -> int:
+        return self.N * self.H * self.W
+
+    @property
+    def ptr(self) -> ctypes.c_void_p:
+        return ctypes.c_void_p(self.buf.data_ptr())
+
+    @staticmethod
+    def new(N: int, H: int, W: int, C: int, device) -> "Act":
+        cs = _rup(C, 8)
+        return Act(torch.empty(N * H * W * cs, dtype=torch.float32, device=device), N, H, W, C, cs, 0)
+
+    def slice(self, c0: int, C: int) -> "Act":
+        if c0 % 4:
+            raise RuntimeError("hyperpri_amd: channel slices must start at a multiple of 4")
+        return Act(self.buf, self.N, self.H, self.W, C, self.cs, self.coff + c0)
+
+    def to_tensor(self) -> torch.Tensor:
+        """Logical (N,C,H,W) tensor aliasing this view (channels-last strides, no copy)."""
+        return torch.as_strided(self.buf, (self.N, self.C, self.H, self.W),
+                                (self.H * self.W * self.cs, 1, self.W * self.cs, self.cs), self.coff)
+
+    @staticmethod
+    def from_tensor(t: torch.Tensor) -> "Act":
+        """(N,C,H,W) tensor -> Act.  Zero-copy when t is channels-last with a stride that already
+        provides the zero pad; otherwise one nchw->nhwc HIP transpose (dataset.py:267-271 hands NCHW)."""
+        _require_cuda(t, "input tensor")
+        N, C, H, W = t.shape
+        st = t.stride()
+        cs = st[3] if W > 1 else (st[2] if H > 1 else C)
+        if (C % 8 == 0 and st[1] == 1 and cs >= C and cs % 4 == 0 and (W == 1 or st[3] == cs)
+                and (H == 1 or st[2] == W * cs) and (N == 1 or st[0] == H * W * cs)
+                and t.data_ptr() % 16 == 0):
+            a = Act(t, N, H, W, C, cs, 0)
+            a.buf = t  # data_ptr() of the view is element (0,0,0,0)
+            return a
+        if not t.is_contiguous():
+            t = t.contiguous()   # rare: arbitrary strides from the caller
+        a = Act.new(N, H, W, C, t.device)
+        _lib.call("hpri_nchw_to_nhwc", _p(t), a.ptr, N, C, H * W, a.cs, 0, a.cw, _stream())
+        return a
+
+    def to_nchw(self) -> torch.Tensor:
+        out = torch.empty((self.N, self.C, self.H, self.W), dtype=torch.float32, device=self.buf.device)
+        _lib.call("hpri_nhwc_to_nchw", self.ptr, _p(out), self.N, self.C, self.H * self.W, self.cs, self.coff, 0, _stream())
+        return out
+
+
+class Tape:
+    """Reverse-mode tape over Acts.  ``nodes`` are closures run in reverse; ``grads`` maps id(Act) to
+    the Act holding its gradient; parameter gradients are collected by id(parameter)."""
+
+    def __init__(self, record: bool):
+        self.record = record
+        self.nodes: List[Callable[["Tape"], None]] = []
+        self.grads: Dict[int, Act] = {}
+        self.param_grads: Dict[int, torch.Tensor] = {}
+        self.keep: List[object] = []
+
+    def grad_slot(self, a: Act) -> Tuple[Act, bool]:
+        """(gradient view for ``a``, accumulate?) -- allocates a fresh buffer the first time."""
+        g = self.grads.get(id(a))
+        if g is not None:
+            return g, True
+        g = Act.new(a.N, a.H, a.W, a.C, a.buf.device)
+        self.grads[id(a)] = g
+        return g, False
+
+    def set_grad_view(self, a: Act, view: Act) -> None:
+        """Give ``a`` the gradient ``view`` (a slice of another gradient buffer) without copying;
+        if ``a`` already has a gradient the view is added into it."""
+        g = self.grads.get(id(a))
+        if g is None:
+            self.grads[id(a)] = view
+        else:
+            _lib.call("hpri_copy_slice", view.ptr, view.cs, view.coff, g.ptr, g.cs, g.coff, g.P, _rup(a.C, 4), 1, _stream())
+
+    def param_slot(self, p: torch.Tensor) -> Tuple[torch.Tensor, int]:
+        g = self.param_grads.get(id(p))
+        if g is not None:
+            return g, 1
+        g = torch.empty(p.shape, dtype=torch.float32, device=p.device)
+        self.param_grads[id(p)] = g
+        return g, 0
+
+    def backward(self) -> None:
+        for node in reversed(self.nodes):
+            node(self)
+        self.nodes.clear()
+        self.keep.clear()
+
+
+class BNRef:
+    """The tensors of one nn.BatchNorm{1,2,3}d (model_parts.py:23,26; models.py:113,172,178)."""
+    __slots__ = ("weight", "bias", "running_mean", "running_var", "num_batches_tracked", "eps", "momentum")
+
+    def __init__(self, m: torch.nn.modules.batchnorm._BatchNorm):
+        if not (m.affine and m.track_running_stats):
+            raise RuntimeError("hyperpri_amd: BatchNorm must be affine with running statistics (reference default)")
+        self.weight, self.bias = m.weight, m.bias
+        self.running_mean, self.running_var = m.running_mean, m.running_var
+        self.num_batches_tracked = m.num_batches_tracked
+        self.eps = float(m.eps)
+        self.momentum = 0.1 if m.momentum is None else float(m.momentum)
+
+
+def _ws(nfloats: int, device) -> torch.Tensor:
+    return torch.empty(max(int(nfloats), 4), dtype=torch.float32, device=device)
+
+
+def _pack(w: torch.Tensor, mode: int, K: int, ncols: int, T: int, cup: int, d1: int) -> Tuple[torch.Tensor, int]:
+    ncols_pad = _rup(ncols, 64)
+    n = _lib.load().hpri_packed_weight_floats(K, ncols_pad, T)
+    wp = torch.empty(n, dtype=torch.float32, device=w.device)
+    _lib.call("hpri_pack_weight", _p(w), _p(wp), mode, K, ncols, ncols_pad, T, cup, 0, d1, _stream())
+    return wp, ncols_pad
+
+
+def _conv_launch(x: Act, wp: torch.Tensor, bias: Optional[torch.Tensor], y: Act, stats: Optional[torch.Tensor],
+                 N: int, H: int, W: int, cin_pad: int, cout: int, cout_pad: int, y_cw: int, ks: int,
+                 amode: int = A_DIRECT, epi: int = E_DIRECT, accumulate: int = 0,
+                 H2: int = 0, W2: int = 0, py0: int = 0, px0: int = 0, cup: int = 0) -> None:
+    _lib.call("hpri_conv_fwd", x.ptr, x.cs, x.coff, _p(wp), _p(bias), y.ptr, y.cs, y.coff, _p(stats),
+              N, H, W, cin_pad, cout, cout_pad, y_cw, ks, amode, epi, accumulate, H2, W2, py0, px0, cup, _stream())
+
+
+# --------------------------------------------------------------------------------------------------
+# conv (3x3 pad 1 | 1x1 | Linear) [+ BatchNorm + ReLU]
+# --------------------------------------------------------------------------------------------------
+def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.Tensor], bn: Optional[BNRef],
+                 train: bool, ks: int, groups: int = 1, relu: bool = True, need_dx: bool = True) -> Act:
+    """Conv2d(k=ks, pad=ks//2) -> BatchNorm -> ReLU  (model_parts.py:22-27; models.py:169-180 with the
+    Conv3d weight (F,1,D,3,3) read as (F,D,3,3); models.py:108-114 for Linear -> BatchNorm1d -> ReLU with
+    ks = 1 and ``groups`` = images, each image being its own BN batch, models.py:132)."""
+    dev = x.buf.device
+    T = ks * ks
+    cout = weight.shape[0]
+    cin = weight.numel() // (cout * T)
+    if cin != x.C:
+        raise RuntimeError(f"hyperpri_amd: conv expects {cin} input channels, got {x.C}")
+    cin_pad = x.cw
+    wp, cout_pad = _pack(weight, 0, cin, cout, T, 0, cin)
+    yr = Act.new(x.N, x.H, x.W, cout, dev)
+    use_batch = bn is not None and train
+    stats = None
+    tiles = 0
+    if use_batch:
+        tiles = _lib.load().hpri_conv_fwd_tiles(x.N, x.H, x.W, cout_pad)
+        stats = torch.empty(tiles * cout_pad * 4, dtype=torch.float32, device=dev)
+    _conv_launch(x, wp, bias, yr, stats, x.N, x.H, x.W, cin_pad, cout, cout_pad, yr.cw, ks)
+    del wp
+    if bn is None:
+        y = yr
+        st = None
+    else:
+        G = groups if use_batch else 1
+        st = torch.empty(5 * G * cout, dtype=torch.float32, device=dev)   # mean, invstd, var_unbiased, scale, shift
+        mean, invstd, varu, scale, shift = (st[i * G * cout:(i + 1) * G * cout] for i in range(5))
+        if use_batch:
+            _lib.call("hpri_bn_finalize", _p(stats), tiles // G, G, cout_pad, cout, _p(bn.weight), _p(bn.bias),
+                      bn.eps, bn.momentum, _p(mean), _p(invstd), _p(varu), _p(scale), _p(shift),
+                      _p(bn.running_mean), _p(bn.running_var), _p(bn.num_batches_tracked), _stream())
+        else:
+            _lib.call("hpri_bn_eval_prepare", _p(bn.running_mean), _p(bn.running_var), _p(bn.weight), _p(bn.bias),
+                      bn.eps, cout, _p(mean), _p(invstd), _p(scale), _p(shift), _stream())
+        y = Act.new(x.N, x.H, x.W, cout, dev)
+        ppg = (x.P // G)
+        _lib.call("hpri_bn_apply_relu", yr.ptr, yr.cs, yr.coff, y.ptr, y.cs, y.coff, _p(scale), _p(shift),
+                  x.P, ppg, cout, y.cw, int(relu), _stream())
+    if not tape.record:
+        return y
+
+    def bwd(tp: Tape) -> None:
+        g = tp.grads.pop(id(y), None)
+        if g is None:
+            return
+        if bn is not None:
+            dyr = Act.new(x.N, x.H, x.W, cout, dev)
+            G = groups if use_batch else 1
+            nblk = ctypes.c_int(); cpart = ctypes.c_int()
+            _lib.call("hpri_col_reduce_plan", x.P // G, G, cout, ctypes.byref(nblk), ctypes.byref(cpart))
+            ws = _ws(G * nblk.value * 2 * cpart.value + G * 2 * cout, dev)
+            dgam, acc_g = tp.param_slot(bn.weight)
+            dbet, _ = tp.param_slot(bn.bias)
+            mean, invstd, varu, scale, shift = (st[i * G * cout:(i + 1) * G * cout] for i in range(5))
+            _lib.call("hpri_bn_relu_bwd", g.ptr, g.cs, g.coff, yr.ptr, yr.cs, yr.coff, dyr.ptr, dyr.cs, dyr.coff,
+                      _p(mean), _p(invstd), _p(scale), _p(shift), _p(dgam), _p(dbet), acc_g, _p(ws), ws.numel(),
+                      x.P, x.P // G, cout, dyr.cw, int(relu), int(use_batch), _stream())
+        else:
+            dyr = g
+        if bias is not None:
+            db, acc_b = tp.param_slot(bias)
+            nblk = ctypes.c_int(); cpart = ctypes.c_int()
+            _lib.call("hpri_col_reduce_plan", x.P, 1, cout, ctypes.byref(nblk), ctypes.byref(cpart))
+            ws = _ws(nblk.value * 2 * cpart.value + 2 * cout, dev)
+            _lib.call("hpri_col_sum", dyr.ptr, dyr.cs, dyr.coff, _p(db), acc_b, _p(ws), ws.numel(), x.P, cout, _stream())
+        dw, acc_w = tp.param_slot(weight)
+        _wgrad(x, dyr, dw, acc_w, cin, cout, ks)
+        if need_dx:
+            wpd, cin_cols_pad = _pack(weight, 1, cout, cin, T, 0, cin)
+            gx, acc = tp.grad_slot(x)
+            _conv_launch(dyr, wpd, None, gx, None, x.N, x.H, x.W, dyr.cw, cin, cin_cols_pad, gx.cw, ks, accumulate=int(acc))
+
+    tape.nodes.append(bwd)
+    return y
+
+
+def _wgrad(x: Act, dy: Act, dw: torch.Tensor, accumulate: int, cin: int, cout: int, ks: int,
+           bmode: int = A_DIRECT, dst_mode: int = 0, N: int = 0, H: int = 0, W: int = 0,
+           H2: int = 0, W2: int = 0, py0: int = 0, px0: int = 0, cup: int = 0) -> None:
+    N, H, W = (N or x.N), (H or x.H), (W or x.W)
+    cin_pad = x.cw
+    cout_pad = _rup(cout, 64)
+    splits = ctypes.c_int(); cr = ctypes.c_int(); nr = ctypes.c_int()
+    _lib.call("hpri_wgrad_plan", N, H, W, cin_pad, cout_pad, ks, ctypes.byref(splits), ctypes.byref(cr), ctypes.byref(nr))
+    ws = _ws(splits.value * ks * ks * cr.value * nr.value, x.buf.device)
+    dy_cvalid = (4 * cup) if bmode == A_S2D else dy.cw
+    _lib.call("hpri_conv_wgrad", x.ptr, x.cs, x.coff, cin_pad, dy.ptr, dy.cs, dy.coff, dy_cvalid, _p(ws), ws.numel(),
+              _p(dw), N, H, W, cin, cin_pad, cout, cout_pad, ks, bmode, dst_mode, accumulate, H2, W2, py0, px0, cup,
+              _stream())
+
+
+# --------------------------------------------------------------------------------------------------
+# MaxPool2d(2)
+# --------------------------------------------------------------------------------------------------
+def maxpool2(tape: Tape, x: Act) -> Act:
+    """nn.MaxPool2d(2) (floor), model_parts.py:40."""
+    if x.H < 2 or x.W < 2:
+        raise RuntimeError("hyperpri_amd: MaxPool2d(2) needs H, W >= 2")
+    y = Act.new(x.N, x.H // 2, x.W // 2, x.C, x.buf.device)
+    _lib.call("hpri_maxpool2_fwd", x.ptr, x.cs, x.coff, y.ptr, y.cs, y.coff, x.N, x.H, x.W, x.cw, _stream())
+    if tape.record:
+        def bwd(tp: Tape) -> None:
+            g = tp.grads.pop(id(y), None)
+            if g is None:
+                return
+            gx, acc = tp.grad_slot(x)
+            _lib.call("hpri_maxpool2_bwd", x.ptr, x.cs, x.coff, g.ptr, g.cs, g.coff, gx.ptr, gx.cs, gx.coff,
+                      x.N, x.H, x.W, _rup(x.C, 4), int(acc), _stream())
+        tape.nodes.append(bwd)
+    return y
+
+
+# --------------------------------------------------------------------------------------------------
+# ConvTranspose2d(k2,s2) -> zero-pad -> concat with the skip
+# --------------------------------------------------------------------------------------------------
+def up_concat(tape: Tape, x1: Act, skip: Act, weight: torch.Tensor, bias: Optional[torch.Tensor],
+              need_dx1: bool = True) -> Act:
+    """cat([skip, pad(ConvTranspose2d(x1))], dim=1): model_parts.py:63-64,73-87 (and models.py:230-239).
+    The transposed conv is one GEMM per input pixel (Cin -> 4*Cup) whose epilogue scatters the 2x2
+    patches straight into channels [Cskip, Cskip+Cup) of the concat buffer; the pad ring is zeroed."""
+    dev = x1.buf.device
+    cin, cup = weight.shape[0], weight.shape[1]
+    if cin != x1.C or skip.N != x1.N:
+        raise RuntimeError("hyperpri_amd: Up: channel/batch mismatch")
+    H2, W2 = skip.H, skip.W
+    dY, dX = H2 - 2 * x1.H, W2 - 2 * x1.W
+    if dY < 0 or dX < 0:
+        raise RuntimeError("hyperpri_amd: Up: skip smaller than upsampled input (negative pad) is not supported")
+    if skip.C % 4 or cup % 4:
+        raise RuntimeError("hyperpri_amd: Up: channel counts must be multiples of 4")
+    py0, px0 = dY // 2, dX // 2
+    cat = Act.new(skip.N, H2, W2, skip.C + cup, dev)
+    _lib.call("hpri_copy_slice", skip.ptr, skip.cs, skip.coff, cat.ptr, cat.cs, cat.coff, cat.P, skip.C, 0, _stream())
+    ups = cat.slice(skip.C, cup)
+    if dY or dX:
+        _lib.call("hpri_fill_pad", ups.ptr, ups.cs, ups.coff, ups.N, H2, W2, cup, py0, py0 + 2 * x1.H, px0, px0 + 2 * x1.W, _stream())
+    if cat.cw > cat.C:
+        _lib.call("hpri_fill_pad", cat.ptr, cat.cs, cat.coff + cat.C, cat.N, H2, W2, cat.cw - cat.C, 0, 0, 0, 0, _stream())
+    wp, ncols_pad = _pack(weight, 2, cin, 4 * cup, 1, cup, cup)
+    _conv_launch(x1, wp, bias, ups, None, x1.N, x1.H, x1.W, x1.cw, 4 * cup, ncols_pad, 4 * cup, 1,
+                 epi=E_D2S, H2=H2, W2=W2, py0=py0, px0=px0, cup=cup)
+    del wp
+    if tape.record:
+        def bwd(tp: Tape) -> None:
+            g = tp.grads.pop(id(cat), None)
+            if g is None:
+                return
+            tp.set_grad_view(skip, g.slice(0, skip.C))
+            gu = g.slice(skip.C, cup)
+            if dY or dX:   # F.pad's backward drops the ring
+                _lib.call("hpri_fill_pad", gu.ptr, gu.cs, gu.coff, gu.N, H2, W2, cup, py0, py0 + 2 * x1.H, px0, px0 + 2 * x1.W, _stream())
+            if bias is not None:
+                db, acc_b = tp.param_slot(bias)
+                nblk = ctypes.c_int(); cpart = ctypes.c_int()
+                _lib.call("hpri_col_reduce_plan", gu.P, 1, cup, ctypes.byref(nblk), ctypes.byref(cpart))
+                ws = _ws(nblk.value * 2 * cpart.value + 2 * cup, dev)
+                _lib.call("hpri_col_sum", gu.ptr, gu.cs, gu.coff, _p(db), acc_b, _p(ws), ws.numel(), gu.P, cup, _stream())
+            dw, acc_w = tp.param_slot(weight)
+            _wgrad(x1, gu, dw, acc_w, cin, 4 * cup, 1, bmode=A_S2D, dst_mode=1, H2=H2, W2=W2, py0=py0, px0=px0, cup=cup)
+            if need_dx1:
+                wpd, cols_pad = _pack(weight, 3, 4 * cup, cin, 1, cup, cup)
+                gx, acc = tp.grad_slot(x1)
+                _conv_launch(gu, wpd, None, gx, None, x1.N, x1.H, x1.W, 4 * cup, cin, cols_pad, gx.cw, 1,
+                             amode=A_S2D, accumulate=int(acc), H2=H2, W2=W2, py0=py0, px0=px0, cup=cup)
+        tape.nodes.append(bwd)
+    return cat
+
+
+def concat_channels(tape: Tape, a: Act, b: Act) -> Act:
+    """torch.cat((a, b), -1) of two per-pixel feature maps (SpectralUNET skip, models.py:139-143)."""
+    if a.C % 4:
+        raise RuntimeError("hyperpri_amd: concat: first operand's channel count must be a multiple of 4")
+    dev = a.buf.device
+    cat = Act.new(a.N, a.H, a.W, a.C + b.C, dev)
+    _lib.call("hpri_copy_slice", a.ptr, a.cs, a.coff, cat.ptr, cat.cs, cat.coff, cat.P, a.C, 0, _stream())
+    _lib.call("hpri_copy_slice", b.ptr, b.cs, b.coff, cat.ptr, cat.cs, cat.coff + a.C, cat.P, _rup(b.C, 4), 0, _stream())
+    tail = cat.cw - (a.C + _rup(b.C, 4))
+    if tail > 0:
+        _lib.call("hpri_fill_pad", cat.ptr, cat.cs, cat.coff + a.C + _rup(b.C, 4), cat.N, cat.H, cat.W, tail, 0, 0, 0, 0, _stream())
+    if tape.record:
+        def bwd(tp: Tape) -> None:
+            g = tp.grads.pop(id(cat), None)
+            if g is None:
+                return
+            tp.set_grad_view(a, g.slice(0, a.C))
+            tp.set_grad_view(b, g.slice(a.C, b.C))
+        tape.nodes.append(bwd)
+    return cat
+
+
+# --------------------------------------------------------------------------------------------------
+# 1x1 output conv / final Linear
+# --------------------------------------------------------------------------------------------------
+def out_conv(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.Tensor], need_dx: bool = True):
+    """nn.Conv2d(C, n_classes, 1) (model_parts.py:96) / nn.Linear(2F, n_classes) (models.py:103,143).
+    Returns (logits NCHW tensor, register_grad) -- the caller hands the incoming NCHW gradient to
+    ``register_grad`` before running the tape backwards."""
+    K = weight.shape[0]
+    C = weight.numel() // K
+    if C != x.C:
+        raise RuntimeError(f"hyperpri_amd: out conv expects {C} channels, got {x.C}")
+    dev = x.buf.device
+    y = torch.empty((x.N, K, x.H, x.W), dtype=torch.float32, device=dev)
+    _lib.call("hpri_outconv_fwd", x.ptr, x.cs, x.coff, _p(weight), _p(bias), _p(y), x.N, x.H * x.W, C, K, _stream())
+    holder: Dict[str, torch.Tensor] = {}
+    if tape.record:
+        def bwd(tp: Tape) -> None:
+            gy = holder.pop("g", None)
+            if gy is None:
+                return
+            gy = gy.contiguous()
+            dw, acc_w = tp.param_slot(weight)
+            db = None
+            if bias is not None:
+                db, _ = tp.param_slot(bias)
+            nblk = ctypes.c_int(); cpart = ctypes.c_int()
+            _lib.call("hpri_outconv_bwd_plan", x.N, x.H * x.W, C, K, ctypes.byref(nblk), ctypes.byref(cpart))
+            ws = _ws(nblk.value * K * 2 * cpart.value, dev)
+            if need_dx:
+                gx, acc = tp.grad_slot(x)
+                gxp, gcs, gco, gcw = gx.ptr, gx.cs, gx.coff, gx.cw
+            else:
+                gxp, gcs, gco, gcw, acc = ctypes.c_void_p(0), 0, 0, 0, False
+            _lib.call("hpri_outconv_bwd", _p(gy), x.ptr, x.cs, x.coff, _p(weight), gxp, gcs, gco, gcw, int(acc),
+                      _p(dw), _p(db), acc_w, _p(ws), ws.numel(), x.N, x.H * x.W, C, K, _stream())
+        tape.nodes.append(bwd)
+    return y, holder
+
+
+# --------------------------------------------------------------------------------------------------
+# synthetic data on the device (bench / tests): same counter-based generator as synth.py
+# --------------------------------------------------------------------------------------------------
+def synth_fill_(t: torch.Tensor, seed: int, mode: int = 0, thr: float = 0.0, scale: float = 1.0) -> torch.Tensor:
+    _require_cuda(t, "synth target")
+    if not t.is_contiguous():
+        raise RuntimeError("synth_fill_: tensor must be contiguous")
+    _lib.call("hpri_synth_fill", _p(t), t.numel(), seed % (1 << 64), mode, thr, scale, _stream())
+    return t

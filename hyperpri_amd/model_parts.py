@@ -1,0 +1,96 @@
+"""Drop-in replacements for the reference's U-Net building blocks (src/Experiments/model_parts.py).
+
+Same class names, constructor signatures, sub-module names and registration order as the reference
+(``DoubleConv`` :14-31, ``Down`` :34-45, ``Up`` :48-90, ``OutConv`` :93-99), so ``state_dict`` keys,
+default initialisation under ``torch.manual_seed`` and checkpoint loading are unchanged.  The
+``torch.nn`` layers inside are only parameter containers: ``forward`` runs hand-written HIP kernels
+(fp32 MFMA implicit-GEMM convs, fused BN+ReLU, max-pool, transposed-conv scatter into the concat
+buffer) through ``engine``/``autograd`` and never calls a torch compute op.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F  # re-exported: the reference star-imports this module (models.py:14)
+
+from . import engine as E
+from .autograd import run
+
+__all__ = ["DoubleConv", "Down", "Up", "OutConv", "torch", "nn", "F"]
+
+
+def _double_conv_ops(tape, x, seq, train, need_dx=True):
+    """(conv3x3 -> BN -> ReLU) x 2 on an Act; ``seq`` is the 6-entry nn.Sequential container."""
+    h = E.conv_bn_relu(tape, x, seq[0].weight, seq[0].bias, E.BNRef(seq[1]), train, 3, need_dx=need_dx)
+    return E.conv_bn_relu(tape, h, seq[3].weight, seq[3].bias, E.BNRef(seq[4]), train, 3)
+
+
+class DoubleConv(nn.Module):
+    """(convolution => [BN] => ReLU) * 2 -- reference model_parts.py:14-31."""
+
+    def __init__(self, in_channels, out_channels, mid_channels=None):
+        super().__init__()
+        mid = mid_channels if mid_channels else out_channels
+        layers = [nn.Conv2d(in_channels, mid, kernel_size=3, padding=1), nn.BatchNorm2d(mid), nn.ReLU(inplace=True),
+                  nn.Conv2d(mid, out_channels, kernel_size=3, padding=1), nn.BatchNorm2d(out_channels),
+                  nn.ReLU(inplace=True)]
+        self.double_conv = nn.Sequential(*layers)
+
+    def _ops(self, tape, x, need_dx=True):
+        return _double_conv_ops(tape, x, self.double_conv, self.training, need_dx)
+
+    def forward(self, x):
+        return run(lambda tape, a, need: self._ops(tape, a[0], need[0]), [x], list(self.parameters()))
+
+
+class Down(nn.Module):
+    """MaxPool2d(2) then DoubleConv -- reference model_parts.py:34-45."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.maxpool_conv = nn.Sequential(nn.MaxPool2d(2), DoubleConv(in_channels, out_channels))
+
+    def forward(self, x):
+        dc = self.maxpool_conv[1]
+        return run(lambda tape, a, need: dc._ops(tape, E.maxpool2(tape, a[0])), [x], list(self.parameters()))
+
+
+class Up(nn.Module):
+    """ConvTranspose2d(k2,s2) -> zero-pad to the skip -> cat([skip, up]) -> DoubleConv
+    (reference model_parts.py:48-90, the ``bilinear=False, use_attention=False`` path every HyperPRI
+    experiment configures: params_HyperPRI.py:53-55,210-211)."""
+
+    def __init__(self, in_channels, out_channels, bilinear=True, use_attention=False):
+        super().__init__()
+        self.use_attention = use_attention
+        self.bilinear = bilinear
+        if bilinear:
+            self.up = nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True)
+            if use_attention:
+                self.conv = DoubleConv(in_channels // 2, out_channels // 2, in_channels // 2)
+            else:
+                self.conv = DoubleConv(in_channels, out_channels // 2, in_channels // 2)
+        else:
+            self.up = nn.ConvTranspose2d(in_channels, in_channels // 2, kernel_size=2, stride=2)
+            self.conv = DoubleConv(in_channels // 2 if use_attention else in_channels, out_channels)
+
+    def forward(self, x1, x2):
+        if self.bilinear or self.use_attention:
+            raise NotImplementedError(
+                "hyperpri_amd: Up(bilinear=True) / Up(use_attention=True) have no HIP kernels yet; every HyperPRI "
+                "experiment uses bilinear=False, use_attention=False (params_HyperPRI.py:53-55,210-211).")
+
+        def prog(tape, a, need):
+            cat = E.up_concat(tape, a[0], a[1], self.up.weight, self.up.bias, need_dx1=need[0])
+            return self.conv._ops(tape, cat)
+        return run(prog, [x1, x2], list(self.parameters()))
+
+
+class OutConv(nn.Module):
+    """1x1 conv to the class logits -- reference model_parts.py:93-99."""
+
+    def __init__(self, in_channels, out_channels):
+        super(OutConv, self).__init__()
+        self.conv = nn.Conv2d(in_channels, out_channels, kernel_size=1)
+
+    def forward(self, x):
+        return run(lambda tape, a, need: E.out_conv(tape, a[0], self.conv.weight, self.conv.bias, need[0]),
+                   [x], list(self.parameters()))

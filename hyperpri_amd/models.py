@@ -1,0 +1,198 @@
+"""Drop-in replacements for the reference's networks (src/Experiments/models.py): ``UNet`` :23-68,
+``SpectralUNET`` :71-145, ``CubeNET`` :148-247, ``initialize_model`` :250-276,
+``translate_load_dir`` :279-292.  Constructor signatures, attribute names, parameter registration
+order and ``state_dict`` keys (including CubeNET's aliased ``first_conv.*`` / ``inc.0.*``) match the
+reference, so ``params_HyperPRI.py``, ``PLTrainer.py`` and saved checkpoints work unchanged; the
+forward/backward arithmetic runs in hand-written HIP kernels (see ``engine``).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import engine as E
+from .autograd import run
+from .model_parts import *  # noqa: F401,F403  (the reference's callers star-import everything)
+from .model_parts import DoubleConv, Down, OutConv, Up
+
+
+def set_parameter_requires_grad(model, feature_extraction):
+    if feature_extraction:
+        for p in model.parameters():
+            p.requires_grad = False
+
+
+class UNet(nn.Module):
+    def __init__(self, n_channels, n_classes, bilinear=True, feature_extraction=False, use_attention=False,
+                 analyze=False):
+        super(UNet, self).__init__()
+        self.n_channels, self.n_classes = n_channels, n_classes
+        self.bilinear, self.use_attention, self.analyze = bilinear, use_attention, analyze
+        factor = 2 if bilinear else 1
+        w = [64 * 2 ** i for i in range(5)]          # 64,128,256,512,1024 (models.py:34-39)
+        self.inc = DoubleConv(n_channels, w[0])
+        self.down1 = Down(w[0], w[1])
+        self.down2 = Down(w[1], w[2])
+        self.down3 = Down(w[2], w[3])
+        self.down4 = Down(w[3], w[4] // factor)
+        self.up1 = Up(w[4], w[3], bilinear, use_attention=use_attention)
+        self.up2 = Up(w[3], w[2], bilinear, use_attention=use_attention)
+        self.up3 = Up(w[2], w[1], bilinear, use_attention=use_attention)
+        self.up4 = Up(w[1], w[0] * factor, bilinear, use_attention=use_attention)
+        self.outc = OutConv(w[0], n_classes)
+
+    def forward(self, x):
+        x1 = self.inc(x)
+        x2 = self.down1(x1)
+        x3 = self.down2(x2)
+        x4 = self.down3(x3)
+        x5 = self.down4(x4)
+        y = self.up1(x5, x4)
+        y = self.up2(y, x3)
+        y = self.up3(y, x2)
+        y = self.up4(y, x1)
+        logits = self.outc(y)
+        if self.analyze:
+            return (logits, logits, torch.sigmoid(logits))
+        return logits
+
+
+class SpectralUNET(torch.nn.Module):
+    """Per-pixel MLP "U-Net" (models.py:71-145).  Every Linear is a 1x1 conv over the H*W pixels of an
+    image; BatchNorm1d statistics are per image because the reference loops over images (:132)."""
+
+    def __init__(self, hsi_depth, n_classes, bn_feats=16, bnorm=True):
+        super(SpectralUNET, self).__init__()
+        self.hsi_depth = self.n_channels = hsi_depth
+        self.n_classes = n_classes
+        self.layer_feats = [bn_feats] * 5
+        self._bnorm = bnorm
+        f = bn_feats
+        self.tail = self._basic_module(hsi_depth, f, bn=bnorm)
+        self.down1 = self._basic_module(f, f, bn=bnorm)
+        self.down2 = self._basic_module(f, f, bn=bnorm)
+        self.down3 = self._basic_module(f, f, bn=bnorm)
+        self.down4 = self._basic_module(f, f, bn=bnorm)
+        self.up1 = self._basic_module(f, f, bn=bnorm)
+        self.up2 = self._basic_module(2 * f, f, bn=bnorm)
+        self.up3 = self._basic_module(2 * f, f, bn=bnorm)
+        self.up4 = self._basic_module(2 * f, f, bn=bnorm)
+        self.outc = torch.nn.Linear(2 * f, self.n_classes)
+
+    def _basic_module(self, in_feats, out_feats, bn=True):
+        if not bn:
+            return torch.nn.Sequential(torch.nn.Linear(in_feats, out_feats), torch.nn.ReLU())
+        return torch.nn.Sequential(torch.nn.Linear(in_feats, out_feats), torch.nn.BatchNorm1d(out_feats),
+                                   torch.nn.ReLU())
+
+    def _layer(self, tape, x, seq, need_dx=True):
+        bn = E.BNRef(seq[1]) if self._bnorm else None
+        return E.conv_bn_relu(tape, x, seq[0].weight, seq[0].bias, bn, self.training, 1, groups=x.N, need_dx=need_dx)
+
+    def forward(self, x):
+        if self.n_classes != 1 and x.shape[0] > 0:
+            # models.py:144 reshapes (R*C, n_classes) as (n_classes, R, C): only meaningful for 1 class
+            raise NotImplementedError("hyperpri_amd: SpectralUNET supports n_classes == 1 (as the reference's reshape does)")
+
+        def prog(tape, a, need):
+            x0 = self._layer(tape, a[0], self.tail, need[0])
+            x1 = self._layer(tape, x0, self.down1)
+            x2 = self._layer(tape, x1, self.down2)
+            x3 = self._layer(tape, x2, self.down3)
+            x4 = self._layer(tape, x3, self.down4)
+            t = self._layer(tape, x4, self.up1)
+            t = self._layer(tape, E.concat_channels(tape, x3, t), self.up2)
+            t = self._layer(tape, E.concat_channels(tape, x2, t), self.up3)
+            t = self._layer(tape, E.concat_channels(tape, x1, t), self.up4)
+            return E.out_conv(tape, E.concat_channels(tape, x0, t), self.outc.weight, self.outc.bias)
+        return run(prog, [x], list(self.parameters()))
+
+
+class CubeNET(torch.nn.Module):
+    """UNet whose first layer is Conv3d(1 -> first_depth, (D,3,3)) over the whole spectrum
+    (models.py:148-247) -- computed as a 3x3 conv over D input channels."""
+
+    def __init__(self, hsi_depth, n_classes, first_depth=64, bilinear=True, use_attention=False, analyze=False):
+        super(CubeNET, self).__init__()
+        self.n_channels = 1
+        self.depth, self.first_depth, self.n_classes = hsi_depth, first_depth, n_classes
+        self.bilinear, self.use_attention, self.analyze = bilinear, use_attention, analyze
+        factor = 2 if bilinear else 1
+        self.first_conv = torch.nn.Conv3d(1, first_depth, kernel_size=(self.depth, 3, 3), padding=(0, 1, 1))
+        self.inc = torch.nn.Sequential(self.first_conv, torch.nn.BatchNorm3d(first_depth), torch.nn.ReLU(inplace=True))
+        self.inc2 = torch.nn.Sequential(torch.nn.Conv2d(first_depth, first_depth, kernel_size=3, padding=1),
+                                        torch.nn.BatchNorm2d(first_depth), torch.nn.ReLU(inplace=True))
+        C = 128
+        self.down1 = Down(first_depth, C)
+        self.down2 = Down(C, C * 2)
+        self.down3 = Down(C * 2, C * 4)
+        self.down4 = Down(C * 4, C * 8 // factor)
+        self.up1 = Up(C * 8, C * 4, bilinear, use_attention=use_attention)
+        self.up2 = Up(C * 4, C * 2, bilinear, use_attention=use_attention)
+        self.up3 = Up(C * 2, C, bilinear, use_attention=use_attention)
+        if first_depth == 64:
+            self.up4 = Up(C, 64 * factor, bilinear, use_attention=use_attention)
+        elif bilinear:
+            self.upsample4 = nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True)
+            self.upconv4 = DoubleConv(C + first_depth, 64, 64)
+        else:
+            self.upsample4 = nn.ConvTranspose2d(C, 64, kernel_size=2, stride=2)
+            self.upconv4 = DoubleConv(64 + first_depth, 64)
+        self.outc = OutConv(64, self.n_classes)
+
+    def _stem(self, x):
+        def prog(tape, a, need):
+            h = E.conv_bn_relu(tape, a[0], self.first_conv.weight, self.first_conv.bias, E.BNRef(self.inc[1]),
+                               self.training, 3, need_dx=need[0])
+            return E.conv_bn_relu(tape, h, self.inc2[0].weight, self.inc2[0].bias, E.BNRef(self.inc2[1]),
+                                  self.training, 3)
+        params = list(self.inc.parameters()) + list(self.inc2.parameters())
+        return run(prog, [x], params)
+
+    def forward(self, x):
+        if x.dim() != 5 or x.shape[2] != self.depth:
+            raise ValueError(f"CubeNET expects (N,1,{self.depth},R,C), got {tuple(x.shape)}")
+        x1 = self._stem(x)
+        x2 = self.down1(x1)
+        x3 = self.down2(x2)
+        x4 = self.down3(x3)
+        x5 = self.down4(x4)
+        y = self.up1(x5, x4)
+        y = self.up2(y, x3)
+        y = self.up3(y, x2)
+        if self.first_depth == 64:
+            y = self.up4(y, x1)
+        else:
+            if self.bilinear:
+                raise NotImplementedError("hyperpri_amd: CubeNET(bilinear=True) has no HIP kernels yet")
+
+            def prog(tape, a, need):
+                cat = E.up_concat(tape, a[0], a[1], self.upsample4.weight, self.upsample4.bias, need_dx1=need[0])
+                return self.upconv4._ops(tape, cat)
+            y = run(prog, [y, x1], list(self.upsample4.parameters()) + list(self.upconv4.parameters()))
+        logits = self.outc(y)
+        if self.analyze:
+            return (logits, logits, torch.sigmoid(logits))
+        return logits
+
+
+def initialize_model(model_name, num_classes, Network_parameters, analyze=False):
+    """Name -> model factory with the reference's dictionary keys (models.py:250-276)."""
+    p = Network_parameters
+    if model_name == 'UNET':
+        return UNet(p['channels'], num_classes, bilinear=p['bilinear'], feature_extraction=p['feature_extraction'],
+                    use_attention=p['use_attention'], analyze=analyze)
+    if model_name == 'SpectralUNET':
+        return SpectralUNET(p['hsi_hi'] - p['hsi_lo'], num_classes, bn_feats=p['spectral_bn_size'])
+    if model_name == 'CubeNET':
+        return CubeNET(p['hsi_hi'] - p['hsi_lo'], num_classes, first_depth=p['3d_featmaps'], bilinear=p['bilinear'],
+                       use_attention=p['use_attention'], analyze=analyze)
+    raise RuntimeError('Invalid model')
+
+
+def translate_load_dir(model_name, net_params):
+    """Model name -> checkpoint directory name (models.py:279-292)."""
+    if model_name == 'SpectralUNET':
+        return f"{model_name}_{net_params['spectral_bn_size']}"
+    if model_name == 'CubeNET':
+        return f"{model_name}_{net_params['3d_featmaps']}"
+    return "UNET"

@@ -1,0 +1,123 @@
+/* hyperpri_hip.h -- C ABI of libhyperpri_hip.so (MI355X / gfx950 only).
+ *
+ * The reference (GatorSense/HyperPRI) has no FFI: its hot path is plain torch.nn modules
+ * (src/Experiments/model_parts.py, src/Experiments/models.py) whose arithmetic lives in ATen/cuDNN.
+ * This library is what a maintainer would bind in their place: one launcher per kernel family and
+ * direction, plain pointers and sizes, no torch types.  hyperpri_amd/_lib.py holds the ctypes binding;
+ * INTEGRATION.md shows the reference-side shim.
+ *
+ * Conventions
+ *   - Activations are fp32 NHWC.  A tensor view is (pointer, cs, coff): element (pixel p, channel c)
+ *     lives at ptr[p*cs + coff + c]; cs and coff are multiples of 4 (16-byte channel vectors) and the
+ *     pointer is 16-byte aligned.  Views into a wider buffer are how skip-concat (model_parts.py:87)
+ *     costs no copy on the consumer side.
+ *   - Every buffer, including workspaces, is owned by the caller (PyTorch caching allocator); the
+ *     library never allocates, frees or synchronises.  All launches go to the given hipStream_t.
+ *   - Return value: 0 = ok, <0 = error (HPRI_ERR_*); hpri_last_error() returns the thread's message.
+ *     Nothing throws across the ABI.
+ *   - Launchers are re-entrant and hold no state (autograd calls them from worker threads).
+ */
+#ifndef HYPERPRI_HIP_H
+#define HYPERPRI_HIP_H
+
+#include <stddef.h>
+#include <hip/hip_runtime_api.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HPRI_OK 0
+#define HPRI_ERR_ARG (-1)
+#define HPRI_ERR_UNSUPPORTED (-2)
+#define HPRI_ERR_WORKSPACE (-3)
+#define HPRI_ERR_LAUNCH (-4)
+
+#define HPRI_A_DIRECT 0 /* A operand read in place                                   */
+#define HPRI_A_S2D 1    /* A operand gathered as 2x2 stride-2 patches (convT grads)  */
+#define HPRI_E_DIRECT 0 /* NHWC store                                                */
+#define HPRI_E_D2S 1    /* 2x2 stride-2 pixel-shuffle store (convT forward)          */
+
+int hpri_version(void);
+const char* hpri_last_error(void);
+
+/* ---- weight packing: nn.Parameter layouts -> [chunk][tap][32][Ncols_pad] LDS panels ---------------
+ * mode 0 conv fwd   (replaces cuDNN's filter transform for nn.Conv2d, model_parts.py:22,25,96; nn.Conv3d
+ *                    models.py:169; nn.Linear models.py:108,103)
+ * mode 1 conv dgrad (autograd of the same), mode 2 convT fwd (model_parts.py:63; models.py:198),
+ * mode 3 convT dgrad.  K = reduction length per tap, Ncols = GEMM columns, src_d1 = dim 1 of the
+ * source tensor. */
+size_t hpri_packed_weight_floats(int K, int Ncols_pad, int T);
+int hpri_pack_weight(const float* w, float* wp, int mode, int K, int Ncols, int Ncols_pad, int T, int Cup,
+                     int src_d0, int src_d1, hipStream_t stream);
+
+/* ---- implicit-GEMM convolution, fp32 MFMA (conv_fwd.hip) ----------------------------------------
+ * Replaces F.conv2d / F.conv3d / F.linear / F.conv_transpose2d forward and their data gradients
+ * (model_parts.py:22,25,63,96; models.py:108,169,177,198).  stats (optional) receives per-tile
+ * BatchNorm partials: hpri_conv_fwd_tiles(...) * Cout_pad float4 (mean, M2, count, 0). */
+int hpri_conv_fwd_tiles(int N, int H, int W, int Cout_pad);
+int hpri_conv_fwd(const float* x, int x_cs, int x_coff, const float* wp, const float* bias, float* y, int y_cs,
+                  int y_coff, float* stats, int N, int H, int W, int Cin_pad, int Cout, int Cout_pad, int y_cw,
+                  int KS, int amode, int epi, int accumulate, int H2, int W2, int py0, int px0, int Cup,
+                  hipStream_t stream);
+
+/* ---- weight gradients, fp32 MFMA, deterministic split-K (conv_wgrad.hip) --------------------------
+ * Replaces the wgrad half of autograd for the same layers.  dst_mode 0 writes OIHW / (out,in),
+ * dst_mode 1 writes ConvTranspose2d's (Cin,Cout,2,2).  Workspace: splits*KS*KS*Cr*Nr floats. */
+int hpri_wgrad_plan(int N, int H, int W, int Cin_pad, int Cout_pad, int KS, int* splits, int* Cr, int* Nr);
+int hpri_conv_wgrad(const float* x, int x_cs, int x_coff, int x_cvalid, const float* dy, int dy_cs, int dy_coff,
+                    int dy_cvalid, float* ws, size_t ws_floats, float* dw, int N, int H, int W, int Cin, int Cin_pad,
+                    int Cout, int Cout_pad, int KS, int bmode, int dst_mode, int accumulate, int H2, int W2, int py0,
+                    int px0, int Cup, hipStream_t stream);
+
+/* ---- BatchNorm (+ReLU) (bn.hip): nn.BatchNorm2d/3d/1d + nn.ReLU, model_parts.py:23-27; models.py:113-114,
+ * 172-173,178-179.  G groups = independent statistic sets (G = N for SpectralUNET's per-image loop,
+ * models.py:132). */
+int hpri_bn_finalize(const float* partials, int tiles_per_group, int G, int Cp, int C, const float* gamma,
+                     const float* beta, float eps, float momentum, float* mean, float* invstd, float* var_unbiased,
+                     float* scale, float* shift, float* running_mean, float* running_var,
+                     long long* num_batches_tracked, hipStream_t stream);
+int hpri_bn_eval_prepare(const float* running_mean, const float* running_var, const float* gamma, const float* beta,
+                         float eps, int C, float* mean, float* invstd, float* scale, float* shift, hipStream_t stream);
+int hpri_bn_apply_relu(const float* x, int x_cs, int x_coff, float* y, int y_cs, int y_coff, const float* scale,
+                       const float* shift, long long P, long long pix_per_group, int C, int Cw, int relu,
+                       hipStream_t stream);
+int hpri_col_reduce_plan(long long pix_per_group, int G, int C, int* nblk, int* Cpart);
+int hpri_bn_relu_bwd(const float* dy, int dy_cs, int dy_coff, const float* x, int x_cs, int x_coff, float* dx,
+                     int dx_cs, int dx_coff, const float* mean, const float* invstd, const float* scale,
+                     const float* shift, float* dgamma, float* dbeta, int accumulate_param_grads, float* workspace,
+                     size_t ws_floats, long long P, long long pix_per_group, int C, int Cw, int relu,
+                     int use_batch_stats, hipStream_t stream);
+int hpri_col_sum(const float* src, int cs, int coff, float* out, int accumulate, float* workspace, size_t ws_floats,
+                 long long P, int C, hipStream_t stream);
+
+/* ---- bandwidth-bound ops (elementwise.hip) ---------------------------------------------------------
+ * layout change at the module boundary (dataset.py:267-271 hands NC(D)HW), nn.MaxPool2d(2)
+ * (model_parts.py:40), F.pad + torch.cat (model_parts.py:77-87; models.py:235-239), OutConv / final Linear
+ * (model_parts.py:96; models.py:103,143), synthetic generator. */
+int hpri_nchw_to_nhwc(const float* src, float* dst, int N, int C, long long P, int cs, int coff, int Cw,
+                      hipStream_t stream);
+int hpri_nhwc_to_nchw(const float* src, float* dst, int N, int C, long long P, int cs, int coff, int accumulate,
+                      hipStream_t stream);
+int hpri_maxpool2_fwd(const float* x, int x_cs, int x_coff, float* y, int y_cs, int y_coff, int N, int H, int W, int C,
+                      hipStream_t stream);
+int hpri_maxpool2_bwd(const float* x, int x_cs, int x_coff, const float* dy, int dy_cs, int dy_coff, float* dx,
+                      int dx_cs, int dx_coff, int N, int H, int W, int C, int accumulate, hipStream_t stream);
+int hpri_copy_slice(const float* src, int s_cs, int s_coff, float* dst, int d_cs, int d_coff, long long P, int C,
+                    int accumulate, hipStream_t stream);
+int hpri_fill_pad(float* dst, int cs, int coff, int N, int H, int W, int C, int y0, int y1, int x0, int x1,
+                  hipStream_t stream);
+int hpri_fill(float* dst, long long n, float value, hipStream_t stream);
+int hpri_outconv_fwd(const float* x, int x_cs, int x_coff, const float* w, const float* b, float* y, int N,
+                     long long P, int C, int K, hipStream_t stream);
+int hpri_outconv_bwd_plan(int N, long long P, int C, int K, int* nblk, int* Cpart);
+int hpri_outconv_bwd(const float* dy, const float* x, int x_cs, int x_coff, const float* w, float* dx, int dx_cs,
+                     int dx_coff, int dx_cw, int dx_accumulate, float* dw, float* db, int accumulate_param_grads,
+                     float* workspace, size_t ws_floats, int N, long long P, int C, int K, hipStream_t stream);
+int hpri_synth_fill(float* dst, long long n, unsigned long long seed, int mode, float thr, float scale,
+                    hipStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HYPERPRI_HIP_H */

@@ -1,0 +1,76 @@
+"""CPU-side checks of the C-ABI boundary: the library loads and exports every symbol the header
+declares; argument validation returns error codes instead of launching (no GPU needed)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_exports_every_declared_symbol():
+    from hyperpri_amd import _lib
+    decls = _lib.parse_header()
+    names = set(re.findall(r"\b(hpri_\w+)\s*\(", open(os.path.join(ROOT, "include", "hyperpri_hip.h")).read()))
+    assert names and names == set(decls.keys())
+    lib = _lib.load()
+    for n in names:
+        assert hasattr(lib, n), n
+    assert lib.hpri_version() >= 100
+
+
+def test_bad_arguments_are_rejected_without_launch():
+    from hyperpri_amd import _lib
+    lib = _lib.load()
+    null = ctypes.c_void_p(0)
+    rc = lib.hpri_conv_fwd(null, 8, 0, null, null, null, 8, 0, null, 1, 4, 4, 8, 8, 64, 8, 3, 0, 0, 0, 0, 0, 0, 0, 0, null)
+    assert rc == -1 and b"null" in lib.hpri_last_error()
+    rc = lib.hpri_maxpool2_fwd(null, 8, 0, null, 8, 0, 1, 4, 4, 8, null)
+    assert rc == -1
+    with pytest.raises(RuntimeError):
+        _lib.call("hpri_fill", null, 0, 0.0, null)
+
+
+def test_plans_are_pure_host_functions():
+    from hyperpri_amd import _lib
+    lib = _lib.load()
+    s, cr, nr = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    assert lib.hpri_wgrad_plan(2, 608, 968, 64, 64, 3, ctypes.byref(s), ctypes.byref(cr), ctypes.byref(nr)) == 0
+    assert s.value >= 1 and cr.value == 64 and nr.value == 64
+    assert lib.hpri_conv_fwd_tiles(2, 608, 968, 64) == 2 * 76 * 31
+    assert lib.hpri_packed_weight_floats(238, 64, 9) == 8 * 9 * 32 * 64
+
+
+def test_modules_keep_reference_state_dict_and_init():
+    import json
+    import torch
+    import hyperpri_amd as H
+    known = json.load(open(os.path.join(ROOT, "tests", "golden", "known_answers.json")))
+    for nm, m in [("unet3_full", H.UNet(3, 1, bilinear=False)), ("cubenet64_full", H.CubeNET(238, 1, 64, bilinear=False)),
+                  ("cubenet128_full", H.CubeNET(300, 1, 128, bilinear=False)),
+                  ("spectral1650_full", H.SpectralUNET(238, 1, 1650))]:
+        sd = m.state_dict()
+        assert list(sd.keys()) == known[nm]["keys"]
+        assert [list(v.shape) for v in sd.values()] == known[nm]["shapes"]
+    c = known["counts"]
+    assert sum(p.numel() for p in H.UNet(3, 1, bilinear=False).parameters()) == c["UNet(3,1)"]["elements"]
+    for seed_key, mk in [("init_seed7_unet3", lambda: H.UNet(3, 1, bilinear=False)),
+                         ("init_seed7_cubenet64_d6", lambda: H.CubeNET(6, 1, 64, bilinear=False)),
+                         ("init_seed7_spectral_10_4", lambda: H.SpectralUNET(10, 1, 4))]:
+        torch.manual_seed(7)
+        sd = mk().state_dict()
+        for k, v in known[seed_key].items():
+            assert [float(t) for t in sd[k].flatten()[:4]] == v, (seed_key, k)
+    m = H.CubeNET(6, 1, 64, bilinear=False)
+    assert m.first_conv.weight is m.inc[0].weight      # aliased parameter, models.py:169-171
+    assert H.initialize_model('UNET', 1, {'channels': 3, 'bilinear': False, 'feature_extraction': False,
+                                          'use_attention': False}).n_channels == 3
+    assert H.translate_load_dir('CubeNET', {'3d_featmaps': 64}) == 'CubeNET_64'
+
+
+def test_cpu_inputs_fail_loudly():
+    import torch
+    import hyperpri_amd as H
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        H.OutConv(4, 1)(torch.zeros(1, 4, 2, 2))

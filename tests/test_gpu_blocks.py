@@ -1,0 +1,112 @@
+"""HIP modules (through the C ABI) against the golden fixtures captured from the reference modules and
+against the CPU oracle.  Needs a real MI355X: run with ``-m gpu``."""
+import os
+from collections import OrderedDict
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import hyperpri_oracle as O
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+DEV = "cuda:0"
+
+
+def _load(name):
+    return np.load(os.path.join(G, name + ".npz"))
+
+
+def _shapes(mod):
+    return OrderedDict((k, tuple(v.shape)) for k, v in mod.state_dict().items())
+
+
+def _close(a, b, rtol, atol, msg=""):
+    a = a.detach().cpu().contiguous().numpy() if torch.is_tensor(a) else a
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol, err_msg=msg)
+
+
+def _block(name, mod, seed0, nin):
+    import hyperpri_amd  # noqa: F401
+    z = _load(name)
+    mod.load_state_dict(O.synth_state_dict(_shapes(mod), seed0=seed0, bn_random=True))
+    mod = mod.to(DEV).train()
+    xs = [torch.from_numpy(z[f"in{i}"]).to(DEV).requires_grad_(True) for i in range(nin)]
+    out = mod(*xs)
+    assert out.shape == z["out_train"].shape
+    _close(out, z["out_train"], 1e-4, 2e-5, "train forward")
+    (out * torch.from_numpy(z["dout"]).to(DEV)).sum().backward()
+    for i, x in enumerate(xs):
+        _close(x.grad, z[f"din{i}"], 1e-3, 2e-5, f"input grad {i}")
+    for k, p in mod.named_parameters():
+        ref = z["grad/" + k]
+        # conv biases in front of a training-mode BN have a mathematically zero gradient (rounding noise)
+        _close(p.grad, ref, 1e-3, 3e-5 * max(1.0, float(np.abs(ref).max())), "grad " + k)
+    for k, b in mod.named_buffers():
+        _close(b.float() if b.dtype != torch.float32 else b, z["buf/" + k].astype(np.float32), 1e-4, 1e-5, "buffer " + k)
+    mod.eval()
+    with torch.no_grad():
+        oe = mod(*[x.detach() for x in xs])
+    _close(oe, z["out_eval"], 1e-4, 2e-5, "eval forward")
+
+
+def test_doubleconv():
+    from hyperpri_amd import DoubleConv
+    _block("block_doubleconv", DoubleConv(5, 7), 2000, 1)
+
+
+def test_doubleconv_mid():
+    from hyperpri_amd import DoubleConv
+    _block("block_doubleconv_mid", DoubleConv(6, 4, 9), 2100, 1)
+
+
+def test_down():
+    from hyperpri_amd import Down
+    _block("block_down", Down(4, 6), 2200, 1)
+
+
+def test_up():
+    from hyperpri_amd import Up
+    _block("block_up", Up(8, 4, bilinear=False), 2300, 2)
+
+
+def test_up_big():
+    from hyperpri_amd import Up
+    _block("block_up_big", Up(64, 32, bilinear=False), 2400, 2)
+
+
+def test_outconv():
+    from hyperpri_amd import OutConv
+    _block("block_outconv", OutConv(6, 2), 2500, 1)
+
+
+@pytest.mark.parametrize("N,Cin,H,W,Cout,ks", [(2, 5, 9, 11, 7, 3), (1, 64, 20, 70, 128, 3), (2, 40, 13, 37, 64, 3),
+                                               (1, 24, 5, 33, 200, 1), (2, 256, 9, 40, 64, 3)])
+def test_conv_fwd_bwd_vs_torch(N, Cin, H, W, Cout, ks):
+    """Bare conv (no BN) forward, data-gradient and weight/bias gradients vs torch CPU conv2d."""
+    from hyperpri_amd import engine as E
+    from hyperpri_amd.autograd import run
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(N * 1000 + Cin + H)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, ks, ks, generator=g) / (Cin * ks * ks) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    r = torch.randn(N, Cout, H, W, generator=g)
+    xc, wc, bc = (t.clone().requires_grad_(True) for t in (x, w, b))
+    yc = F.conv2d(xc, wc, bc, padding=ks // 2)
+    (yc * r).sum().backward()
+    xd, wd, bd = (t.to(DEV).requires_grad_(True) for t in (x, w, b))
+    yd = run(lambda tape, a, need: E.conv_bn_relu(tape, a[0], wd, bd, None, True, ks, need_dx=need[0]), [xd], [wd, bd])
+    _close(yd, yc.detach().numpy(), 1e-4, 1e-4, "conv forward")
+    (yd * r.to(DEV)).sum().backward()
+    _close(xd.grad, xc.grad.numpy(), 1e-4, 2e-4, "conv dgrad")
+    _close(wd.grad, wc.grad.numpy(), 1e-4, 1e-3, "conv wgrad")
+    _close(bd.grad, bc.grad.numpy(), 1e-4, 1e-3, "conv bias grad")
+
+
+def test_cpu_tensor_raises():
+    from hyperpri_amd import DoubleConv
+    m = DoubleConv(4, 4)
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 4, 8, 8))

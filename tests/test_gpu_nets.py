@@ -1,0 +1,98 @@
+"""Whole networks on the HIP path vs the golden fixtures from the reference and vs the CPU oracle.
+Tolerances: logits within 1e-3 (north_star), loss within 1e-5, Dice/IoU identical to 4 dp,
+gradient L2 norms within 1e-3 relative.  Needs a real MI355X: ``-m gpu``."""
+import os
+from collections import OrderedDict
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import hyperpri_oracle as O
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+DEV = "cuda:0"
+
+
+def _load(name):
+    return np.load(os.path.join(G, name + ".npz"))
+
+
+def _u(seed, shape):
+    return torch.from_numpy(O._u(seed, int(np.prod(shape))).reshape(shape).copy())
+
+
+def _mk(name):
+    import hyperpri_amd as H
+    return {
+        "net_unet3_tiny": lambda: H.UNet(3, 1, bilinear=False),
+        "net_cubenet64_tiny": lambda: H.CubeNET(6, 1, first_depth=64, bilinear=False),
+        "net_cubenet128_tiny": lambda: H.CubeNET(6, 1, first_depth=128, bilinear=False),
+        "net_spectral_tiny": lambda: H.SpectralUNET(10, 1, 4),
+        "net_spectral_f48": lambda: H.SpectralUNET(22, 1, 48),
+    }[name]()
+
+
+CASES = [("net_unet3_tiny", 1234, (2, 3, 36, 50), 4321, 0.9), ("net_cubenet64_tiny", 1235, (2, 1, 6, 36, 50), 4321, 0.9),
+         ("net_cubenet128_tiny", 1236, (2, 1, 6, 36, 50), 4321, 0.9), ("net_spectral_tiny", 1237, (3, 10, 7, 9), 4322, 0.7),
+         ("net_spectral_f48", 1238, (2, 22, 12, 20), 4323, 0.7)]
+
+
+@pytest.mark.parametrize("name,xseed,xshape,mseed,thr", CASES, ids=[c[0] for c in CASES])
+def test_tiny_net_vs_golden(name, xseed, xshape, mseed, thr):
+    z = _load(name)
+    net = _mk(name)
+    shapes = OrderedDict((k, tuple(v.shape)) for k, v in net.state_dict().items())
+    net.load_state_dict(O.synth_state_dict(shapes))
+    net = net.to(DEV).train()
+    x = _u(xseed, xshape).to(DEV)
+    mask = (_u(mseed, (xshape[0], 1) + tuple(xshape[-2:])) > thr).float().to(DEV)
+    logits = net(x)
+    assert logits.is_contiguous() and logits.shape == z["logits"].shape
+    loss = torch.nn.BCEWithLogitsLoss()(logits, mask)
+    loss.backward()
+    lg = logits.detach().cpu()
+    assert np.abs(lg.numpy() - z["logits"]).max() < 1e-3            # north_star: logits within 1e-3 fp32
+    assert abs(float(loss) - float(z["loss"])) < 1e-5
+    acc, dice, iou = O.seg_metrics(lg, mask.cpu())
+    assert round(dice, 4) == round(float(z["dice"]), 4) and round(iou, 4) == round(float(z["iou"]), 4)
+    names = list(z["grad_names"])
+    grads = OrderedDict((k, p.grad) for k, p in net.named_parameters())
+    assert names == list(grads.keys())
+    for i, k in enumerate(names):
+        g = grads[k].detach().double().flatten().cpu()
+        ref = z["grad_l2"][i]
+        # biases in front of train-mode BN: true gradient is 0, both sides hold rounding noise
+        assert abs(float(g.norm()) - ref) <= 2e-3 * ref + 2e-6, (k, float(g.norm()), ref)
+    for k, b in net.named_buffers():
+        if ("buf/" + k) in z.files:
+            np.testing.assert_allclose(b.detach().cpu().numpy().astype(np.float64), z["buf/" + k].astype(np.float64),
+                                       rtol=1e-4, atol=1e-5, err_msg=k)
+    net.eval()
+    with torch.no_grad():
+        le = net(x).cpu().numpy()
+    assert np.abs(le - z["logits_eval"]).max() < 1e-3
+
+
+def test_odd_geometry_vs_oracle():
+    """121 -> 60 floor and the 120 -> 121 right pad of the real geometry, at a size the
+    oracle finishes in seconds: UNet on (1,3,76,121)."""
+    import hyperpri_amd as H
+    net = H.UNet(3, 1, bilinear=False)
+    shapes = OrderedDict((k, tuple(v.shape)) for k, v in net.state_dict().items())
+    sd = O.synth_state_dict(shapes)
+    net.load_state_dict(sd)
+    net = net.to(DEV).train()
+    x = _u(77, (1, 3, 76, 121))
+    mask = (_u(78, (1, 1, 76, 121)) > 0.8).float()
+    ref_logits, ref_loss, ref_grads = O.train_step(O.unet_forward, sd, x, mask)
+    logits = net(x.to(DEV))
+    loss = torch.nn.BCEWithLogitsLoss()(logits, mask.to(DEV))
+    loss.backward()
+    assert (logits.detach().cpu() - ref_logits).abs().max() < 1e-3
+    assert abs(float(loss) - ref_loss) < 1e-5
+    for k, p in net.named_parameters():
+        r = ref_grads[k]
+        err = (p.grad.detach().cpu() - r).abs().max()
+        assert err <= 2e-3 * r.abs().max() + 2e-6, (k, float(err), float(r.abs().max()))
