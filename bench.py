@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""HSI cubes/sec, forward+backward, for the HyperPRI CubeNET-64 hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1] / configs[3]): CubeNET(238, 1, first_depth=64, bilinear=False) in train
+mode on synthetic 608x968x238 fp32 cubes, per-rank batch 2 (params_HyperPRI.py:178), loss =
+BCEWithLogitsLoss (params_HyperPRI.py:223), one step = forward + loss + backward (+ gradient all-reduce
+for N > 1; optimizer excluded).  Inputs are generated on the device by the counter-based
+generator before the timed region.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+H, W, BANDS, BATCH = 608, 968, 238, 2
+GFLOP_PER_CUBE = 2910.17          # fwd 1023.84 + bwd 1886.32 (measured on the reference modules)
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: FP32 matrix peak (v_mfma_f32_32x32x2_f32)
+
+
+def synth_init_(net):
+    """Generator-defined weights on the device: k-th parameter = (2u(1000+k)-1)/sqrt(fan_in); BN gamma=1, beta=0."""
+    from hyperpri_amd.engine import synth_fill_
+    bn_params = set()
+    for m in net.modules():
+        if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+            bn_params.add(id(m.weight)); bn_params.add(id(m.bias))
+    fan_in = 1
+    with torch.no_grad():
+        for k, p in enumerate(net.parameters()):
+            if id(p) in bn_params:
+                continue                      # default init already gamma=1, beta=0
+            if p.dim() >= 2:
+                fan_in = p.shape[1] * int(math.prod(p.shape[2:]))
+            synth_fill_(p.data, 1000 + k, mode=2, scale=1.0 / math.sqrt(fan_in))
+
+
+def cpu_baseline():
+    """The CPU oracle (validated against the reference modules) on this box's host cores: CubeNET-64,
+    batch 1, one warm-up + one timed forward+backward step."""
+    from collections import OrderedDict
+    import numpy as np
+    from oracle import hyperpri_oracle as O
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    torch.set_num_threads(cores)
+    sd = O.synth_state_dict(O.cubenet_shapes(BANDS, 1, 64))
+    x = torch.from_numpy(O._u(1234, BANDS * H * W).reshape(1, 1, BANDS, H, W).copy())
+    mask = (torch.from_numpy(O._u(4321, H * W).reshape(1, 1, H, W).copy()) > 0.9).float()
+    times = []
+    for _ in range(2):
+        work = OrderedDict((k, v.clone()) for k, v in sd.items())
+        t0 = time.perf_counter()
+        O.train_step(O.cubenet_forward, work, x, mask, first_depth=64)
+        times.append(time.perf_counter() - t0)
+    return {"value": 1.0 / times[-1], "unit": "cubes/s", "cores": cores, "kind": "port",
+            "sample": "1 warm-up + 1 timed fwd+bwd step of CubeNET-64 on ONE 238x608x968 cube (batch 1), "
+                      "oracle/hyperpri_oracle.py on torch-CPU (Conv3d first layer as the reference), "
+                      f"{times[-1]:.2f} s/step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true", help="skip the per-kernel HIP-event pass")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import hyperpri_amd as HP
+    from hyperpri_amd import engine
+    from hyperpri_amd.ddp import GradSync
+
+    net = HP.CubeNET(BANDS, 1, first_depth=64, bilinear=False).to(dev).train()
+    synth_init_(net)
+    sync = GradSync(net) if world > 1 else None
+    x = torch.empty((BATCH, 1, BANDS, H, W), dtype=torch.float32, device=dev)
+    mask = torch.empty((BATCH, 1, H, W), dtype=torch.float32, device=dev)
+    for i in range(BATCH):
+        n = rank * BATCH + i                        # global sample index -> seeds 1234+n / 4321+n
+        engine.synth_fill_(x[i], 1234 + n, mode=0)
+        engine.synth_fill_(mask[i], 4321 + n, mode=1, thr=0.9)
+    crit = torch.nn.BCEWithLogitsLoss()
+
+    def step():
+        for p in net.parameters():
+            p.grad = None
+        loss = crit(net(x), mask)
+        loss.backward()
+        if sync is not None:
+            sync.finish()
+        return loss
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    loss_val = float(loss.detach())
+
+    roofline = None
+    if rank == 0 and not args.no_roofline:
+        # per-kernel HIP events on the launching stream over 2 extra steps (events perturb the timing
+        # slightly, so they are kept out of the headline region)
+        engine.enable_event_log(True)
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        summ = engine.event_log_summary()
+        engine.enable_event_log(False)
+        dom = max(summ.items(), key=lambda kv: kv[1]["total_ms"])
+        roofline = {"bound": "mfma", "kernel": dom[0], "achieved": round(dom[1]["tflops"], 2),
+                    "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(dom[1]["tflops"] / PEAK_F32_MFMA_TFLOPS, 4),
+                    "traffic": None, "avg_launch_ms": round(dom[1]["avg_ms"], 4), "launches_per_step": dom[1]["launches"] // 2,
+                    "algorithmic_gflop_per_launch": round(dom[1]["flops_per_launch"] / 1e9, 3),
+                    "all_mfma_kernels": {k: {"avg_ms": round(v["avg_ms"], 4), "tflops": round(v["tflops"], 2),
+                                             "launches_per_step": v["launches"] // 2,
+                                             "ms_per_step": round(v["total_ms"] / 2, 3)} for k, v in sorted(summ.items())}}
+    elif world > 1:
+        pass
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline()
+
+    if world > 1:
+        dist.barrier()
+    if rank == 0:
+        cubes = world * BATCH * args.steps
+        value = cubes / dt
+        out = {
+            "metric": "HSI cubes/sec (608x968x238) fwd+bwd", "value": round(value, 4), "unit": "cubes/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "CubeNET-64 n_channels=238 HSI 608x968 fp32, per-GPU batch 2, train mode, "
+                                   "BCEWithLogits, fwd+bwd" + (" + RCCL grad all-reduce" if world > 1 else ""),
+                       "global_batch": world * BATCH, "parallelism": f"dp{world}"},
+            "loss": round(loss_val, 6),
+            "model_tflops": round(value * GFLOP_PER_CUBE / 1e3 / world, 2),
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

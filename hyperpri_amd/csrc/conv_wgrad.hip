@@ -191,17 +191,17 @@ extern "C" int hpri_wgrad_plan(int N, int H, int W, int Cin_pad, int Cout_pad, i
 
 extern "C" int hpri_conv_wgrad(const float* x, int x_cs, int x_coff, int x_cvalid,
                                const float* dy, int dy_cs, int dy_coff, int dy_cvalid,
-                               float* ws, size_t ws_floats, float* dw,
-                               int N, int H, int W, int Cin, int Cin_pad, int Cout, int Cout_pad,
-                               int KS, int bmode, int dst_mode, int accumulate,
+                               float* ws, size_t ws_floats,
+                               int N, int H, int W, int Cin_pad, int Cout_pad,
+                               int KS, int bmode,
                                int H2, int W2, int py0, int px0, int Cup, hipStream_t stream) {
-  HPRI_REQUIRE(x && dy && ws && dw, "conv_wgrad: null pointer");
+  HPRI_REQUIRE(x && dy && ws, "conv_wgrad: null pointer");
   HPRI_REQUIRE(KS == 1 || KS == 3, "conv_wgrad: kernel size must be 1 or 3");
   HPRI_REQUIRE(x_cs % 4 == 0 && x_coff % 4 == 0 && dy_cs % 4 == 0 && dy_coff % 4 == 0 && x_cvalid % 4 == 0 && dy_cvalid % 4 == 0,
                "conv_wgrad: channel strides/offsets/valid counts must be multiples of 4");
-  HPRI_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "conv_wgrad: empty problem");
+  HPRI_REQUIRE(N > 0 && H > 0 && W > 0 && Cin_pad > 0 && Cout_pad > 0, "conv_wgrad: empty problem");
   if (bmode == HPRI_A_S2D) {
-    HPRI_REQUIRE(KS == 1 && Cup > 0 && Cup % 4 == 0 && Cout == 4 * Cup, "conv_wgrad: S2D needs KS==1 and Cout == 4*Cup");
+    HPRI_REQUIRE(KS == 1 && Cup > 0 && Cup % 4 == 0, "conv_wgrad: S2D needs KS==1 and Cup % 4 == 0");
     HPRI_REQUIRE(py0 >= 0 && px0 >= 0 && 2 * H + py0 <= H2 && 2 * W + px0 <= W2, "conv_wgrad: patch grid exceeds the hi-res image");
   }
   WgradArgs a;
@@ -222,6 +222,17 @@ extern "C" int hpri_conv_wgrad(const float* x, int x_cs, int x_coff, int x_cvali
   else if (bmode == HPRI_A_S2D) hipLaunchKernelGGL((conv_wgrad_kernel<1, 2, 2, HPRI_A_S2D>), grid, dim3(256), 0, stream, a);
   else hipLaunchKernelGGL((conv_wgrad_kernel<1, 2, 2, HPRI_A_DIRECT>), grid, dim3(256), 0, stream, a);
   HPRI_CHECK_LAUNCH();
+  return HPRI_OK;
+}
+
+// Fixed-order sum of the partial slabs written by hpri_conv_wgrad into the parameter-gradient tensor.
+extern "C" int hpri_wgrad_reduce(const float* ws, float* dw, int N, int H, int W, int Cin, int Cin_pad, int Cout,
+                                 int Cout_pad, int KS, int dst_mode, int Cup, int accumulate, hipStream_t stream) {
+  HPRI_REQUIRE(ws && dw && Cin > 0 && Cout > 0, "wgrad_reduce: bad arguments");
+  if (dst_mode == 1) HPRI_REQUIRE(Cup > 0 && Cout == 4 * Cup, "wgrad_reduce: convT layout needs Cout == 4*Cup");
+  int splits, Cr, Nr;
+  hpri_wgrad_plan(N, H, W, Cin_pad, Cout_pad, KS, &splits, &Cr, &Nr);
+  const int T = KS * KS;
   const size_t total = (size_t)T * Cin * Cout;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)hpri_cdiv64(total, 256)), dim3(256), 0, stream,
                      ws, dw, splits, T, Cr, Nr, Cin, Cout, dst_mode, Cup, accumulate);

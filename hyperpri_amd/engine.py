@@ -160,6 +160,49 @@ class BNRef:
         self.momentum = 0.1 if m.momentum is None else float(m.momentum)
 
 
+# ---- optional per-kernel HIP-event log (bench.py's roofline leg) --------------------------------------
+# When enabled, the two MFMA kernel families are bracketed by events on the launching stream and tagged
+# with their template instantiation and ALGORITHMIC flops (2*M*N*K with the true, unpadded channel counts).
+_EVENT_LOG = None
+
+
+def enable_event_log(on: bool = True):
+    global _EVENT_LOG
+    _EVENT_LOG = {} if on else None
+    return _EVENT_LOG
+
+
+class _timed:
+    __slots__ = ("tag", "flops", "e0")
+
+    def __init__(self, tag: str, flops: float):
+        self.tag, self.flops, self.e0 = tag, flops, None
+
+    def __enter__(self):
+        if _EVENT_LOG is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+
+    def __exit__(self, *exc):
+        if self.e0 is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            _EVENT_LOG.setdefault(self.tag, []).append((self.e0, e1, self.flops))
+        return False
+
+
+def event_log_summary():
+    """{tag: {"launches", "total_ms", "avg_ms", "flops_per_launch", "tflops"}} (call after a device sync)."""
+    out = {}
+    for tag, evs in (_EVENT_LOG or {}).items():
+        ms = [a.elapsed_time(b) for a, b, _ in evs]
+        fl = sum(f for _, _, f in evs)
+        tot = sum(ms)
+        out[tag] = {"launches": len(evs), "total_ms": tot, "avg_ms": tot / len(evs), "flops_per_launch": fl / len(evs),
+                    "tflops": fl / (tot * 1e-3) / 1e12 if tot > 0 else 0.0}
+    return out
+
+
 def _ws(nfloats: int, device) -> torch.Tensor:
     return torch.empty(max(int(nfloats), 4), dtype=torch.float32, device=device)
 
@@ -175,9 +218,11 @@ def _pack(w: torch.Tensor, mode: int, K: int, ncols: int, T: int, cup: int, d1: 
 def _conv_launch(x: Act, wp: torch.Tensor, bias: Optional[torch.Tensor], y: Act, stats: Optional[torch.Tensor],
                  N: int, H: int, W: int, cin_pad: int, cout: int, cout_pad: int, y_cw: int, ks: int,
                  amode: int = A_DIRECT, epi: int = E_DIRECT, accumulate: int = 0,
-                 H2: int = 0, W2: int = 0, py0: int = 0, px0: int = 0, cup: int = 0) -> None:
-    _lib.call("hpri_conv_fwd", x.ptr, x.cs, x.coff, _p(wp), _p(bias), y.ptr, y.cs, y.coff, _p(stats),
-              N, H, W, cin_pad, cout, cout_pad, y_cw, ks, amode, epi, accumulate, H2, W2, py0, px0, cup, _stream())
+                 H2: int = 0, W2: int = 0, py0: int = 0, px0: int = 0, cup: int = 0, cin_true: int = 0) -> None:
+    tag = f"conv_fwd<{ks},{'2x2' if cout_pad % 128 == 0 else '4x1'},{'s2d' if amode else 'direct'},{'d2s' if epi else 'direct'}>"
+    with _timed(tag, 2.0 * N * H * W * (cin_true or cin_pad) * cout * ks * ks):
+        _lib.call("hpri_conv_fwd", x.ptr, x.cs, x.coff, _p(wp), _p(bias), y.ptr, y.cs, y.coff, _p(stats),
+                  N, H, W, cin_pad, cout, cout_pad, y_cw, ks, amode, epi, accumulate, H2, W2, py0, px0, cup, _stream())
 
 
 # --------------------------------------------------------------------------------------------------
@@ -203,7 +248,7 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
     if use_batch:
         tiles = _lib.load().hpri_conv_fwd_tiles(x.N, x.H, x.W, cout_pad)
         stats = torch.empty(tiles * cout_pad * 4, dtype=torch.float32, device=dev)
-    _conv_launch(x, wp, bias, yr, stats, x.N, x.H, x.W, cin_pad, cout, cout_pad, yr.cw, ks)
+    _conv_launch(x, wp, bias, yr, stats, x.N, x.H, x.W, cin_pad, cout, cout_pad, yr.cw, ks, cin_true=cin)
     del wp
     if bn is None:
         y = yr
@@ -255,7 +300,8 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
         if need_dx:
             wpd, cin_cols_pad = _pack(weight, 1, cout, cin, T, 0, cin)
             gx, acc = tp.grad_slot(x)
-            _conv_launch(dyr, wpd, None, gx, None, x.N, x.H, x.W, dyr.cw, cin, cin_cols_pad, gx.cw, ks, accumulate=int(acc))
+            _conv_launch(dyr, wpd, None, gx, None, x.N, x.H, x.W, dyr.cw, cin, cin_cols_pad, gx.cw, ks, accumulate=int(acc),
+                         cin_true=cout)
 
     tape.nodes.append(bwd)
     return y
@@ -271,8 +317,10 @@ def _wgrad(x: Act, dy: Act, dw: torch.Tensor, accumulate: int, cin: int, cout: i
     _lib.call("hpri_wgrad_plan", N, H, W, cin_pad, cout_pad, ks, ctypes.byref(splits), ctypes.byref(cr), ctypes.byref(nr))
     ws = _ws(splits.value * ks * ks * cr.value * nr.value, x.buf.device)
     dy_cvalid = (4 * cup) if bmode == A_S2D else dy.cw
-    _lib.call("hpri_conv_wgrad", x.ptr, x.cs, x.coff, cin_pad, dy.ptr, dy.cs, dy.coff, dy_cvalid, _p(ws), ws.numel(),
-              _p(dw), N, H, W, cin, cin_pad, cout, cout_pad, ks, bmode, dst_mode, accumulate, H2, W2, py0, px0, cup,
+    with _timed(f"conv_wgrad<{ks},{'s2d' if bmode == A_S2D else 'direct'}>", 2.0 * N * H * W * cin * cout * ks * ks):
+        _lib.call("hpri_conv_wgrad", x.ptr, x.cs, x.coff, cin_pad, dy.ptr, dy.cs, dy.coff, dy_cvalid, _p(ws), ws.numel(),
+                  N, H, W, cin_pad, cout_pad, ks, bmode, H2, W2, py0, px0, cup, _stream())
+    _lib.call("hpri_wgrad_reduce", _p(ws), _p(dw), N, H, W, cin, cin_pad, cout, cout_pad, ks, dst_mode, cup, accumulate,
               _stream())
 
 
@@ -325,7 +373,7 @@ def up_concat(tape: Tape, x1: Act, skip: Act, weight: torch.Tensor, bias: Option
         _lib.call("hpri_fill_pad", cat.ptr, cat.cs, cat.coff + cat.C, cat.N, H2, W2, cat.cw - cat.C, 0, 0, 0, 0, _stream())
     wp, ncols_pad = _pack(weight, 2, cin, 4 * cup, 1, cup, cup)
     _conv_launch(x1, wp, bias, ups, None, x1.N, x1.H, x1.W, x1.cw, 4 * cup, ncols_pad, 4 * cup, 1,
-                 epi=E_D2S, H2=H2, W2=W2, py0=py0, px0=px0, cup=cup)
+                 epi=E_D2S, H2=H2, W2=W2, py0=py0, px0=px0, cup=cup, cin_true=cin)
     del wp
     if tape.record:
         def bwd(tp: Tape) -> None:
@@ -348,7 +396,7 @@ def up_concat(tape: Tape, x1: Act, skip: Act, weight: torch.Tensor, bias: Option
                 wpd, cols_pad = _pack(weight, 3, 4 * cup, cin, 1, cup, cup)
                 gx, acc = tp.grad_slot(x1)
                 _conv_launch(gu, wpd, None, gx, None, x1.N, x1.H, x1.W, 4 * cup, cin, cols_pad, gx.cw, 1,
-                             amode=A_S2D, accumulate=int(acc), H2=H2, W2=W2, py0=py0, px0=px0, cup=cup)
+                             amode=A_S2D, accumulate=int(acc), H2=H2, W2=W2, py0=py0, px0=px0, cup=cup, cin_true=4 * cup)
         tape.nodes.append(bwd)
     return cat
 

@@ -66,9 +66,10 @@ int hpri_conv_fwd(const float* x, int x_cs, int x_coff, const float* wp, const f
  * dst_mode 1 writes ConvTranspose2d's (Cin,Cout,2,2).  Workspace: splits*KS*KS*Cr*Nr floats. */
 int hpri_wgrad_plan(int N, int H, int W, int Cin_pad, int Cout_pad, int KS, int* splits, int* Cr, int* Nr);
 int hpri_conv_wgrad(const float* x, int x_cs, int x_coff, int x_cvalid, const float* dy, int dy_cs, int dy_coff,
-                    int dy_cvalid, float* ws, size_t ws_floats, float* dw, int N, int H, int W, int Cin, int Cin_pad,
-                    int Cout, int Cout_pad, int KS, int bmode, int dst_mode, int accumulate, int H2, int W2, int py0,
-                    int px0, int Cup, hipStream_t stream);
+                    int dy_cvalid, float* ws, size_t ws_floats, int N, int H, int W, int Cin_pad, int Cout_pad, int KS,
+                    int bmode, int H2, int W2, int py0, int px0, int Cup, hipStream_t stream);
+int hpri_wgrad_reduce(const float* ws, float* dw, int N, int H, int W, int Cin, int Cin_pad, int Cout, int Cout_pad,
+                      int KS, int dst_mode, int Cup, int accumulate, hipStream_t stream);
 
 /* ---- BatchNorm (+ReLU) (bn.hip): nn.BatchNorm2d/3d/1d + nn.ReLU, model_parts.py:23-27; models.py:113-114,
  * 172-173,178-179.  G groups = independent statistic sets (G = N for SpectralUNET's per-image loop,

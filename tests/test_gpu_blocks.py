@@ -41,7 +41,11 @@ def _block(name, mod, seed0, nin):
         _close(x.grad, z[f"din{i}"], 1e-3, 2e-5, f"input grad {i}")
     for k, p in mod.named_parameters():
         ref = z["grad/" + k]
-        # conv biases in front of a training-mode BN have a mathematically zero gradient (rounding noise)
+        if k.endswith("double_conv.0.bias") or k.endswith("double_conv.3.bias"):
+            # a conv bias in front of a training-mode BN has a mathematically ZERO gradient: both sides
+            # hold only fp32 rounding noise of a sum over all pixels, so compare against zero
+            assert float(p.grad.abs().max()) < 1e-3 and float(np.abs(ref).max()) < 1e-3, k
+            continue
         _close(p.grad, ref, 1e-3, 3e-5 * max(1.0, float(np.abs(ref).max())), "grad " + k)
     for k, b in mod.named_buffers():
         _close(b.float() if b.dtype != torch.float32 else b, z["buf/" + k].astype(np.float32), 1e-4, 1e-5, "buffer " + k)

