@@ -14,14 +14,14 @@ __global__ void bn_finalize_kernel(const float4* __restrict__ part, int tiles_pe
                                    const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                    float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ var_unbiased,
                                    float* __restrict__ scale, float* __restrict__ shift) {
-  // block = 8 slices x 32 channels; grid = (ceil(C/32), G)
-  __shared__ double s1[8][32], s2[8][32], sn[8][32];
+  // block = 32 slices x 32 channels (1024 threads); grid = (ceil(C/32), G)
+  __shared__ double s1[32][32], s2[32][32], sn[32][32];
   const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cl, g = blockIdx.y;
   double a1 = 0.0, a2 = 0.0, an = 0.0;
   if (c < C) {
     const float4* p = part + (size_t)g * tiles_per_group * Cp + c;
-    for (int t = sl; t < tiles_per_group; t += 8) {
+    for (int t = sl; t < tiles_per_group; t += 32) {
       const float4 v = p[(size_t)t * Cp];
       const double m = v.x, n = v.z;
       a1 += n * m;
@@ -33,7 +33,7 @@ __global__ void bn_finalize_kernel(const float4* __restrict__ part, int tiles_pe
   __syncthreads();
   if (sl == 0 && c < C) {
     double t1 = 0.0, t2 = 0.0, tn = 0.0;
-    for (int k = 0; k < 8; ++k) { t1 += s1[k][cl]; t2 += s2[k][cl]; tn += sn[k][cl]; }
+    for (int k = 0; k < 32; ++k) { t1 += s1[k][cl]; t2 += s2[k][cl]; tn += sn[k][cl]; }
     const double mu = t1 / tn;
     double var = t2 / tn - mu * mu;
     if (var < 0.0) var = 0.0;
@@ -80,28 +80,35 @@ __global__ void bn_eval_prepare_kernel(const float* __restrict__ rm, const float
 // -------------------------------------------------------------------------------------------------
 // y = relu(x*scale + shift)  (float4 over channels; pad channels C..Cw are written as zeros)
 // -------------------------------------------------------------------------------------------------
+// grid = (pixel blocks, ceil(Cw4/CQ), G); block = 256 = ROWS x CQ channel quads; per-channel constants live in
+// registers for the whole pixel loop (no integer division, no per-element parameter loads)
 __global__ void bn_apply_relu_kernel(const float* __restrict__ x, int x_cs, int x_coff, float* __restrict__ y,
                                      int y_cs, int y_coff, const float* __restrict__ scale,
-                                     const float* __restrict__ shift, long long P, long long pix_per_group, int C,
-                                     int Cw, int relu) {
-  const int c4n = Cw >> 2;
-  const long long total = P * c4n;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const long long p = i / c4n;
-    const int c = (int)(i - p * c4n) * 4;
-    const int g = (int)(p / pix_per_group);
-    const float4 v = *reinterpret_cast<const float4*>(x + p * x_cs + x_coff + c);
-    float in[4] = {v.x, v.y, v.z, v.w}, out[4];
+                                     const float* __restrict__ shift, int pix_per_group, int C, int Cw, int CQ,
+                                     int relu) {
+  const int rows = 256 / CQ;
+  const int cq = threadIdx.x % CQ, pr = threadIdx.x / CQ;
+  const int c = (blockIdx.y * CQ + cq) * 4;
+  if (c >= Cw) return;
+  const int g = blockIdx.z;
+  float sc[4], sh[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      float r = 0.f;
-      if (c + j < C) {
-        r = in[j] * scale[g * C + c + j] + shift[g * C + c + j];
-        if (relu) r = fmaxf(r, 0.f);
-      }
-      out[j] = r;
-    }
-    *reinterpret_cast<float4*>(y + p * y_cs + y_coff + c) = make_float4(out[0], out[1], out[2], out[3]);
+  for (int j = 0; j < 4; ++j) {
+    const bool ok = c + j < C;
+    sc[j] = ok ? scale[g * C + c + j] : 0.f;
+    sh[j] = ok ? shift[g * C + c + j] : 0.f;
+  }
+  const int per = (pix_per_group + gridDim.x - 1) / gridDim.x;
+  const int q0 = blockIdx.x * per;
+  const int q1 = min(pix_per_group, q0 + per);
+  const size_t base = (size_t)g * pix_per_group;
+  for (int q = q0 + pr; q < q1; q += rows) {
+    const size_t p = base + q;
+    const float4 v = *reinterpret_cast<const float4*>(x + p * x_cs + x_coff + c);
+    float4 o;
+    o.x = v.x * sc[0] + sh[0]; o.y = v.y * sc[1] + sh[1]; o.z = v.z * sc[2] + sh[2]; o.w = v.w * sc[3] + sh[3];
+    if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+    *reinterpret_cast<float4*>(y + p * y_cs + y_coff + c) = o;
   }
 }
 
@@ -172,19 +179,19 @@ __global__ void col_reduce_kernel(const float* __restrict__ dy, int dy_cs, int d
 
 // stage 2: sums[g][k][c] = sum over blocks (double accumulation, fixed order); k in {0,1}
 __global__ void col_finalize_kernel(const float* __restrict__ part, int nblk, int Cpart, int C, float* __restrict__ sums) {
-  __shared__ double s[2][8][32];
+  __shared__ double s[2][32][32];
   const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cl, g = blockIdx.y;
   double a1 = 0.0, a2 = 0.0;
   if (c < C) {
     const float* p = part + (size_t)g * nblk * 2 * Cpart + c;
-    for (int b = sl; b < nblk; b += 8) { a1 += p[(size_t)b * 2 * Cpart]; a2 += p[(size_t)b * 2 * Cpart + Cpart]; }
+    for (int b = sl; b < nblk; b += 32) { a1 += p[(size_t)b * 2 * Cpart]; a2 += p[(size_t)b * 2 * Cpart + Cpart]; }
   }
   s[0][sl][cl] = a1; s[1][sl][cl] = a2;
   __syncthreads();
   if (sl == 0 && c < C) {
     double t1 = 0.0, t2 = 0.0;
-    for (int k = 0; k < 8; ++k) { t1 += s[0][k][cl]; t2 += s[1][k][cl]; }
+    for (int k = 0; k < 32; ++k) { t1 += s[0][k][cl]; t2 += s[1][k][cl]; }
     sums[((size_t)g * 2) * C + c] = (float)t1;
     sums[((size_t)g * 2 + 1) * C + c] = (float)t2;
   }
@@ -197,49 +204,73 @@ __global__ void bn_param_grad_kernel(const float* __restrict__ sums, int G, int 
   if (c >= C) return;
   float a = 0.f, b = 0.f;
   for (int g = 0; g < G; ++g) { b += sums[((size_t)g * 2) * C + c]; a += sums[((size_t)g * 2 + 1) * C + c]; }
-  dgamma[c] = accumulate ? dgamma[c] + a : a;
+  if (dgamma != nullptr) dgamma[c] = accumulate ? dgamma[c] + a : a;
   dbeta[c] = accumulate ? dbeta[c] + b : b;
 }
 
 // dx = scale * (g - s1/Np - xhat * s2/Np)   (training) ;  dx = scale * g  (eval: use_batch_stats = 0)
+// same 2-D mapping as bn_apply_relu_kernel; also emits per-block column sums of dx (the conv-bias gradient)
 __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, int dy_cs, int dy_coff, const float* __restrict__ x,
                                     int x_cs, int x_coff, float* __restrict__ dx, int dx_cs, int dx_coff,
                                     const float* __restrict__ mean, const float* __restrict__ invstd,
                                     const float* __restrict__ scale, const float* __restrict__ shift,
-                                    const float* __restrict__ sums, long long P, long long pix_per_group, int C, int Cw,
-                                    int relu, int use_batch_stats) {
-  const int c4n = Cw >> 2;
-  const long long total = P * c4n;
-  const float inv_np = 1.f / (float)pix_per_group;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const long long p = i / c4n;
-    const int c = (int)(i - p * c4n) * 4;
-    const int g = (int)(p / pix_per_group);
-    const float4 dv = *reinterpret_cast<const float4*>(dy + p * dy_cs + dy_coff + c);
-    const float4 xv = *reinterpret_cast<const float4*>(x + p * x_cs + x_coff + c);
-    const float d[4] = {dv.x, dv.y, dv.z, dv.w}, xx[4] = {xv.x, xv.y, xv.z, xv.w};
-    float o[4];
+                                    const float* __restrict__ sums, int pix_per_group, int C, int Cw, int CQ,
+                                    int relu, int use_batch_stats, float* __restrict__ dxpart, int Cpart) {
+  __shared__ float4 red[256];
+  const int rows = 256 / CQ;
+  const int cq = threadIdx.x % CQ, pr = threadIdx.x / CQ;
+  const int c = (blockIdx.y * CQ + cq) * 4;
+  const int g = blockIdx.z;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  if (c < Cw) {
+    const float inv_np = 1.f / (float)pix_per_group;
+    float sc[4], sh[4], mu[4], is[4], k1[4], k2[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      float r = 0.f;
-      if (c + j < C) {
-        const int k = g * C + c + j;
-        const float sc = scale[k];
-        const float gj = (!relu || (xx[j] * sc + shift[k] > 0.f)) ? d[j] : 0.f;
-        if (use_batch_stats) {
-          const float xh = (xx[j] - mean[k]) * invstd[k];
-          r = sc * (gj - sums[((size_t)g * 2) * C + c + j] * inv_np - xh * sums[((size_t)g * 2 + 1) * C + c + j] * inv_np);
-        } else {
-          r = sc * gj;
-        }
-      }
-      o[j] = r;
+      const bool ok = c + j < C;
+      const int k = g * C + c + j;
+      sc[j] = ok ? scale[k] : 0.f;
+      sh[j] = ok ? shift[k] : 0.f;
+      mu[j] = ok ? mean[k] : 0.f;
+      is[j] = ok ? invstd[k] : 0.f;
+      k1[j] = (ok && use_batch_stats) ? sums[((size_t)g * 2) * C + c + j] * inv_np : 0.f;
+      k2[j] = (ok && use_batch_stats) ? sums[((size_t)g * 2 + 1) * C + c + j] * inv_np : 0.f;
     }
-    *reinterpret_cast<float4*>(dx + p * dx_cs + dx_coff + c) = make_float4(o[0], o[1], o[2], o[3]);
+    const int per = (pix_per_group + gridDim.x - 1) / gridDim.x;
+    const int q0 = blockIdx.x * per;
+    const int q1 = min(pix_per_group, q0 + per);
+    const size_t base = (size_t)g * pix_per_group;
+    for (int q = q0 + pr; q < q1; q += rows) {
+      const size_t p = base + q;
+      const float4 dv = *reinterpret_cast<const float4*>(dy + p * dy_cs + dy_coff + c);
+      const float4 xv = *reinterpret_cast<const float4*>(x + p * x_cs + x_coff + c);
+      const float d[4] = {dv.x, dv.y, dv.z, dv.w}, xx[4] = {xv.x, xv.y, xv.z, xv.w};
+      float o[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float gj = (!relu || (xx[j] * sc[j] + sh[j] > 0.f)) ? d[j] : 0.f;
+        const float xh = (xx[j] - mu[j]) * is[j];
+        o[j] = (c + j < C) ? sc[j] * (gj - k1[j] - xh * k2[j]) : 0.f;   // pad channels stay exactly zero
+        acc[j] += o[j];
+      }
+      *reinterpret_cast<float4*>(dx + p * dx_cs + dx_coff + c) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+  }
+  if (dxpart != nullptr) {
+    red[threadIdx.x] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    __syncthreads();
+    if (pr == 0 && c < Cpart) {
+      float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int r = 0; r < rows; ++r) { const float4 a = red[r * CQ + cq]; t.x += a.x; t.y += a.y; t.z += a.z; t.w += a.w; }
+      float* o = dxpart + ((size_t)(g * gridDim.x + blockIdx.x) * 2) * Cpart + c;
+      *reinterpret_cast<float4*>(o) = t;
+      *reinterpret_cast<float4*>(o + Cpart) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
   }
 }
 
 // ------------------------------------------- C ABI ---------------------------------------------
+static inline int pick_cq(int c4) { int q = 1; while (q < c4 && q < 64) q <<= 1; return q; }
 static inline int ew_blocks(long long total) {
   long long b = (total + 255) / 256;
   if (b > 8192) b = 8192;
@@ -254,7 +285,7 @@ extern "C" int hpri_bn_finalize(const float* partials, int tiles_per_group, int 
                                 hipStream_t stream) {
   HPRI_REQUIRE(partials && gamma && beta && mean && invstd && var_unbiased && scale && shift, "bn_finalize: null pointer");
   HPRI_REQUIRE(tiles_per_group > 0 && G > 0 && C > 0 && Cp >= C, "bn_finalize: bad sizes");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(hpri_cdiv(C, 32), G), dim3(256), 0, stream,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(hpri_cdiv(C, 32), G), dim3(1024), 0, stream,
                      reinterpret_cast<const float4*>(partials), tiles_per_group, Cp, C, gamma, beta, eps, mean, invstd,
                      var_unbiased, scale, shift);
   HPRI_CHECK_LAUNCH();
@@ -284,18 +315,22 @@ extern "C" int hpri_bn_apply_relu(const float* x, int x_cs, int x_coff, float* y
                    Cw + x_coff <= x_cs && Cw + y_coff <= y_cs,
                "bn_apply_relu: channel layout must be float4-aligned and fit the strides");
   HPRI_REQUIRE(P > 0 && pix_per_group > 0 && P % pix_per_group == 0, "bn_apply_relu: bad pixel counts");
-  hipLaunchKernelGGL(bn_apply_relu_kernel, dim3(ew_blocks(P * (Cw >> 2))), dim3(256), 0, stream, x, x_cs, x_coff, y, y_cs,
-                     y_coff, scale, shift, P, pix_per_group, C, Cw, relu);
+  const int G = (int)(P / pix_per_group);
+  const int c4 = Cw >> 2, cq = pick_cq(c4), rows = 256 / cq, ycols = hpri_cdiv(c4, cq);
+  long long nbx = 4096 / ((long long)ycols * G);
+  const long long maxb = (pix_per_group + rows * 4 - 1) / (rows * 4);
+  if (nbx > maxb) nbx = maxb;
+  if (nbx < 1) nbx = 1;
+  hipLaunchKernelGGL(bn_apply_relu_kernel, dim3((unsigned)nbx, ycols, G), dim3(256), 0, stream, x, x_cs, x_coff, y, y_cs,
+                     y_coff, scale, shift, (int)pix_per_group, C, Cw, cq, relu);
   HPRI_CHECK_LAUNCH();
   return HPRI_OK;
 }
 
-static inline int pick_cq(int c4) { int q = 1; while (q < c4 && q < 64) q <<= 1; return q; }
-
 extern "C" int hpri_col_reduce_plan(long long pix_per_group, int G, int C, int* nblk, int* Cpart) {
   const int c4 = hpri_cdiv(C, 4), cq = pick_cq(c4), rows = 256 / cq;
   const int ycols = hpri_cdiv(c4, cq);
-  long long nb = 2048 / ((long long)ycols * G);
+  long long nb = 1024 / ((long long)ycols * G);
   const long long maxb = (pix_per_group + rows * 8 - 1) / (rows * 8);
   if (nb > maxb) nb = maxb;
   if (nb < 1) nb = 1;
@@ -304,40 +339,53 @@ extern "C" int hpri_col_reduce_plan(long long pix_per_group, int G, int C, int* 
   return HPRI_OK;
 }
 
-// BN(+ReLU) backward: reduce -> finalize -> parameter grads -> dx.  workspace = partials
-// (G*nblk*2*Cpart floats, hpri_col_reduce_plan) followed by sums (G*2*C floats).
+// BN(+ReLU) backward: reduce -> finalize -> parameter grads -> dx (+ column sums of dx = gradient of the bias of
+// the conv in front, optional).  workspace floats = 2 * (G*nblk*2*Cpart + G*2*C), see hpri_col_reduce_plan.
 extern "C" int hpri_bn_relu_bwd(const float* dy, int dy_cs, int dy_coff, const float* x, int x_cs, int x_coff,
                                 float* dx, int dx_cs, int dx_coff, const float* mean, const float* invstd,
                                 const float* scale, const float* shift, float* dgamma, float* dbeta,
-                                int accumulate_param_grads, float* workspace, size_t ws_floats, long long P,
-                                long long pix_per_group, int C, int Cw, int relu, int use_batch_stats,
-                                hipStream_t stream) {
+                                int accumulate_param_grads, float* dbias, int accumulate_dbias, float* workspace,
+                                size_t ws_floats, long long P, long long pix_per_group, int C, int Cw, int relu,
+                                int use_batch_stats, hipStream_t stream) {
   HPRI_REQUIRE(dy && x && dx && mean && invstd && scale && shift && workspace, "bn_relu_bwd: null pointer");
   HPRI_REQUIRE(Cw % 4 == 0 && Cw >= C && dy_cs % 4 == 0 && x_cs % 4 == 0 && dx_cs % 4 == 0 && dy_coff % 4 == 0 &&
                    x_coff % 4 == 0 && dx_coff % 4 == 0, "bn_relu_bwd: channel layout must be float4-aligned");
-  HPRI_REQUIRE(P > 0 && pix_per_group > 0 && P % pix_per_group == 0, "bn_relu_bwd: bad pixel counts");
+  HPRI_REQUIRE(P > 0 && pix_per_group > 0 && P % pix_per_group == 0 && pix_per_group < (1ll << 31), "bn_relu_bwd: bad pixel counts");
   const int G = (int)(P / pix_per_group);
   int nblk, Cpart;
   hpri_col_reduce_plan(pix_per_group, G, C, &nblk, &Cpart);
-  const size_t need = (size_t)G * nblk * 2 * Cpart + (size_t)G * 2 * C;
-  if (need > ws_floats) return hpri_set_error(HPRI_ERR_WORKSPACE, "bn_relu_bwd: workspace too small");
+  const size_t half = (size_t)G * nblk * 2 * Cpart + (size_t)G * 2 * C;
+  if (2 * half > ws_floats) return hpri_set_error(HPRI_ERR_WORKSPACE, "bn_relu_bwd: workspace too small");
   float* part = workspace;
   float* sums = workspace + (size_t)G * nblk * 2 * Cpart;
-  const int c4 = hpri_cdiv(C, 4), cq = pick_cq(c4);
-  hipLaunchKernelGGL((col_reduce_kernel<0>), dim3(nblk, hpri_cdiv(c4, cq), G), dim3(256), 0, stream, dy, dy_cs, dy_coff, x,
+  float* dxpart = workspace + half;
+  float* dxsums = dxpart + (size_t)G * nblk * 2 * Cpart;
+  const int c4 = hpri_cdiv(C, 4), cq = pick_cq(c4), ycols = hpri_cdiv(c4, cq);
+  hipLaunchKernelGGL((col_reduce_kernel<0>), dim3(nblk, ycols, G), dim3(256), 0, stream, dy, dy_cs, dy_coff, x,
                      x_cs, x_coff, mean, invstd, scale, shift, pix_per_group, C, cq, relu, part, Cpart);
   HPRI_CHECK_LAUNCH();
-  hipLaunchKernelGGL(col_finalize_kernel, dim3(hpri_cdiv(C, 32), G), dim3(256), 0, stream, part, nblk, Cpart, C, sums);
+  hipLaunchKernelGGL(col_finalize_kernel, dim3(hpri_cdiv(C, 32), G), dim3(1024), 0, stream, part, nblk, Cpart, C, sums);
   HPRI_CHECK_LAUNCH();
   if (dgamma != nullptr && dbeta != nullptr) {
     hipLaunchKernelGGL(bn_param_grad_kernel, dim3(hpri_cdiv(C, 256)), dim3(256), 0, stream, sums, G, C, dgamma, dbeta,
                        accumulate_param_grads);
     HPRI_CHECK_LAUNCH();
   }
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(P * (Cw >> 2))), dim3(256), 0, stream, dy, dy_cs, dy_coff, x, x_cs,
-                     x_coff, dx, dx_cs, dx_coff, mean, invstd, scale, shift, sums, P, pix_per_group, C, Cw, relu,
-                     use_batch_stats);
+  // the apply kernel uses the same (pixel blocks x channel columns x groups) grid as the reduce, so its dx column
+  // partials have the reduce's layout; Cw may add one more channel column than C (zero pads)
+  const int ycols_w = hpri_cdiv(Cw >> 2, cq);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nblk, ycols_w, G), dim3(256), 0, stream, dy, dy_cs, dy_coff, x, x_cs,
+                     x_coff, dx, dx_cs, dx_coff, mean, invstd, scale, shift, sums, (int)pix_per_group, C, Cw, cq, relu,
+                     use_batch_stats, dbias != nullptr ? dxpart : nullptr, Cpart);
   HPRI_CHECK_LAUNCH();
+  if (dbias != nullptr) {
+    hipLaunchKernelGGL(col_finalize_kernel, dim3(hpri_cdiv(C, 32), G), dim3(1024), 0, stream, dxpart, nblk, Cpart, C, dxsums);
+    HPRI_CHECK_LAUNCH();
+    // dxsums[g][0][c] = per-group column sums; "dbeta" path of the param-grad kernel adds the groups
+    hipLaunchKernelGGL(bn_param_grad_kernel, dim3(hpri_cdiv(C, 256)), dim3(256), 0, stream, dxsums, G, C, nullptr, dbias,
+                       accumulate_dbias);
+    HPRI_CHECK_LAUNCH();
+  }
   return HPRI_OK;
 }
 
@@ -357,10 +405,10 @@ extern "C" int hpri_col_sum(const float* src, int cs, int coff, float* out, int 
   hipLaunchKernelGGL((col_reduce_kernel<1>), dim3(nblk, hpri_cdiv(c4, cq), 1), dim3(256), 0, stream, src, cs, coff, nullptr, 0,
                      0, nullptr, nullptr, nullptr, nullptr, P, C, cq, 0, part, Cpart);
   HPRI_CHECK_LAUNCH();
-  hipLaunchKernelGGL(col_finalize_kernel, dim3(hpri_cdiv(C, 32), 1), dim3(256), 0, stream, part, nblk, Cpart, C, sums);
+  hipLaunchKernelGGL(col_finalize_kernel, dim3(hpri_cdiv(C, 32), 1), dim3(1024), 0, stream, part, nblk, Cpart, C, sums);
   HPRI_CHECK_LAUNCH();
   // sums[0][c] holds the column sums; reuse the param-grad kernel's "dbeta" path
-  hipLaunchKernelGGL(bn_param_grad_kernel, dim3(hpri_cdiv(C, 256)), dim3(256), 0, stream, sums, 1, C, sums + C, out, accumulate);
+  hipLaunchKernelGGL(bn_param_grad_kernel, dim3(hpri_cdiv(C, 256)), dim3(256), 0, stream, sums, 1, C, nullptr, out, accumulate);
   HPRI_CHECK_LAUNCH();
   return HPRI_OK;
 }

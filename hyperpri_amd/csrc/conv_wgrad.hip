@@ -17,7 +17,7 @@
 struct WgradArgs {
   const float* x; int x_cs; int x_coff; int x_cvalid;   // conv input (NHWC), readable channels
   const float* dy; int dy_cs; int dy_coff; int dy_cvalid; // gradient of the conv output
-  float* ws;             // [splits][T][Cr][Nr] partial slabs
+  float* ws;             // [splits][T][Nr][Cr] partial slabs
   int N, H, W;
   int strips_x, strips_y, total_strips, strips_per_split;
   int Cr, Nr;            // padded slab dims (gridDim.y*BC, gridDim.z*BNW)
@@ -126,13 +126,14 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
           for (int i = 0; i < CT; ++i)
 #pragma unroll
             for (int j = 0; j < NT; ++j)
-              acc[t][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[t][i][j], 0, 0, 0);
+              acc[t][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[j], af[i], acc[t][i][j], 0, 0, 0);
         }
       }
     }
   }
 
-  // partial slab: ws[split][t][c][n]; acc rows = c (A operand), cols = n (B operand)
+  // partial slab: ws[split][t][n][c]; MFMA rows = n (A operand = dY), cols = c (B operand = X) so that
+  // lanes store consecutive c -- the order the reduce kernel and the OIHW gradient want
   float* slab = a.ws + (size_t)blockIdx.x * T * a.Cr * a.Nr;
 #pragma unroll
   for (int t = 0; t < T; ++t)
@@ -140,33 +141,54 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
     for (int i = 0; i < CT; ++i)
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
-        const int n = n_blk + wn * (NT * 32) + j * 32 + li;
+        const int c = c_blk + wc * (CT * 32) + i * 32 + li;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int c = c_blk + wc * (CT * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          slab[((size_t)t * a.Cr + c) * a.Nr + n] = acc[t][i][j][r];
+          const int n = n_blk + wn * (NT * 32) + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          slab[((size_t)t * a.Nr + n) * a.Cr + c] = acc[t][i][j][r];
         }
       }
 }
 
-// dst modes of the reduce: 0 = conv weight OIHW  dW[n][c][t]            (c < Cin, n < Cout)
-//                          1 = convT weight      dW[c][co][tap], n = tap*Cup + co
-__global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int splits, int T,
-                                    int Cr, int Nr, int Cin, int Cout, int mode, int Cup, int accumulate) {
-  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t total = (size_t)T * Cin * Cout;
-  if (idx >= total) return;
-  const int n = (int)(idx % Cout);
-  const int c = (int)((idx / Cout) % Cin);
-  const int t = (int)(idx / ((size_t)Cout * Cin));
+// Fixed-order reduction of the partial slabs into the parameter gradient.
+//   block = 32 c-lanes x 32 split-slices (1024 threads); one block per (n, 32-channel tile); every thread keeps the
+//   T taps of its (n, c) in registers, the slices are combined through LDS in slice order (deterministic), and
+//   the block's 32*T results -- contiguous in OIHW -- are written coalesced.
+// dst modes: 0 = conv weight OIHW dW[n][c][t];  1 = convT weight dW[c][co][tap] with n = tap*Cup + co (T == 1)
+template <int T>
+__global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int splits,
+                                                            int Cr, int Nr, int Cin, int Cout, int mode, int Cup,
+                                                            int accumulate) {
+  __shared__ float red[32][32 * T + 1];
+  const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int n = blockIdx.y, c = blockIdx.x * 32 + cl;
   const size_t slab = (size_t)T * Cr * Nr;
-  const float* p = ws + ((size_t)t * Cr + c) * Nr + n;
-  float s = 0.f;
-  for (int k = 0; k < splits; ++k) s += p[(size_t)k * slab];
-  size_t o;
-  if (mode == 0) o = ((size_t)n * Cin + c) * T + t;
-  else { const int tap = n / Cup, co = n - tap * Cup; o = ((size_t)c * Cup + co) * 4 + tap; }
-  dw[o] = accumulate ? dw[o] + s : s;
+  float acc[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) acc[t] = 0.f;
+  if (c < Cin) {
+    const float* p = ws + (size_t)n * Cr + c;
+    for (int k = sl; k < splits; k += 32) {
+#pragma unroll
+      for (int t = 0; t < T; ++t) acc[t] += p[(size_t)k * slab + (size_t)t * Nr * Cr];
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < T; ++t) red[sl][cl * T + t] = acc[t];
+  __syncthreads();
+  // 32*T outputs per block: thread o sums the 32 slices of output o = cl*T + t
+  for (int o = threadIdx.x; o < 32 * T; o += 1024) {
+    float s = 0.f;
+#pragma unroll 8
+    for (int k = 0; k < 32; ++k) s += red[k][o];
+    const int cc = blockIdx.x * 32 + o / T, t = o % T;
+    if (cc < Cin) {
+      size_t off;
+      if (mode == 0) off = ((size_t)n * Cin + cc) * T + t;
+      else { const int tap = n / Cup, co = n - tap * Cup; off = ((size_t)cc * Cup + co) * 4 + tap; }
+      dw[off] = accumulate ? dw[off] + s : s;
+    }
+  }
 }
 
 static inline void wgrad_cfg(int KS, int* bc, int* bn) {
@@ -180,7 +202,7 @@ extern "C" int hpri_wgrad_plan(int N, int H, int W, int Cin_pad, int Cout_pad, i
   int bc, bn; wgrad_cfg(KS, &bc, &bn);
   const int cblk = hpri_cdiv(Cin_pad, bc), nblk = hpri_cdiv(Cout_pad, bn);
   const int total = N * hpri_cdiv(H, 2) * hpri_cdiv(W, 32);
-  int s = hpri_cdiv(2048, cblk * nblk);          // ~4 workgroups per CU slot (256 CUs x 2)
+  int s = hpri_cdiv(512, cblk * nblk);           // one round of 256 CUs x 2 resident workgroups
   if (s > total) s = total;
   if (s < 1) s = 1;
   const int per = hpri_cdiv(total, s);
@@ -232,10 +254,9 @@ extern "C" int hpri_wgrad_reduce(const float* ws, float* dw, int N, int H, int W
   if (dst_mode == 1) HPRI_REQUIRE(Cup > 0 && Cout == 4 * Cup, "wgrad_reduce: convT layout needs Cout == 4*Cup");
   int splits, Cr, Nr;
   hpri_wgrad_plan(N, H, W, Cin_pad, Cout_pad, KS, &splits, &Cr, &Nr);
-  const int T = KS * KS;
-  const size_t total = (size_t)T * Cin * Cout;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)hpri_cdiv64(total, 256)), dim3(256), 0, stream,
-                     ws, dw, splits, T, Cr, Nr, Cin, Cout, dst_mode, Cup, accumulate);
+  dim3 grid((unsigned)hpri_cdiv(Cin, 32), (unsigned)Cout);
+  if (KS == 3) hipLaunchKernelGGL((wgrad_reduce_kernel<9>), grid, dim3(1024), 0, stream, ws, dw, splits, Cr, Nr, Cin, Cout, dst_mode, Cup, accumulate);
+  else hipLaunchKernelGGL((wgrad_reduce_kernel<1>), grid, dim3(1024), 0, stream, ws, dw, splits, Cr, Nr, Cin, Cout, dst_mode, Cup, accumulate);
   HPRI_CHECK_LAUNCH();
   return HPRI_OK;
 }

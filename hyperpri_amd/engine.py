@@ -164,6 +164,7 @@ class BNRef:
 # When enabled, the two MFMA kernel families are bracketed by events on the launching stream and tagged
 # with their template instantiation and ALGORITHMIC flops (2*M*N*K with the true, unpadded channel counts).
 _EVENT_LOG = None
+SHAPE_TAGS = False   # tools/layer_profile.py: key the log by problem shape too
 
 
 def enable_event_log(on: bool = True):
@@ -220,6 +221,8 @@ def _conv_launch(x: Act, wp: torch.Tensor, bias: Optional[torch.Tensor], y: Act,
                  amode: int = A_DIRECT, epi: int = E_DIRECT, accumulate: int = 0,
                  H2: int = 0, W2: int = 0, py0: int = 0, px0: int = 0, cup: int = 0, cin_true: int = 0) -> None:
     tag = f"conv_fwd<{ks},{'2x2' if cout_pad % 128 == 0 else '4x1'},{'s2d' if amode else 'direct'},{'d2s' if epi else 'direct'}>"
+    if SHAPE_TAGS:
+        tag += f" N{N} {H}x{W} K{cin_pad} N{cout}"
     with _timed(tag, 2.0 * N * H * W * (cin_true or cin_pad) * cout * ks * ks):
         _lib.call("hpri_conv_fwd", x.ptr, x.cs, x.coff, _p(wp), _p(bias), y.ptr, y.cs, y.coff, _p(stats),
                   N, H, W, cin_pad, cout, cout_pad, y_cw, ks, amode, epi, accumulate, H2, W2, py0, px0, cup, _stream())
@@ -280,21 +283,22 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
             G = groups if use_batch else 1
             nblk = ctypes.c_int(); cpart = ctypes.c_int()
             _lib.call("hpri_col_reduce_plan", x.P // G, G, cout, ctypes.byref(nblk), ctypes.byref(cpart))
-            ws = _ws(G * nblk.value * 2 * cpart.value + G * 2 * cout, dev)
+            ws = _ws(2 * (G * nblk.value * 2 * cpart.value + G * 2 * cout), dev)
             dgam, acc_g = tp.param_slot(bn.weight)
             dbet, _ = tp.param_slot(bn.bias)
+            db, acc_b = (tp.param_slot(bias) if bias is not None else (None, 0))
             mean, invstd, varu, scale, shift = (st[i * G * cout:(i + 1) * G * cout] for i in range(5))
             _lib.call("hpri_bn_relu_bwd", g.ptr, g.cs, g.coff, yr.ptr, yr.cs, yr.coff, dyr.ptr, dyr.cs, dyr.coff,
-                      _p(mean), _p(invstd), _p(scale), _p(shift), _p(dgam), _p(dbet), acc_g, _p(ws), ws.numel(),
-                      x.P, x.P // G, cout, dyr.cw, int(relu), int(use_batch), _stream())
+                      _p(mean), _p(invstd), _p(scale), _p(shift), _p(dgam), _p(dbet), acc_g, _p(db), acc_b,
+                      _p(ws), ws.numel(), x.P, x.P // G, cout, dyr.cw, int(relu), int(use_batch), _stream())
         else:
             dyr = g
-        if bias is not None:
-            db, acc_b = tp.param_slot(bias)
-            nblk = ctypes.c_int(); cpart = ctypes.c_int()
-            _lib.call("hpri_col_reduce_plan", x.P, 1, cout, ctypes.byref(nblk), ctypes.byref(cpart))
-            ws = _ws(nblk.value * 2 * cpart.value + 2 * cout, dev)
-            _lib.call("hpri_col_sum", dyr.ptr, dyr.cs, dyr.coff, _p(db), acc_b, _p(ws), ws.numel(), x.P, cout, _stream())
+            if bias is not None:
+                db, acc_b = tp.param_slot(bias)
+                nblk = ctypes.c_int(); cpart = ctypes.c_int()
+                _lib.call("hpri_col_reduce_plan", x.P, 1, cout, ctypes.byref(nblk), ctypes.byref(cpart))
+                ws = _ws(nblk.value * 2 * cpart.value + 2 * cout, dev)
+                _lib.call("hpri_col_sum", dyr.ptr, dyr.cs, dyr.coff, _p(db), acc_b, _p(ws), ws.numel(), x.P, cout, _stream())
         dw, acc_w = tp.param_slot(weight)
         _wgrad(x, dyr, dw, acc_w, cin, cout, ks)
         if need_dx:
@@ -317,7 +321,10 @@ def _wgrad(x: Act, dy: Act, dw: torch.Tensor, accumulate: int, cin: int, cout: i
     _lib.call("hpri_wgrad_plan", N, H, W, cin_pad, cout_pad, ks, ctypes.byref(splits), ctypes.byref(cr), ctypes.byref(nr))
     ws = _ws(splits.value * ks * ks * cr.value * nr.value, x.buf.device)
     dy_cvalid = (4 * cup) if bmode == A_S2D else dy.cw
-    with _timed(f"conv_wgrad<{ks},{'s2d' if bmode == A_S2D else 'direct'}>", 2.0 * N * H * W * cin * cout * ks * ks):
+    tag = f"conv_wgrad<{ks},{'s2d' if bmode == A_S2D else 'direct'}>"
+    if SHAPE_TAGS:
+        tag += f" N{N} {H}x{W} C{cin_pad} N{cout}"
+    with _timed(tag, 2.0 * N * H * W * cin * cout * ks * ks):
         _lib.call("hpri_conv_wgrad", x.ptr, x.cs, x.coff, cin_pad, dy.ptr, dy.cs, dy.coff, dy_cvalid, _p(ws), ws.numel(),
                   N, H, W, cin_pad, cout_pad, ks, bmode, H2, W2, py0, px0, cup, _stream())
     _lib.call("hpri_wgrad_reduce", _p(ws), _p(dw), N, H, W, cin, cin_pad, cout, cout_pad, ks, dst_mode, cup, accumulate,

@@ -86,9 +86,9 @@ int hpri_bn_apply_relu(const float* x, int x_cs, int x_coff, float* y, int y_cs,
 int hpri_col_reduce_plan(long long pix_per_group, int G, int C, int* nblk, int* Cpart);
 int hpri_bn_relu_bwd(const float* dy, int dy_cs, int dy_coff, const float* x, int x_cs, int x_coff, float* dx,
                      int dx_cs, int dx_coff, const float* mean, const float* invstd, const float* scale,
-                     const float* shift, float* dgamma, float* dbeta, int accumulate_param_grads, float* workspace,
-                     size_t ws_floats, long long P, long long pix_per_group, int C, int Cw, int relu,
-                     int use_batch_stats, hipStream_t stream);
+                     const float* shift, float* dgamma, float* dbeta, int accumulate_param_grads, float* dbias,
+                     int accumulate_dbias, float* workspace, size_t ws_floats, long long P, long long pix_per_group,
+                     int C, int Cw, int relu, int use_batch_stats, hipStream_t stream);
 int hpri_col_sum(const float* src, int cs, int coff, float* out, int accumulate, float* workspace, size_t ws_floats,
                  long long P, int C, hipStream_t stream);
 
