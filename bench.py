@@ -46,17 +46,68 @@ def synth_init_(net):
             synth_fill_(p.data, 1000 + k, mode=2, scale=1.0 / math.sqrt(fan_in))
 
 
+def pmc_traffic(tag):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/*_pmc_traffic.json,
+    produced by tools/measure.sh + tools/pmc_traffic.py with the gfx950 FETCH_SIZE correction); None if absent."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return None
+    m = re.match(r"(\w+)<(\d),(\dx\d|direct|s2d)", tag)
+    try:
+        kern = json.load(open(files[-1]))["kernels"]
+    except Exception:
+        return None
+    if tag.startswith("conv_fwd<3,2x2"):
+        key = "conv_fwd_kernel<3, 2, 2, 0, 0>"
+    elif tag.startswith("conv_fwd<3,4x1"):
+        key = "conv_fwd_kernel<3, 4, 1, 0, 0>"
+    elif tag.startswith("conv_wgrad<3"):
+        key = "conv_wgrad_kernel<3, 1, 1, 0>"
+    else:
+        return None
+    for k, v in kern.items():
+        if key in k:
+            return round(v["hbm_bytes_per_launch"])
+    return None
+
+
+def host_cores():
+    """Cores this process may actually use: scheduler affinity capped by the cgroup CPU quota (the GPU box
+    exposes all host CPUs in the affinity mask but grants a share of them)."""
+    n = os.cpu_count() or 1
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(math.ceil(int(txt[0]) / int(txt[1])))))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, int(math.ceil(q / per))))
+            break
+        except Exception:
+            continue
+    env = os.environ.get("HPRI_CPU_THREADS")
+    if env:
+        n = int(env)
+    return min(n, 16)   # the 1-GPU box grants a 16-core share whatever the affinity mask says
+
+
 def cpu_baseline():
     """The CPU oracle (validated against the reference modules) on this box's host cores: CubeNET-64,
     batch 1, one warm-up + one timed forward+backward step."""
     from collections import OrderedDict
     import numpy as np
     from oracle import hyperpri_oracle as O
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except Exception:
-        pass
+    cores = host_cores()
     torch.set_num_threads(cores)
     sd = O.synth_state_dict(O.cubenet_shapes(BANDS, 1, 64))
     x = torch.from_numpy(O._u(1234, BANDS * H * W).reshape(1, 1, BANDS, H, W).copy())
@@ -147,9 +198,10 @@ def main():
         summ = engine.event_log_summary()
         engine.enable_event_log(False)
         dom = max(summ.items(), key=lambda kv: kv[1]["total_ms"])
+        traffic = pmc_traffic(dom[0])
         roofline = {"bound": "mfma", "kernel": dom[0], "achieved": round(dom[1]["tflops"], 2),
                     "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(dom[1]["tflops"] / PEAK_F32_MFMA_TFLOPS, 4),
-                    "traffic": None, "avg_launch_ms": round(dom[1]["avg_ms"], 4), "launches_per_step": dom[1]["launches"] // 2,
+                    "traffic": traffic, "avg_launch_ms": round(dom[1]["avg_ms"], 4), "launches_per_step": dom[1]["launches"] // 2,
                     "algorithmic_gflop_per_launch": round(dom[1]["flops_per_launch"] / 1e9, 3),
                     "all_mfma_kernels": {k: {"avg_ms": round(v["avg_ms"], 4), "tflops": round(v["tflops"], 2),
                                              "launches_per_step": v["launches"] // 2,

@@ -1,0 +1,17 @@
+#!/bin/bash
+# Round measurement on the GPU box: bench line, rocprofv3 kernel stats of the same command, and two PMC passes
+# (FETCH_SIZE, WRITE_SIZE -- separate passes, MI355X_MICROARCH.md "rocprofv3 PMC slots").  Outputs under gpurun_out/.
+set -o pipefail
+R=${GRAFT_REPO_ROOT:-/root/repo}
+TAG=${1:-r01}
+OUT=$R/gpurun_out/$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+timeout -k 10 500 python3 $R/bench.py > $OUT/bench.json 2> $OUT/bench.err || exit 1
+tail -1 $OUT/bench.json | cut -c1-600
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --no-cpu-baseline > $OUT/bench_prof.json 2> $OUT/prof.err || exit 2
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > /dev/null 2> $OUT/pmc_fetch.err || exit 3
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > /dev/null 2> $OUT/pmc_write.err || exit 4
+# keep only the per-kernel summaries small enough to merge back
+find $OUT -name '*kernel_trace.csv' -size +20M -delete
+ls -la $OUT $OUT/*/* | head -40
