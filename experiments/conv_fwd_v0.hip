@@ -85,82 +85,81 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvFwdArgs a) {
     *reinterpret_cast<f32x4*>(b_lds + (buf_) * 32 * BN + row * BN + c4 * 4) = breg[p];             \
   }
 
-  // ---- A halo chunk: global -> registers (prefetched one chunk ahead) -> LDS ----
-  f32x4 areg[NLD_A];
-#define LOAD_A(c0_)                                                                                   \
-  {                                                                                                   \
-    const int kq = min(8, (a.Cin_pad - (c0_)) >> 2); /* valid float4 per pixel in this chunk */       \
-    _Pragma("unroll") for (int p = 0; p < NLD_A; ++p) {                                               \
-      const int f = tid + p * 256;                                                                    \
-      const int pix = f >> 3, q = f & 7;                                                              \
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};                                                                 \
-      if (pix < HP && q < kq) {                                                                       \
-        const int hy = pix / HW, hx = pix - hy * HW;                                                  \
-        const int iy = y0 + hy - PAD, ix = x0 + hx - PAD;                                             \
-        if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) {                                             \
-          if (AMODE == HPRI_A_DIRECT) {                                                               \
-            v = *reinterpret_cast<const f32x4*>(                                                      \
-                a.x + ((size_t)(img * a.H + iy) * a.W + ix) * a.x_cs + a.x_coff + (c0_) + q * 4);     \
-          } else { /* S2D: k = tap*Cup + co ; source pixel (2*iy + t_y + py0, 2*ix + t_x + px0) */    \
-            const int k4 = (c0_) + q * 4;                                                             \
-            const int tp = k4 / a.Cup, co = k4 - tp * a.Cup;                                          \
-            const int sy = 2 * iy + (tp >> 1) + a.py0, sx = 2 * ix + (tp & 1) + a.px0;                \
-            v = *reinterpret_cast<const f32x4*>(                                                      \
-                a.x + ((size_t)(img * a.H2 + sy) * a.W2 + sx) * a.x_cs + a.x_coff + co);              \
-          }                                                                                           \
-        }                                                                                             \
-      }                                                                                               \
-      areg[p] = v;                                                                                    \
-    }                                                                                                 \
-  }
-#define STORE_A()                                                                                     \
-  _Pragma("unroll") for (int p = 0; p < NLD_A; ++p) {                                                 \
-    const int f = tid + p * 256;                                                                      \
-    const int pix = f >> 3, q = f & 7;                                                                \
-    if (pix < HP) *reinterpret_cast<f32x4*>(a_lds + pix * CS + q * 4) = areg[p];                      \
-  }
+  // ---- A halo chunk: global -> registers -> LDS ----
+  auto load_a_chunk = [&](int c0) {
+    const int kq = min(8, (a.Cin_pad - c0) >> 2);   // valid float4 per pixel in this chunk
+    f32x4 areg[NLD_A];
+#pragma unroll
+    for (int p = 0; p < NLD_A; ++p) {
+      const int f = tid + p * 256;
+      const int pix = f >> 3, q = f & 7;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (pix < HP && q < kq) {
+        const int hy = pix / HW, hx = pix - hy * HW;
+        const int iy = y0 + hy - PAD, ix = x0 + hx - PAD;
+        if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) {
+          if (AMODE == HPRI_A_DIRECT) {
+            v = *reinterpret_cast<const f32x4*>(
+                a.x + ((size_t)(img * a.H + iy) * a.W + ix) * a.x_cs + a.x_coff + c0 + q * 4);
+          } else {  // S2D: k = tap*Cup + co ; source pixel (2*iy + t_y + py0, 2*ix + t_x + px0)
+            const int k4 = c0 + q * 4;
+            const int tap = k4 / a.Cup, co = k4 - tap * a.Cup;
+            const int sy = 2 * iy + (tap >> 1) + a.py0, sx = 2 * ix + (tap & 1) + a.px0;
+            v = *reinterpret_cast<const f32x4*>(
+                a.x + ((size_t)(img * a.H2 + sy) * a.W2 + sx) * a.x_cs + a.x_coff + co);
+          }
+        }
+      }
+      areg[p] = v;
+    }
+#pragma unroll
+    for (int p = 0; p < NLD_A; ++p) {
+      const int f = tid + p * 256;
+      const int pix = f >> 3, q = f & 7;
+      if (pix < HP) *reinterpret_cast<f32x4*>(a_lds + pix * CS + q * 4) = areg[p];
+    }
+  };
 
   const int a_base = ((wm * 2) * HW + li) * CS + lh * 4;
   const int b_base = lh * 4 * BN + wn * 64 + li;
 
-#define MFMA_GROUP(g_)                                                                                \
-  {                                                                                                   \
-    f32x4 af[2];                                                                                      \
-    float bf[2][4];                                                                                   \
-    _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)                                                  \
-        af[mt] = *reinterpret_cast<const f32x4*>(ap + mt * HW * CS + (g_) * 8);                       \
-    _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                                  \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j) bf[nt][j] = bp[((g_) * 8 + j) * BN + nt * 32];  \
-    _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                     \
-        _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)                                              \
-            _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                          \
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mt][j], bf[nt][j], acc[mt][nt], 0, 0, 0); \
-  }
-
   LOAD_PANEL(0)
-  LOAD_A(0)
   for (int s = 0; s < S; ++s) {
     const int chunk = s / T, tap = s - chunk * T;
     if (tap == 0) {
       __syncthreads();                 // everyone is done reading the previous A chunk
-      STORE_A()
+      load_a_chunk(chunk * 32);
     }
     STORE_PANEL(s & 1)
     __syncthreads();                   // panel s (and the A chunk) visible
     if (s + 1 < S) { LOAD_PANEL(s + 1) }
-    if (tap == T - 1 && chunk + 1 < nchunks) { LOAD_A((chunk + 1) * 32) }   // lands during this panel's MFMAs
 
     const int kg = min(4, (a.Cin_pad - chunk * 32) >> 3);
     const int dy = tap / KS, dx = tap - dy * KS;
     const float* ap = a_lds + a_base + (dy * HW + dx) * CS;
     const float* bp = b_lds + (s & 1) * 32 * BN + b_base;
-    for (int g = 0; g < kg; ++g) MFMA_GROUP(g)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      if (g < kg) {
+        f32x4 af[2];
+        float bf[2][4];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+          af[mt] = *reinterpret_cast<const f32x4*>(ap + mt * HW * CS + g * 8);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) bf[nt][j] = bp[(g * 8 + j) * BN + nt * 32];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mt][j], bf[nt][j], acc[mt][nt], 0, 0, 0);
+      }
+    }
   }
-#undef MFMA_GROUP
-#undef LOAD_A
-#undef STORE_A
-#undef LOAD_PANEL
-#undef STORE_PANEL
 
   // ------------------------------- epilogue -------------------------------
   // acc[mt][nt][r]: pixel row = wm*2+mt, pixel col = (r&3) + 8*(r>>2) + 4*lh, channel = nb*BN + wn*64 + nt*32 + li

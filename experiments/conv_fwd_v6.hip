@@ -154,7 +154,11 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvFwdArgs a) {
     const int dy = tap / KS, dx = tap - dy * KS;
     const float* ap = a_lds + a_base + (dy * HW + dx) * CS;
     const float* bp = b_lds + (s & 1) * 32 * BN + b_base;
-    for (int g = 0; g < kg; ++g) MFMA_GROUP(g)
+    if (kg == 4) {                     // full 32-channel chunk: branch-free, LDS reads pipeline across groups
+      MFMA_GROUP(0) __builtin_amdgcn_sched_barrier(0); MFMA_GROUP(1) __builtin_amdgcn_sched_barrier(0); MFMA_GROUP(2) __builtin_amdgcn_sched_barrier(0); MFMA_GROUP(3)
+    } else {
+      for (int g = 0; g < kg; ++g) MFMA_GROUP(g)
+    }
   }
 #undef MFMA_GROUP
 #undef LOAD_A

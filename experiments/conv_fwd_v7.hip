@@ -123,19 +123,18 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvFwdArgs a) {
   const int a_base = ((wm * 2) * HW + li) * CS + lh * 4;
   const int b_base = lh * 4 * BN + wn * 64 + li;
 
-#define MFMA_GROUP(g_)                                                                                \
+#define LOADF(af_, bf_, g_)                                                                           \
   {                                                                                                   \
-    f32x4 af[2];                                                                                      \
-    float bf[2][4];                                                                                   \
     _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)                                                  \
-        af[mt] = *reinterpret_cast<const f32x4*>(ap + mt * HW * CS + (g_) * 8);                       \
+        af_[mt] = *reinterpret_cast<const f32x4*>(ap + mt * HW * CS + (g_) * 8);                      \
     _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                                  \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j) bf[nt][j] = bp[((g_) * 8 + j) * BN + nt * 32];  \
-    _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                     \
-        _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)                                              \
-            _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                          \
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mt][j], bf[nt][j], acc[mt][nt], 0, 0, 0); \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) bf_[nt][j] = bp[((g_) * 8 + j) * BN + nt * 32]; \
   }
+#define MFMAS(af_, bf_)                                                                               \
+  _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                       \
+      _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)                                                \
+          _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                            \
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af_[mt][j], bf_[nt][j], acc[mt][nt], 0, 0, 0);
 
   LOAD_PANEL(0)
   LOAD_A(0)
@@ -154,9 +153,21 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvFwdArgs a) {
     const int dy = tap / KS, dx = tap - dy * KS;
     const float* ap = a_lds + a_base + (dy * HW + dx) * CS;
     const float* bp = b_lds + (s & 1) * 32 * BN + b_base;
-    for (int g = 0; g < kg; ++g) MFMA_GROUP(g)
+    // fragments for group g+1 are read from LDS while the 16 MFMAs of group g issue (explicit double buffer)
+    f32x4 af0[2], af1[2];
+    float bf0[2][4], bf1[2][4];
+    LOADF(af0, bf0, 0)
+    for (int g = 0; g < kg; g += 2) {
+      if (g + 1 < kg) LOADF(af1, bf1, g + 1)
+      MFMAS(af0, bf0)
+      if (g + 1 < kg) {
+        if (g + 2 < kg) LOADF(af0, bf0, g + 2)
+        MFMAS(af1, bf1)
+      }
+    }
   }
-#undef MFMA_GROUP
+#undef LOADF
+#undef MFMAS
 #undef LOAD_A
 #undef STORE_A
 #undef LOAD_PANEL

@@ -19,6 +19,9 @@
 // Epilogue: + bias, NHWC store (or 2x2 scatter), optional accumulate, optional per-tile BatchNorm
 // partial statistics (mean, M2, count) for the training-mode BN that follows every conv in the model.
 #include "common.h"
+__device__ unsigned long long g_dbg[8192 * 8];
+#define STAMP(var) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
+extern "C" int hpri_debug_read(void* dst, size_t bytes) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_dbg), bytes, 0, hipMemcpyDeviceToHost); }
 
 struct ConvFwdArgs {
   const float* x; int x_cs; int x_coff;
@@ -137,25 +140,35 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvFwdArgs a) {
                 acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mt][j], bf[nt][j], acc[mt][nt], 0, 0, 0); \
   }
 
+  unsigned long long d1 = 0, d2 = 0, d3 = 0, d4 = 0, d0 = 0, tA, tB, tC, tD, tE, tS, tF;
+  STAMP(tS)
   LOAD_PANEL(0)
   LOAD_A(0)
   for (int s = 0; s < S; ++s) {
     const int chunk = s / T, tap = s - chunk * T;
+    STAMP(tA)
     if (tap == 0) {
       __syncthreads();                 // everyone is done reading the previous A chunk
       STORE_A()
     }
     STORE_PANEL(s & 1)
+    STAMP(tB)
     __syncthreads();                   // panel s (and the A chunk) visible
+    STAMP(tC)
     if (s + 1 < S) { LOAD_PANEL(s + 1) }
     if (tap == T - 1 && chunk + 1 < nchunks) { LOAD_A((chunk + 1) * 32) }   // lands during this panel's MFMAs
+    STAMP(tD)
 
     const int kg = min(4, (a.Cin_pad - chunk * 32) >> 3);
     const int dy = tap / KS, dx = tap - dy * KS;
     const float* ap = a_lds + a_base + (dy * HW + dx) * CS;
     const float* bp = b_lds + (s & 1) * 32 * BN + b_base;
     for (int g = 0; g < kg; ++g) MFMA_GROUP(g)
+    STAMP(tE)
+    d1 += tB - tA; d2 += tC - tB; d3 += tD - tC; d4 += tE - tD;
   }
+  STAMP(tF)
+  d0 = tF - tS;
 #undef MFMA_GROUP
 #undef LOAD_A
 #undef STORE_A
@@ -216,6 +229,11 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvFwdArgs a) {
     }
   }
 
+  if (lane == 0 && blockIdx.y == 0 && blockIdx.x < 8192 / 4) {
+    unsigned long long tG; STAMP(tG)
+    unsigned long long* o = g_dbg + ((size_t)blockIdx.x * 4 + wave) * 8;
+    o[0] = d0; o[1] = d1; o[2] = d2; o[3] = d3; o[4] = d4; o[5] = tG - tF; o[6] = S;
+  }
   if (a.stats != nullptr) {
     // per-tile, per-channel (mean, M2, count) over the tile's valid pixels; two passes over the
     // accumulators (sum, then squared deviations from the tile mean) -- no E[x^2]-E[x]^2 cancellation.

@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the conv_fwd / conv_wgrad launchers for A/B-ing kernel variants: each argument is a
+libhyperpri_hip.so build; all are timed interleaved in one process on the same random data (rule 24)."""
+import ctypes
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from hyperpri_amd import _lib  # noqa: E402
+
+SHAPES = [  # N, H, W, Cin, Cout, ks
+    (2, 304, 484, 128, 128, 3),
+    (2, 608, 968, 64, 64, 3),
+    (2, 76, 121, 512, 512, 3),
+    (2, 38, 60, 1024, 1024, 3),
+]
+
+
+def load(path):
+    lib = ctypes.CDLL(path)
+    for name, (restype, argtypes) in _lib.parse_header().items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = restype, argtypes
+    return lib
+
+
+def main():
+    libs = [(os.path.basename(p), load(p)) for p in sys.argv[1:]]
+    dev = torch.device("cuda", 0)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    mode = os.environ.get("MODE", "fwd")
+    for (N, H, W, Cin, Cout, ks) in SHAPES:
+        x = torch.randn(N * H * W * Cin, device=dev)
+        w = torch.randn(Cout * Cin * ks * ks, device=dev) * 0.05
+        b = torch.randn(Cout, device=dev)
+        y = torch.empty(N * H * W * Cout, device=dev)
+        cout_pad = (Cout + 63) // 64 * 64
+        flops = 2.0 * N * H * W * Cin * Cout * ks * ks
+        res = {}
+        preps = []
+        for name, lib in libs:
+            nfl = lib.hpri_packed_weight_floats(Cin, cout_pad, ks * ks)
+            wp = torch.empty(nfl, device=dev)
+            assert lib.hpri_pack_weight(P(w), P(wp), 0, Cin, Cout, cout_pad, ks * ks, 0, 0, Cin, st) == 0
+            tiles = lib.hpri_conv_fwd_tiles(N, H, W, cout_pad)
+            stats = torch.empty(tiles * cout_pad * 4, device=dev)
+            s, cr, nr = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+            lib.hpri_wgrad_plan(N, H, W, Cin, cout_pad, ks, ctypes.byref(s), ctypes.byref(cr), ctypes.byref(nr))
+            ws = torch.empty(s.value * ks * ks * cr.value * nr.value, device=dev)
+            preps.append((wp, stats, ws))
+        for rnd in range(5):
+            for (name, lib), (wp, stats, ws) in zip(libs, preps):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                reps = 5
+                e0.record()
+                for _ in range(reps):
+                    if mode == "fwd":
+                        rc = lib.hpri_conv_fwd(P(x), Cin, 0, P(wp), P(b), P(y), Cout, 0, P(stats), N, H, W, Cin, Cout, cout_pad,
+                                               Cout, ks, 0, 0, 0, 0, 0, 0, 0, 0, st)
+                    else:
+                        rc = lib.hpri_conv_wgrad(P(x), Cin, 0, Cin, P(y), Cout, 0, Cout, P(ws), ws.numel(), N, H, W, Cin, cout_pad,
+                                                 ks, 0, 0, 0, 0, 0, 0, st)
+                    assert rc == 0, lib.hpri_last_error()
+                e1.record()
+                torch.cuda.synchronize()
+                if rnd > 0:
+                    res.setdefault(name, []).append(e0.elapsed_time(e1) / reps)
+        line = f"{mode} N{N} {H}x{W} {Cin}->{Cout} k{ks}: "
+        for name, _ in libs:
+            ms = sorted(res[name])
+            line += f" {name}: med {flops / ms[len(ms) // 2] / 1e9:6.1f} TF (min-time {flops / ms[0] / 1e9:6.1f})"
+        print(line, flush=True)
+
+
+if __name__ == "__main__":
+    main()
