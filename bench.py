@@ -131,6 +131,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="skip the per-kernel HIP-event pass")
+    ap.add_argument("--force-sync", action="store_true",
+                    help="rehearsal: run the RCCL GradSync path (process group, hooks, all-reduce) even with one rank")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -140,8 +142,10 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_pg = world > 1 or args.force_sync
+    if use_pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import hyperpri_amd as HP
@@ -150,7 +154,7 @@ def main():
 
     net = HP.CubeNET(BANDS, 1, first_depth=64, bilinear=False).to(dev).train()
     synth_init_(net)
-    sync = GradSync(net) if world > 1 else None
+    sync = GradSync(net, force=args.force_sync) if use_pg else None
     x = torch.empty((BATCH, 1, BANDS, H, W), dtype=torch.float32, device=dev)
     mask = torch.empty((BATCH, 1, H, W), dtype=torch.float32, device=dev)
     for i in range(BATCH):
@@ -169,7 +173,7 @@ def main():
         return loss
 
     def fence():
-        if world > 1:
+        if use_pg:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -206,14 +210,12 @@ def main():
                     "all_mfma_kernels": {k: {"avg_ms": round(v["avg_ms"], 4), "tflops": round(v["tflops"], 2),
                                              "launches_per_step": v["launches"] // 2,
                                              "ms_per_step": round(v["total_ms"] / 2, 3)} for k, v in sorted(summ.items())}}
-    elif world > 1:
-        pass
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline()
 
-    if world > 1:
+    if use_pg:
         dist.barrier()
     if rank == 0:
         cubes = world * BATCH * args.steps
@@ -230,7 +232,7 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_pg:
         dist.destroy_process_group()
 
 

@@ -420,3 +420,135 @@ extern "C" int hpri_synth_fill(float* dst, long long n, unsigned long long seed,
   HPRI_CHECK_LAUNCH();
   return HPRI_OK;
 }
+
+// ---------------------------------- bilinear x2 upsample (align_corners=True) ---------------------
+// nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True), model_parts.py:57 / models.py:195.
+// ATen semantics: src = dst * (in-1)/(out-1); i0 = (int)src; l1 = src - i0; i1 = i0 + (i0 < in-1).
+// The result is written at pixel offset (py0, px0) of a (possibly larger, padded) destination image.
+__device__ __forceinline__ void bil_coord(int o, int in, int out, int* i0, int* i1, float* l0, float* l1) {
+  const float scale = (out > 1) ? (float)(in - 1) / (float)(out - 1) : 0.f;
+  const float src = scale * (float)o;
+  const int a = (int)src;
+  *i0 = a; *i1 = a + ((a < in - 1) ? 1 : 0);
+  *l1 = src - (float)a; *l0 = 1.f - *l1;
+}
+
+__global__ void upsample2x_fwd_kernel(const float* __restrict__ x, int x_cs, int x_coff, float* __restrict__ y, int y_cs,
+                                      int y_coff, int N, int H, int W, int H2, int W2, int py0, int px0, int C4) {
+  const int OH = 2 * H, OW = 2 * W;
+  const long long total = (long long)N * OH * OW * C4;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4) * 4;
+    long long r = i / C4;
+    const int ox = (int)(r % OW); r /= OW;
+    const int oy = (int)(r % OH);
+    const int n = (int)(r / OH);
+    int y0, y1, x0, x1; float ly0, ly1, lx0, lx1;
+    bil_coord(oy, H, OH, &y0, &y1, &ly0, &ly1);
+    bil_coord(ox, W, OW, &x0, &x1, &lx0, &lx1);
+    const float* b = x + (long long)n * H * W * x_cs + x_coff + c;
+    const float4 v00 = *reinterpret_cast<const float4*>(b + ((long long)y0 * W + x0) * x_cs);
+    const float4 v01 = *reinterpret_cast<const float4*>(b + ((long long)y0 * W + x1) * x_cs);
+    const float4 v10 = *reinterpret_cast<const float4*>(b + ((long long)y1 * W + x0) * x_cs);
+    const float4 v11 = *reinterpret_cast<const float4*>(b + ((long long)y1 * W + x1) * x_cs);
+    float4 o;
+    o.x = ly0 * (lx0 * v00.x + lx1 * v01.x) + ly1 * (lx0 * v10.x + lx1 * v11.x);
+    o.y = ly0 * (lx0 * v00.y + lx1 * v01.y) + ly1 * (lx0 * v10.y + lx1 * v11.y);
+    o.z = ly0 * (lx0 * v00.z + lx1 * v01.z) + ly1 * (lx0 * v10.z + lx1 * v11.z);
+    o.w = ly0 * (lx0 * v00.w + lx1 * v01.w) + ly1 * (lx0 * v10.w + lx1 * v11.w);
+    *reinterpret_cast<float4*>(y + (((long long)n * H2 + oy + py0) * W2 + ox + px0) * y_cs + y_coff + c) = o;
+  }
+}
+
+// gradient w.r.t. the low-res input as a GATHER (deterministic): input pixel (iy,ix) collects from the <= 4x4
+// output pixels whose interpolation footprint contains it.
+__global__ void upsample2x_bwd_kernel(const float* __restrict__ dy, int dy_cs, int dy_coff, float* __restrict__ dx,
+                                      int dx_cs, int dx_coff, int N, int H, int W, int H2, int W2, int py0, int px0,
+                                      int C4, int accumulate) {
+  const int OH = 2 * H, OW = 2 * W;
+  const long long total = (long long)N * H * W * C4;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4) * 4;
+    long long r = i / C4;
+    const int ix = (int)(r % W); r /= W;
+    const int iy = (int)(r % H);
+    const int n = (int)(r / H);
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    const int oy_lo = max(0, 2 * iy - 3), oy_hi = min(OH - 1, 2 * iy + 3);
+    const int ox_lo = max(0, 2 * ix - 3), ox_hi = min(OW - 1, 2 * ix + 3);
+    for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+      int y0, y1; float ly0, ly1;
+      bil_coord(oy, H, OH, &y0, &y1, &ly0, &ly1);
+      float wy = 0.f;
+      if (y0 == iy) wy += ly0;
+      if (y1 == iy) wy += ly1;
+      if (wy == 0.f) continue;
+      for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+        int x0, x1; float lx0, lx1;
+        bil_coord(ox, W, OW, &x0, &x1, &lx0, &lx1);
+        float wx = 0.f;
+        if (x0 == ix) wx += lx0;
+        if (x1 == ix) wx += lx1;
+        if (wx == 0.f) continue;
+        const float4 g = *reinterpret_cast<const float4*>(dy + (((long long)n * H2 + oy + py0) * W2 + ox + px0) * dy_cs + dy_coff + c);
+        const float w = wy * wx;
+        acc[0] += w * g.x; acc[1] += w * g.y; acc[2] += w * g.z; acc[3] += w * g.w;
+      }
+    }
+    float* p = dx + (((long long)n * H + iy) * W + ix) * dx_cs + dx_coff + c;
+    if (accumulate) {
+      const float4 old = *reinterpret_cast<const float4*>(p);
+      acc[0] += old.x; acc[1] += old.y; acc[2] += old.z; acc[3] += old.w;
+    }
+    *reinterpret_cast<float4*>(p) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  }
+}
+
+// out = a * b (the reference's "attention", model_parts.py:84-85), float4 over channels; accumulate adds into out
+__global__ void mul_kernel(const float* __restrict__ a, int a_cs, int a_coff, const float* __restrict__ b, int b_cs,
+                           int b_coff, float* __restrict__ o, int o_cs, int o_coff, long long P, int C4, int accumulate) {
+  const long long total = P * C4;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long p = i / C4;
+    const int c = (int)(i - p * C4) * 4;
+    const float4 u = *reinterpret_cast<const float4*>(a + p * a_cs + a_coff + c);
+    const float4 v = *reinterpret_cast<const float4*>(b + p * b_cs + b_coff + c);
+    float4 w = make_float4(u.x * v.x, u.y * v.y, u.z * v.z, u.w * v.w);
+    float* q = o + p * o_cs + o_coff + c;
+    if (accumulate) { const float4 z = *reinterpret_cast<const float4*>(q); w.x += z.x; w.y += z.y; w.z += z.z; w.w += z.w; }
+    *reinterpret_cast<float4*>(q) = w;
+  }
+}
+
+extern "C" int hpri_upsample2x_fwd(const float* x, int x_cs, int x_coff, float* y, int y_cs, int y_coff, int N, int H,
+                                   int W, int H2, int W2, int py0, int px0, int C, hipStream_t stream) {
+  HPRI_REQUIRE(x && y && N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "upsample2x_fwd: bad arguments");
+  HPRI_REQ_V4(x_cs, x_coff); HPRI_REQ_V4(y_cs, y_coff);
+  HPRI_REQUIRE(py0 >= 0 && px0 >= 0 && 2 * H + py0 <= H2 && 2 * W + px0 <= W2, "upsample2x_fwd: output exceeds the destination image");
+  hipLaunchKernelGGL(upsample2x_fwd_kernel, dim3(ew_blocks((long long)N * 4 * H * W * (C / 4))), dim3(256), 0, stream, x, x_cs,
+                     x_coff, y, y_cs, y_coff, N, H, W, H2, W2, py0, px0, C / 4);
+  HPRI_CHECK_LAUNCH();
+  return HPRI_OK;
+}
+
+extern "C" int hpri_upsample2x_bwd(const float* dy, int dy_cs, int dy_coff, float* dx, int dx_cs, int dx_coff, int N,
+                                   int H, int W, int H2, int W2, int py0, int px0, int C, int accumulate,
+                                   hipStream_t stream) {
+  HPRI_REQUIRE(dy && dx && N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "upsample2x_bwd: bad arguments");
+  HPRI_REQ_V4(dy_cs, dy_coff); HPRI_REQ_V4(dx_cs, dx_coff);
+  HPRI_REQUIRE(py0 >= 0 && px0 >= 0 && 2 * H + py0 <= H2 && 2 * W + px0 <= W2, "upsample2x_bwd: region exceeds the source image");
+  hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(ew_blocks((long long)N * H * W * (C / 4))), dim3(256), 0, stream, dy, dy_cs,
+                     dy_coff, dx, dx_cs, dx_coff, N, H, W, H2, W2, py0, px0, C / 4, accumulate);
+  HPRI_CHECK_LAUNCH();
+  return HPRI_OK;
+}
+
+extern "C" int hpri_mul(const float* a, int a_cs, int a_coff, const float* b, int b_cs, int b_coff, float* out, int o_cs,
+                        int o_coff, long long P, int C, int accumulate, hipStream_t stream) {
+  HPRI_REQUIRE(a && b && out && P > 0 && C > 0 && C % 4 == 0, "mul: bad arguments");
+  HPRI_REQ_V4(a_cs, a_coff); HPRI_REQ_V4(b_cs, b_coff); HPRI_REQ_V4(o_cs, o_coff);
+  hipLaunchKernelGGL(mul_kernel, dim3(ew_blocks(P * (C / 4))), dim3(256), 0, stream, a, a_cs, a_coff, b, b_cs, b_coff, out, o_cs,
+                     o_coff, P, C / 4, accumulate);
+  HPRI_CHECK_LAUNCH();
+  return HPRI_OK;
+}

@@ -35,9 +35,10 @@ class _Bucket:
 
 class GradSync:
     def __init__(self, module: torch.nn.Module, bucket_mb: float = 48.0, process_group=None,
-                 broadcast_buffers: bool = False):
+                 broadcast_buffers: bool = False, force: bool = False):
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.collective = self.world > 1 or (force and dist.is_initialized())   # force: rehearse with one rank
         params = [p for p in module.parameters() if p.requires_grad]
         cap = int(bucket_mb * (1 << 20))
         self.buckets: List[_Bucket] = []
@@ -72,7 +73,7 @@ class GradSync:
         n = p.numel()
         b.flat[b.offsets[i]:b.offsets[i] + n].copy_(p.grad.reshape(-1))
         b.pending -= 1
-        if b.pending == 0 and self.world > 1:
+        if b.pending == 0 and self.collective:
             b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def finish(self) -> None:
@@ -83,7 +84,7 @@ class GradSync:
                 for i, p in enumerate(b.params):
                     if p.grad is None:
                         b.flat[b.offsets[i]:b.offsets[i] + p.numel()].zero_()
-                if self.world > 1 and b.work is None:
+                if self.collective and b.work is None:
                     b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             if b.work is not None:
                 b.work.wait()

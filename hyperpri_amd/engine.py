@@ -353,59 +353,121 @@ def maxpool2(tape: Tape, x: Act) -> Act:
 
 
 # --------------------------------------------------------------------------------------------------
-# ConvTranspose2d(k2,s2) -> zero-pad -> concat with the skip
+# upsample (ConvTranspose2d k2 s2 | bilinear x2) -> zero-pad -> concat with / multiply by the skip
 # --------------------------------------------------------------------------------------------------
-def up_concat(tape: Tape, x1: Act, skip: Act, weight: torch.Tensor, bias: Optional[torch.Tensor],
-              need_dx1: bool = True) -> Act:
-    """cat([skip, pad(ConvTranspose2d(x1))], dim=1): model_parts.py:63-64,73-87 (and models.py:230-239).
-    The transposed conv is one GEMM per input pixel (Cin -> 4*Cup) whose epilogue scatters the 2x2
-    patches straight into channels [Cskip, Cskip+Cup) of the concat buffer; the pad ring is zeroed."""
+def _upsample_into(tape: Tape, x1: Act, dst: Act, weight: Optional[torch.Tensor], bias: Optional[torch.Tensor],
+                   need_dx1: bool) -> None:
+    """Write up(x1), zero-padded to dst's H x W (left = floor(d/2), model_parts.py:73-80), into the view ``dst``.
+    ``weight`` given: ConvTranspose2d(k2,s2) as one GEMM per input pixel (Cin -> 4*Cup) whose epilogue scatters the
+    2x2 patches (model_parts.py:63-64); ``weight`` None: nn.Upsample(2, 'bilinear', align_corners=True) (:57)."""
     dev = x1.buf.device
-    cin, cup = weight.shape[0], weight.shape[1]
-    if cin != x1.C or skip.N != x1.N:
-        raise RuntimeError("hyperpri_amd: Up: channel/batch mismatch")
-    H2, W2 = skip.H, skip.W
+    H2, W2 = dst.H, dst.W
     dY, dX = H2 - 2 * x1.H, W2 - 2 * x1.W
     if dY < 0 or dX < 0:
-        raise RuntimeError("hyperpri_amd: Up: skip smaller than upsampled input (negative pad) is not supported")
-    if skip.C % 4 or cup % 4:
-        raise RuntimeError("hyperpri_amd: Up: channel counts must be multiples of 4")
+        raise RuntimeError("hyperpri_amd: Up: skip smaller than the upsampled input (negative pad) is not supported")
     py0, px0 = dY // 2, dX // 2
-    cat = Act.new(skip.N, H2, W2, skip.C + cup, dev)
-    _lib.call("hpri_copy_slice", skip.ptr, skip.cs, skip.coff, cat.ptr, cat.cs, cat.coff, cat.P, skip.C, 0, _stream())
-    ups = cat.slice(skip.C, cup)
+    cup = dst.C
+    if cup % 4:
+        raise RuntimeError("hyperpri_amd: Up: channel counts must be multiples of 4")
     if dY or dX:
-        _lib.call("hpri_fill_pad", ups.ptr, ups.cs, ups.coff, ups.N, H2, W2, cup, py0, py0 + 2 * x1.H, px0, px0 + 2 * x1.W, _stream())
+        _lib.call("hpri_fill_pad", dst.ptr, dst.cs, dst.coff, dst.N, H2, W2, cup, py0, py0 + 2 * x1.H, px0, px0 + 2 * x1.W, _stream())
+    if weight is not None:
+        cin = weight.shape[0]
+        if cin != x1.C or weight.shape[1] != cup:
+            raise RuntimeError("hyperpri_amd: Up: ConvTranspose2d channel mismatch")
+        wp, ncols_pad = _pack(weight, 2, cin, 4 * cup, 1, cup, cup)
+        _conv_launch(x1, wp, bias, dst, None, x1.N, x1.H, x1.W, x1.cw, 4 * cup, ncols_pad, 4 * cup, 1,
+                     epi=E_D2S, H2=H2, W2=W2, py0=py0, px0=px0, cup=cup, cin_true=cin)
+        del wp
+    else:
+        if x1.C != cup:
+            raise RuntimeError("hyperpri_amd: Up: bilinear upsampling keeps the channel count")
+        _lib.call("hpri_upsample2x_fwd", x1.ptr, x1.cs, x1.coff, dst.ptr, dst.cs, dst.coff, x1.N, x1.H, x1.W, H2, W2,
+                  py0, px0, cup, _stream())
+    if not tape.record:
+        return
+
+    def bwd(tp: Tape) -> None:
+        gu = tp.grads.pop(id(dst), None)
+        if gu is None:
+            return
+        if weight is None:
+            if need_dx1:
+                gx, acc = tp.grad_slot(x1)
+                _lib.call("hpri_upsample2x_bwd", gu.ptr, gu.cs, gu.coff, gx.ptr, gx.cs, gx.coff, x1.N, x1.H, x1.W, H2, W2,
+                          py0, px0, _rup(cup, 4), int(acc), _stream())
+            return
+        cin = weight.shape[0]
+        if dY or dX:   # F.pad's backward drops the ring
+            _lib.call("hpri_fill_pad", gu.ptr, gu.cs, gu.coff, gu.N, H2, W2, cup, py0, py0 + 2 * x1.H, px0, px0 + 2 * x1.W, _stream())
+        if bias is not None:
+            db, acc_b = tp.param_slot(bias)
+            nblk = ctypes.c_int(); cpart = ctypes.c_int()
+            _lib.call("hpri_col_reduce_plan", gu.P, 1, cup, ctypes.byref(nblk), ctypes.byref(cpart))
+            ws = _ws(nblk.value * 2 * cpart.value + 2 * cup, dev)
+            _lib.call("hpri_col_sum", gu.ptr, gu.cs, gu.coff, _p(db), acc_b, _p(ws), ws.numel(), gu.P, cup, _stream())
+        dw, acc_w = tp.param_slot(weight)
+        _wgrad(x1, gu, dw, acc_w, cin, 4 * cup, 1, bmode=A_S2D, dst_mode=1, H2=H2, W2=W2, py0=py0, px0=px0, cup=cup)
+        if need_dx1:
+            wpd, cols_pad = _pack(weight, 3, 4 * cup, cin, 1, cup, cup)
+            gx, acc = tp.grad_slot(x1)
+            _conv_launch(gu, wpd, None, gx, None, x1.N, x1.H, x1.W, 4 * cup, cin, cols_pad, gx.cw, 1,
+                         amode=A_S2D, accumulate=int(acc), H2=H2, W2=W2, py0=py0, px0=px0, cup=cup, cin_true=4 * cup)
+    tape.nodes.append(bwd)
+
+
+def up_concat(tape: Tape, x1: Act, skip: Act, weight: Optional[torch.Tensor], bias: Optional[torch.Tensor],
+              need_dx1: bool = True) -> Act:
+    """cat([skip, pad(up(x1))], dim=1): model_parts.py:63-64,73-87 (and models.py:230-239).  One buffer
+    [N,H,W,Cskip+Cup]: the skip is copied into channels [0,Cskip), the upsampling kernel writes [Cskip,Cskip+Cup)
+    directly; in backward the split is free (channel-slice views of the consumer's input gradient)."""
+    dev = x1.buf.device
+    cup = weight.shape[1] if weight is not None else x1.C
+    if skip.N != x1.N:
+        raise RuntimeError("hyperpri_amd: Up: batch mismatch")
+    if skip.C % 4:
+        raise RuntimeError("hyperpri_amd: Up: channel counts must be multiples of 4")
+    cat = Act.new(skip.N, skip.H, skip.W, skip.C + cup, dev)
+    _lib.call("hpri_copy_slice", skip.ptr, skip.cs, skip.coff, cat.ptr, cat.cs, cat.coff, cat.P, skip.C, 0, _stream())
     if cat.cw > cat.C:
-        _lib.call("hpri_fill_pad", cat.ptr, cat.cs, cat.coff + cat.C, cat.N, H2, W2, cat.cw - cat.C, 0, 0, 0, 0, _stream())
-    wp, ncols_pad = _pack(weight, 2, cin, 4 * cup, 1, cup, cup)
-    _conv_launch(x1, wp, bias, ups, None, x1.N, x1.H, x1.W, x1.cw, 4 * cup, ncols_pad, 4 * cup, 1,
-                 epi=E_D2S, H2=H2, W2=W2, py0=py0, px0=px0, cup=cup, cin_true=cin)
-    del wp
+        _lib.call("hpri_fill_pad", cat.ptr, cat.cs, cat.coff + cat.C, cat.N, cat.H, cat.W, cat.cw - cat.C, 0, 0, 0, 0, _stream())
+    ups = cat.slice(skip.C, cup)
+    _upsample_into(tape, x1, ups, weight, bias, need_dx1)
     if tape.record:
         def bwd(tp: Tape) -> None:
             g = tp.grads.pop(id(cat), None)
             if g is None:
                 return
             tp.set_grad_view(skip, g.slice(0, skip.C))
-            gu = g.slice(skip.C, cup)
-            if dY or dX:   # F.pad's backward drops the ring
-                _lib.call("hpri_fill_pad", gu.ptr, gu.cs, gu.coff, gu.N, H2, W2, cup, py0, py0 + 2 * x1.H, px0, px0 + 2 * x1.W, _stream())
-            if bias is not None:
-                db, acc_b = tp.param_slot(bias)
-                nblk = ctypes.c_int(); cpart = ctypes.c_int()
-                _lib.call("hpri_col_reduce_plan", gu.P, 1, cup, ctypes.byref(nblk), ctypes.byref(cpart))
-                ws = _ws(nblk.value * 2 * cpart.value + 2 * cup, dev)
-                _lib.call("hpri_col_sum", gu.ptr, gu.cs, gu.coff, _p(db), acc_b, _p(ws), ws.numel(), gu.P, cup, _stream())
-            dw, acc_w = tp.param_slot(weight)
-            _wgrad(x1, gu, dw, acc_w, cin, 4 * cup, 1, bmode=A_S2D, dst_mode=1, H2=H2, W2=W2, py0=py0, px0=px0, cup=cup)
-            if need_dx1:
-                wpd, cols_pad = _pack(weight, 3, 4 * cup, cin, 1, cup, cup)
-                gx, acc = tp.grad_slot(x1)
-                _conv_launch(gu, wpd, None, gx, None, x1.N, x1.H, x1.W, 4 * cup, cin, cols_pad, gx.cw, 1,
-                             amode=A_S2D, accumulate=int(acc), H2=H2, W2=W2, py0=py0, px0=px0, cup=cup, cin_true=4 * cup)
+            tp.grads[id(ups)] = g.slice(skip.C, cup)
         tape.nodes.append(bwd)
     return cat
+
+
+def up_attention(tape: Tape, x1: Act, skip: Act, weight: Optional[torch.Tensor], bias: Optional[torch.Tensor],
+                 need_dx1: bool = True) -> Act:
+    """skip * pad(up(x1)) -- the reference's ``use_attention`` branch, model_parts.py:84-85."""
+    dev = x1.buf.device
+    cup = weight.shape[1] if weight is not None else x1.C
+    if cup != skip.C or skip.N != x1.N:
+        raise RuntimeError("hyperpri_amd: Up(use_attention): skip and upsampled tensors must have equal shapes")
+    u = Act.new(skip.N, skip.H, skip.W, cup, dev)
+    if u.cw > u.C:
+        _lib.call("hpri_fill_pad", u.ptr, u.cs, u.coff + u.C, u.N, u.H, u.W, u.cw - u.C, 0, 0, 0, 0, _stream())
+    _upsample_into(tape, x1, u, weight, bias, need_dx1)
+    y = Act.new(skip.N, skip.H, skip.W, cup, dev)
+    _lib.call("hpri_mul", skip.ptr, skip.cs, skip.coff, u.ptr, u.cs, u.coff, y.ptr, y.cs, y.coff, y.P, y.cw, 0, _stream())
+    if tape.record:
+        def bwd(tp: Tape) -> None:
+            g = tp.grads.pop(id(y), None)
+            if g is None:
+                return
+            gs, acc_s = tp.grad_slot(skip)
+            _lib.call("hpri_mul", g.ptr, g.cs, g.coff, u.ptr, u.cs, u.coff, gs.ptr, gs.cs, gs.coff, y.P, _rup(cup, 4), int(acc_s), _stream())
+            gu, acc_u = tp.grad_slot(u)
+            _lib.call("hpri_mul", g.ptr, g.cs, g.coff, skip.ptr, skip.cs, skip.coff, gu.ptr, gu.cs, gu.coff, y.P, _rup(cup, 4), int(acc_u), _stream())
+        tape.nodes.append(bwd)
+    return y
 
 
 def concat_channels(tape: Tape, a: Act, b: Act) -> Act:

@@ -54,9 +54,9 @@ class Down(nn.Module):
 
 
 class Up(nn.Module):
-    """ConvTranspose2d(k2,s2) -> zero-pad to the skip -> cat([skip, up]) -> DoubleConv
-    (reference model_parts.py:48-90, the ``bilinear=False, use_attention=False`` path every HyperPRI
-    experiment configures: params_HyperPRI.py:53-55,210-211)."""
+    """up -> zero-pad to the skip -> cat([skip, up]) (or skip*up when ``use_attention``) -> DoubleConv
+    (reference model_parts.py:48-90).  ``up`` is ConvTranspose2d(k2,s2) for ``bilinear=False`` -- the path every
+    HyperPRI experiment configures (params_HyperPRI.py:53-55,210-211) -- or bilinear x2 upsampling."""
 
     def __init__(self, in_channels, out_channels, bilinear=True, use_attention=False):
         super().__init__()
@@ -73,14 +73,12 @@ class Up(nn.Module):
             self.conv = DoubleConv(in_channels // 2 if use_attention else in_channels, out_channels)
 
     def forward(self, x1, x2):
-        if self.bilinear or self.use_attention:
-            raise NotImplementedError(
-                "hyperpri_amd: Up(bilinear=True) / Up(use_attention=True) have no HIP kernels yet; every HyperPRI "
-                "experiment uses bilinear=False, use_attention=False (params_HyperPRI.py:53-55,210-211).")
+        w = None if self.bilinear else self.up.weight
+        b = None if self.bilinear else self.up.bias
+        join = E.up_attention if self.use_attention else E.up_concat
 
         def prog(tape, a, need):
-            cat = E.up_concat(tape, a[0], a[1], self.up.weight, self.up.bias, need_dx1=need[0])
-            return self.conv._ops(tape, cat)
+            return self.conv._ops(tape, join(tape, a[0], a[1], w, b, need_dx1=need[0]))
         return run(prog, [x1, x2], list(self.parameters()))
 
 

@@ -162,11 +162,11 @@ class CubeNET(torch.nn.Module):
         if self.first_depth == 64:
             y = self.up4(y, x1)
         else:
-            if self.bilinear:
-                raise NotImplementedError("hyperpri_amd: CubeNET(bilinear=True) has no HIP kernels yet")
+            w4 = None if self.bilinear else self.upsample4.weight
+            b4 = None if self.bilinear else self.upsample4.bias
 
             def prog(tape, a, need):
-                cat = E.up_concat(tape, a[0], a[1], self.upsample4.weight, self.upsample4.bias, need_dx1=need[0])
+                cat = E.up_concat(tape, a[0], a[1], w4, b4, need_dx1=need[0])
                 return self.upconv4._ops(tape, cat)
             y = run(prog, [y, x1], list(self.upsample4.parameters()) + list(self.upconv4.parameters()))
         logits = self.outc(y)

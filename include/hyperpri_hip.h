@@ -115,6 +115,15 @@ int hpri_outconv_bwd_plan(int N, long long P, int C, int K, int* nblk, int* Cpar
 int hpri_outconv_bwd(const float* dy, const float* x, int x_cs, int x_coff, const float* w, float* dx, int dx_cs,
                      int dx_coff, int dx_cw, int dx_accumulate, float* dw, float* db, int accumulate_param_grads,
                      float* workspace, size_t ws_floats, int N, long long P, int C, int K, hipStream_t stream);
+/* nn.Upsample(scale_factor=2, 'bilinear', align_corners=True) (model_parts.py:57; models.py:195) writing at a pixel
+ * offset of a padded destination, its gather-form gradient, and the element-wise "attention" product x2*x1
+ * (model_parts.py:84-85). */
+int hpri_upsample2x_fwd(const float* x, int x_cs, int x_coff, float* y, int y_cs, int y_coff, int N, int H, int W, int H2,
+                        int W2, int py0, int px0, int C, hipStream_t stream);
+int hpri_upsample2x_bwd(const float* dy, int dy_cs, int dy_coff, float* dx, int dx_cs, int dx_coff, int N, int H, int W,
+                        int H2, int W2, int py0, int px0, int C, int accumulate, hipStream_t stream);
+int hpri_mul(const float* a, int a_cs, int a_coff, const float* b, int b_cs, int b_coff, float* out, int o_cs, int o_coff,
+             long long P, int C, int accumulate, hipStream_t stream);
 int hpri_synth_fill(float* dst, long long n, unsigned long long seed, int mode, float thr, float scale,
                     hipStream_t stream);
 

@@ -105,7 +105,7 @@ def unet_forward(sd: SD, x: Tensor, train: bool = True, bilinear: bool = False,
 
 
 def cubenet_forward(sd: SD, x: Tensor, first_depth: int = 64, train: bool = True,
-                    conv3d: bool = True) -> Tensor:
+                    conv3d: bool = True, bilinear: bool = False, use_attention: bool = False) -> Tensor:
     """CubeNET.forward, models.py:202-247 (bilinear=False, use_attention=False -- the configured
     path, params_HyperPRI.py:210-211).  ``conv3d=False`` evaluates the first layer as the
     algebraically identical Conv2d over D input channels."""
@@ -125,13 +125,16 @@ def cubenet_forward(sd: SD, x: Tensor, first_depth: int = 64, train: bool = True
     x3 = down(sd, "down2.", x2, train)
     x4 = down(sd, "down3.", x3, train)
     x5 = down(sd, "down4.", x4, train)
-    y = up(sd, "up1.", x5, x4, train)
-    y = up(sd, "up2.", y, x3, train)
-    y = up(sd, "up3.", y, x2, train)
+    y = up(sd, "up1.", x5, x4, train, bilinear, use_attention)
+    y = up(sd, "up2.", y, x3, train, bilinear, use_attention)
+    y = up(sd, "up3.", y, x2, train, bilinear, use_attention)
     if first_depth == 64:
-        y = up(sd, "up4.", y, x1, train)                                             # :228
+        y = up(sd, "up4.", y, x1, train, bilinear, use_attention)                    # :228
     else:                                                                            # :229-240
-        y = F.conv_transpose2d(y, sd["upsample4.weight"], sd["upsample4.bias"], stride=2)
+        if bilinear:
+            y = F.interpolate(y, scale_factor=2, mode="bilinear", align_corners=True)
+        else:
+            y = F.conv_transpose2d(y, sd["upsample4.weight"], sd["upsample4.bias"], stride=2)
         y = _pad_to(y, x1)
         y = torch.cat([x1, y], dim=1)
         y = double_conv(sd, "upconv4.", y, train)
@@ -190,27 +193,35 @@ def _dc_keys(sd, p, cin, cout, mid=None):
     _bn_keys(sd, p + "double_conv.4", cout)
 
 
-def _up_keys(sd, p, cin, cout):
-    sd[p + "up.weight"] = (cin, cin // 2, 2, 2)          # ConvTranspose2d layout (Cin,Cout,kh,kw)
-    sd[p + "up.bias"] = (cin // 2,)
-    _dc_keys(sd, p + "conv.", cin, cout)
+def _up_keys(sd, p, cin, cout, bilinear=False, attention=False):
+    """Up.__init__, model_parts.py:51-68."""
+    if bilinear:                                         # nn.Upsample has no parameters
+        _dc_keys(sd, p + "conv.", cin // 2 if attention else cin, cout // 2, cin // 2)
+    else:
+        sd[p + "up.weight"] = (cin, cin // 2, 2, 2)      # ConvTranspose2d layout (Cin,Cout,kh,kw)
+        sd[p + "up.bias"] = (cin // 2,)
+        _dc_keys(sd, p + "conv.", cin // 2 if attention else cin, cout)
 
 
-def unet_shapes(n_channels: int, n_classes: int) -> "OrderedDict[str, tuple]":
-    """state_dict keys/shapes of UNet(n_channels, n_classes, bilinear=False), models.py:24-51."""
+def unet_shapes(n_channels: int, n_classes: int, bilinear: bool = False,
+                use_attention: bool = False) -> "OrderedDict[str, tuple]":
+    """state_dict keys/shapes of UNet(n_channels, n_classes, bilinear, use_attention), models.py:24-51."""
+    f = 2 if bilinear else 1
     sd = OrderedDict()
     _dc_keys(sd, "inc.", n_channels, 64)
-    for i, (a, b) in enumerate([(64, 128), (128, 256), (256, 512), (512, 1024)], 1):
+    for i, (a, b) in enumerate([(64, 128), (128, 256), (256, 512), (512, 1024 // f)], 1):
         _dc_keys(sd, f"down{i}.maxpool_conv.1.", a, b)
-    for i, (a, b) in enumerate([(1024, 512), (512, 256), (256, 128), (128, 64)], 1):
-        _up_keys(sd, f"up{i}.", a, b)
+    for i, (a, b) in enumerate([(1024, 512), (512, 256), (256, 128), (128, 64 * f)], 1):
+        _up_keys(sd, f"up{i}.", a, b, bilinear, use_attention)
     _conv_keys(sd, "outc.conv", n_classes, 64, 1)
     return sd
 
 
-def cubenet_shapes(depth: int, n_classes: int, first_depth: int = 64) -> "OrderedDict[str, tuple]":
-    """state_dict keys/shapes of CubeNET(depth, n_classes, first_depth, bilinear=False),
+def cubenet_shapes(depth: int, n_classes: int, first_depth: int = 64, bilinear: bool = False,
+                   use_attention: bool = False) -> "OrderedDict[str, tuple]":
+    """state_dict keys/shapes of CubeNET(depth, n_classes, first_depth, bilinear, use_attention),
     models.py:149-200.  ``first_conv.*`` and ``inc.0.*`` alias one tensor (models.py:169-171)."""
+    f = 2 if bilinear else 1
     sd = OrderedDict()
     _conv_keys(sd, "first_conv", first_depth, 1, 3)
     sd["first_conv.weight"] = (first_depth, 1, depth, 3, 3)
@@ -219,12 +230,14 @@ def cubenet_shapes(depth: int, n_classes: int, first_depth: int = 64) -> "Ordere
     _bn_keys(sd, "inc.1", first_depth)
     _conv_keys(sd, "inc2.0", first_depth, first_depth, 3)
     _bn_keys(sd, "inc2.1", first_depth)
-    for i, (a, b) in enumerate([(first_depth, 128), (128, 256), (256, 512), (512, 1024)], 1):
+    for i, (a, b) in enumerate([(first_depth, 128), (128, 256), (256, 512), (512, 1024 // f)], 1):
         _dc_keys(sd, f"down{i}.maxpool_conv.1.", a, b)
     for i, (a, b) in enumerate([(1024, 512), (512, 256), (256, 128)], 1):
-        _up_keys(sd, f"up{i}.", a, b)
+        _up_keys(sd, f"up{i}.", a, b, bilinear, use_attention)
     if first_depth == 64:
-        _up_keys(sd, "up4.", 128, 64)
+        _up_keys(sd, "up4.", 128, 64 * f, bilinear, use_attention)
+    elif bilinear:
+        _dc_keys(sd, "upconv4.", 128 + first_depth, 64, 64)
     else:
         sd["upsample4.weight"] = (128, 64, 2, 2)
         sd["upsample4.bias"] = (64,)

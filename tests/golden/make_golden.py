@@ -133,6 +133,12 @@ def main():
     block_fixture("block_up", RP.Up(8, 4, bilinear=False), [u(14, (1, 8, 3, 5)), u(15, (1, 4, 6, 11))], 2300)
     block_fixture("block_up_big", RP.Up(64, 32, bilinear=False), [u(16, (2, 64, 5, 37)), u(17, (2, 32, 11, 75))], 2400)
     block_fixture("block_outconv", RP.OutConv(6, 2), [u(18, (2, 6, 5, 7))], 2500)
+    # Up variants no HyperPRI experiment configures (SURVEY.md 8 a3'): bilinear upsampling and the "attention" product
+    block_fixture("block_up_bilinear", RP.Up(16, 8, bilinear=True), [u(19, (2, 8, 5, 9)), u(20, (2, 8, 11, 19))], 2600)
+    block_fixture("block_up_attn", RP.Up(16, 8, bilinear=False, use_attention=True),
+                  [u(21, (2, 16, 5, 9)), u(22, (2, 8, 11, 19))], 2700)
+    block_fixture("block_up_bilinear_attn", RP.Up(16, 8, bilinear=True, use_attention=True),
+                  [u(23, (2, 8, 5, 9)), u(24, (2, 8, 10, 18))], 2800)
 
     # (ii) tiny full networks -------------------------------------------------------------
     known = OrderedDict()
@@ -146,6 +152,12 @@ def main():
     shp = net_fixture("net_cubenet128_tiny", RM.CubeNET(6, 1, first_depth=128, bilinear=False),
                       u(1236, (2, 1, 6, h, w)), m)
     known["cubenet128_d6"] = {"keys": list(shp.keys()), "shapes": [list(s) for s in shp.values()]}
+    net_fixture("net_unet3_bilinear_tiny", RM.UNet(3, 1, bilinear=True), u(1239, (2, 3, h, w)), m)
+    net_fixture("net_unet3_attn_tiny", RM.UNet(3, 1, bilinear=True, use_attention=True), u(1240, (2, 3, h, w)), m)
+    net_fixture("net_cubenet64_bilinear_tiny", RM.CubeNET(6, 1, first_depth=64, bilinear=True),
+                u(1241, (2, 1, 6, h, w)), m)
+    # (CubeNET(first_depth=128, bilinear=True) cannot run in the reference: models.py:196 builds DoubleConv(256,..)
+    #  for a 192-channel concat)
     m3 = (u(4322, (3, 1, 7, 9)) > 0.7).float()
     shp = net_fixture("net_spectral_tiny", RM.SpectralUNET(10, 1, 4), u(1237, (3, 10, 7, 9)), m3)
     known["spectral_10_4"] = {"keys": list(shp.keys()), "shapes": [list(s) for s in shp.values()]}

@@ -80,6 +80,14 @@ def test_up_big():
     _block("block_up_big", Up(64, 32, bilinear=False), 2400, 2)
 
 
+@pytest.mark.parametrize("name,bil,att,seed", [("block_up_bilinear", True, False, 2600), ("block_up_attn", False, True, 2700),
+                                               ("block_up_bilinear_attn", True, True, 2800)])
+def test_up_variants(name, bil, att, seed):
+    """Up(bilinear=True) and Up(use_attention=True): SURVEY.md section 8 a3' (not configured by any experiment)."""
+    from hyperpri_amd import Up
+    _block(name, Up(16, 8, bilinear=bil, use_attention=att), seed, 2)
+
+
 def test_outconv():
     from hyperpri_amd import OutConv
     _block("block_outconv", OutConv(6, 2), 2500, 1)

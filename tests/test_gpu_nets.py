@@ -29,13 +29,18 @@ def _mk(name):
         "net_unet3_tiny": lambda: H.UNet(3, 1, bilinear=False),
         "net_cubenet64_tiny": lambda: H.CubeNET(6, 1, first_depth=64, bilinear=False),
         "net_cubenet128_tiny": lambda: H.CubeNET(6, 1, first_depth=128, bilinear=False),
+        "net_unet3_bilinear_tiny": lambda: H.UNet(3, 1, bilinear=True),
+        "net_unet3_attn_tiny": lambda: H.UNet(3, 1, bilinear=True, use_attention=True),
+        "net_cubenet64_bilinear_tiny": lambda: H.CubeNET(6, 1, first_depth=64, bilinear=True),
         "net_spectral_tiny": lambda: H.SpectralUNET(10, 1, 4),
         "net_spectral_f48": lambda: H.SpectralUNET(22, 1, 48),
     }[name]()
 
 
 CASES = [("net_unet3_tiny", 1234, (2, 3, 36, 50), 4321, 0.9), ("net_cubenet64_tiny", 1235, (2, 1, 6, 36, 50), 4321, 0.9),
-         ("net_cubenet128_tiny", 1236, (2, 1, 6, 36, 50), 4321, 0.9), ("net_spectral_tiny", 1237, (3, 10, 7, 9), 4322, 0.7),
+         ("net_cubenet128_tiny", 1236, (2, 1, 6, 36, 50), 4321, 0.9),
+         ("net_unet3_bilinear_tiny", 1239, (2, 3, 36, 50), 4321, 0.9), ("net_unet3_attn_tiny", 1240, (2, 3, 36, 50), 4321, 0.9),
+         ("net_cubenet64_bilinear_tiny", 1241, (2, 1, 6, 36, 50), 4321, 0.9), ("net_spectral_tiny", 1237, (3, 10, 7, 9), 4322, 0.7),
          ("net_spectral_f48", 1238, (2, 22, 12, 20), 4323, 0.7)]
 
 

@@ -74,6 +74,14 @@ def test_block_up(name, cin, cout, seed):
     _block(name, sd, lambda s, x1, x2, t: O.up(s, "", x1, x2, t), seed, 2)
 
 
+@pytest.mark.parametrize("name,bil,att,seed", [("block_up_bilinear", True, False, 2600), ("block_up_attn", False, True, 2700),
+                                               ("block_up_bilinear_attn", True, True, 2800)])
+def test_block_up_variants(name, bil, att, seed):
+    sd = OrderedDict()
+    O._up_keys(sd, "", 16, 8, bil, att)
+    _block(name, sd, lambda s, x1, x2, t: O.up(s, "", x1, x2, t, bil, att), seed, 2)
+
+
 def test_block_outconv():
     sd = OrderedDict()
     O._conv_keys(sd, "conv", 2, 6, 1)
@@ -84,6 +92,9 @@ NETS = [
     ("net_unet3_tiny", lambda: O.unet_shapes(3, 1), O.unet_forward, {}, 1234, (2, 3, 36, 50), 4321),
     ("net_cubenet64_tiny", lambda: O.cubenet_shapes(6, 1, 64), O.cubenet_forward, {"first_depth": 64}, 1235, (2, 1, 6, 36, 50), 4321),
     ("net_cubenet128_tiny", lambda: O.cubenet_shapes(6, 1, 128), O.cubenet_forward, {"first_depth": 128}, 1236, (2, 1, 6, 36, 50), 4321),
+    ("net_unet3_bilinear_tiny", lambda: O.unet_shapes(3, 1, True), O.unet_forward, {"bilinear": True}, 1239, (2, 3, 36, 50), 4321),
+    ("net_unet3_attn_tiny", lambda: O.unet_shapes(3, 1, True, True), O.unet_forward, {"bilinear": True, "use_attention": True}, 1240, (2, 3, 36, 50), 4321),
+    ("net_cubenet64_bilinear_tiny", lambda: O.cubenet_shapes(6, 1, 64, True), O.cubenet_forward, {"first_depth": 64, "bilinear": True}, 1241, (2, 1, 6, 36, 50), 4321),
     ("net_spectral_tiny", lambda: O.spectral_shapes(10, 1, 4), O.spectral_forward, {}, 1237, (3, 10, 7, 9), 4322),
     ("net_spectral_f48", lambda: O.spectral_shapes(22, 1, 48), O.spectral_forward, {}, 1238, (2, 22, 12, 20), 4323),
 ]
