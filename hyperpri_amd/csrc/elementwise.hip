@@ -552,3 +552,31 @@ extern "C" int hpri_mul(const float* a, int a_cs, int a_coff, const float* b, in
   HPRI_CHECK_LAUNCH();
   return HPRI_OK;
 }
+
+// element-granular slice copy for channel offsets / counts that are not multiples of 4 (SpectralUNET's
+// F = 1650 concat, models.py:139-143); channels [C, Cz) of the destination are zero-filled
+__global__ void copy_slice_any_kernel(const float* __restrict__ s, int s_cs, int s_coff, float* __restrict__ d, int d_cs,
+                                      int d_coff, long long P, int C, int Cz, int accumulate) {
+  const int per = Cz > C ? Cz : C;
+  const long long total = P * per;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long p = i / per;
+    const int c = (int)(i - p * per);
+    float* o = d + p * d_cs + d_coff + c;
+    if (c < C) {
+      const float v = s[p * s_cs + s_coff + c];
+      *o = accumulate ? *o + v : v;
+    } else if (!accumulate) {
+      *o = 0.f;
+    }
+  }
+}
+
+extern "C" int hpri_copy_slice_any(const float* src, int s_cs, int s_coff, float* dst, int d_cs, int d_coff, long long P,
+                                   int C, int Cz, int accumulate, hipStream_t stream) {
+  HPRI_REQUIRE(src && dst && P > 0 && C > 0 && C + s_coff <= s_cs && (Cz > C ? Cz : C) + d_coff <= d_cs, "copy_slice_any: bad arguments");
+  hipLaunchKernelGGL(copy_slice_any_kernel, dim3(ew_blocks(P * (Cz > C ? Cz : C))), dim3(256), 0, stream, src, s_cs, s_coff, dst,
+                     d_cs, d_coff, P, C, Cz, accumulate);
+  HPRI_CHECK_LAUNCH();
+  return HPRI_OK;
+}

@@ -471,23 +471,36 @@ def up_attention(tape: Tape, x1: Act, skip: Act, weight: Optional[torch.Tensor],
 
 
 def concat_channels(tape: Tape, a: Act, b: Act) -> Act:
-    """torch.cat((a, b), -1) of two per-pixel feature maps (SpectralUNET skip, models.py:139-143)."""
-    if a.C % 4:
-        raise RuntimeError("hyperpri_amd: concat: first operand's channel count must be a multiple of 4")
+    """torch.cat((a, b), -1) of two per-pixel feature maps (SpectralUNET skip, models.py:139-143).  When a.C is a
+    multiple of 4 both halves are 16-byte aligned channel slices (vector copies, gradient views); otherwise
+    (F = 1650) the second half lives at an unaligned offset and is moved by the element-granular copy."""
     dev = a.buf.device
     cat = Act.new(a.N, a.H, a.W, a.C + b.C, dev)
-    _lib.call("hpri_copy_slice", a.ptr, a.cs, a.coff, cat.ptr, cat.cs, cat.coff, cat.P, a.C, 0, _stream())
-    _lib.call("hpri_copy_slice", b.ptr, b.cs, b.coff, cat.ptr, cat.cs, cat.coff + a.C, cat.P, _rup(b.C, 4), 0, _stream())
-    tail = cat.cw - (a.C + _rup(b.C, 4))
-    if tail > 0:
-        _lib.call("hpri_fill_pad", cat.ptr, cat.cs, cat.coff + a.C + _rup(b.C, 4), cat.N, cat.H, cat.W, tail, 0, 0, 0, 0, _stream())
+    aligned = a.C % 4 == 0
+    if aligned:
+        _lib.call("hpri_copy_slice", a.ptr, a.cs, a.coff, cat.ptr, cat.cs, cat.coff, cat.P, a.C, 0, _stream())
+        _lib.call("hpri_copy_slice", b.ptr, b.cs, b.coff, cat.ptr, cat.cs, cat.coff + a.C, cat.P, _rup(b.C, 4), 0, _stream())
+        tail = cat.cw - (a.C + _rup(b.C, 4))
+        if tail > 0:
+            _lib.call("hpri_fill_pad", cat.ptr, cat.cs, cat.coff + a.C + _rup(b.C, 4), cat.N, cat.H, cat.W, tail, 0, 0, 0, 0, _stream())
+    else:
+        _lib.call("hpri_copy_slice_any", a.ptr, a.cs, a.coff, cat.ptr, cat.cs, cat.coff, cat.P, a.C, 0, 0, _stream())
+        _lib.call("hpri_copy_slice_any", b.ptr, b.cs, b.coff, cat.ptr, cat.cs, cat.coff + a.C, cat.P, b.C,
+                  cat.cw - a.C, 0, _stream())
     if tape.record:
         def bwd(tp: Tape) -> None:
             g = tp.grads.pop(id(cat), None)
             if g is None:
                 return
-            tp.set_grad_view(a, g.slice(0, a.C))
-            tp.set_grad_view(b, g.slice(a.C, b.C))
+            # first half: aligned view (its channels beyond a.C belong to the other half -- every consumer of a
+            # gradient view masks channels >= C)
+            tp.set_grad_view(a, Act(g.buf, g.N, g.H, g.W, a.C, g.cs, g.coff))
+            if aligned:
+                tp.set_grad_view(b, g.slice(a.C, b.C))
+            else:
+                gb, acc = tp.grad_slot(b)
+                _lib.call("hpri_copy_slice_any", g.ptr, g.cs, g.coff + a.C, gb.ptr, gb.cs, gb.coff, g.P, b.C,
+                          0 if acc else gb.cw, int(acc), _stream())
         tape.nodes.append(bwd)
     return cat
 

@@ -106,6 +106,8 @@ int hpri_maxpool2_bwd(const float* x, int x_cs, int x_coff, const float* dy, int
                       int dx_cs, int dx_coff, int N, int H, int W, int C, int accumulate, hipStream_t stream);
 int hpri_copy_slice(const float* src, int s_cs, int s_coff, float* dst, int d_cs, int d_coff, long long P, int C,
                     int accumulate, hipStream_t stream);
+int hpri_copy_slice_any(const float* src, int s_cs, int s_coff, float* dst, int d_cs, int d_coff, long long P, int C,
+                        int Cz, int accumulate, hipStream_t stream);
 int hpri_fill_pad(float* dst, int cs, int coff, int N, int H, int W, int C, int y0, int y1, int x0, int x1,
                   hipStream_t stream);
 int hpri_fill(float* dst, long long n, float value, hipStream_t stream);

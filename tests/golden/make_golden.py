@@ -164,6 +164,10 @@ def main():
     shp = net_fixture("net_spectral_f48", RM.SpectralUNET(22, 1, 48), u(1238, (2, 22, 12, 20)),
                       (u(4323, (2, 1, 12, 20)) > 0.7).float())
 
+    # F = 50 (not a multiple of 4, like the configured 1650): exercises the unaligned concat offset
+    net_fixture("net_spectral_f50", RM.SpectralUNET(22, 1, 50), u(1242, (2, 22, 9, 14)),
+                (u(4324, (2, 1, 9, 14)) > 0.7).float())
+
     # (iv) known answers --------------------------------------------------------------------
     def count(mod):
         ps = list(mod.parameters())

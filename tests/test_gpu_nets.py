@@ -34,6 +34,7 @@ def _mk(name):
         "net_cubenet64_bilinear_tiny": lambda: H.CubeNET(6, 1, first_depth=64, bilinear=True),
         "net_spectral_tiny": lambda: H.SpectralUNET(10, 1, 4),
         "net_spectral_f48": lambda: H.SpectralUNET(22, 1, 48),
+        "net_spectral_f50": lambda: H.SpectralUNET(22, 1, 50),
     }[name]()
 
 
@@ -41,7 +42,7 @@ CASES = [("net_unet3_tiny", 1234, (2, 3, 36, 50), 4321, 0.9), ("net_cubenet64_ti
          ("net_cubenet128_tiny", 1236, (2, 1, 6, 36, 50), 4321, 0.9),
          ("net_unet3_bilinear_tiny", 1239, (2, 3, 36, 50), 4321, 0.9), ("net_unet3_attn_tiny", 1240, (2, 3, 36, 50), 4321, 0.9),
          ("net_cubenet64_bilinear_tiny", 1241, (2, 1, 6, 36, 50), 4321, 0.9), ("net_spectral_tiny", 1237, (3, 10, 7, 9), 4322, 0.7),
-         ("net_spectral_f48", 1238, (2, 22, 12, 20), 4323, 0.7)]
+         ("net_spectral_f48", 1238, (2, 22, 12, 20), 4323, 0.7), ("net_spectral_f50", 1242, (2, 22, 9, 14), 4324, 0.7)]
 
 
 @pytest.mark.parametrize("name,xseed,xshape,mseed,thr", CASES, ids=[c[0] for c in CASES])

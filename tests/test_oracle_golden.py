@@ -97,6 +97,7 @@ NETS = [
     ("net_cubenet64_bilinear_tiny", lambda: O.cubenet_shapes(6, 1, 64, True), O.cubenet_forward, {"first_depth": 64, "bilinear": True}, 1241, (2, 1, 6, 36, 50), 4321),
     ("net_spectral_tiny", lambda: O.spectral_shapes(10, 1, 4), O.spectral_forward, {}, 1237, (3, 10, 7, 9), 4322),
     ("net_spectral_f48", lambda: O.spectral_shapes(22, 1, 48), O.spectral_forward, {}, 1238, (2, 22, 12, 20), 4323),
+    ("net_spectral_f50", lambda: O.spectral_shapes(22, 1, 50), O.spectral_forward, {}, 1242, (2, 22, 9, 14), 4324),
 ]
 
 
