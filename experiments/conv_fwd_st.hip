@@ -34,8 +34,6 @@ struct ConvFwdArgs {
   int tiles_x, tiles_y;
   int accumulate;        // y += result instead of y = result
   int H2, W2, py0, px0, Cup;  // S2D / D2S geometry: hi-res image dims, pad offsets, channels per tap
-  int ksplit;            // >1: blockIdx.z takes a slice of the K chunks and stores raw partial sums to ws
-  float* ws;             // [ksplit][N*H*W][Cout_pad] partial sums (split-K only)
 };
 
 template <int KS, int WM, int WN, int AMODE, int EPI>
@@ -60,6 +58,12 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvFwdArgs a) {
   const int y0 = ty * TH, x0 = tx * TW;
   const int nb = blockIdx.y;
 
+#ifdef HPRI_STAGGER_F
+  {
+    const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y;
+    if ((lin >> 8) & 1) { for (int i = 0; i < HPRI_STAGGER_F; ++i) __builtin_amdgcn_s_sleep(100); }
+  }
+#endif
   f32x16 acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -68,11 +72,8 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvFwdArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int nchunks_all = (a.Cin_pad + 31) >> 5;
-  const int cps = (nchunks_all + a.ksplit - 1) / a.ksplit;          // chunks per K split
-  const int chunk0 = blockIdx.z * cps;
-  const int nchunks = min(nchunks_all, chunk0 + cps);               // this block runs chunks [chunk0, nchunks)
-  const int S0 = chunk0 * T, S = nchunks * T;
+  const int nchunks = (a.Cin_pad + 31) >> 5;
+  const int S = nchunks * T;
   const float* wpanel = a.wp + (size_t)nb * BN;
 
   // ---- B panel prefetch registers (macros, not lambdas: keeps breg[] in VGPRs) ----
@@ -142,9 +143,9 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvFwdArgs a) {
                 acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mt][j], bf[nt][j], acc[mt][nt], 0, 0, 0); \
   }
 
-  LOAD_PANEL(S0)
-  LOAD_A(chunk0 * 32)
-  for (int s = S0; s < S; ++s) {
+  LOAD_PANEL(0)
+  LOAD_A(0)
+  for (int s = 0; s < S; ++s) {
     const int chunk = s / T, tap = s - chunk * T;
     if (tap == 0) {
       __syncthreads();                 // everyone is done reading the previous A chunk
@@ -168,25 +169,6 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvFwdArgs a) {
 #undef STORE_PANEL
 
   // ------------------------------- epilogue -------------------------------
-  if (a.ksplit > 1) {   // raw partial sums; bias, store and BN statistics happen in splitk_finish_kernel
-    float* wsz = a.ws + (size_t)blockIdx.z * ((size_t)a.N * a.H * a.W) * a.Cout_pad;
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-      const int iy = y0 + wm * 2 + mt;
-      if (iy >= a.H) continue;
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
-        const int n = nb * BN + wn * 64 + nt * 32 + li;
-        float* row = wsz + ((size_t)(img * a.H + iy) * a.W) * a.Cout_pad + n;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int ix = x0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          if (ix < a.W) row[(size_t)ix * a.Cout_pad] = acc[mt][nt][r];
-        }
-      }
-    }
-    return;
-  }
   // acc[mt][nt][r]: pixel row = wm*2+mt, pixel col = (r&3) + 8*(r>>2) + 4*lh, channel = nb*BN + wn*64 + nt*32 + li
   float bv[2];
 #pragma unroll
@@ -286,82 +268,13 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvFwdArgs a) {
   }
 }
 
-// Split-K epilogue: y = sum_z ws[z] + bias (fixed order), NHWC store (optionally accumulating), and per-block BN
-// partial statistics (mean, M2, count) over SK_PIX consecutive pixels of one image.
-// grid = (pixel blocks per image, ceil(Cw4 / CQ), N); block = 256 = ROWS x CQ channel quads.
-#define SK_PIX 256
-__global__ void splitk_finish_kernel(const float* __restrict__ ws, int ksplit, int Cout_pad, const float* __restrict__ bias,
-                                     float* __restrict__ y, int y_cs, int y_coff, float4* __restrict__ stats, int HW,
-                                     long long P, int Cout, int y_cw, int CQ, int accumulate) {
-  __shared__ float4 red[256];
-  const int rows = 256 / CQ;
-  const int cq = threadIdx.x % CQ, pr = threadIdx.x / CQ;
-  const int c = (blockIdx.y * CQ + cq) * 4;
-  const int img = blockIdx.z;
-  const int q0 = blockIdx.x * SK_PIX, q1 = min(HW, q0 + SK_PIX);
-  const float cnt = (float)(q1 - q0);
-  const bool live = c < y_cw;
-  float b[4] = {0.f, 0.f, 0.f, 0.f};
-  if (live && bias != nullptr) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) if (c + j < Cout) b[j] = bias[c + j];
-  }
-  float sum[4] = {0.f, 0.f, 0.f, 0.f};
-  if (live) {
-    for (int q = q0 + pr; q < q1; q += rows) {
-      const size_t p = (size_t)img * HW + q;
-      float v[4] = {b[0], b[1], b[2], b[3]};
-      for (int z = 0; z < ksplit; ++z) {
-        const float4 t = *reinterpret_cast<const float4*>(ws + ((size_t)z * P + p) * Cout_pad + c);
-        v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) if (c + j >= Cout) v[j] = 0.f;
-      float* o = y + p * y_cs + y_coff + c;
-      if (accumulate) { const float4 old = *reinterpret_cast<const float4*>(o); v[0] += old.x; v[1] += old.y; v[2] += old.z; v[3] += old.w; }
-      *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) sum[j] += v[j];
-    }
-  }
-  if (stats == nullptr) return;
-  red[threadIdx.x] = make_float4(sum[0], sum[1], sum[2], sum[3]);
-  __syncthreads();
-  float mean[4];
-  {
-    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int r = 0; r < rows; ++r) { const float4 u = red[r * CQ + cq]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
-    mean[0] = t.x / cnt; mean[1] = t.y / cnt; mean[2] = t.z / cnt; mean[3] = t.w / cnt;
-  }
-  __syncthreads();
-  float m2[4] = {0.f, 0.f, 0.f, 0.f};
-  if (live) {
-    for (int q = q0 + pr; q < q1; q += rows) {   // second pass re-reads what this thread just wrote
-      const float4 t = *reinterpret_cast<const float4*>(y + ((size_t)img * HW + q) * y_cs + y_coff + c);
-      const float d0 = t.x - mean[0], d1 = t.y - mean[1], d2 = t.z - mean[2], d3 = t.w - mean[3];
-      m2[0] += d0 * d0; m2[1] += d1 * d1; m2[2] += d2 * d2; m2[3] += d3 * d3;
-    }
-  }
-  red[threadIdx.x] = make_float4(m2[0], m2[1], m2[2], m2[3]);
-  __syncthreads();
-  if (pr == 0 && c < Cout_pad) {
-    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int r = 0; r < rows; ++r) { const float4 u = red[r * CQ + cq]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
-    float4* o = stats + ((size_t)img * gridDim.x + blockIdx.x) * Cout_pad + c;
-    o[0] = make_float4(mean[0], t.x, cnt, 0.f);
-    o[1] = make_float4(mean[1], t.y, cnt, 0.f);
-    o[2] = make_float4(mean[2], t.z, cnt, 0.f);
-    o[3] = make_float4(mean[3], t.w, cnt, 0.f);
-  }
-}
-
 template <int KS, int WM, int WN, int AMODE, int EPI>
 static int launch_conv(const ConvFwdArgs& a0, hipStream_t stream) {
   ConvFwdArgs a = a0;
   constexpr int TH = 2 * WM, BN = 64 * WN;
   a.tiles_x = hpri_cdiv(a.W, 32);
   a.tiles_y = hpri_cdiv(a.H, TH);
-  dim3 grid((unsigned)(a.N * a.tiles_y * a.tiles_x), (unsigned)(a.Cout_pad / BN), (unsigned)a.ksplit);
+  dim3 grid((unsigned)(a.N * a.tiles_y * a.tiles_x), (unsigned)(a.Cout_pad / BN));
   hipLaunchKernelGGL((conv_fwd_kernel<KS, WM, WN, AMODE, EPI>), grid, dim3(256), 0, stream, a);
   HPRI_CHECK_LAUNCH();
   return HPRI_OK;
@@ -372,46 +285,16 @@ static inline void conv_cfg(int Cout_pad, int* wm, int* wn) {
   if (Cout_pad % 128 == 0) { *wm = 2; *wn = 2; } else { *wm = 4; *wn = 1; }
 }
 
-// Split-K plan (host only).  A layer whose natural grid leaves CUs idle or badly balanced (38x60 and 76x121 levels)
-// is cut along K so that the number of equal-sized workgroups per CU is close to an integer.
-static inline int conv_ksplit(int N, int H, int W, int Cin_pad, int Cout_pad, int KS, int epi, int amode) {
-  if (epi != HPRI_E_DIRECT) return 1;
+extern "C" int hpri_conv_fwd_tiles(int N, int H, int W, int Cout_pad) {
   int wm, wn; conv_cfg(Cout_pad, &wm, &wn);
-  const long long blocks = (long long)N * hpri_cdiv(H, 2 * wm) * hpri_cdiv(W, 32) * (Cout_pad / (64 * wn));
-  const int nchunks = hpri_cdiv(Cin_pad, 32);
-  if (blocks >= 2048) return 1;                       // >= 8 workgroups per CU: balance is already fine
-  int best = 1; double best_eff = 0.0;
-  for (int k = 1; k <= 4; ++k) {
-    if (k > 1 && nchunks / k < 4) break;              // keep >= 4 chunks (128 channels x taps) per split
-    const double per_cu = (double)blocks * k / 256.0;
-    double eff = per_cu / (double)((long long)(per_cu + 0.999999));
-    if (k > 1) eff *= 0.97;                           // price of the extra partial-sum round trip
-    if (eff > best_eff + 1e-9) { best_eff = eff; best = k; }
-  }
-  return best;
-}
-
-extern "C" int hpri_conv_fwd_plan(int N, int H, int W, int Cin_pad, int Cout_pad, int KS, int amode, int epi,
-                                  int* ksplit, int* stat_tiles, size_t* ws_floats) {
-  const int k = conv_ksplit(N, H, W, Cin_pad, Cout_pad, KS, epi, amode);
-  *ksplit = k;
-  if (k > 1) {
-    *stat_tiles = N * hpri_cdiv(H * W, SK_PIX);
-    *ws_floats = (size_t)k * N * H * W * Cout_pad;
-  } else {
-    int wm, wn; conv_cfg(Cout_pad, &wm, &wn);
-    *stat_tiles = N * hpri_cdiv(H, 2 * wm) * hpri_cdiv(W, 32);
-    *ws_floats = 0;
-  }
-  return HPRI_OK;
+  return N * hpri_cdiv(H, 2 * wm) * hpri_cdiv(W, 32);
 }
 
 extern "C" int hpri_conv_fwd(const float* x, int x_cs, int x_coff, const float* wp, const float* bias,
                              float* y, int y_cs, int y_coff, float* stats,
                              int N, int H, int W, int Cin_pad, int Cout, int Cout_pad, int y_cw,
                              int KS, int amode, int epi, int accumulate,
-                             int H2, int W2, int py0, int px0, int Cup, float* ws, size_t ws_floats,
-                             hipStream_t stream) {
+                             int H2, int W2, int py0, int px0, int Cup, hipStream_t stream) {
   HPRI_REQUIRE(x && wp && y, "conv_fwd: null pointer");
   HPRI_REQUIRE(N > 0 && H > 0 && W > 0, "conv_fwd: empty image");
   HPRI_REQUIRE(Cin_pad > 0 && Cin_pad % 8 == 0, "conv_fwd: Cin_pad must be a positive multiple of 8");
@@ -425,14 +308,6 @@ extern "C" int hpri_conv_fwd(const float* x, int x_cs, int x_coff, const float* 
   a.N = N; a.H = H; a.W = W; a.Cin_pad = Cin_pad; a.Cout = Cout; a.Cout_pad = Cout_pad;
   a.y_cw = y_cw < Cout ? Cout : y_cw; a.tiles_x = a.tiles_y = 0; a.accumulate = accumulate;
   a.H2 = H2; a.W2 = W2; a.py0 = py0; a.px0 = px0; a.Cup = Cup;
-  a.ksplit = conv_ksplit(N, H, W, Cin_pad, Cout_pad, KS, epi, amode);
-  a.ws = ws;
-  if (a.ksplit > 1) {
-    if (ws == nullptr || (size_t)a.ksplit * N * H * W * Cout_pad > ws_floats)
-      return hpri_set_error(HPRI_ERR_WORKSPACE, "conv_fwd: split-K workspace too small (see hpri_conv_fwd_plan)");
-    a.stats = nullptr;       // statistics come from the finish kernel
-    a.accumulate = 0;
-  }
   if (epi == HPRI_E_DIRECT) {
     HPRI_REQUIRE(a.y_cw + y_coff <= y_cs, "conv_fwd: output channels exceed the channel stride");
   }
@@ -447,19 +322,10 @@ extern "C" int hpri_conv_fwd(const float* x, int x_cs, int x_coff, const float* 
   }
   int wm, wn; conv_cfg(Cout_pad, &wm, &wn);
 #define HPRI_DISPATCH(KS_, AM_, EP_)                                                        \
-  rc = (wm == 2) ? launch_conv<KS_, 2, 2, AM_, EP_>(a, stream) : launch_conv<KS_, 4, 1, AM_, EP_>(a, stream)
-  int rc;
+  return (wm == 2) ? launch_conv<KS_, 2, 2, AM_, EP_>(a, stream) : launch_conv<KS_, 4, 1, AM_, EP_>(a, stream)
   if (KS == 3) { HPRI_DISPATCH(3, HPRI_A_DIRECT, HPRI_E_DIRECT); }
-  else if (amode == HPRI_A_S2D) { HPRI_DISPATCH(1, HPRI_A_S2D, HPRI_E_DIRECT); }
-  else if (epi == HPRI_E_D2S) { HPRI_DISPATCH(1, HPRI_A_DIRECT, HPRI_E_D2S); }
-  else { HPRI_DISPATCH(1, HPRI_A_DIRECT, HPRI_E_DIRECT); }
+  if (amode == HPRI_A_S2D) { HPRI_DISPATCH(1, HPRI_A_S2D, HPRI_E_DIRECT); }
+  if (epi == HPRI_E_D2S) { HPRI_DISPATCH(1, HPRI_A_DIRECT, HPRI_E_D2S); }
+  HPRI_DISPATCH(1, HPRI_A_DIRECT, HPRI_E_DIRECT);
 #undef HPRI_DISPATCH
-  if (rc != HPRI_OK || a.ksplit == 1) return rc;
-  const int c4 = a.y_cw >> 2;
-  int cq = 1; while (cq < c4 && cq < 64) cq <<= 1;
-  dim3 grid((unsigned)hpri_cdiv(H * W, SK_PIX), (unsigned)hpri_cdiv(hpri_cdiv(a.y_cw, 4), cq), (unsigned)N);
-  hipLaunchKernelGGL(splitk_finish_kernel, grid, dim3(256), 0, stream, ws, a.ksplit, Cout_pad, bias, y, y_cs, y_coff,
-                     reinterpret_cast<float4*>(stats), H * W, (long long)N * H * W, Cout, a.y_cw, cq, accumulate);
-  HPRI_CHECK_LAUNCH();
-  return HPRI_OK;
 }

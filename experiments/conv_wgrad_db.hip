@@ -1,0 +1,271 @@
+// Weight-gradient GEMMs on the CDNA4 matrix cores, exact fp32 (v_mfma_f32_32x32x2_f32):
+//   dW[tap][c][n] = sum over pixels p of  X[p + off(tap)][c] * dY[p][n]
+// i.e. the K dimension of the GEMM is the pixel index.  Serves the 3x3 convs (model_parts.py:22,25;
+// models.py:169,177), Linear (models.py:108,143; KS=1) and ConvTranspose2d k2s2 (model_parts.py:63;
+// KS=1 with the dY operand gathered as 2x2 stride-2 patches, B_S2D).
+//
+// Work split: grid.y x grid.z tiles the (c, n) output, grid.x splits the pixel range ("split-K") into
+// contiguous runs of 2x32-pixel strips.  Every workgroup keeps its KS*KS x (c-tile x n-tile) output in
+// accumulators for its whole run and writes ONE partial slab; hpri_wgrad_reduce sums the slabs in a fixed
+// order (deterministic -- no float atomics) straight into the OIHW / (Cin,Cout,2,2) gradient tensor.
+//
+// Per strip the X halo ((2+KS-1) x (32+KS-1) pixels x BC channels) and the dY strip (64 pixels x BNW
+// channels) are staged in LDS as [pixel][channel]; MFMA lanes index the channel, so every ds_read_b32 is
+// 32 consecutive dwords (conflict-free) and the NHWC global loads are full 128-byte lines.
+#include "common.h"
+
+struct WgradArgs {
+  const float* x; int x_cs; int x_coff; int x_cvalid;   // conv input (NHWC), readable channels
+  const float* dy; int dy_cs; int dy_coff; int dy_cvalid; // gradient of the conv output
+  float* ws;             // [splits][T][Nr][Cr] partial slabs
+  int N, H, W;
+  int strips_x, strips_y, total_strips, strips_per_split;
+  int Cr, Nr;            // padded slab dims (gridDim.y*BC, gridDim.z*BNW)
+  int H2, W2, py0, px0, Cup;  // S2D geometry for dY (convT): hi-res dims, pad offsets, channels per tap
+};
+
+template <int KS, int CT, int NT, int BMODE>
+__global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(WgradArgs a) {
+  constexpr int T = KS * KS, PAD = KS / 2;
+  constexpr int SH = 2, SW = 32, HH = SH + KS - 1, HW = SW + KS - 1, HP = HH * HW;
+  constexpr int BC = 64 * CT, BNW = 64 * NT;
+  constexpr int NLD_X = (HP * (BC / 4) + 255) / 256;
+  constexpr int NLD_Y = (64 * (BNW / 4)) / 256;
+  constexpr int STAGE = HP * BC + 64 * BNW;
+  __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wc = wave >> 1, wn = wave & 1;
+  const int c_blk = blockIdx.y * BC, n_blk = blockIdx.z * BNW;
+
+  f32x16 acc[T][CT][NT];
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int i = 0; i < CT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][i][j][r] = 0.f;
+
+  const int s_begin = blockIdx.x * a.strips_per_split;
+  const int s_end = min(a.total_strips, s_begin + a.strips_per_split);
+
+  f32x4 xr[NLD_X], yr[NLD_Y];
+#define LOAD_STRIP(st_)                                                                               \
+  {                                                                                                   \
+    int q_ = (st_);                                                                                   \
+    const int sx = q_ % a.strips_x; q_ /= a.strips_x;                                                 \
+    const int sy = q_ % a.strips_y;                                                                   \
+    const int img = q_ / a.strips_y;                                                                  \
+    const int y0 = sy * SH, x0 = sx * SW;                                                             \
+    _Pragma("unroll") for (int p = 0; p < NLD_X; ++p) {                                               \
+      const int f = tid + p * 256;                                                                    \
+      const int pix = f / (BC / 4), c4 = f % (BC / 4);                                                \
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};                                                                 \
+      if (pix < HP) {                                                                                 \
+        const int hy = pix / HW, hx = pix - hy * HW;                                                  \
+        const int iy = y0 + hy - PAD, ix = x0 + hx - PAD;                                             \
+        const int c = c_blk + c4 * 4;                                                                 \
+        if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W && c < a.x_cvalid)                             \
+          v = *reinterpret_cast<const f32x4*>(a.x + ((size_t)(img * a.H + iy) * a.W + ix) * a.x_cs + a.x_coff + c); \
+      }                                                                                               \
+      xr[p] = v;                                                                                      \
+    }                                                                                                 \
+    _Pragma("unroll") for (int p = 0; p < NLD_Y; ++p) {                                               \
+      const int f = tid + p * 256;                                                                    \
+      const int pix = f / (BNW / 4), n4 = f % (BNW / 4);                                              \
+      const int iy = y0 + (pix >> 5), ix = x0 + (pix & 31);                                           \
+      const int n = n_blk + n4 * 4;                                                                   \
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};                                                                 \
+      if (iy < a.H && ix < a.W && n < a.dy_cvalid) {                                                  \
+        if (BMODE == HPRI_A_DIRECT) {                                                                 \
+          v = *reinterpret_cast<const f32x4*>(a.dy + ((size_t)(img * a.H + iy) * a.W + ix) * a.dy_cs + a.dy_coff + n); \
+        } else {                                                                                      \
+          const int tap = n / a.Cup, co = n - tap * a.Cup;                                            \
+          const int yy = 2 * iy + (tap >> 1) + a.py0, xx = 2 * ix + (tap & 1) + a.px0;                \
+          v = *reinterpret_cast<const f32x4*>(a.dy + ((size_t)(img * a.H2 + yy) * a.W2 + xx) * a.dy_cs + a.dy_coff + co); \
+        }                                                                                             \
+      }                                                                                               \
+      yr[p] = v;                                                                                      \
+    }                                                                                                 \
+  }
+#define STORE_STRIP(buf_)                                                                             \
+  {                                                                                                   \
+    float* xl = smem + (buf_) * STAGE;                                                                \
+    float* yl = xl + HP * BC;                                                                         \
+    _Pragma("unroll") for (int p = 0; p < NLD_X; ++p) {                                               \
+      const int f = tid + p * 256;                                                                    \
+      if (f < HP * (BC / 4)) *reinterpret_cast<f32x4*>(xl + f * 4) = xr[p];                           \
+    }                                                                                                 \
+    _Pragma("unroll") for (int p = 0; p < NLD_Y; ++p) {                                               \
+      const int f = tid + p * 256;                                                                    \
+      *reinterpret_cast<f32x4*>(yl + f * 4) = yr[p];                                                  \
+    }                                                                                                 \
+  }
+
+  if (s_begin < s_end) { LOAD_STRIP(s_begin) STORE_STRIP(0) }
+  __syncthreads();
+  for (int st = s_begin; st < s_end; ++st) {
+    const int buf = (st - s_begin) & 1;
+    if (st + 1 < s_end) LOAD_STRIP(st + 1)      // in flight during this strip's MFMAs
+    const float* x_lds = smem + buf * STAGE;
+    const float* y_lds = x_lds + HP * BC;
+    const float* xb = x_lds + lh * BC + wc * (CT * 32) + li;
+    const float* yb = y_lds + lh * BNW + wn * (NT * 32) + li;
+#pragma unroll
+    for (int py = 0; py < SH; ++py) {
+#pragma unroll 4
+      for (int kx = 0; kx < 16; ++kx) {
+        float bf[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) bf[j] = yb[(py * 32 + 2 * kx) * BNW + j * 32];
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+          const int dy = t / KS, dx = t - dy * KS;
+          float af[CT];
+#pragma unroll
+          for (int i = 0; i < CT; ++i) af[i] = xb[((py + dy) * HW + 2 * kx + dx) * BC + i * 32];
+#pragma unroll
+          for (int i = 0; i < CT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+              acc[t][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[j], af[i], acc[t][i][j], 0, 0, 0);
+        }
+      }
+    }
+    if (st + 1 < s_end) STORE_STRIP(buf ^ 1)     // the other stage was last read one iteration ago (barrier below)
+    __syncthreads();
+  }
+#undef LOAD_STRIP
+#undef STORE_STRIP
+
+  // partial slab: ws[split][t][n][c]; MFMA rows = n (A operand = dY), cols = c (B operand = X) so that
+  // lanes store consecutive c -- the order the reduce kernel and the OIHW gradient want
+  float* slab = a.ws + (size_t)blockIdx.x * T * a.Cr * a.Nr;
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int i = 0; i < CT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int c = c_blk + wc * (CT * 32) + i * 32 + li;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int n = n_blk + wn * (NT * 32) + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          slab[((size_t)t * a.Nr + n) * a.Cr + c] = acc[t][i][j][r];
+        }
+      }
+}
+
+// Fixed-order reduction of the partial slabs into the parameter gradient.
+//   block = 32 c-lanes x 32 split-slices (1024 threads); one block per (n, 32-channel tile); every thread keeps the
+//   T taps of its (n, c) in registers, the slices are combined through LDS in slice order (deterministic), and
+//   the block's 32*T results -- contiguous in OIHW -- are written coalesced.
+// dst modes: 0 = conv weight OIHW dW[n][c][t];  1 = convT weight dW[c][co][tap] with n = tap*Cup + co (T == 1)
+template <int T>
+__global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int splits,
+                                                            int Cr, int Nr, int Cin, int Cout, int mode, int Cup,
+                                                            int accumulate) {
+  __shared__ float red[32][32 * T + 1];
+  const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int n = blockIdx.y, c = blockIdx.x * 32 + cl;
+  const size_t slab = (size_t)T * Cr * Nr;
+  float acc[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) acc[t] = 0.f;
+  if (c < Cin) {
+    const float* p = ws + (size_t)n * Cr + c;
+    for (int k = sl; k < splits; k += 32) {
+#pragma unroll
+      for (int t = 0; t < T; ++t) acc[t] += p[(size_t)k * slab + (size_t)t * Nr * Cr];
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < T; ++t) red[sl][cl * T + t] = acc[t];
+  __syncthreads();
+  // 32*T outputs per block: thread o sums the 32 slices of output o = cl*T + t
+  for (int o = threadIdx.x; o < 32 * T; o += 1024) {
+    float s = 0.f;
+#pragma unroll 8
+    for (int k = 0; k < 32; ++k) s += red[k][o];
+    const int cc = blockIdx.x * 32 + o / T, t = o % T;
+    if (cc < Cin) {
+      size_t off;
+      if (mode == 0) off = ((size_t)n * Cin + cc) * T + t;
+      else { const int tap = n / Cup, co = n - tap * Cup; off = ((size_t)cc * Cup + co) * 4 + tap; }
+      dw[off] = accumulate ? dw[off] + s : s;
+    }
+  }
+}
+
+static inline void wgrad_cfg(int KS, int* bc, int* bn) {
+  if (KS == 3) { *bc = 64; *bn = 64; } else { *bc = 128; *bn = 128; }
+}
+
+// Number of pixel splits for a given problem; the caller sizes the workspace as
+// splits * KS*KS * Cr * Nr floats (hpri_wgrad_workspace).
+extern "C" int hpri_wgrad_plan(int N, int H, int W, int Cin_pad, int Cout_pad, int KS,
+                               int* splits, int* Cr, int* Nr) {
+  int bc, bn; wgrad_cfg(KS, &bc, &bn);
+  const int cblk = hpri_cdiv(Cin_pad, bc), nblk = hpri_cdiv(Cout_pad, bn);
+  const int total = N * hpri_cdiv(H, 2) * hpri_cdiv(W, 32);
+  int s = hpri_cdiv(512, cblk * nblk);           // one round of 256 CUs x 2 resident workgroups
+  if (s > total) s = total;
+  if (s < 1) s = 1;
+  const int per = hpri_cdiv(total, s);
+  s = hpri_cdiv(total, per);
+  *splits = s; *Cr = cblk * bc; *Nr = nblk * bn;
+  return HPRI_OK;
+}
+
+extern "C" int hpri_conv_wgrad(const float* x, int x_cs, int x_coff, int x_cvalid,
+                               const float* dy, int dy_cs, int dy_coff, int dy_cvalid,
+                               float* ws, size_t ws_floats,
+                               int N, int H, int W, int Cin_pad, int Cout_pad,
+                               int KS, int bmode,
+                               int H2, int W2, int py0, int px0, int Cup, hipStream_t stream) {
+  HPRI_REQUIRE(x && dy && ws, "conv_wgrad: null pointer");
+  HPRI_REQUIRE(KS == 1 || KS == 3, "conv_wgrad: kernel size must be 1 or 3");
+  HPRI_REQUIRE(x_cs % 4 == 0 && x_coff % 4 == 0 && dy_cs % 4 == 0 && dy_coff % 4 == 0 && x_cvalid % 4 == 0 && dy_cvalid % 4 == 0,
+               "conv_wgrad: channel strides/offsets/valid counts must be multiples of 4");
+  HPRI_REQUIRE(N > 0 && H > 0 && W > 0 && Cin_pad > 0 && Cout_pad > 0, "conv_wgrad: empty problem");
+  if (bmode == HPRI_A_S2D) {
+    HPRI_REQUIRE(KS == 1 && Cup > 0 && Cup % 4 == 0, "conv_wgrad: S2D needs KS==1 and Cup % 4 == 0");
+    HPRI_REQUIRE(py0 >= 0 && px0 >= 0 && 2 * H + py0 <= H2 && 2 * W + px0 <= W2, "conv_wgrad: patch grid exceeds the hi-res image");
+  }
+  WgradArgs a;
+  a.x = x; a.x_cs = x_cs; a.x_coff = x_coff; a.x_cvalid = x_cvalid;
+  a.dy = dy; a.dy_cs = dy_cs; a.dy_coff = dy_coff; a.dy_cvalid = dy_cvalid;
+  a.ws = ws; a.N = N; a.H = H; a.W = W;
+  a.strips_x = hpri_cdiv(W, 32); a.strips_y = hpri_cdiv(H, 2);
+  a.total_strips = N * a.strips_x * a.strips_y;
+  int splits, Cr, Nr;
+  hpri_wgrad_plan(N, H, W, Cin_pad, Cout_pad, KS, &splits, &Cr, &Nr);
+  a.strips_per_split = hpri_cdiv(a.total_strips, splits);
+  a.Cr = Cr; a.Nr = Nr; a.H2 = H2; a.W2 = W2; a.py0 = py0; a.px0 = px0; a.Cup = Cup;
+  const int T = KS * KS;
+  if ((size_t)splits * T * Cr * Nr > ws_floats) return hpri_set_error(HPRI_ERR_WORKSPACE, "conv_wgrad: workspace too small");
+  int bc, bn; wgrad_cfg(KS, &bc, &bn);
+  dim3 grid((unsigned)splits, (unsigned)(Cr / bc), (unsigned)(Nr / bn));
+  if (KS == 3) hipLaunchKernelGGL((conv_wgrad_kernel<3, 1, 1, HPRI_A_DIRECT>), grid, dim3(256), 0, stream, a);
+  else if (bmode == HPRI_A_S2D) hipLaunchKernelGGL((conv_wgrad_kernel<1, 2, 2, HPRI_A_S2D>), grid, dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL((conv_wgrad_kernel<1, 2, 2, HPRI_A_DIRECT>), grid, dim3(256), 0, stream, a);
+  HPRI_CHECK_LAUNCH();
+  return HPRI_OK;
+}
+
+// Fixed-order sum of the partial slabs written by hpri_conv_wgrad into the parameter-gradient tensor.
+extern "C" int hpri_wgrad_reduce(const float* ws, float* dw, int N, int H, int W, int Cin, int Cin_pad, int Cout,
+                                 int Cout_pad, int KS, int dst_mode, int Cup, int accumulate, hipStream_t stream) {
+  HPRI_REQUIRE(ws && dw && Cin > 0 && Cout > 0, "wgrad_reduce: bad arguments");
+  if (dst_mode == 1) HPRI_REQUIRE(Cup > 0 && Cout == 4 * Cup, "wgrad_reduce: convT layout needs Cout == 4*Cup");
+  int splits, Cr, Nr;
+  hpri_wgrad_plan(N, H, W, Cin_pad, Cout_pad, KS, &splits, &Cr, &Nr);
+  dim3 grid((unsigned)hpri_cdiv(Cin, 32), (unsigned)Cout);
+  if (KS == 3) hipLaunchKernelGGL((wgrad_reduce_kernel<9>), grid, dim3(1024), 0, stream, ws, dw, splits, Cr, Nr, Cin, Cout, dst_mode, Cup, accumulate);
+  else hipLaunchKernelGGL((wgrad_reduce_kernel<1>), grid, dim3(1024), 0, stream, ws, dw, splits, Cr, Nr, Cin, Cout, dst_mode, Cup, accumulate);
+  HPRI_CHECK_LAUNCH();
+  return HPRI_OK;
+}

@@ -220,12 +220,17 @@ def _conv_launch(x: Act, wp: torch.Tensor, bias: Optional[torch.Tensor], y: Act,
                  N: int, H: int, W: int, cin_pad: int, cout: int, cout_pad: int, y_cw: int, ks: int,
                  amode: int = A_DIRECT, epi: int = E_DIRECT, accumulate: int = 0,
                  H2: int = 0, W2: int = 0, py0: int = 0, px0: int = 0, cup: int = 0, cin_true: int = 0) -> None:
+    ksplit = ctypes.c_int(); tiles = ctypes.c_int(); wsf = ctypes.c_size_t()
+    _lib.call("hpri_conv_fwd_plan", N, H, W, cin_pad, cout_pad, ks, amode, epi, ctypes.byref(ksplit), ctypes.byref(tiles),
+              ctypes.byref(wsf))
+    ws = _ws(wsf.value, x.buf.device) if wsf.value else None
     tag = f"conv_fwd<{ks},{'2x2' if cout_pad % 128 == 0 else '4x1'},{'s2d' if amode else 'direct'},{'d2s' if epi else 'direct'}>"
     if SHAPE_TAGS:
         tag += f" N{N} {H}x{W} K{cin_pad} N{cout}"
     with _timed(tag, 2.0 * N * H * W * (cin_true or cin_pad) * cout * ks * ks):
         _lib.call("hpri_conv_fwd", x.ptr, x.cs, x.coff, _p(wp), _p(bias), y.ptr, y.cs, y.coff, _p(stats),
-                  N, H, W, cin_pad, cout, cout_pad, y_cw, ks, amode, epi, accumulate, H2, W2, py0, px0, cup, _stream())
+                  N, H, W, cin_pad, cout, cout_pad, y_cw, ks, amode, epi, accumulate, H2, W2, py0, px0, cup,
+                  _p(ws), wsf.value, _stream())
 
 
 # --------------------------------------------------------------------------------------------------
@@ -249,7 +254,10 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
     stats = None
     tiles = 0
     if use_batch:
-        tiles = _lib.load().hpri_conv_fwd_tiles(x.N, x.H, x.W, cout_pad)
+        ksp = ctypes.c_int(); tl = ctypes.c_int(); wsf = ctypes.c_size_t()
+        _lib.call("hpri_conv_fwd_plan", x.N, x.H, x.W, cin_pad, cout_pad, ks, A_DIRECT, E_DIRECT, ctypes.byref(ksp),
+                  ctypes.byref(tl), ctypes.byref(wsf))
+        tiles = tl.value
         stats = torch.empty(tiles * cout_pad * 4, dtype=torch.float32, device=dev)
     _conv_launch(x, wp, bias, yr, stats, x.N, x.H, x.W, cin_pad, cout, cout_pad, yr.cw, ks, cin_true=cin)
     del wp

@@ -53,13 +53,15 @@ int hpri_pack_weight(const float* w, float* wp, int mode, int K, int Ncols, int 
 
 /* ---- implicit-GEMM convolution, fp32 MFMA (conv_fwd.hip) ----------------------------------------
  * Replaces F.conv2d / F.conv3d / F.linear / F.conv_transpose2d forward and their data gradients
- * (model_parts.py:22,25,63,96; models.py:108,169,177,198).  stats (optional) receives per-tile
- * BatchNorm partials: hpri_conv_fwd_tiles(...) * Cout_pad float4 (mean, M2, count, 0). */
-int hpri_conv_fwd_tiles(int N, int H, int W, int Cout_pad);
+ * (model_parts.py:22,25,63,96; models.py:108,169,177,198).  hpri_conv_fwd_plan (host only) returns the split-K
+ * factor chosen for the shape, the workspace it needs, and the number of BatchNorm partial records: stats
+ * (optional) receives stat_tiles * Cout_pad float4 (mean, M2, count, 0), image-major. */
+int hpri_conv_fwd_plan(int N, int H, int W, int Cin_pad, int Cout_pad, int KS, int amode, int epi, int* ksplit,
+                       int* stat_tiles, size_t* ws_floats);
 int hpri_conv_fwd(const float* x, int x_cs, int x_coff, const float* wp, const float* bias, float* y, int y_cs,
                   int y_coff, float* stats, int N, int H, int W, int Cin_pad, int Cout, int Cout_pad, int y_cw,
-                  int KS, int amode, int epi, int accumulate, int H2, int W2, int py0, int px0, int Cup,
-                  hipStream_t stream);
+                  int KS, int amode, int epi, int accumulate, int H2, int W2, int py0, int px0, int Cup, float* ws,
+                  size_t ws_floats, hipStream_t stream);
 
 /* ---- weight gradients, fp32 MFMA, deterministic split-K (conv_wgrad.hip) --------------------------
  * Replaces the wgrad half of autograd for the same layers.  dst_mode 0 writes OIHW / (out,in),

@@ -24,7 +24,7 @@ def test_bad_arguments_are_rejected_without_launch():
     from hyperpri_amd import _lib
     lib = _lib.load()
     null = ctypes.c_void_p(0)
-    rc = lib.hpri_conv_fwd(null, 8, 0, null, null, null, 8, 0, null, 1, 4, 4, 8, 8, 64, 8, 3, 0, 0, 0, 0, 0, 0, 0, 0, null)
+    rc = lib.hpri_conv_fwd(null, 8, 0, null, null, null, 8, 0, null, 1, 4, 4, 8, 8, 64, 8, 3, 0, 0, 0, 0, 0, 0, 0, 0, null, 0, null)
     assert rc == -1 and b"null" in lib.hpri_last_error()
     rc = lib.hpri_maxpool2_fwd(null, 8, 0, null, 8, 0, 1, 4, 4, 8, null)
     assert rc == -1
@@ -38,7 +38,11 @@ def test_plans_are_pure_host_functions():
     s, cr, nr = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
     assert lib.hpri_wgrad_plan(2, 608, 968, 64, 64, 3, ctypes.byref(s), ctypes.byref(cr), ctypes.byref(nr)) == 0
     assert s.value >= 1 and cr.value == 64 and nr.value == 64
-    assert lib.hpri_conv_fwd_tiles(2, 608, 968, 64) == 2 * 76 * 31
+    k, t, w = ctypes.c_int(), ctypes.c_int(), ctypes.c_size_t()
+    assert lib.hpri_conv_fwd_plan(2, 608, 968, 64, 64, 3, 0, 0, ctypes.byref(k), ctypes.byref(t), ctypes.byref(w)) == 0
+    assert (k.value, t.value, w.value) == (1, 2 * 76 * 31, 0)
+    assert lib.hpri_conv_fwd_plan(2, 38, 60, 1024, 1024, 3, 0, 0, ctypes.byref(k), ctypes.byref(t), ctypes.byref(w)) == 0
+    assert k.value > 1 and t.value == 2 * 9 and w.value == k.value * 2 * 38 * 60 * 1024
     assert lib.hpri_packed_weight_floats(238, 64, 9) == 8 * 9 * 32 * 64
 
 
