@@ -13,7 +13,7 @@ from typing import Callable, List, Sequence
 
 import torch
 
-from .engine import Act, Tape, _require_cuda
+from .engine import Act, Tape, _require_cuda, join_side
 
 
 def _as4d(t: torch.Tensor) -> torch.Tensor:
@@ -61,6 +61,8 @@ class _HipFn(torch.autograd.Function):
         else:
             ctx.holder["g"] = gout
         tape.backward()
+        if tape.used_side:
+            join_side(gout.device)          # weight gradients issued on the side stream
         need = ctx.needs_input_grad[3:]
         res = []
         for i, a in enumerate(ctx.acts):

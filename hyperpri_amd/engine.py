@@ -112,6 +112,7 @@ class Tape:
         self.grads: Dict[int, Act] = {}
         self.param_grads: Dict[int, torch.Tensor] = {}
         self.keep: List[object] = []
+        self.used_side = False
 
     def grad_slot(self, a: Act) -> Tuple[Act, bool]:
         """(gradient view for ``a``, accumulate?) -- allocates a fresh buffer the first time."""
@@ -202,6 +203,28 @@ def event_log_summary():
         out[tag] = {"launches": len(evs), "total_ms": tot, "avg_ms": tot / len(evs), "flops_per_launch": fl / len(evs),
                     "tflops": fl / (tot * 1e-3) / 1e12 if tot > 0 else 0.0}
     return out
+
+
+# ---- side stream: weight gradients run beside the data gradient of the same layer -------------------------
+# The two GEMMs of a conv's backward are independent; issuing wgrad on a second HIP stream lets its workgroups
+# fill the CUs the dgrad kernel's tail leaves idle (and vice versa).  Joined before gradients leave the node.
+SIDE_STREAM = False   # measured on MI355X: no gain for this workload (58.3 vs 57.8 ms/step); kept as an opt-in
+_side_streams: Dict[int, "torch.cuda.Stream"] = {}
+
+
+def _side(device) -> "torch.cuda.Stream":
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    st = _side_streams.get(idx)
+    if st is None:
+        st = _side_streams[idx] = torch.cuda.Stream(device=device)
+    return st
+
+
+def join_side(device) -> None:
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    st = _side_streams.get(idx)
+    if st is not None:
+        torch.cuda.current_stream(device).wait_stream(st)
 
 
 def _ws(nfloats: int, device) -> torch.Tensor:
@@ -308,7 +331,16 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
                 ws = _ws(nblk.value * 2 * cpart.value + 2 * cout, dev)
                 _lib.call("hpri_col_sum", dyr.ptr, dyr.cs, dyr.coff, _p(db), acc_b, _p(ws), ws.numel(), x.P, cout, _stream())
         dw, acc_w = tp.param_slot(weight)
-        _wgrad(x, dyr, dw, acc_w, cin, cout, ks)
+        if SIDE_STREAM and need_dx and _EVENT_LOG is None:
+            main, side = torch.cuda.current_stream(dev), _side(dev)
+            side.wait_stream(main)                      # dyr (and everything before it) is ready
+            with torch.cuda.stream(side):
+                _wgrad(x, dyr, dw, acc_w, cin, cout, ks)
+            for t in (x.buf, dyr.buf, dw):               # keep the caching allocator from recycling them early
+                t.record_stream(side)
+            tp.used_side = True
+        else:
+            _wgrad(x, dyr, dw, acc_w, cin, cout, ks)
         if need_dx:
             wpd, cin_cols_pad = _pack(weight, 1, cout, cin, T, 0, cin)
             gx, acc = tp.grad_slot(x)

@@ -10,7 +10,8 @@ import torch  # noqa: E402
 
 from hyperpri_amd import _lib  # noqa: E402
 
-SHAPES = [  # N, H, W, Cin, Cout, ks
+import json
+SHAPES = json.loads(os.environ["SHAPES"]) if "SHAPES" in os.environ else [  # N, H, W, Cin, Cout, ks
     (2, 304, 484, 128, 128, 3),
     (2, 608, 968, 64, 64, 3),
     (2, 76, 121, 512, 512, 3),
@@ -48,7 +49,7 @@ def main():
             stats = torch.empty((N * ((H + 3) // 4) * ((W + 31) // 32) + 64) * cout_pad * 4, device=dev)
             s, cr, nr = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
             lib.hpri_wgrad_plan(N, H, W, Cin, cout_pad, ks, ctypes.byref(s), ctypes.byref(cr), ctypes.byref(nr))
-            ws = torch.empty(s.value * ks * ks * cr.value * nr.value, device=dev)
+            ws = torch.empty(max(s.value * ks * ks * cr.value * nr.value, 4 * N * H * W * cout_pad), device=dev)
             preps.append((wp, stats, ws))
         for rnd in range(5):
             for (name, lib), (wp, stats, ws) in zip(libs, preps):
@@ -58,7 +59,7 @@ def main():
                 for _ in range(reps):
                     if mode == "fwd":
                         rc = lib.hpri_conv_fwd(P(x), Cin, 0, P(wp), P(b), P(y), Cout, 0, P(stats), N, H, W, Cin, Cout, cout_pad,
-                                               Cout, ks, 0, 0, 0, 0, 0, 0, 0, 0, st)
+                                               Cout, ks, 0, 0, 0, 0, 0, 0, 0, 0, P(ws), ws.numel(), st)
                     else:
                         rc = lib.hpri_conv_wgrad(P(x), Cin, 0, Cin, P(y), Cout, 0, Cout, P(ws), ws.numel(), N, H, W, Cin, cout_pad,
                                                  ks, 0, 0, 0, 0, 0, 0, st)
