@@ -20,45 +20,65 @@
 // partial statistics (mean, M2, count) for the training-mode BN that follows every conv in the model.
 #include "common.h"
 
+#define HPRI_MAXSEG 4
 struct ConvFwdArgs {
   const float* x; int x_cs; int x_coff;
   const float* wp;       // packed weights [chunks][T][32][Cout_pad]
   const float* bias;     // [Cout] or nullptr
   float* y; int y_cs; int y_coff;
-  float4* stats;         // [N*tiles_y*tiles_x][Cout_pad] (mean, M2, count, 0) or nullptr
+  float4* stats;         // [N*tiles_img][Cout_pad] (mean, M2, count, 0) or nullptr
   int N, H, W;           // GEMM-M image: output pixels (DIRECT) / low-res pixels (S2D, D2S)
   int Cin_pad;           // K per tap, multiple of 8 (for S2D: 4*Cup)
   int Cout;              // valid output channels (for D2S: 4*Cup)
   int Cout_pad;          // multiple of BN
   int y_cw;              // channels written (>= Cout; extra ones get zeros)
-  int tiles_x, tiles_y;
   int accumulate;        // y += result instead of y = result
   int H2, W2, py0, px0, Cup;  // S2D / D2S geometry: hi-res image dims, pad offsets, channels per tap
   int ksplit;            // >1: blockIdx.z takes a slice of the K chunks and stores raw partial sums to ws
   float* ws;             // [ksplit][N*H*W][Cout_pad] partial sums (split-K only)
+  // Tile segments: the image width is cut into column bands of tile width 32, 16, 8 or 4 (tile height grows as the
+  // width shrinks, pixels per tile stay constant) so that W = 484 / 242 / 121 does not round up to 512 / 256 / 128.
+  int nseg, tiles_img;
+  int seg_twl[HPRI_MAXSEG];    // log2(tile width)
+  int seg_xbeg[HPRI_MAXSEG];   // first column of the band
+  int seg_ntx[HPRI_MAXSEG];    // tiles per row of the band
+  int seg_first[HPRI_MAXSEG];  // index (within one image) of the band's first tile
 };
 
 template <int KS, int WM, int WN, int AMODE, int EPI>
 __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvFwdArgs a) {
   constexpr int T = KS * KS, PAD = KS / 2;
-  constexpr int TH = 2 * WM, TW = 32, HH = TH + KS - 1, HW = TW + KS - 1, HP = HH * HW;
+  constexpr int TPIX = 64 * WM;                  // output pixels per tile
+  // largest staged halo over the tile kinds this configuration may use (WM=2: widths 32..4, WM=4: 32..8)
+  constexpr int MAXHP = (KS == 1) ? TPIX : (WM == 2 ? 6 * 34 : 10 * 34);
   constexpr int BN = 64 * WN;
   constexpr int CS = 36;                         // dwords per staged pixel (32 channels + 4 pad)
-  constexpr int NLD_A = (HP * 8 + 255) / 256;    // float4 loads per thread per A chunk
+  constexpr int NLD_A = (MAXHP * 8 + 255) / 256; // float4 loads per thread per A chunk
   constexpr int NLD_B = (32 * BN / 4) / 256;     // float4 loads per thread per B panel
-  __shared__ __attribute__((aligned(16))) float smem[HP * CS + 2 * 32 * BN];
+  __shared__ __attribute__((aligned(16))) float smem[MAXHP * CS + 2 * 32 * BN];
   float* a_lds = smem;
-  float* b_lds = smem + HP * CS;
+  float* b_lds = smem + MAXHP * CS;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
   const int wm = wave / WN, wn = wave % WN;
-  int tile = blockIdx.x;
-  const int tx = tile % a.tiles_x; tile /= a.tiles_x;
-  const int ty = tile % a.tiles_y;
-  const int img = tile / a.tiles_y;
-  const int y0 = ty * TH, x0 = tx * TW;
   const int nb = blockIdx.y;
+
+  // ---- which tile: image, column band (tile kind), position ----
+  const int img = blockIdx.x / a.tiles_img;
+  const int tin = blockIdx.x - img * a.tiles_img;
+  int seg = 0;
+#pragma unroll
+  for (int k = 1; k < HPRI_MAXSEG; ++k)
+    if (k < a.nseg && tin >= a.seg_first[k]) seg = k;
+  const int twl = a.seg_twl[seg];                // log2 tile width
+  const int TW = 1 << twl, RW = 32 >> twl;       // an MFMA M-tile (32 pixels) is RW rows x TW columns
+  const int TH = 2 * WM * RW;                    // tile rows (each wave: 2 M-tiles stacked)
+  const int HW = TW + KS - 1, HP = (TH + KS - 1) * HW;
+  const int tt = tin - a.seg_first[seg];
+  const int ty = tt / a.seg_ntx[seg], tx = tt - ty * a.seg_ntx[seg];
+  const int y0 = ty * TH, x0 = a.seg_xbeg[seg] + tx * TW;
+  const int xlim = min(a.W, a.seg_xbeg[seg] + a.seg_ntx[seg] * TW);   // columns >= xlim belong to the next band
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -73,46 +93,64 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvFwdArgs a) {
   const int chunk0 = blockIdx.z * cps;
   const int nchunks = min(nchunks_all, chunk0 + cps);               // this block runs chunks [chunk0, nchunks)
   const int S0 = chunk0 * T, S = nchunks * T;
-  const float* wpanel = a.wp + (size_t)nb * BN;
 
-  // ---- B panel prefetch registers (macros, not lambdas: keeps breg[] in VGPRs) ----
+  // ---- B panels: per-thread offsets computed once; per panel only the panel base moves ----
+  const float* wpanel = a.wp + (size_t)nb * BN;
+  int boff[NLD_B], blds[NLD_B];
+#pragma unroll
+  for (int p = 0; p < NLD_B; ++p) {
+    const int f = tid + p * 256;
+    const int row = f / (BN / 4), c4 = f % (BN / 4);
+    boff[p] = row * a.Cout_pad + c4 * 4;
+    blds[p] = row * BN + c4 * 4;
+  }
   f32x4 breg[NLD_B];
 #define LOAD_PANEL(s_)                                                                              \
-  _Pragma("unroll") for (int p = 0; p < NLD_B; ++p) {                                               \
-    const int f = tid + p * 256;                                                                    \
-    const int row = f / (BN / 4), c4 = f % (BN / 4);                                                \
-    breg[p] = *reinterpret_cast<const f32x4*>(wpanel + ((size_t)(s_) * 32 + row) * a.Cout_pad + c4 * 4); \
+  {                                                                                                 \
+    const float* pb_ = wpanel + (size_t)(s_) * 32 * a.Cout_pad;                                     \
+    _Pragma("unroll") for (int p = 0; p < NLD_B; ++p)                                               \
+        breg[p] = *reinterpret_cast<const f32x4*>(pb_ + boff[p]);                                   \
   }
 #define STORE_PANEL(buf_)                                                                           \
-  _Pragma("unroll") for (int p = 0; p < NLD_B; ++p) {                                               \
-    const int f = tid + p * 256;                                                                    \
-    const int row = f / (BN / 4), c4 = f % (BN / 4);                                                \
-    *reinterpret_cast<f32x4*>(b_lds + (buf_) * 32 * BN + row * BN + c4 * 4) = breg[p];             \
-  }
+  _Pragma("unroll") for (int p = 0; p < NLD_B; ++p)                                                 \
+      *reinterpret_cast<f32x4*>(b_lds + (buf_) * 32 * BN + blds[p]) = breg[p];
 
-  // ---- A halo chunk: global -> registers (prefetched one chunk ahead) -> LDS ----
+  // ---- A halo: per-thread global offsets (element units, < 2^31) computed ONCE per tile; -1 = zero fill ----
+  // slot f = tid + p*256 -> halo pixel f>>3, 16-byte quad f&7 of the 32-channel chunk
+  int aoff[NLD_A];
+  {
+    const unsigned hw_inv = (65536u + (unsigned)HW - 1u) / (unsigned)HW;   // exact for pix < 2048
+#pragma unroll
+    for (int p = 0; p < NLD_A; ++p) {
+      const int f = tid + p * 256;
+      const int pix = f >> 3, q = f & 7;
+      int off = -1;
+      if (pix < HP) {
+        const int hy = (int)(((unsigned)pix * hw_inv) >> 16), hx = pix - hy * HW;
+        const int iy = y0 + hy - PAD, ix = x0 + hx - PAD;
+        if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) {
+          if (AMODE == HPRI_A_DIRECT) off = ((img * a.H + iy) * a.W + ix) * a.x_cs + a.x_coff + q * 4;
+          else off = ((img * a.H2 + 2 * iy + a.py0) * a.W2 + 2 * ix + a.px0) * a.x_cs + a.x_coff;  // + tap/chan below
+        }
+      }
+      aoff[p] = off;
+    }
+  }
   f32x4 areg[NLD_A];
 #define LOAD_A(c0_)                                                                                   \
   {                                                                                                   \
     const int kq = min(8, (a.Cin_pad - (c0_)) >> 2); /* valid float4 per pixel in this chunk */       \
     _Pragma("unroll") for (int p = 0; p < NLD_A; ++p) {                                               \
-      const int f = tid + p * 256;                                                                    \
-      const int pix = f >> 3, q = f & 7;                                                              \
+      const int q = (tid + p * 256) & 7;                                                              \
       f32x4 v = {0.f, 0.f, 0.f, 0.f};                                                                 \
-      if (pix < HP && q < kq) {                                                                       \
-        const int hy = pix / HW, hx = pix - hy * HW;                                                  \
-        const int iy = y0 + hy - PAD, ix = x0 + hx - PAD;                                             \
-        if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) {                                             \
-          if (AMODE == HPRI_A_DIRECT) {                                                               \
-            v = *reinterpret_cast<const f32x4*>(                                                      \
-                a.x + ((size_t)(img * a.H + iy) * a.W + ix) * a.x_cs + a.x_coff + (c0_) + q * 4);     \
-          } else { /* S2D: k = tap*Cup + co ; source pixel (2*iy + t_y + py0, 2*ix + t_x + px0) */    \
-            const int k4 = (c0_) + q * 4;                                                             \
-            const int tp = k4 / a.Cup, co = k4 - tp * a.Cup;                                          \
-            const int sy = 2 * iy + (tp >> 1) + a.py0, sx = 2 * ix + (tp & 1) + a.px0;                \
-            v = *reinterpret_cast<const f32x4*>(                                                      \
-                a.x + ((size_t)(img * a.H2 + sy) * a.W2 + sx) * a.x_cs + a.x_coff + co);              \
-          }                                                                                           \
+      if (aoff[p] >= 0 && q < kq) {                                                                   \
+        if (AMODE == HPRI_A_DIRECT) {                                                                 \
+          v = *reinterpret_cast<const f32x4*>(a.x + (size_t)(unsigned)aoff[p] + (c0_));              \
+        } else { /* S2D: k = tap*Cup + co ; source pixel (2*iy + t_y + py0, 2*ix + t_x + px0) */      \
+          const int k4 = (c0_) + q * 4;                                                               \
+          const int tp = k4 / a.Cup, co = k4 - tp * a.Cup;                                            \
+          v = *reinterpret_cast<const f32x4*>(a.x + (size_t)(unsigned)aoff[p] +                       \
+                                              ((tp >> 1) * a.W2 + (tp & 1)) * a.x_cs + co);           \
         }                                                                                             \
       }                                                                                               \
       areg[p] = v;                                                                                    \
@@ -121,11 +159,12 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvFwdArgs a) {
 #define STORE_A()                                                                                     \
   _Pragma("unroll") for (int p = 0; p < NLD_A; ++p) {                                                 \
     const int f = tid + p * 256;                                                                      \
-    const int pix = f >> 3, q = f & 7;                                                                \
-    if (pix < HP) *reinterpret_cast<f32x4*>(a_lds + pix * CS + q * 4) = areg[p];                      \
+    if ((f >> 3) < HP) *reinterpret_cast<f32x4*>(a_lds + (f >> 3) * CS + (f & 7) * 4) = areg[p];      \
   }
 
-  const int a_base = ((wm * 2) * HW + li) * CS + lh * 4;
+  // lane -> pixel of its M-tile: row li >> twl, column li & (TW-1)
+  const int a_base = ((wm * 2 * RW + (li >> twl)) * HW + (li & (TW - 1))) * CS + lh * 4;
+  const int a_mt = RW * HW * CS;                 // second M-tile of the wave: RW rows further down
   const int b_base = lh * 4 * BN + wn * 64 + li;
 
 #define MFMA_GROUP(g_)                                                                                \
@@ -133,7 +172,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvFwdArgs a) {
     f32x4 af[2];                                                                                      \
     float bf[2][4];                                                                                   \
     _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)                                                  \
-        af[mt] = *reinterpret_cast<const f32x4*>(ap + mt * HW * CS + (g_) * 8);                       \
+        af[mt] = *reinterpret_cast<const f32x4*>(ap + mt * a_mt + (g_) * 8);                          \
     _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                                  \
         _Pragma("unroll") for (int j = 0; j < 4; ++j) bf[nt][j] = bp[((g_) * 8 + j) * BN + nt * 32];  \
     _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                     \
@@ -168,33 +207,30 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvFwdArgs a) {
 #undef STORE_PANEL
 
   // ------------------------------- epilogue -------------------------------
+  // acc[mt][nt][r]: M-tile pixel m = (r&3) + 8*(r>>2) + 4*lh -> row m >> twl, column m & (TW-1);
+  //                 channel = nb*BN + wn*64 + nt*32 + li
   if (a.ksplit > 1) {   // raw partial sums; bias, store and BN statistics happen in splitk_finish_kernel
     float* wsz = a.ws + (size_t)blockIdx.z * ((size_t)a.N * a.H * a.W) * a.Cout_pad;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
-      const int iy = y0 + wm * 2 + mt;
-      if (iy >= a.H) continue;
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) {
         const int n = nb * BN + wn * 64 + nt * 32 + li;
-        float* row = wsz + ((size_t)(img * a.H + iy) * a.W) * a.Cout_pad + n;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int ix = x0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          if (ix < a.W) row[(size_t)ix * a.Cout_pad] = acc[mt][nt][r];
+          const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;
+          const int iy = y0 + (wm * 2 + mt) * RW + (m >> twl), ix = x0 + (m & (TW - 1));
+          if (iy < a.H && ix < xlim) wsz[((size_t)(img * a.H + iy) * a.W + ix) * a.Cout_pad + n] = acc[mt][nt][r];
         }
       }
     }
     return;
   }
-  // acc[mt][nt][r]: pixel row = wm*2+mt, pixel col = (r&3) + 8*(r>>2) + 4*lh, channel = nb*BN + wn*64 + nt*32 + li
-  float bv[2];
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt) {
     const int n = nb * BN + wn * 64 + nt * 32 + li;
     float b = 0.f;
     if (a.bias != nullptr && n < a.Cout) b = (EPI == HPRI_E_D2S) ? a.bias[n % a.Cup] : a.bias[n];
-    bv[nt] = b;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -203,19 +239,17 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvFwdArgs a) {
 
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
-    const int iy = y0 + wm * 2 + mt;
-    if (iy >= a.H) continue;
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
       const int n = nb * BN + wn * 64 + nt * 32 + li;
       if (EPI == HPRI_E_DIRECT) {
         if (n >= a.y_cw) continue;
-        float* yrow = a.y + ((size_t)(img * a.H + iy) * a.W) * a.y_cs + a.y_coff + n;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int ix = x0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          if (ix < a.W) {
-            float* p = yrow + (size_t)ix * a.y_cs;
+          const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;
+          const int iy = y0 + (wm * 2 + mt) * RW + (m >> twl), ix = x0 + (m & (TW - 1));
+          if (iy < a.H && ix < xlim) {
+            float* p = a.y + ((size_t)(img * a.H + iy) * a.W + ix) * a.y_cs + a.y_coff + n;
             float v = (n < a.Cout) ? acc[mt][nt][r] : 0.f;
             if (a.accumulate) v += *p;
             *p = v;
@@ -224,13 +258,13 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvFwdArgs a) {
       } else {  // D2S: n = tap*Cup + co -> hi-res pixel (2*iy + t_y + py0, 2*ix + t_x + px0), channel co
         if (n >= a.Cout) continue;
         const int tap = n / a.Cup, co = n - tap * a.Cup;
-        const int sy = 2 * iy + (tap >> 1) + a.py0;
-        float* yrow = a.y + ((size_t)(img * a.H2 + sy) * a.W2) * a.y_cs + a.y_coff + co;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int ix = x0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          if (ix < a.W) {
-            float* p = yrow + (size_t)(2 * ix + (tap & 1) + a.px0) * a.y_cs;
+          const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;
+          const int iy = y0 + (wm * 2 + mt) * RW + (m >> twl), ix = x0 + (m & (TW - 1));
+          if (iy < a.H && ix < xlim) {
+            float* p = a.y + ((size_t)(img * a.H2 + 2 * iy + (tap >> 1) + a.py0) * a.W2 + 2 * ix + (tap & 1) + a.px0) * a.y_cs +
+                       a.y_coff + co;
             float v = acc[mt][nt][r];
             if (a.accumulate) v += *p;
             *p = v;
@@ -244,7 +278,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvFwdArgs a) {
     // per-tile, per-channel (mean, M2, count) over the tile's valid pixels; two passes over the
     // accumulators (sum, then squared deviations from the tile mean) -- no E[x^2]-E[x]^2 cancellation.
     float* red = smem;                      // [4 waves][64 channels], reuses the A staging area
-    const int vrows = min(TH, a.H - y0), vcols = min(TW, a.W - x0);
+    const int vrows = min(TH, a.H - y0), vcols = min(TW, xlim - x0);
     const float cnt = (float)(vrows * vcols);
     float mean[2];
     __syncthreads();
@@ -255,11 +289,11 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvFwdArgs a) {
         float sacc = 0.f;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
-          const bool rowok = (y0 + wm * 2 + mt) < a.H;
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            const int ix = x0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            if (rowok && ix < a.W) {
+            const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int iy = y0 + (wm * 2 + mt) * RW + (m >> twl), ix = x0 + (m & (TW - 1));
+            if (iy < a.H && ix < xlim) {
               const float v = acc[mt][nt][r];
               if (pass == 0) sacc += v;
               else { const float d = v - mean[nt]; sacc += d * d; }
@@ -355,21 +389,51 @@ __global__ void splitk_finish_kernel(const float* __restrict__ ws, int ksplit, i
   }
 }
 
+// Tile-shape choice shared by the launcher and the sizing query.
+static inline void conv_cfg(int Cout_pad, int* wm, int* wn) {
+  if (Cout_pad % 128 == 0) { *wm = 2; *wn = 2; } else { *wm = 4; *wn = 1; }
+}
+
+// Cut the image width into column bands of tile width 32 / 16 / 8 / 4 (host only).  Candidates: plain 32-wide
+// rounding up, or full 32-wide tiles followed by a greedy cover of the remainder; the cheaper one in tile
+// pixel-slots (rows round up to the band's tile height) wins.  Returns tiles per image.
+struct ConvSegs { int nseg, tiles_img, twl[HPRI_MAXSEG], xbeg[HPRI_MAXSEG], ntx[HPRI_MAXSEG], first[HPRI_MAXSEG]; };
+static ConvSegs conv_segments(int H, int W, int wm) {
+  const int min_tw = (wm == 2) ? 4 : 8;          // LDS budget of the 256-pixel configuration stops at width 8
+  auto th = [&](int tw) { return 2 * wm * (32 / tw); };
+  auto slots = [&](int tw, int ntx) { return (long long)hpri_cdiv(H, th(tw)) * th(tw) * tw * ntx; };
+  ConvSegs plain{}; plain.nseg = 1; plain.twl[0] = 5; plain.xbeg[0] = 0; plain.ntx[0] = hpri_cdiv(W, 32);
+  long long cost_plain = slots(32, plain.ntx[0]);
+  ConvSegs g{}; long long cost_g = 0; int x = 0;
+  if (W / 32 > 0) { g.twl[g.nseg] = 5; g.xbeg[g.nseg] = 0; g.ntx[g.nseg] = W / 32; cost_g += slots(32, W / 32); x = (W / 32) * 32; g.nseg++; }
+  int rem = W - x;
+  for (int tw = 16; tw >= min_tw && rem > 0; tw >>= 1) {
+    int n = rem / tw;
+    if (tw == min_tw && rem % tw) n += 1;        // last band rounds up
+    if (n > 0 && g.nseg < HPRI_MAXSEG) {
+      int l = 0; while ((1 << l) < tw) ++l;
+      g.twl[g.nseg] = l; g.xbeg[g.nseg] = x; g.ntx[g.nseg] = n; cost_g += slots(tw, n);
+      x += n * tw; rem = W - x; g.nseg++;
+    }
+  }
+  ConvSegs r = (g.nseg > 0 && rem <= 0 && cost_g < cost_plain) ? g : plain;
+  int first = 0;
+  for (int k = 0; k < r.nseg; ++k) { r.first[k] = first; first += hpri_cdiv(H, th(1 << r.twl[k])) * r.ntx[k]; }
+  r.tiles_img = first;
+  return r;
+}
+
 template <int KS, int WM, int WN, int AMODE, int EPI>
 static int launch_conv(const ConvFwdArgs& a0, hipStream_t stream) {
   ConvFwdArgs a = a0;
-  constexpr int TH = 2 * WM, BN = 64 * WN;
-  a.tiles_x = hpri_cdiv(a.W, 32);
-  a.tiles_y = hpri_cdiv(a.H, TH);
-  dim3 grid((unsigned)(a.N * a.tiles_y * a.tiles_x), (unsigned)(a.Cout_pad / BN), (unsigned)a.ksplit);
+  constexpr int BN = 64 * WN;
+  const ConvSegs sg = conv_segments(a.H, a.W, WM);
+  a.nseg = sg.nseg; a.tiles_img = sg.tiles_img;
+  for (int k = 0; k < HPRI_MAXSEG; ++k) { a.seg_twl[k] = sg.twl[k]; a.seg_xbeg[k] = sg.xbeg[k]; a.seg_ntx[k] = sg.ntx[k]; a.seg_first[k] = sg.first[k]; }
+  dim3 grid((unsigned)(a.N * a.tiles_img), (unsigned)(a.Cout_pad / BN), (unsigned)a.ksplit);
   hipLaunchKernelGGL((conv_fwd_kernel<KS, WM, WN, AMODE, EPI>), grid, dim3(256), 0, stream, a);
   HPRI_CHECK_LAUNCH();
   return HPRI_OK;
-}
-
-// Tile-shape choice shared by the launcher and the workspace/partials sizing query.
-static inline void conv_cfg(int Cout_pad, int* wm, int* wn) {
-  if (Cout_pad % 128 == 0) { *wm = 2; *wn = 2; } else { *wm = 4; *wn = 1; }
 }
 
 // Split-K plan (host only).  A layer whose natural grid leaves CUs idle or badly balanced (38x60 and 76x121 levels)
@@ -377,7 +441,7 @@ static inline void conv_cfg(int Cout_pad, int* wm, int* wn) {
 static inline int conv_ksplit(int N, int H, int W, int Cin_pad, int Cout_pad, int KS, int epi, int amode) {
   if (epi != HPRI_E_DIRECT) return 1;
   int wm, wn; conv_cfg(Cout_pad, &wm, &wn);
-  const long long blocks = (long long)N * hpri_cdiv(H, 2 * wm) * hpri_cdiv(W, 32) * (Cout_pad / (64 * wn));
+  const long long blocks = (long long)N * conv_segments(H, W, wm).tiles_img * (Cout_pad / (64 * wn));
   const int nchunks = hpri_cdiv(Cin_pad, 32);
   if (blocks >= 2048) return 1;                       // >= 8 workgroups per CU: balance is already fine
   int best = 1; double best_eff = 0.0;
@@ -400,7 +464,7 @@ extern "C" int hpri_conv_fwd_plan(int N, int H, int W, int Cin_pad, int Cout_pad
     *ws_floats = (size_t)k * N * H * W * Cout_pad;
   } else {
     int wm, wn; conv_cfg(Cout_pad, &wm, &wn);
-    *stat_tiles = N * hpri_cdiv(H, 2 * wm) * hpri_cdiv(W, 32);
+    *stat_tiles = N * conv_segments(H, W, wm).tiles_img;
     *ws_floats = 0;
   }
   return HPRI_OK;
@@ -419,11 +483,12 @@ extern "C" int hpri_conv_fwd(const float* x, int x_cs, int x_coff, const float* 
   HPRI_REQUIRE(x_cs % 4 == 0 && x_coff % 4 == 0, "conv_fwd: input channel stride/offset must be multiples of 4");
   HPRI_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)wp & 15) == 0, "conv_fwd: pointers must be 16-byte aligned");
   HPRI_REQUIRE(KS == 1 || KS == 3, "conv_fwd: kernel size must be 1 or 3");
+  HPRI_REQUIRE((long long)N * (H2 > H ? H2 : H) * (W2 > W ? W2 : W) * x_cs < (1ll << 31), "conv_fwd: input view exceeds 2^31 elements");
   ConvFwdArgs a;
   a.x = x; a.x_cs = x_cs; a.x_coff = x_coff; a.wp = wp; a.bias = bias;
   a.y = y; a.y_cs = y_cs; a.y_coff = y_coff; a.stats = reinterpret_cast<float4*>(stats);
   a.N = N; a.H = H; a.W = W; a.Cin_pad = Cin_pad; a.Cout = Cout; a.Cout_pad = Cout_pad;
-  a.y_cw = y_cw < Cout ? Cout : y_cw; a.tiles_x = a.tiles_y = 0; a.accumulate = accumulate;
+  a.y_cw = y_cw < Cout ? Cout : y_cw; a.accumulate = accumulate;
   a.H2 = H2; a.W2 = W2; a.py0 = py0; a.px0 = px0; a.Cup = Cup;
   a.ksplit = conv_ksplit(N, H, W, Cin_pad, Cout_pad, KS, epi, amode);
   a.ws = ws;
