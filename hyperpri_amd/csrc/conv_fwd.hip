@@ -323,7 +323,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvFwdArgs a) {
 // Split-K epilogue: y = sum_z ws[z] + bias (fixed order), NHWC store (optionally accumulating), and per-block BN
 // partial statistics (mean, M2, count) over SK_PIX consecutive pixels of one image.
 // grid = (pixel blocks per image, ceil(Cw4 / CQ), N); block = 256 = ROWS x CQ channel quads.
-#define SK_PIX 256
+#define SK_PIX 64
 __global__ void splitk_finish_kernel(const float* __restrict__ ws, int ksplit, int Cout_pad, const float* __restrict__ bias,
                                      float* __restrict__ y, int y_cs, int y_coff, float4* __restrict__ stats, int HW,
                                      long long P, int Cout, int y_cw, int CQ, int accumulate) {

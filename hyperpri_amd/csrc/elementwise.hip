@@ -261,19 +261,24 @@ __global__ void outconv_bwd_weight_kernel(const float* __restrict__ dy, const fl
   }
 }
 
+// one 256-thread block per output element: dw[k][c] (c < C) or db[k] (c == C); fixed-order tree in LDS
 __global__ void outconv_bwd_weight_finalize_kernel(const float* __restrict__ part, int nblk, int K, int Cpart, int C,
                                                    float* __restrict__ dw, float* __restrict__ db, int accumulate) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= K * (C + 1)) return;
+  __shared__ double red[256];
+  const int idx = blockIdx.x;
   const int k = idx / (C + 1), c = idx - k * (C + 1);
   double s = 0.0;
-  if (c < C) {
-    for (int b = 0; b < nblk; ++b) s += part[(((size_t)b * K + k) * 2) * Cpart + c];
-    float* o = dw + (size_t)k * C + c;
-    *o = accumulate ? *o + (float)s : (float)s;
-  } else if (db != nullptr) {
-    for (int b = 0; b < nblk; ++b) s += part[(((size_t)b * K + k) * 2 + 1) * Cpart];
-    db[k] = accumulate ? db[k] + (float)s : (float)s;
+  const size_t off = (c < C) ? (size_t)c : (size_t)Cpart;      // bias partial lives at row 1, element 0
+  for (int b = threadIdx.x; b < nblk; b += 256) s += part[(((size_t)b * K + k) * 2) * Cpart + off];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    if (c < C) { float* o = dw + (size_t)k * C + c; *o = accumulate ? *o + (float)red[0] : (float)red[0]; }
+    else if (db != nullptr) db[k] = accumulate ? db[k] + (float)red[0] : (float)red[0];
   }
 }
 
@@ -407,7 +412,7 @@ extern "C" int hpri_outconv_bwd(const float* dy, const float* x, int x_cs, int x
   hipLaunchKernelGGL(outconv_bwd_weight_kernel, dim3(nblk, hpri_cdiv(c4, cq), K), dim3(256), 0, stream, dy, x, x_cs, x_coff,
                      N, P, C, K, cq, workspace, Cpart);
   HPRI_CHECK_LAUNCH();
-  hipLaunchKernelGGL(outconv_bwd_weight_finalize_kernel, dim3(hpri_cdiv(K * (C + 1), 256)), dim3(256), 0, stream, workspace,
+  hipLaunchKernelGGL(outconv_bwd_weight_finalize_kernel, dim3(K * (C + 1)), dim3(256), 0, stream, workspace,
                      nblk, K, Cpart, C, dw, db, accumulate_param_grads);
   HPRI_CHECK_LAUNCH();
   return HPRI_OK;
