@@ -29,6 +29,11 @@ def _as4d(t: torch.Tensor) -> torch.Tensor:
 class _HipFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, program: Callable, n_in: int, params: Sequence[torch.Tensor], *tensors: torch.Tensor):
+        with torch.cuda.device(tensors[0].device):      # launches and current_stream() follow the data's device
+            return _HipFn._forward(ctx, program, n_in, params, *tensors)
+
+    @staticmethod
+    def _forward(ctx, program: Callable, n_in: int, params: Sequence[torch.Tensor], *tensors: torch.Tensor):
         inputs = tensors[:n_in]
         need = list(ctx.needs_input_grad[3:])
         record = any(need)
@@ -52,6 +57,11 @@ class _HipFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gout: torch.Tensor):
+        with torch.cuda.device(gout.device):
+            return _HipFn._backward(ctx, gout)
+
+    @staticmethod
+    def _backward(ctx, gout: torch.Tensor):
         tape: Tape = ctx.tape
         if tape is None:
             raise RuntimeError("hyperpri_amd: backward called twice (retain_graph is not supported)")
@@ -84,6 +94,13 @@ class _HipFn(torch.autograd.Function):
 def run(program: Callable, inputs: Sequence[torch.Tensor], params: Sequence[torch.Tensor]) -> torch.Tensor:
     """Run ``program`` as one autograd node.  ``params`` are the nn.Parameters the program reads (the
     program closes over the owning module; they are listed here so autograd routes their gradients)."""
+    dev = inputs[0].device
     for p in params:
         _require_cuda(p, "module parameter")
+        if p.device != dev:
+            raise RuntimeError(f"hyperpri_amd: parameter on {p.device} but input on {dev}")
+        if not p.is_contiguous():
+            raise RuntimeError("hyperpri_amd: parameters must be contiguous")
+    for t in inputs:
+        _require_cuda(t, "input tensor")
     return _HipFn.apply(program, len(inputs), tuple(params), *inputs, *params)
