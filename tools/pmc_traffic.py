@@ -52,6 +52,37 @@ def main():
         p = os.path.join(src, f)
         if os.path.exists(p):
             shutil.copy(p, os.path.join(root, "profiles", f"{tag}_{f}"))
+    # third pass: SQ/GRBM counters -> in-kernel clock and MFMA pipe utilisation per kernel
+    sqfiles = glob.glob(os.path.join(src, "pmc_sq", "**", "*counter_collection.csv"), recursive=True)
+    if sqfiles:
+        agg = collections.defaultdict(lambda: collections.defaultdict(float))
+        for f in sqfiles:
+            seen = set()
+            for r in csv.DictReader(open(f)):
+                a = agg[r["Kernel_Name"]]
+                a[r["Counter_Name"]] += float(r["Counter_Value"])
+                if r["Dispatch_Id"] not in seen:
+                    seen.add(r["Dispatch_Id"])
+                    a["ns"] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+                    a["n"] += 1
+        sq = {}
+        for k, a in agg.items():
+            if a["ns"] <= 0:
+                continue
+            sq[k] = {"launches": int(a["n"]), "total_ms": a["ns"] / 1e6,
+                     "clock_ghz": a["GRBM_GUI_ACTIVE"] / 8.0 / a["ns"],
+                     "mfma_busy_simds_of_4": a["SQ_VALU_MFMA_BUSY_CYCLES"] / max(a["SQ_BUSY_CU_CYCLES"], 1.0),
+                     "wave_wait_any_frac": a["SQ_WAIT_ANY"] / max(a["SQ_WAVE_CYCLES"], 1.0),
+                     "wave_wait_inst_frac": a["SQ_WAIT_INST_ANY"] / max(a["SQ_WAVE_CYCLES"], 1.0),
+                     "wave_active_frac": a["SQ_ACTIVE_INST_ANY"] / max(a["SQ_WAVE_CYCLES"], 1.0)}
+        with open(os.path.join(root, "profiles", f"{tag}_pmc_sq.json"), "w") as fh:
+            json.dump({"note": "rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY "
+                               "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES on bench.py --steps 2 --warmup 1; clock = "
+                               "GRBM_GUI_ACTIVE/8/duration (MI355X_MICROARCH.md DVFS note); mfma_busy_simds_of_4 = "
+                               "SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CU_CYCLES (4.0 = all four SIMDs' matrix pipes busy)",
+                       "kernels": dict(sorted(sq.items(), key=lambda kv: -kv[1]["total_ms"])[:12])}, fh, indent=1)
+        for k, v in sorted(sq.items(), key=lambda kv: -kv[1]["total_ms"])[:4]:
+            print(f"{k[:50]:50s} clk {v['clock_ghz']:.2f} GHz  mfma busy {v['mfma_busy_simds_of_4']:.2f}/4")
     top = sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"])[:8]
     for k, v in top:
         print(f"{k[:60]:60s} n={v['launches']:4d} rd={v['read_bytes_per_launch'] / 1e6:9.1f} MB wr={v['write_bytes_per_launch'] / 1e6:9.1f} MB")
