@@ -3,7 +3,7 @@
 Drop-in ``torch.nn.Module`` replacements for the reference's ``src/Experiments/models.py`` and
 ``model_parts.py`` whose forward/backward run in hand-written HIP kernels.  See DESIGN.md.
 """
-from .model_parts import DoubleConv, Down, OutConv, Up  # noqa: F401
+from .model_parts import DoubleConv, Down, OutConv, Up, set_precision  # noqa: F401
 from .models import (CubeNET, SpectralUNET, UNet, initialize_model, set_parameter_requires_grad,  # noqa: F401
                      translate_load_dir)
 

@@ -320,6 +320,278 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvFwdArgs a) {
   }
 }
 
+// -------------------------------------------------------------------------------------------------------------
+// bf16 variant (precision mode "bf16": BASELINE.json config C5 names bf16 MFMA): same tiling, bands, split-K and
+// epilogue, but operands are rounded to bf16 while they are staged into LDS and the contraction runs on
+// v_mfma_f32_32x32x16_bf16 (fp32 accumulate, fp32 activations in HBM).  Differences to the fp32 kernel:
+//   * A halo chunk in LDS: [pixel][32 ch bf16 + 8 pad] = 80-byte pitch (conflict-free ds_read_b128 of 8 k-values)
+//   * B panels pre-packed bf16 [tap][n][32 k] (k contiguous per output channel), 80-byte pitch in LDS
+//   * one barrier per KERNEL ROW (KS taps x 32 channels = 6 k16-steps x 4 tiles = 24 MFMAs per wave), because a
+//     bf16 MFMA retires 16x the flops of the fp32 one in half the cycles
+// Only the direct forms (3x3 / 1x1 forward and data gradient); ConvTranspose2d stays on the fp32 kernel.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+template <int KS, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void conv_fwd_bf16_kernel(ConvFwdArgs a) {
+  constexpr int T = KS * KS, PAD = KS / 2;
+  constexpr int AMODE = HPRI_A_DIRECT, EPI = HPRI_E_DIRECT;
+  constexpr int TPIX = 64 * WM;
+  constexpr int MAXHP = (KS == 1) ? TPIX : (WM == 2 ? 6 * 34 : 10 * 34);
+  constexpr int BN = 64 * WN;
+  constexpr int CS = 40;                          // halves per staged pixel / per staged weight row (32 + 8 pad)
+  constexpr int NLD_A = (MAXHP * 8 + 255) / 256;  // float4 global loads per thread per A chunk
+  constexpr int NLD_B = (KS * BN * 4) / 256;      // 16-byte global loads per thread per B stage (KS taps)
+  __shared__ __attribute__((aligned(16))) __bf16 smem_h[MAXHP * CS + 2 * KS * BN * CS];
+  __bf16* a_lds = smem_h;
+  __bf16* b_lds = smem_h + MAXHP * CS;
+  float* smem = reinterpret_cast<float*>(smem_h);  // the statistics epilogue reuses the staging area as floats
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wm = wave / WN, wn = wave % WN;
+  const int nb = blockIdx.y;
+
+  const int img = blockIdx.x / a.tiles_img;
+  const int tin = blockIdx.x - img * a.tiles_img;
+  int seg = 0;
+#pragma unroll
+  for (int k = 1; k < HPRI_MAXSEG; ++k)
+    if (k < a.nseg && tin >= a.seg_first[k]) seg = k;
+  const int twl = a.seg_twl[seg];
+  const int TW = 1 << twl, RW = 32 >> twl;
+  const int TH = 2 * WM * RW;
+  const int HW = TW + KS - 1, HP = (TH + KS - 1) * HW;
+  const int tt = tin - a.seg_first[seg];
+  const int ty = tt / a.seg_ntx[seg], tx = tt - ty * a.seg_ntx[seg];
+  const int y0 = ty * TH, x0 = a.seg_xbeg[seg] + tx * TW;
+  const int xlim = min(a.W, a.seg_xbeg[seg] + a.seg_ntx[seg] * TW);
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nchunks_all = (a.Cin_pad + 31) >> 5;
+  const int cps = (nchunks_all + a.ksplit - 1) / a.ksplit;
+  const int chunk0 = blockIdx.z * cps;
+  const int nchunks = min(nchunks_all, chunk0 + cps);
+  const int S0 = chunk0 * KS, S = nchunks * KS;          // stage = (chunk, kernel row)
+
+  // ---- B stages: KS taps x BN rows x 64 bytes, contiguous per tap in the packed tensor ----
+  const __bf16* wpk = reinterpret_cast<const __bf16*>(a.wp);
+  int boff[NLD_B], blds[NLD_B];
+#pragma unroll
+  for (int p = 0; p < NLD_B; ++p) {
+    const int f = tid + p * 256;
+    const int tap = f / (BN * 4), n = (f >> 2) % BN, q = f & 3;
+    boff[p] = (tap * a.Cout_pad + nb * BN + n) * 32 + q * 8;   // halves, relative to the stage's first tap
+    blds[p] = (tap * BN + n) * CS + q * 8;
+  }
+  f32x4 breg[NLD_B];
+#define LOAD_STAGE(s_)                                                                               \
+  {                                                                                                  \
+    const __bf16* pb_ = wpk + (size_t)(s_) * KS * a.Cout_pad * 32;                                   \
+    _Pragma("unroll") for (int p = 0; p < NLD_B; ++p)                                                \
+        breg[p] = *reinterpret_cast<const f32x4*>(pb_ + boff[p]);                                    \
+  }
+#define STORE_STAGE(buf_)                                                                            \
+  _Pragma("unroll") for (int p = 0; p < NLD_B; ++p)                                                  \
+      *reinterpret_cast<f32x4*>(b_lds + (buf_) * KS * BN * CS + blds[p]) = breg[p];
+
+  // ---- A halo: fp32 in HBM -> registers -> bf16 in LDS ----
+  int aoff[NLD_A];
+  {
+    const unsigned hw_inv = (65536u + (unsigned)HW - 1u) / (unsigned)HW;
+#pragma unroll
+    for (int p = 0; p < NLD_A; ++p) {
+      const int f = tid + p * 256;
+      const int pix = f >> 3, q = f & 7;
+      int off = -1;
+      if (pix < HP) {
+        const int hy = (int)(((unsigned)pix * hw_inv) >> 16), hx = pix - hy * HW;
+        const int iy = y0 + hy - PAD, ix = x0 + hx - PAD;
+        if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) off = ((img * a.H + iy) * a.W + ix) * a.x_cs + a.x_coff + q * 4;
+      }
+      aoff[p] = off;
+    }
+  }
+  f32x4 areg[NLD_A];
+#define LOAD_A(c0_)                                                                                  \
+  {                                                                                                  \
+    const int kq = min(8, (a.Cin_pad - (c0_)) >> 2);                                                 \
+    _Pragma("unroll") for (int p = 0; p < NLD_A; ++p) {                                              \
+      const int q = (tid + p * 256) & 7;                                                             \
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};                                                                \
+      if (aoff[p] >= 0 && q < kq) v = *reinterpret_cast<const f32x4*>(a.x + (size_t)(unsigned)aoff[p] + (c0_)); \
+      areg[p] = v;                                                                                   \
+    }                                                                                                \
+  }
+#define STORE_A()                                                                                    \
+  _Pragma("unroll") for (int p = 0; p < NLD_A; ++p) {                                                \
+    const int f = tid + p * 256;                                                                     \
+    if ((f >> 3) < HP)                                                                               \
+      *reinterpret_cast<bf16x4*>(a_lds + (f >> 3) * CS + (f & 7) * 4) = __builtin_convertvector(areg[p], bf16x4); \
+  }
+
+  const int a_base = ((wm * 2 * RW + (li >> twl)) * HW + (li & (TW - 1))) * CS + lh * 8;
+  const int a_mt = RW * HW * CS;
+  const int b_base = (wn * 64 + li) * CS + lh * 8;
+
+  LOAD_STAGE(S0)
+  LOAD_A(chunk0 * 32)
+  for (int s = S0; s < S; ++s) {
+    const int chunk = s / KS, dy = s - chunk * KS;
+    if (dy == 0) {
+      __syncthreads();
+      STORE_A()
+    }
+    STORE_STAGE(s & 1)
+    __syncthreads();
+    if (s + 1 < S) { LOAD_STAGE(s + 1) }
+    if (dy == KS - 1 && chunk + 1 < nchunks) { LOAD_A((chunk + 1) * 32) }
+
+    const __bf16* ap = a_lds + a_base + dy * HW * CS;
+    const __bf16* bp = b_lds + (s & 1) * KS * BN * CS + b_base;
+#pragma unroll
+    for (int dx = 0; dx < KS; ++dx) {
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        bf16x8 af[2], bf[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) af[mt] = *reinterpret_cast<const bf16x8*>(ap + mt * a_mt + dx * CS + kk * 16);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) bf[nt] = *reinterpret_cast<const bf16x8*>(bp + (dx * BN + nt * 32) * CS + kk * 16);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mt], bf[nt], acc[mt][nt], 0, 0, 0);
+      }
+    }
+  }
+#undef LOAD_STAGE
+#undef STORE_STAGE
+#undef LOAD_A
+#undef STORE_A
+
+  // ------------------------------- epilogue -------------------------------
+  // acc[mt][nt][r]: M-tile pixel m = (r&3) + 8*(r>>2) + 4*lh -> row m >> twl, column m & (TW-1);
+  //                 channel = nb*BN + wn*64 + nt*32 + li
+  if (a.ksplit > 1) {   // raw partial sums; bias, store and BN statistics happen in splitk_finish_kernel
+    float* wsz = a.ws + (size_t)blockIdx.z * ((size_t)a.N * a.H * a.W) * a.Cout_pad;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const int n = nb * BN + wn * 64 + nt * 32 + li;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;
+          const int iy = y0 + (wm * 2 + mt) * RW + (m >> twl), ix = x0 + (m & (TW - 1));
+          if (iy < a.H && ix < xlim) wsz[((size_t)(img * a.H + iy) * a.W + ix) * a.Cout_pad + n] = acc[mt][nt][r];
+        }
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const int n = nb * BN + wn * 64 + nt * 32 + li;
+    float b = 0.f;
+    if (a.bias != nullptr && n < a.Cout) b = (EPI == HPRI_E_D2S) ? a.bias[n % a.Cup] : a.bias[n];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] += b;
+  }
+
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int n = nb * BN + wn * 64 + nt * 32 + li;
+      if (EPI == HPRI_E_DIRECT) {
+        if (n >= a.y_cw) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;
+          const int iy = y0 + (wm * 2 + mt) * RW + (m >> twl), ix = x0 + (m & (TW - 1));
+          if (iy < a.H && ix < xlim) {
+            float* p = a.y + ((size_t)(img * a.H + iy) * a.W + ix) * a.y_cs + a.y_coff + n;
+            float v = (n < a.Cout) ? acc[mt][nt][r] : 0.f;
+            if (a.accumulate) v += *p;
+            *p = v;
+          }
+        }
+      } else {  // D2S: n = tap*Cup + co -> hi-res pixel (2*iy + t_y + py0, 2*ix + t_x + px0), channel co
+        if (n >= a.Cout) continue;
+        const int tap = n / a.Cup, co = n - tap * a.Cup;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;
+          const int iy = y0 + (wm * 2 + mt) * RW + (m >> twl), ix = x0 + (m & (TW - 1));
+          if (iy < a.H && ix < xlim) {
+            float* p = a.y + ((size_t)(img * a.H2 + 2 * iy + (tap >> 1) + a.py0) * a.W2 + 2 * ix + (tap & 1) + a.px0) * a.y_cs +
+                       a.y_coff + co;
+            float v = acc[mt][nt][r];
+            if (a.accumulate) v += *p;
+            *p = v;
+          }
+        }
+      }
+    }
+  }
+
+  if (a.stats != nullptr) {
+    // per-tile, per-channel (mean, M2, count) over the tile's valid pixels; two passes over the
+    // accumulators (sum, then squared deviations from the tile mean) -- no E[x^2]-E[x]^2 cancellation.
+    float* red = smem;                      // [4 waves][64 channels], reuses the A staging area
+    const int vrows = min(TH, a.H - y0), vcols = min(TW, xlim - x0);
+    const float cnt = (float)(vrows * vcols);
+    float mean[2];
+    __syncthreads();
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        float sacc = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int iy = y0 + (wm * 2 + mt) * RW + (m >> twl), ix = x0 + (m & (TW - 1));
+            if (iy < a.H && ix < xlim) {
+              const float v = acc[mt][nt][r];
+              if (pass == 0) sacc += v;
+              else { const float d = v - mean[nt]; sacc += d * d; }
+            }
+          }
+        }
+        sacc += __shfl_xor(sacc, 32);
+        if (lh == 0) red[wave * 64 + nt * 32 + li] = sacc;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        float t = 0.f;
+#pragma unroll
+        for (int m = 0; m < WM; ++m) t += red[(m * WN + wn) * 64 + nt * 32 + li];
+        if (pass == 0) mean[nt] = t / cnt;
+        else if (wm == 0 && lh == 0) {
+          const int n = nb * BN + wn * 64 + nt * 32 + li;
+          a.stats[(size_t)blockIdx.x * a.Cout_pad + n] = make_float4(mean[nt], t, cnt, 0.f);
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
 // Split-K epilogue: y = sum_z ws[z] + bias (fixed order), NHWC store (optionally accumulating), and per-block BN
 // partial statistics (mean, M2, count) over SK_PIX consecutive pixels of one image.
 // grid = (pixel blocks per image, ceil(Cw4 / CQ), N); block = 256 = ROWS x CQ channel quads.
@@ -467,6 +739,61 @@ extern "C" int hpri_conv_fwd_plan(int N, int H, int W, int Cin_pad, int Cout_pad
     *stat_tiles = N * conv_segments(H, W, wm).tiles_img;
     *ws_floats = 0;
   }
+  return HPRI_OK;
+}
+
+template <int KS, int WM, int WN>
+static int launch_conv_bf16(const ConvFwdArgs& a0, hipStream_t stream) {
+  ConvFwdArgs a = a0;
+  constexpr int BN = 64 * WN;
+  const ConvSegs sg = conv_segments(a.H, a.W, WM);
+  a.nseg = sg.nseg; a.tiles_img = sg.tiles_img;
+  for (int k = 0; k < HPRI_MAXSEG; ++k) { a.seg_twl[k] = sg.twl[k]; a.seg_xbeg[k] = sg.xbeg[k]; a.seg_ntx[k] = sg.ntx[k]; a.seg_first[k] = sg.first[k]; }
+  dim3 grid((unsigned)(a.N * a.tiles_img), (unsigned)(a.Cout_pad / BN), (unsigned)a.ksplit);
+  hipLaunchKernelGGL((conv_fwd_bf16_kernel<KS, WM, WN>), grid, dim3(256), 0, stream, a);
+  HPRI_CHECK_LAUNCH();
+  return HPRI_OK;
+}
+
+// bf16-operand variant of hpri_conv_fwd (direct 3x3 / 1x1 forms only); wp from hpri_pack_weight_bf16.
+extern "C" int hpri_conv_fwd_bf16(const float* x, int x_cs, int x_coff, const void* wp, const float* bias,
+                                  float* y, int y_cs, int y_coff, float* stats,
+                                  int N, int H, int W, int Cin_pad, int Cout, int Cout_pad, int y_cw,
+                                  int KS, int accumulate, float* ws, size_t ws_floats, hipStream_t stream) {
+  HPRI_REQUIRE(x && wp && y, "conv_fwd_bf16: null pointer");
+  HPRI_REQUIRE(N > 0 && H > 0 && W > 0, "conv_fwd_bf16: empty image");
+  HPRI_REQUIRE(Cin_pad > 0 && Cin_pad % 8 == 0, "conv_fwd_bf16: Cin_pad must be a positive multiple of 8");
+  HPRI_REQUIRE(Cout_pad % 64 == 0 && Cout <= Cout_pad && Cout > 0, "conv_fwd_bf16: Cout_pad must be a multiple of 64 >= Cout");
+  HPRI_REQUIRE(x_cs % 4 == 0 && x_coff % 4 == 0, "conv_fwd_bf16: input channel stride/offset must be multiples of 4");
+  HPRI_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)wp & 15) == 0, "conv_fwd_bf16: pointers must be 16-byte aligned");
+  HPRI_REQUIRE(KS == 1 || KS == 3, "conv_fwd_bf16: kernel size must be 1 or 3");
+  HPRI_REQUIRE((long long)N * H * W * x_cs < (1ll << 31), "conv_fwd_bf16: input view exceeds 2^31 elements");
+  ConvFwdArgs a;
+  a.x = x; a.x_cs = x_cs; a.x_coff = x_coff; a.wp = reinterpret_cast<const float*>(wp); a.bias = bias;
+  a.y = y; a.y_cs = y_cs; a.y_coff = y_coff; a.stats = reinterpret_cast<float4*>(stats);
+  a.N = N; a.H = H; a.W = W; a.Cin_pad = Cin_pad; a.Cout = Cout; a.Cout_pad = Cout_pad;
+  a.y_cw = y_cw < Cout ? Cout : y_cw; a.accumulate = accumulate;
+  a.H2 = a.W2 = a.py0 = a.px0 = a.Cup = 0;
+  HPRI_REQUIRE(a.y_cw + y_coff <= y_cs, "conv_fwd_bf16: output channels exceed the channel stride");
+  a.ksplit = conv_ksplit(N, H, W, Cin_pad, Cout_pad, KS, HPRI_E_DIRECT, HPRI_A_DIRECT);
+  a.ws = ws;
+  if (a.ksplit > 1) {
+    if (ws == nullptr || (size_t)a.ksplit * N * H * W * Cout_pad > ws_floats)
+      return hpri_set_error(HPRI_ERR_WORKSPACE, "conv_fwd_bf16: split-K workspace too small (see hpri_conv_fwd_plan)");
+    a.stats = nullptr;
+    a.accumulate = 0;
+  }
+  int wm, wn; conv_cfg(Cout_pad, &wm, &wn);
+  int rc;
+  if (KS == 3) rc = (wm == 2) ? launch_conv_bf16<3, 2, 2>(a, stream) : launch_conv_bf16<3, 4, 1>(a, stream);
+  else rc = (wm == 2) ? launch_conv_bf16<1, 2, 2>(a, stream) : launch_conv_bf16<1, 4, 1>(a, stream);
+  if (rc != HPRI_OK || a.ksplit == 1) return rc;
+  const int c4 = a.y_cw >> 2;
+  int cq = 1; while (cq < c4 && cq < 64) cq <<= 1;
+  dim3 grid((unsigned)hpri_cdiv(H * W, SK_PIX), (unsigned)hpri_cdiv(hpri_cdiv(a.y_cw, 4), cq), (unsigned)N);
+  hipLaunchKernelGGL(splitk_finish_kernel, grid, dim3(256), 0, stream, ws, a.ksplit, Cout_pad, bias, y, y_cs, y_coff,
+                     reinterpret_cast<float4*>(stats), H * W, (long long)N * H * W, Cout, a.y_cw, cq, accumulate);
+  HPRI_CHECK_LAUNCH();
   return HPRI_OK;
 }
 

@@ -8,6 +8,7 @@ closure on the tape; ``model_parts.py`` / ``models.py`` compose them into the re
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Callable, Dict, List, Optional, Tuple
 
 import torch
@@ -16,6 +17,14 @@ from . import _lib
 
 A_DIRECT, A_S2D = 0, 1
 E_DIRECT, E_D2S = 0, 1
+
+# Arithmetic of the conv / linear contractions:
+#   "fp32" (default) -- exact fp32 on v_mfma_f32_32x32x2_f32: the mode every 1e-3-logit parity claim refers to
+#   "bf16"           -- forward and data-gradient operands rounded to bf16, v_mfma_f32_32x32x16_bf16 with fp32
+#                       accumulate (BASELINE.json config C5); weight gradients and everything else stay fp32.
+#                       Dice/IoU-level parity only (bf16 operands move logits by ~2e-2).
+PRECISIONS = ("fp32", "bf16")
+DEFAULT_PRECISION = os.environ.get("HPRI_PRECISION", "fp32")
 
 
 def _rup(x: int, m: int) -> int:
@@ -239,6 +248,29 @@ def _pack(w: torch.Tensor, mode: int, K: int, ncols: int, T: int, cup: int, d1: 
     return wp, ncols_pad
 
 
+def _pack_bf16(w: torch.Tensor, mode: int, K: int, ncols: int, T: int, d1: int) -> Tuple[torch.Tensor, int]:
+    ncols_pad = _rup(ncols, 64)
+    chunks = (K + 31) // 32
+    wp = torch.empty(chunks * T * ncols_pad * 32, dtype=torch.bfloat16, device=w.device)
+    _lib.call("hpri_pack_weight_bf16", _p(w), _p(wp), mode, K, ncols, ncols_pad, T, d1, _stream())
+    return wp, ncols_pad
+
+
+def _conv_launch_bf16(x: Act, wp: torch.Tensor, bias: Optional[torch.Tensor], y: Act, stats: Optional[torch.Tensor],
+                      N: int, H: int, W: int, cin_pad: int, cout: int, cout_pad: int, y_cw: int, ks: int,
+                      accumulate: int = 0, cin_true: int = 0) -> None:
+    ksplit = ctypes.c_int(); tiles = ctypes.c_int(); wsf = ctypes.c_size_t()
+    _lib.call("hpri_conv_fwd_plan", N, H, W, cin_pad, cout_pad, ks, A_DIRECT, E_DIRECT, ctypes.byref(ksplit), ctypes.byref(tiles),
+              ctypes.byref(wsf))
+    ws = _ws(wsf.value, x.buf.device) if wsf.value else None
+    tag = f"conv_fwd_bf16<{ks},{'2x2' if cout_pad % 128 == 0 else '4x1'}>"
+    if SHAPE_TAGS:
+        tag += f" N{N} {H}x{W} K{cin_pad} N{cout}"
+    with _timed(tag, 2.0 * N * H * W * (cin_true or cin_pad) * cout * ks * ks):
+        _lib.call("hpri_conv_fwd_bf16", x.ptr, x.cs, x.coff, _p(wp), _p(bias), y.ptr, y.cs, y.coff, _p(stats),
+                  N, H, W, cin_pad, cout, cout_pad, y_cw, ks, accumulate, _p(ws), wsf.value, _stream())
+
+
 def _conv_launch(x: Act, wp: torch.Tensor, bias: Optional[torch.Tensor], y: Act, stats: Optional[torch.Tensor],
                  N: int, H: int, W: int, cin_pad: int, cout: int, cout_pad: int, y_cw: int, ks: int,
                  amode: int = A_DIRECT, epi: int = E_DIRECT, accumulate: int = 0,
@@ -260,7 +292,8 @@ def _conv_launch(x: Act, wp: torch.Tensor, bias: Optional[torch.Tensor], y: Act,
 # conv (3x3 pad 1 | 1x1 | Linear) [+ BatchNorm + ReLU]
 # --------------------------------------------------------------------------------------------------
 def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.Tensor], bn: Optional[BNRef],
-                 train: bool, ks: int, groups: int = 1, relu: bool = True, need_dx: bool = True) -> Act:
+                 train: bool, ks: int, groups: int = 1, relu: bool = True, need_dx: bool = True,
+                 precision: Optional[str] = None) -> Act:
     """Conv2d(k=ks, pad=ks//2) -> BatchNorm -> ReLU  (model_parts.py:22-27; models.py:169-180 with the
     Conv3d weight (F,1,D,3,3) read as (F,D,3,3); models.py:108-114 for Linear -> BatchNorm1d -> ReLU with
     ks = 1 and ``groups`` = images, each image being its own BN batch, models.py:132)."""
@@ -271,7 +304,13 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
     if cin != x.C:
         raise RuntimeError(f"hyperpri_amd: conv expects {cin} input channels, got {x.C}")
     cin_pad = x.cw
-    wp, cout_pad = _pack(weight, 0, cin, cout, T, 0, cin)
+    prec = precision or DEFAULT_PRECISION
+    if prec not in PRECISIONS:
+        raise RuntimeError(f"hyperpri_amd: unknown precision {prec!r}; choose from {PRECISIONS}")
+    if prec == "bf16":
+        wp, cout_pad = _pack_bf16(weight, 0, cin, cout, T, cin)
+    else:
+        wp, cout_pad = _pack(weight, 0, cin, cout, T, 0, cin)
     yr = Act.new(x.N, x.H, x.W, cout, dev)
     use_batch = bn is not None and train
     stats = None
@@ -282,7 +321,10 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
                   ctypes.byref(tl), ctypes.byref(wsf))
         tiles = tl.value
         stats = torch.empty(tiles * cout_pad * 4, dtype=torch.float32, device=dev)
-    _conv_launch(x, wp, bias, yr, stats, x.N, x.H, x.W, cin_pad, cout, cout_pad, yr.cw, ks, cin_true=cin)
+    if prec == "bf16":
+        _conv_launch_bf16(x, wp, bias, yr, stats, x.N, x.H, x.W, cin_pad, cout, cout_pad, yr.cw, ks, cin_true=cin)
+    else:
+        _conv_launch(x, wp, bias, yr, stats, x.N, x.H, x.W, cin_pad, cout, cout_pad, yr.cw, ks, cin_true=cin)
     del wp
     if bn is None:
         y = yr
@@ -342,10 +384,15 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
         else:
             _wgrad(x, dyr, dw, acc_w, cin, cout, ks)
         if need_dx:
-            wpd, cin_cols_pad = _pack(weight, 1, cout, cin, T, 0, cin)
             gx, acc = tp.grad_slot(x)
-            _conv_launch(dyr, wpd, None, gx, None, x.N, x.H, x.W, dyr.cw, cin, cin_cols_pad, gx.cw, ks, accumulate=int(acc),
-                         cin_true=cout)
+            if prec == "bf16":
+                wpd, cin_cols_pad = _pack_bf16(weight, 1, cout, cin, T, cin)
+                _conv_launch_bf16(dyr, wpd, None, gx, None, x.N, x.H, x.W, dyr.cw, cin, cin_cols_pad, gx.cw, ks,
+                                  accumulate=int(acc), cin_true=cout)
+            else:
+                wpd, cin_cols_pad = _pack(weight, 1, cout, cin, T, 0, cin)
+                _conv_launch(dyr, wpd, None, gx, None, x.N, x.H, x.W, dyr.cw, cin, cin_cols_pad, gx.cw, ks, accumulate=int(acc),
+                             cin_true=cout)
 
     tape.nodes.append(bwd)
     return y

@@ -14,13 +14,23 @@ import torch.nn.functional as F  # re-exported: the reference star-imports this 
 from . import engine as E
 from .autograd import run
 
-__all__ = ["DoubleConv", "Down", "Up", "OutConv", "torch", "nn", "F"]
+__all__ = ["DoubleConv", "Down", "Up", "OutConv", "torch", "nn", "F", "set_precision"]
 
 
-def _double_conv_ops(tape, x, seq, train, need_dx=True):
+def _double_conv_ops(tape, x, seq, train, need_dx=True, precision=None):
     """(conv3x3 -> BN -> ReLU) x 2 on an Act; ``seq`` is the 6-entry nn.Sequential container."""
-    h = E.conv_bn_relu(tape, x, seq[0].weight, seq[0].bias, E.BNRef(seq[1]), train, 3, need_dx=need_dx)
-    return E.conv_bn_relu(tape, h, seq[3].weight, seq[3].bias, E.BNRef(seq[4]), train, 3)
+    h = E.conv_bn_relu(tape, x, seq[0].weight, seq[0].bias, E.BNRef(seq[1]), train, 3, need_dx=need_dx, precision=precision)
+    return E.conv_bn_relu(tape, h, seq[3].weight, seq[3].bias, E.BNRef(seq[4]), train, 3, precision=precision)
+
+
+def set_precision(module, precision):
+    """Select the contraction arithmetic ("fp32" exact, default | "bf16" MFMA) for ``module`` and all its children.
+    Not part of the reference API; the default keeps the reference's fp32 semantics."""
+    if precision not in E.PRECISIONS:
+        raise ValueError(f"precision must be one of {E.PRECISIONS}")
+    for m in module.modules():
+        m.hpri_precision = precision
+    return module
 
 
 class DoubleConv(nn.Module):
@@ -35,7 +45,7 @@ class DoubleConv(nn.Module):
         self.double_conv = nn.Sequential(*layers)
 
     def _ops(self, tape, x, need_dx=True):
-        return _double_conv_ops(tape, x, self.double_conv, self.training, need_dx)
+        return _double_conv_ops(tape, x, self.double_conv, self.training, need_dx, getattr(self, "hpri_precision", None))
 
     def forward(self, x):
         return run(lambda tape, a, need: self._ops(tape, a[0], need[0]), [x], list(self.parameters()))

@@ -86,7 +86,8 @@ class SpectralUNET(torch.nn.Module):
 
     def _layer(self, tape, x, seq, need_dx=True):
         bn = E.BNRef(seq[1]) if self._bnorm else None
-        return E.conv_bn_relu(tape, x, seq[0].weight, seq[0].bias, bn, self.training, 1, groups=x.N, need_dx=need_dx)
+        return E.conv_bn_relu(tape, x, seq[0].weight, seq[0].bias, bn, self.training, 1, groups=x.N, need_dx=need_dx,
+                              precision=getattr(self, "hpri_precision", None))
 
     def forward(self, x):
         if self.n_classes != 1 and x.shape[0] > 0:
@@ -141,10 +142,11 @@ class CubeNET(torch.nn.Module):
 
     def _stem(self, x):
         def prog(tape, a, need):
+            prec = getattr(self, "hpri_precision", None)
             h = E.conv_bn_relu(tape, a[0], self.first_conv.weight, self.first_conv.bias, E.BNRef(self.inc[1]),
-                               self.training, 3, need_dx=need[0])
+                               self.training, 3, need_dx=need[0], precision=prec)
             return E.conv_bn_relu(tape, h, self.inc2[0].weight, self.inc2[0].bias, E.BNRef(self.inc2[1]),
-                                  self.training, 3)
+                                  self.training, 3, precision=prec)
         params = list(self.inc.parameters()) + list(self.inc2.parameters())
         return run(prog, [x], params)
 
