@@ -150,6 +150,145 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
       }
 }
 
+// -------------------------------------------------------------------------------------------------------------
+// bf16 variant (precision mode "bf16"): X and dY are rounded to bf16 while staged into LDS as [pixel][channel]
+// (192 / 320-byte pitch); the MFMA operands need 8 consecutive PIXELS per lane, i.e. the transpose of that image,
+// which gfx950's ds_read_b64_tr_b16 delivers for free (4 pixels x 16 channels per 16-lane group, column-major).
+// v_mfma_f32_32x32x16_bf16, fp32 accumulate; same slab layout and fixed-order reduce as the fp32 kernel.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef bf16x4 __attribute__((address_space(3))) * lds_bf16x4_ptr;
+
+__device__ __forceinline__ bf16x8 tr_frag(const __bf16* p, int pitch4) {
+  // p: this lane's address for pixel row (8h + q); rows +4 further down supply k-slots 4..7
+  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(p));
+  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(p + pitch4));
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+template <int KS, int CT, int NT>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradArgs a) {
+  constexpr int T = KS * KS, PAD = KS / 2;
+  constexpr int SH = 2, SW = 32, HH = SH + KS - 1, HW = SW + KS - 1, HP = HH * HW;
+  constexpr int BC = 64 * CT, BNW = 64 * NT;
+  constexpr int PX = BC + 32, PY = BNW + 32;      // halves per staged pixel: data + 32 pad, i.e. a pitch of 48 / 80 dwords
+                                                  // = 16 (mod 32): the 4 pixel rows of a transposed read hit disjoint banks
+  constexpr int NLD_X = (HP * (BC / 4) + 255) / 256;
+  constexpr int NLD_Y = (64 * (BNW / 4)) / 256;
+  __shared__ __attribute__((aligned(16))) __bf16 smem[HP * PX + 64 * PY];
+  __bf16* x_lds = smem;
+  __bf16* y_lds = smem + HP * PX;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wc = wave >> 1, wn = wave & 1;
+  const int c_blk = blockIdx.y * BC, n_blk = blockIdx.z * BNW;
+  // transposed-read lane roles: 16-lane group = (k half h, channel half g); lane i of the group addresses pixel row
+  // q = i>>2, channel quad p = i&3 and receives channel i of the block
+  const int lg = (lane >> 4) & 1, lh = lane >> 5, lq = (lane >> 2) & 3, lp = lane & 3;
+  const int li = lane & 31;
+
+  f32x16 acc[T][CT][NT];
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int i = 0; i < CT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][i][j][r] = 0.f;
+
+  const int s_begin = blockIdx.x * a.strips_per_split;
+  const int s_end = min(a.total_strips, s_begin + a.strips_per_split);
+  const __bf16* xb = x_lds + (lh * 8 + lq) * PX + wc * (CT * 32) + lg * 16 + lp * 4;
+  const __bf16* yb = y_lds + (lh * 8 + lq) * PY + wn * (NT * 32) + lg * 16 + lp * 4;
+
+  for (int st = s_begin; st < s_end; ++st) {
+    int q = st;
+    const int sx = q % a.strips_x; q /= a.strips_x;
+    const int sy = q % a.strips_y;
+    const int img = q / a.strips_y;
+    const int y0 = sy * SH, x0 = sx * SW;
+
+    f32x4 xr[NLD_X], yr[NLD_Y];
+#pragma unroll
+    for (int p = 0; p < NLD_X; ++p) {
+      const int f = tid + p * 256;
+      const int pix = f / (BC / 4), c4 = f % (BC / 4);
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (pix < HP) {
+        const int hy = pix / HW, hx = pix - hy * HW;
+        const int iy = y0 + hy - PAD, ix = x0 + hx - PAD;
+        const int c = c_blk + c4 * 4;
+        if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W && c < a.x_cvalid)
+          v = *reinterpret_cast<const f32x4*>(a.x + ((size_t)(img * a.H + iy) * a.W + ix) * a.x_cs + a.x_coff + c);
+      }
+      xr[p] = v;
+    }
+#pragma unroll
+    for (int p = 0; p < NLD_Y; ++p) {
+      const int f = tid + p * 256;
+      const int pix = f / (BNW / 4), n4 = f % (BNW / 4);
+      const int iy = y0 + (pix >> 5), ix = x0 + (pix & 31);
+      const int n = n_blk + n4 * 4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (iy < a.H && ix < a.W && n < a.dy_cvalid)
+        v = *reinterpret_cast<const f32x4*>(a.dy + ((size_t)(img * a.H + iy) * a.W + ix) * a.dy_cs + a.dy_coff + n);
+      yr[p] = v;
+    }
+    __syncthreads();   // previous strip's LDS reads are finished
+#pragma unroll
+    for (int p = 0; p < NLD_X; ++p) {
+      const int f = tid + p * 256;
+      const int pix = f / (BC / 4), c4 = f % (BC / 4);
+      if (pix < HP) *reinterpret_cast<bf16x4*>(x_lds + pix * PX + c4 * 4) = __builtin_convertvector(xr[p], bf16x4);
+    }
+#pragma unroll
+    for (int p = 0; p < NLD_Y; ++p) {
+      const int f = tid + p * 256;
+      const int pix = f / (BNW / 4), n4 = f % (BNW / 4);
+      *reinterpret_cast<bf16x4*>(y_lds + pix * PY + n4 * 4) = __builtin_convertvector(yr[p], bf16x4);
+    }
+    __syncthreads();
+
+    // 4 k16-steps: strip pixels 16*ks .. 16*ks+15 (row ks>>1, columns 16*(ks&1) ..)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int py = ks >> 1, pxo = 16 * (ks & 1);
+      bf16x8 af[NT];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) af[j] = tr_frag(yb + (ks * 16) * PY + j * 32, 4 * PY);
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        const int dy = t / KS, dx = t - dy * KS;
+        bf16x8 bfr[CT];
+#pragma unroll
+        for (int i = 0; i < CT; ++i) bfr[i] = tr_frag(xb + ((py + dy) * HW + pxo + dx) * PX + i * 32, 4 * PX);
+#pragma unroll
+        for (int i = 0; i < CT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            acc[t][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[j], bfr[i], acc[t][i][j], 0, 0, 0);
+      }
+    }
+  }
+
+  // partial slab ws[split][t][n][c]: MFMA rows = n (A operand = dY), cols = c (B operand = X)
+  float* slab = a.ws + (size_t)blockIdx.x * T * a.Cr * a.Nr;
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int i = 0; i < CT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int c = c_blk + wc * (CT * 32) + i * 32 + li;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int n = n_blk + wn * (NT * 32) + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          slab[((size_t)t * a.Nr + n) * a.Cr + c] = acc[t][i][j][r];
+        }
+      }
+}
+
 // Fixed-order reduction of the partial slabs into the parameter gradient.
 //   block = 32 c-lanes x 32 split-slices (1024 threads); one block per (n, 32-channel tile); every thread keeps the
 //   T taps of its (n, c) in registers, the slices are combined through LDS in slice order (deterministic), and
@@ -243,6 +382,36 @@ extern "C" int hpri_conv_wgrad(const float* x, int x_cs, int x_coff, int x_cvali
   if (KS == 3) hipLaunchKernelGGL((conv_wgrad_kernel<3, 1, 1, HPRI_A_DIRECT>), grid, dim3(256), 0, stream, a);
   else if (bmode == HPRI_A_S2D) hipLaunchKernelGGL((conv_wgrad_kernel<1, 2, 2, HPRI_A_S2D>), grid, dim3(256), 0, stream, a);
   else hipLaunchKernelGGL((conv_wgrad_kernel<1, 2, 2, HPRI_A_DIRECT>), grid, dim3(256), 0, stream, a);
+  HPRI_CHECK_LAUNCH();
+  return HPRI_OK;
+}
+
+// bf16-operand variant of hpri_conv_wgrad (direct forms only; same plan, workspace and reduce).
+extern "C" int hpri_conv_wgrad_bf16(const float* x, int x_cs, int x_coff, int x_cvalid,
+                                    const float* dy, int dy_cs, int dy_coff, int dy_cvalid,
+                                    float* ws, size_t ws_floats,
+                                    int N, int H, int W, int Cin_pad, int Cout_pad, int KS, hipStream_t stream) {
+  HPRI_REQUIRE(x && dy && ws, "conv_wgrad_bf16: null pointer");
+  HPRI_REQUIRE(KS == 1 || KS == 3, "conv_wgrad_bf16: kernel size must be 1 or 3");
+  HPRI_REQUIRE(x_cs % 4 == 0 && x_coff % 4 == 0 && dy_cs % 4 == 0 && dy_coff % 4 == 0 && x_cvalid % 4 == 0 && dy_cvalid % 4 == 0,
+               "conv_wgrad_bf16: channel strides/offsets/valid counts must be multiples of 4");
+  HPRI_REQUIRE(N > 0 && H > 0 && W > 0 && Cin_pad > 0 && Cout_pad > 0, "conv_wgrad_bf16: empty problem");
+  WgradArgs a;
+  a.x = x; a.x_cs = x_cs; a.x_coff = x_coff; a.x_cvalid = x_cvalid;
+  a.dy = dy; a.dy_cs = dy_cs; a.dy_coff = dy_coff; a.dy_cvalid = dy_cvalid;
+  a.ws = ws; a.N = N; a.H = H; a.W = W;
+  a.strips_x = hpri_cdiv(W, 32); a.strips_y = hpri_cdiv(H, 2);
+  a.total_strips = N * a.strips_x * a.strips_y;
+  int splits, Cr, Nr;
+  hpri_wgrad_plan(N, H, W, Cin_pad, Cout_pad, KS, &splits, &Cr, &Nr);
+  a.strips_per_split = hpri_cdiv(a.total_strips, splits);
+  a.Cr = Cr; a.Nr = Nr; a.H2 = a.W2 = a.py0 = a.px0 = a.Cup = 0;
+  const int T = KS * KS;
+  if ((size_t)splits * T * Cr * Nr > ws_floats) return hpri_set_error(HPRI_ERR_WORKSPACE, "conv_wgrad_bf16: workspace too small");
+  int bc, bn; wgrad_cfg(KS, &bc, &bn);
+  dim3 grid((unsigned)splits, (unsigned)(Cr / bc), (unsigned)(Nr / bn));
+  if (KS == 3) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<3, 1, 1>), grid, dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL((conv_wgrad_bf16_kernel<1, 2, 2>), grid, dim3(256), 0, stream, a);
   HPRI_CHECK_LAUNCH();
   return HPRI_OK;
 }

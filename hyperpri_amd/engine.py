@@ -20,8 +20,9 @@ E_DIRECT, E_D2S = 0, 1
 
 # Arithmetic of the conv / linear contractions:
 #   "fp32" (default) -- exact fp32 on v_mfma_f32_32x32x2_f32: the mode every 1e-3-logit parity claim refers to
-#   "bf16"           -- forward and data-gradient operands rounded to bf16, v_mfma_f32_32x32x16_bf16 with fp32
-#                       accumulate (BASELINE.json config C5); weight gradients and everything else stay fp32.
+#   "bf16"           -- conv / linear operands (forward, data gradient, weight gradient) rounded to bf16,
+#                       v_mfma_f32_32x32x16_bf16 with fp32 accumulate (BASELINE.json config C5); activations in HBM,
+#                       BN, pooling, ConvTranspose2d and the 1x1 output conv stay fp32.
 #                       Dice/IoU-level parity only (bf16 operands move logits by ~2e-2).
 PRECISIONS = ("fp32", "bf16")
 DEFAULT_PRECISION = os.environ.get("HPRI_PRECISION", "fp32")
@@ -377,12 +378,12 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
             main, side = torch.cuda.current_stream(dev), _side(dev)
             side.wait_stream(main)                      # dyr (and everything before it) is ready
             with torch.cuda.stream(side):
-                _wgrad(x, dyr, dw, acc_w, cin, cout, ks)
+                _wgrad(x, dyr, dw, acc_w, cin, cout, ks, bf16=(prec == "bf16"))
             for t in (x.buf, dyr.buf, dw):               # keep the caching allocator from recycling them early
                 t.record_stream(side)
             tp.used_side = True
         else:
-            _wgrad(x, dyr, dw, acc_w, cin, cout, ks)
+            _wgrad(x, dyr, dw, acc_w, cin, cout, ks, bf16=(prec == "bf16"))
         if need_dx:
             gx, acc = tp.grad_slot(x)
             if prec == "bf16":
@@ -400,7 +401,7 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
 
 def _wgrad(x: Act, dy: Act, dw: torch.Tensor, accumulate: int, cin: int, cout: int, ks: int,
            bmode: int = A_DIRECT, dst_mode: int = 0, N: int = 0, H: int = 0, W: int = 0,
-           H2: int = 0, W2: int = 0, py0: int = 0, px0: int = 0, cup: int = 0) -> None:
+           H2: int = 0, W2: int = 0, py0: int = 0, px0: int = 0, cup: int = 0, bf16: bool = False) -> None:
     N, H, W = (N or x.N), (H or x.H), (W or x.W)
     cin_pad = x.cw
     cout_pad = _rup(cout, 64)
@@ -408,9 +409,16 @@ def _wgrad(x: Act, dy: Act, dw: torch.Tensor, accumulate: int, cin: int, cout: i
     _lib.call("hpri_wgrad_plan", N, H, W, cin_pad, cout_pad, ks, ctypes.byref(splits), ctypes.byref(cr), ctypes.byref(nr))
     ws = _ws(splits.value * ks * ks * cr.value * nr.value, x.buf.device)
     dy_cvalid = (4 * cup) if bmode == A_S2D else dy.cw
-    tag = f"conv_wgrad<{ks},{'s2d' if bmode == A_S2D else 'direct'}>"
+    tag = f"conv_wgrad{'_bf16' if bf16 else ''}<{ks},{'s2d' if bmode == A_S2D else 'direct'}>"
     if SHAPE_TAGS:
         tag += f" N{N} {H}x{W} C{cin_pad} N{cout}"
+    if bf16 and bmode == A_DIRECT:
+        with _timed(tag, 2.0 * N * H * W * cin * cout * ks * ks):
+            _lib.call("hpri_conv_wgrad_bf16", x.ptr, x.cs, x.coff, cin_pad, dy.ptr, dy.cs, dy.coff, dy_cvalid, _p(ws), ws.numel(),
+                      N, H, W, cin_pad, cout_pad, ks, _stream())
+        _lib.call("hpri_wgrad_reduce", _p(ws), _p(dw), N, H, W, cin, cin_pad, cout, cout_pad, ks, dst_mode, cup, accumulate,
+                  _stream())
+        return
     with _timed(tag, 2.0 * N * H * W * cin * cout * ks * ks):
         _lib.call("hpri_conv_wgrad", x.ptr, x.cs, x.coff, cin_pad, dy.ptr, dy.cs, dy.coff, dy_cvalid, _p(ws), ws.numel(),
                   N, H, W, cin_pad, cout_pad, ks, bmode, H2, W2, py0, px0, cup, _stream())

@@ -79,6 +79,9 @@ int hpri_wgrad_plan(int N, int H, int W, int Cin_pad, int Cout_pad, int KS, int*
 int hpri_conv_wgrad(const float* x, int x_cs, int x_coff, int x_cvalid, const float* dy, int dy_cs, int dy_coff,
                     int dy_cvalid, float* ws, size_t ws_floats, int N, int H, int W, int Cin_pad, int Cout_pad, int KS,
                     int bmode, int H2, int W2, int py0, int px0, int Cup, hipStream_t stream);
+int hpri_conv_wgrad_bf16(const float* x, int x_cs, int x_coff, int x_cvalid, const float* dy, int dy_cs, int dy_coff,
+                         int dy_cvalid, float* ws, size_t ws_floats, int N, int H, int W, int Cin_pad, int Cout_pad,
+                         int KS, hipStream_t stream);
 int hpri_wgrad_reduce(const float* ws, float* dw, int N, int H, int W, int Cin, int Cin_pad, int Cout, int Cout_pad,
                       int KS, int dst_mode, int Cup, int accumulate, hipStream_t stream);
 

@@ -129,7 +129,7 @@ def test_cpu_tensor_raises():
 def test_conv_bf16_mode_vs_torch_on_rounded_operands(N, Cin, H, W, Cout, ks):
     """precision="bf16": the kernel rounds activations and weights to bf16 (RNE) and accumulates in fp32, so it must
     agree with torch's fp32 conv evaluated on the bf16-rounded operands to fp32-summation accuracy (forward and data
-    gradient; the weight gradient stays on the exact fp32 kernel)."""
+    and weight gradients)."""
     from hyperpri_amd import engine as E
     from hyperpri_amd.autograd import run
     import torch.nn.functional as F
@@ -139,16 +139,13 @@ def test_conv_bf16_mode_vs_torch_on_rounded_operands(N, Cin, H, W, Cout, ks):
     b = torch.randn(Cout, generator=g)
     r = torch.randn(N, Cout, H, W, generator=g)
     rb = lambda t: t.to(torch.bfloat16).to(torch.float32)
-    xc = rb(x).requires_grad_(True)
-    yc = F.conv2d(xc, rb(w), b, padding=ks // 2)
-    yc.backward(rb(r))                       # dgrad operands (dy, w) are rounded too
+    xc, wq = rb(x).requires_grad_(True), rb(w).requires_grad_(True)
+    yc = F.conv2d(xc, wq, b, padding=ks // 2)
+    yc.backward(rb(r))                       # dgrad / wgrad operands (dy, w, x) are rounded too
     xd, wd, bd = (t.to(DEV).requires_grad_(True) for t in (x, w, b))
     yd = run(lambda tape, a, need: E.conv_bn_relu(tape, a[0], wd, bd, None, True, ks, need_dx=need[0], precision="bf16"),
              [xd], [wd, bd])
     _close(yd, yc.detach().numpy(), 1e-4, 2e-4, "bf16 conv forward")
     yd.backward(r.to(DEV))
     _close(xd.grad, xc.grad.numpy(), 1e-4, 3e-4, "bf16 conv dgrad")
-    # weight gradient: exact fp32 on unrounded operands
-    xe, we = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
-    (F.conv2d(xe, we, b, padding=ks // 2) * r).sum().backward()
-    _close(wd.grad, we.grad.numpy(), 1e-4, 1e-3, "fp32 wgrad in bf16 mode")
+    _close(wd.grad, wq.grad.numpy(), 1e-4, 2e-3, "bf16 conv wgrad")

@@ -66,6 +66,9 @@ def main():
                     elif mode == "fwd_bf16":
                         rc = lib.hpri_conv_fwd_bf16(P(x), Cin, 0, P(wpb), P(b), P(y), Cout, 0, P(stats), N, H, W, Cin, Cout,
                                                     cout_pad, Cout, ks, 0, P(ws), ws.numel(), st)
+                    elif mode == "wgrad_bf16":
+                        rc = lib.hpri_conv_wgrad_bf16(P(x), Cin, 0, Cin, P(y), Cout, 0, Cout, P(ws), ws.numel(), N, H, W, Cin,
+                                                      cout_pad, ks, st)
                     else:
                         rc = lib.hpri_conv_wgrad(P(x), Cin, 0, Cin, P(y), Cout, 0, Cout, P(ws), ws.numel(), N, H, W, Cin, cout_pad,
                                                  ks, 0, 0, 0, 0, 0, 0, st)

@@ -52,13 +52,14 @@ def main():
     nval = int(sys.argv[1]) if len(sys.argv) > 1 else 14
     ksteps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
     tag = sys.argv[3] if len(sys.argv) > 3 else "r01"
+    precision = sys.argv[4] if len(sys.argv) > 4 else "fp32"
     dev = torch.device("cuda", 0)
     torch.set_num_threads(bench.host_cores())
     val = list(range(45, 45 + nval))
     net = HP.CubeNET(D, 1, first_depth=64, bilinear=False)
     sd = O.synth_state_dict(O.cubenet_shapes(D, 1, 64))
     net.load_state_dict(sd)
-    net = net.to(dev)
+    net = HP.set_precision(net.to(dev), precision)
     rows = []
     t0 = time.time()
     compare(net, sd, val, True, dev, rows, "init/train-BN")
@@ -87,14 +88,18 @@ def main():
         losses.append(float(loss.detach()))
     sd2 = OrderedDict((k, v.detach().cpu().clone()) for k, v in net.state_dict().items())
     compare(net, sd2, val, False, dev, rows, f"adam{ksteps}/eval-BN")
-    out = {"cubes": val, "adam_steps": ksteps, "train_losses": losses, "rows": rows,
+    out = {"precision": precision, "cubes": val, "adam_steps": ksteps, "train_losses": losses, "rows": rows,
            "all_dice_equal_4dp": all(r["dice_equal_4dp"] for r in rows), "all_iou_equal_4dp": all(r["iou_equal_4dp"] for r in rows),
-           "max_abs_dlogit": max(r["max_abs_dlogit"] for r in rows), "seconds": time.time() - t0}
+           "max_abs_dlogit": max(r["max_abs_dlogit"] for r in rows),
+           "max_abs_ddice": max(abs(r["dice_hip"] - r["dice_oracle"]) for r in rows),
+           "max_abs_diou": max(abs(r["iou_hip"] - r["iou_oracle"]) for r in rows),
+           "max_sign_flip_fraction": max(r["sign_flips"] for r in rows) / float(H * W), "seconds": time.time() - t0}
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     for d in ("profiles", "gpurun_out"):
         with open(os.path.join(ROOT, d, f"{tag}_dice_parity.json"), "w") as f:
             json.dump(out, f, indent=1)
-    print("summary:", {k: out[k] for k in ("all_dice_equal_4dp", "all_iou_equal_4dp", "max_abs_dlogit", "seconds")})
+    print("summary:", {k: out[k] for k in ("precision", "all_dice_equal_4dp", "all_iou_equal_4dp", "max_abs_dlogit",
+                                           "max_abs_ddice", "max_abs_diou", "max_sign_flip_fraction", "seconds")})
 
 
 if __name__ == "__main__":
