@@ -169,13 +169,16 @@ __device__ __forceinline__ bf16x8 tr_frag(const __bf16* p, int pitch4) {
 template <int KS, int CT, int NT>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradArgs a) {
   constexpr int T = KS * KS, PAD = KS / 2;
-  constexpr int SH = 2, SW = 32, HH = SH + KS - 1, HW = SW + KS - 1, HP = HH * HW;
+  // one staged unit = SQ vertically adjacent 2x32 strips (SQ*64 pixels): the bf16 MFMAs retire so fast that the
+  // staging + barrier cost must be amortised over more pixels than in the fp32 kernel
+  constexpr int SQ = (KS == 3) ? 2 : 1;
+  constexpr int SH = 2 * SQ, SW = 32, HH = SH + KS - 1, HW = SW + KS - 1, HP = HH * HW, NPIX = SH * SW;
   constexpr int BC = 64 * CT, BNW = 64 * NT;
   constexpr int PX = BC + 32, PY = BNW + 32;      // halves per staged pixel: data + 32 pad, i.e. a pitch of 48 / 80 dwords
                                                   // = 16 (mod 32): the 4 pixel rows of a transposed read hit disjoint banks
   constexpr int NLD_X = (HP * (BC / 4) + 255) / 256;
-  constexpr int NLD_Y = (64 * (BNW / 4)) / 256;
-  __shared__ __attribute__((aligned(16))) __bf16 smem[HP * PX + 64 * PY];
+  constexpr int NLD_Y = (NPIX * (BNW / 4)) / 256;
+  __shared__ __attribute__((aligned(16))) __bf16 smem[HP * PX + NPIX * PY];
   __bf16* x_lds = smem;
   __bf16* y_lds = smem + HP * PX;
 
@@ -197,19 +200,23 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][i][j][r] = 0.f;
 
-  const int s_begin = blockIdx.x * a.strips_per_split;
-  const int s_end = min(a.total_strips, s_begin + a.strips_per_split);
+  // strips_y counts 2-row strips; this kernel walks them SQ at a time: unit = (img, unit row, strip column)
+  const int units_y = (a.strips_y + SQ - 1) / SQ;
+  const int total_units = a.N * units_y * a.strips_x;
+  const int units_per_split = (total_units + gridDim.x - 1) / gridDim.x;
+  const int u_begin = blockIdx.x * units_per_split;
+  const int u_end = min(total_units, u_begin + units_per_split);
   const __bf16* xb = x_lds + (lh * 8 + lq) * PX + wc * (CT * 32) + lg * 16 + lp * 4;
   const __bf16* yb = y_lds + (lh * 8 + lq) * PY + wn * (NT * 32) + lg * 16 + lp * 4;
 
-  for (int st = s_begin; st < s_end; ++st) {
+  for (int st = u_begin; st < u_end; ++st) {
     int q = st;
     const int sx = q % a.strips_x; q /= a.strips_x;
-    const int sy = q % a.strips_y;
-    const int img = q / a.strips_y;
+    const int sy = q % units_y;
+    const int img = q / units_y;
     const int y0 = sy * SH, x0 = sx * SW;
 
-    f32x4 xr[NLD_X], yr[NLD_Y];
+    bf16x4 xr[NLD_X], yr[NLD_Y];               // converted to bf16 right after the load: half the staging registers
 #pragma unroll
     for (int p = 0; p < NLD_X; ++p) {
       const int f = tid + p * 256;
@@ -222,7 +229,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradArgs a) {
         if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W && c < a.x_cvalid)
           v = *reinterpret_cast<const f32x4*>(a.x + ((size_t)(img * a.H + iy) * a.W + ix) * a.x_cs + a.x_coff + c);
       }
-      xr[p] = v;
+      xr[p] = __builtin_convertvector(v, bf16x4);
     }
 #pragma unroll
     for (int p = 0; p < NLD_Y; ++p) {
@@ -233,26 +240,26 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradArgs a) {
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (iy < a.H && ix < a.W && n < a.dy_cvalid)
         v = *reinterpret_cast<const f32x4*>(a.dy + ((size_t)(img * a.H + iy) * a.W + ix) * a.dy_cs + a.dy_coff + n);
-      yr[p] = v;
+      yr[p] = __builtin_convertvector(v, bf16x4);
     }
-    __syncthreads();   // previous strip's LDS reads are finished
+    __syncthreads();   // previous unit's LDS reads are finished
 #pragma unroll
     for (int p = 0; p < NLD_X; ++p) {
       const int f = tid + p * 256;
       const int pix = f / (BC / 4), c4 = f % (BC / 4);
-      if (pix < HP) *reinterpret_cast<bf16x4*>(x_lds + pix * PX + c4 * 4) = __builtin_convertvector(xr[p], bf16x4);
+      if (pix < HP) *reinterpret_cast<bf16x4*>(x_lds + pix * PX + c4 * 4) = xr[p];
     }
 #pragma unroll
     for (int p = 0; p < NLD_Y; ++p) {
       const int f = tid + p * 256;
       const int pix = f / (BNW / 4), n4 = f % (BNW / 4);
-      *reinterpret_cast<bf16x4*>(y_lds + pix * PY + n4 * 4) = __builtin_convertvector(yr[p], bf16x4);
+      *reinterpret_cast<bf16x4*>(y_lds + pix * PY + n4 * 4) = yr[p];
     }
     __syncthreads();
 
-    // 4 k16-steps: strip pixels 16*ks .. 16*ks+15 (row ks>>1, columns 16*(ks&1) ..)
+    // NPIX/16 k16-steps: unit pixels 16*ks .. 16*ks+15 (row ks>>1, columns 16*(ks&1) ..)
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
+    for (int ks = 0; ks < NPIX / 16; ++ks) {
       const int py = ks >> 1, pxo = 16 * (ks & 1);
       bf16x8 af[NT];
 #pragma unroll
