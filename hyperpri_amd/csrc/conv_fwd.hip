@@ -115,7 +115,8 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvFwdArgs a) {
   _Pragma("unroll") for (int p = 0; p < NLD_B; ++p)                                                 \
       *reinterpret_cast<f32x4*>(b_lds + (buf_) * 32 * BN + blds[p]) = breg[p];
 
-  // ---- A halo: per-thread global offsets (element units, < 2^31) computed ONCE per tile; -1 = zero fill ----
+  // ---- A halo: per-thread offsets inside this image (element units, < 2^31) computed ONCE per tile; -1 = zero fill ----
+  const float* ximg = a.x + (size_t)img * (AMODE == HPRI_A_DIRECT ? (size_t)a.H * a.W : (size_t)a.H2 * a.W2) * a.x_cs;
   // slot f = tid + p*256 -> halo pixel f>>3, 16-byte quad f&7 of the 32-channel chunk
   int aoff[NLD_A];
   {
@@ -129,8 +130,8 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvFwdArgs a) {
         const int hy = (int)(((unsigned)pix * hw_inv) >> 16), hx = pix - hy * HW;
         const int iy = y0 + hy - PAD, ix = x0 + hx - PAD;
         if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) {
-          if (AMODE == HPRI_A_DIRECT) off = ((img * a.H + iy) * a.W + ix) * a.x_cs + a.x_coff + q * 4;
-          else off = ((img * a.H2 + 2 * iy + a.py0) * a.W2 + 2 * ix + a.px0) * a.x_cs + a.x_coff;  // + tap/chan below
+          if (AMODE == HPRI_A_DIRECT) off = (iy * a.W + ix) * a.x_cs + a.x_coff + q * 4;
+          else off = ((2 * iy + a.py0) * a.W2 + 2 * ix + a.px0) * a.x_cs + a.x_coff;  // + tap/chan below
         }
       }
       aoff[p] = off;
@@ -145,11 +146,11 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvFwdArgs a) {
       f32x4 v = {0.f, 0.f, 0.f, 0.f};                                                                 \
       if (aoff[p] >= 0 && q < kq) {                                                                   \
         if (AMODE == HPRI_A_DIRECT) {                                                                 \
-          v = *reinterpret_cast<const f32x4*>(a.x + (size_t)(unsigned)aoff[p] + (c0_));              \
+          v = *reinterpret_cast<const f32x4*>(ximg + (size_t)(unsigned)aoff[p] + (c0_));             \
         } else { /* S2D: k = tap*Cup + co ; source pixel (2*iy + t_y + py0, 2*ix + t_x + px0) */      \
           const int k4 = (c0_) + q * 4;                                                               \
           const int tp = k4 / a.Cup, co = k4 - tp * a.Cup;                                            \
-          v = *reinterpret_cast<const f32x4*>(a.x + (size_t)(unsigned)aoff[p] +                       \
+          v = *reinterpret_cast<const f32x4*>(ximg + (size_t)(unsigned)aoff[p] +                      \
                                               ((tp >> 1) * a.W2 + (tp & 1)) * a.x_cs + co);           \
         }                                                                                             \
       }                                                                                               \
@@ -403,6 +404,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_bf16_kernel(ConvFwdArgs a) {
       *reinterpret_cast<f32x4*>(b_lds + (buf_) * KS * BN * CS + blds[p]) = breg[p];
 
   // ---- A halo: fp32 in HBM -> registers -> bf16 in LDS ----
+  const float* ximg = a.x + (size_t)img * a.H * a.W * a.x_cs;
   int aoff[NLD_A];
   {
     const unsigned hw_inv = (65536u + (unsigned)HW - 1u) / (unsigned)HW;
@@ -414,7 +416,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_bf16_kernel(ConvFwdArgs a) {
       if (pix < HP) {
         const int hy = (int)(((unsigned)pix * hw_inv) >> 16), hx = pix - hy * HW;
         const int iy = y0 + hy - PAD, ix = x0 + hx - PAD;
-        if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) off = ((img * a.H + iy) * a.W + ix) * a.x_cs + a.x_coff + q * 4;
+        if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) off = (iy * a.W + ix) * a.x_cs + a.x_coff + q * 4;
       }
       aoff[p] = off;
     }
@@ -426,7 +428,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_bf16_kernel(ConvFwdArgs a) {
     _Pragma("unroll") for (int p = 0; p < NLD_A; ++p) {                                              \
       const int q = (tid + p * 256) & 7;                                                             \
       f32x4 v = {0.f, 0.f, 0.f, 0.f};                                                                \
-      if (aoff[p] >= 0 && q < kq) v = *reinterpret_cast<const f32x4*>(a.x + (size_t)(unsigned)aoff[p] + (c0_)); \
+      if (aoff[p] >= 0 && q < kq) v = *reinterpret_cast<const f32x4*>(ximg + (size_t)(unsigned)aoff[p] + (c0_)); \
       areg[p] = v;                                                                                   \
     }                                                                                                \
   }
@@ -767,7 +769,7 @@ extern "C" int hpri_conv_fwd_bf16(const float* x, int x_cs, int x_coff, const vo
   HPRI_REQUIRE(x_cs % 4 == 0 && x_coff % 4 == 0, "conv_fwd_bf16: input channel stride/offset must be multiples of 4");
   HPRI_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)wp & 15) == 0, "conv_fwd_bf16: pointers must be 16-byte aligned");
   HPRI_REQUIRE(KS == 1 || KS == 3, "conv_fwd_bf16: kernel size must be 1 or 3");
-  HPRI_REQUIRE((long long)N * H * W * x_cs < (1ll << 31), "conv_fwd_bf16: input view exceeds 2^31 elements");
+  HPRI_REQUIRE((long long)H * W * x_cs < (1ll << 31), "conv_fwd_bf16: one image of the input view exceeds 2^31 elements");
   ConvFwdArgs a;
   a.x = x; a.x_cs = x_cs; a.x_coff = x_coff; a.wp = reinterpret_cast<const float*>(wp); a.bias = bias;
   a.y = y; a.y_cs = y_cs; a.y_coff = y_coff; a.stats = reinterpret_cast<float4*>(stats);
@@ -810,7 +812,7 @@ extern "C" int hpri_conv_fwd(const float* x, int x_cs, int x_coff, const float* 
   HPRI_REQUIRE(x_cs % 4 == 0 && x_coff % 4 == 0, "conv_fwd: input channel stride/offset must be multiples of 4");
   HPRI_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)wp & 15) == 0, "conv_fwd: pointers must be 16-byte aligned");
   HPRI_REQUIRE(KS == 1 || KS == 3, "conv_fwd: kernel size must be 1 or 3");
-  HPRI_REQUIRE((long long)N * (H2 > H ? H2 : H) * (W2 > W ? W2 : W) * x_cs < (1ll << 31), "conv_fwd: input view exceeds 2^31 elements");
+  HPRI_REQUIRE((long long)(H2 > H ? H2 : H) * (W2 > W ? W2 : W) * x_cs < (1ll << 31), "conv_fwd: one image of the input view exceeds 2^31 elements");
   ConvFwdArgs a;
   a.x = x; a.x_cs = x_cs; a.x_coff = x_coff; a.wp = wp; a.bias = bias;
   a.y = y; a.y_cs = y_cs; a.y_coff = y_coff; a.stats = reinterpret_cast<float4*>(stats);
