@@ -333,10 +333,9 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvFwdArgs a) {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
-template <int KS, int WM, int WN>
+template <int KS, int WM, int WN, int AMODE, int EPI>
 __global__ __launch_bounds__(256, 2) void conv_fwd_bf16_kernel(ConvFwdArgs a) {
   constexpr int T = KS * KS, PAD = KS / 2;
-  constexpr int AMODE = HPRI_A_DIRECT, EPI = HPRI_E_DIRECT;
   constexpr int TPIX = 64 * WM;
   constexpr int MAXHP = (KS == 1) ? TPIX : (WM == 2 ? 6 * 34 : 10 * 34);
   constexpr int BN = 64 * WN;
@@ -404,7 +403,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_bf16_kernel(ConvFwdArgs a) {
       *reinterpret_cast<f32x4*>(b_lds + (buf_) * KS * BN * CS + blds[p]) = breg[p];
 
   // ---- A halo: fp32 in HBM -> registers -> bf16 in LDS ----
-  const float* ximg = a.x + (size_t)img * a.H * a.W * a.x_cs;
+  const float* ximg = a.x + (size_t)img * (AMODE == HPRI_A_DIRECT ? (size_t)a.H * a.W : (size_t)a.H2 * a.W2) * a.x_cs;
   int aoff[NLD_A];
   {
     const unsigned hw_inv = (65536u + (unsigned)HW - 1u) / (unsigned)HW;
@@ -416,7 +415,10 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_bf16_kernel(ConvFwdArgs a) {
       if (pix < HP) {
         const int hy = (int)(((unsigned)pix * hw_inv) >> 16), hx = pix - hy * HW;
         const int iy = y0 + hy - PAD, ix = x0 + hx - PAD;
-        if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) off = (iy * a.W + ix) * a.x_cs + a.x_coff + q * 4;
+        if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) {
+          if (AMODE == HPRI_A_DIRECT) off = (iy * a.W + ix) * a.x_cs + a.x_coff + q * 4;
+          else off = ((2 * iy + a.py0) * a.W2 + 2 * ix + a.px0) * a.x_cs + a.x_coff;   // + tap / channel per chunk
+        }
       }
       aoff[p] = off;
     }
@@ -428,7 +430,16 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_bf16_kernel(ConvFwdArgs a) {
     _Pragma("unroll") for (int p = 0; p < NLD_A; ++p) {                                              \
       const int q = (tid + p * 256) & 7;                                                             \
       f32x4 v = {0.f, 0.f, 0.f, 0.f};                                                                \
-      if (aoff[p] >= 0 && q < kq) v = *reinterpret_cast<const f32x4*>(ximg + (size_t)(unsigned)aoff[p] + (c0_)); \
+      if (aoff[p] >= 0 && q < kq) {                                                                  \
+        if (AMODE == HPRI_A_DIRECT) {                                                                \
+          v = *reinterpret_cast<const f32x4*>(ximg + (size_t)(unsigned)aoff[p] + (c0_));            \
+        } else { /* S2D: k = tap*Cup + co ; source pixel (2*iy + t_y + py0, 2*ix + t_x + px0) */     \
+          const int k4 = (c0_) + q * 4;                                                              \
+          const int tp = k4 / a.Cup, co = k4 - tp * a.Cup;                                           \
+          v = *reinterpret_cast<const f32x4*>(ximg + (size_t)(unsigned)aoff[p] +                     \
+                                              ((tp >> 1) * a.W2 + (tp & 1)) * a.x_cs + co);          \
+        }                                                                                            \
+      }                                                                                              \
       areg[p] = v;                                                                                   \
     }                                                                                                \
   }
@@ -744,7 +755,7 @@ extern "C" int hpri_conv_fwd_plan(int N, int H, int W, int Cin_pad, int Cout_pad
   return HPRI_OK;
 }
 
-template <int KS, int WM, int WN>
+template <int KS, int WM, int WN, int AMODE, int EPI>
 static int launch_conv_bf16(const ConvFwdArgs& a0, hipStream_t stream) {
   ConvFwdArgs a = a0;
   constexpr int BN = 64 * WN;
@@ -752,16 +763,17 @@ static int launch_conv_bf16(const ConvFwdArgs& a0, hipStream_t stream) {
   a.nseg = sg.nseg; a.tiles_img = sg.tiles_img;
   for (int k = 0; k < HPRI_MAXSEG; ++k) { a.seg_twl[k] = sg.twl[k]; a.seg_xbeg[k] = sg.xbeg[k]; a.seg_ntx[k] = sg.ntx[k]; a.seg_first[k] = sg.first[k]; }
   dim3 grid((unsigned)(a.N * a.tiles_img), (unsigned)(a.Cout_pad / BN), (unsigned)a.ksplit);
-  hipLaunchKernelGGL((conv_fwd_bf16_kernel<KS, WM, WN>), grid, dim3(256), 0, stream, a);
+  hipLaunchKernelGGL((conv_fwd_bf16_kernel<KS, WM, WN, AMODE, EPI>), grid, dim3(256), 0, stream, a);
   HPRI_CHECK_LAUNCH();
   return HPRI_OK;
 }
 
-// bf16-operand variant of hpri_conv_fwd (direct 3x3 / 1x1 forms only); wp from hpri_pack_weight_bf16.
+// bf16-operand variant of hpri_conv_fwd (same modes); wp from hpri_pack_weight_bf16.
 extern "C" int hpri_conv_fwd_bf16(const float* x, int x_cs, int x_coff, const void* wp, const float* bias,
                                   float* y, int y_cs, int y_coff, float* stats,
                                   int N, int H, int W, int Cin_pad, int Cout, int Cout_pad, int y_cw,
-                                  int KS, int accumulate, float* ws, size_t ws_floats, hipStream_t stream) {
+                                  int KS, int amode, int epi, int accumulate, int H2, int W2, int py0, int px0, int Cup,
+                                  float* ws, size_t ws_floats, hipStream_t stream) {
   HPRI_REQUIRE(x && wp && y, "conv_fwd_bf16: null pointer");
   HPRI_REQUIRE(N > 0 && H > 0 && W > 0, "conv_fwd_bf16: empty image");
   HPRI_REQUIRE(Cin_pad > 0 && Cin_pad % 8 == 0, "conv_fwd_bf16: Cin_pad must be a positive multiple of 8");
@@ -769,15 +781,24 @@ extern "C" int hpri_conv_fwd_bf16(const float* x, int x_cs, int x_coff, const vo
   HPRI_REQUIRE(x_cs % 4 == 0 && x_coff % 4 == 0, "conv_fwd_bf16: input channel stride/offset must be multiples of 4");
   HPRI_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)wp & 15) == 0, "conv_fwd_bf16: pointers must be 16-byte aligned");
   HPRI_REQUIRE(KS == 1 || KS == 3, "conv_fwd_bf16: kernel size must be 1 or 3");
-  HPRI_REQUIRE((long long)H * W * x_cs < (1ll << 31), "conv_fwd_bf16: one image of the input view exceeds 2^31 elements");
+  HPRI_REQUIRE((long long)(H2 > H ? H2 : H) * (W2 > W ? W2 : W) * x_cs < (1ll << 31), "conv_fwd_bf16: one image of the input view exceeds 2^31 elements");
   ConvFwdArgs a;
   a.x = x; a.x_cs = x_cs; a.x_coff = x_coff; a.wp = reinterpret_cast<const float*>(wp); a.bias = bias;
   a.y = y; a.y_cs = y_cs; a.y_coff = y_coff; a.stats = reinterpret_cast<float4*>(stats);
   a.N = N; a.H = H; a.W = W; a.Cin_pad = Cin_pad; a.Cout = Cout; a.Cout_pad = Cout_pad;
   a.y_cw = y_cw < Cout ? Cout : y_cw; a.accumulate = accumulate;
-  a.H2 = a.W2 = a.py0 = a.px0 = a.Cup = 0;
-  HPRI_REQUIRE(a.y_cw + y_coff <= y_cs, "conv_fwd_bf16: output channels exceed the channel stride");
-  a.ksplit = conv_ksplit(N, H, W, Cin_pad, Cout_pad, KS, HPRI_E_DIRECT, HPRI_A_DIRECT);
+  a.H2 = H2; a.W2 = W2; a.py0 = py0; a.px0 = px0; a.Cup = Cup;
+  if (epi == HPRI_E_DIRECT) HPRI_REQUIRE(a.y_cw + y_coff <= y_cs, "conv_fwd_bf16: output channels exceed the channel stride");
+  if (amode == HPRI_A_S2D || epi == HPRI_E_D2S) {
+    HPRI_REQUIRE(KS == 1, "conv_fwd_bf16: S2D/D2S need KS == 1");
+    HPRI_REQUIRE(Cup > 0 && Cup % 4 == 0, "conv_fwd_bf16: Cup must be a positive multiple of 4");
+    HPRI_REQUIRE(py0 >= 0 && px0 >= 0 && 2 * H + py0 <= H2 && 2 * W + px0 <= W2, "conv_fwd_bf16: 2x2 patch grid exceeds the hi-res image");
+    HPRI_REQUIRE(stats == nullptr, "conv_fwd_bf16: statistics epilogue is only available for direct stores");
+    if (amode == HPRI_A_S2D) HPRI_REQUIRE(Cin_pad == 4 * Cup, "conv_fwd_bf16: S2D needs Cin_pad == 4*Cup");
+    if (epi == HPRI_E_D2S) HPRI_REQUIRE(Cout == 4 * Cup, "conv_fwd_bf16: D2S needs Cout == 4*Cup");
+    HPRI_REQUIRE(!(amode == HPRI_A_S2D && epi == HPRI_E_D2S), "conv_fwd_bf16: S2D and D2S are exclusive");
+  }
+  a.ksplit = conv_ksplit(N, H, W, Cin_pad, Cout_pad, KS, epi, amode);
   a.ws = ws;
   if (a.ksplit > 1) {
     if (ws == nullptr || (size_t)a.ksplit * N * H * W * Cout_pad > ws_floats)
@@ -787,8 +808,13 @@ extern "C" int hpri_conv_fwd_bf16(const float* x, int x_cs, int x_coff, const vo
   }
   int wm, wn; conv_cfg(Cout_pad, &wm, &wn);
   int rc;
-  if (KS == 3) rc = (wm == 2) ? launch_conv_bf16<3, 2, 2>(a, stream) : launch_conv_bf16<3, 4, 1>(a, stream);
-  else rc = (wm == 2) ? launch_conv_bf16<1, 2, 2>(a, stream) : launch_conv_bf16<1, 4, 1>(a, stream);
+#define HPRI_DISPATCH_B(KS_, AM_, EP_)                                                      \
+  rc = (wm == 2) ? launch_conv_bf16<KS_, 2, 2, AM_, EP_>(a, stream) : launch_conv_bf16<KS_, 4, 1, AM_, EP_>(a, stream)
+  if (KS == 3) { HPRI_DISPATCH_B(3, HPRI_A_DIRECT, HPRI_E_DIRECT); }
+  else if (amode == HPRI_A_S2D) { HPRI_DISPATCH_B(1, HPRI_A_S2D, HPRI_E_DIRECT); }
+  else if (epi == HPRI_E_D2S) { HPRI_DISPATCH_B(1, HPRI_A_DIRECT, HPRI_E_D2S); }
+  else { HPRI_DISPATCH_B(1, HPRI_A_DIRECT, HPRI_E_DIRECT); }
+#undef HPRI_DISPATCH_B
   if (rc != HPRI_OK || a.ksplit == 1) return rc;
   const int c4 = a.y_cw >> 2;
   int cq = 1; while (cq < c4 && cq < 64) cq <<= 1;

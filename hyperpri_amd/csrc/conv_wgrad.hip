@@ -166,7 +166,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const __bf16* p, int pitch4) {
   return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-template <int KS, int CT, int NT>
+template <int KS, int CT, int NT, int BMODE>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradArgs a) {
   constexpr int T = KS * KS, PAD = KS / 2;
   // one staged unit = SQ vertically adjacent 2x32 strips (SQ*64 pixels): the bf16 MFMAs retire so fast that the
@@ -238,8 +238,15 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradArgs a) {
       const int iy = y0 + (pix >> 5), ix = x0 + (pix & 31);
       const int n = n_blk + n4 * 4;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (iy < a.H && ix < a.W && n < a.dy_cvalid)
-        v = *reinterpret_cast<const f32x4*>(a.dy + ((size_t)(img * a.H + iy) * a.W + ix) * a.dy_cs + a.dy_coff + n);
+      if (iy < a.H && ix < a.W && n < a.dy_cvalid) {
+        if (BMODE == HPRI_A_DIRECT) {
+          v = *reinterpret_cast<const f32x4*>(a.dy + ((size_t)(img * a.H + iy) * a.W + ix) * a.dy_cs + a.dy_coff + n);
+        } else {   // S2D (ConvTranspose2d): column n = tap*Cup + co lives at hi-res pixel (2*iy + t_y + py0, 2*ix + t_x + px0)
+          const int tap = n / a.Cup, co = n - tap * a.Cup;
+          const int yy = 2 * iy + (tap >> 1) + a.py0, xx = 2 * ix + (tap & 1) + a.px0;
+          v = *reinterpret_cast<const f32x4*>(a.dy + ((size_t)(img * a.H2 + yy) * a.W2 + xx) * a.dy_cs + a.dy_coff + co);
+        }
+      }
       yr[p] = __builtin_convertvector(v, bf16x4);
     }
     __syncthreads();   // previous unit's LDS reads are finished
@@ -393,16 +400,21 @@ extern "C" int hpri_conv_wgrad(const float* x, int x_cs, int x_coff, int x_cvali
   return HPRI_OK;
 }
 
-// bf16-operand variant of hpri_conv_wgrad (direct forms only; same plan, workspace and reduce).
+// bf16-operand variant of hpri_conv_wgrad (same modes, plan, workspace and reduce).
 extern "C" int hpri_conv_wgrad_bf16(const float* x, int x_cs, int x_coff, int x_cvalid,
                                     const float* dy, int dy_cs, int dy_coff, int dy_cvalid,
                                     float* ws, size_t ws_floats,
-                                    int N, int H, int W, int Cin_pad, int Cout_pad, int KS, hipStream_t stream) {
+                                    int N, int H, int W, int Cin_pad, int Cout_pad, int KS, int bmode,
+                                    int H2, int W2, int py0, int px0, int Cup, hipStream_t stream) {
   HPRI_REQUIRE(x && dy && ws, "conv_wgrad_bf16: null pointer");
   HPRI_REQUIRE(KS == 1 || KS == 3, "conv_wgrad_bf16: kernel size must be 1 or 3");
   HPRI_REQUIRE(x_cs % 4 == 0 && x_coff % 4 == 0 && dy_cs % 4 == 0 && dy_coff % 4 == 0 && x_cvalid % 4 == 0 && dy_cvalid % 4 == 0,
                "conv_wgrad_bf16: channel strides/offsets/valid counts must be multiples of 4");
   HPRI_REQUIRE(N > 0 && H > 0 && W > 0 && Cin_pad > 0 && Cout_pad > 0, "conv_wgrad_bf16: empty problem");
+  if (bmode == HPRI_A_S2D) {
+    HPRI_REQUIRE(KS == 1 && Cup > 0 && Cup % 4 == 0, "conv_wgrad_bf16: S2D needs KS==1 and Cup % 4 == 0");
+    HPRI_REQUIRE(py0 >= 0 && px0 >= 0 && 2 * H + py0 <= H2 && 2 * W + px0 <= W2, "conv_wgrad_bf16: patch grid exceeds the hi-res image");
+  }
   WgradArgs a;
   a.x = x; a.x_cs = x_cs; a.x_coff = x_coff; a.x_cvalid = x_cvalid;
   a.dy = dy; a.dy_cs = dy_cs; a.dy_coff = dy_coff; a.dy_cvalid = dy_cvalid;
@@ -412,13 +424,14 @@ extern "C" int hpri_conv_wgrad_bf16(const float* x, int x_cs, int x_coff, int x_
   int splits, Cr, Nr;
   hpri_wgrad_plan(N, H, W, Cin_pad, Cout_pad, KS, &splits, &Cr, &Nr);
   a.strips_per_split = hpri_cdiv(a.total_strips, splits);
-  a.Cr = Cr; a.Nr = Nr; a.H2 = a.W2 = a.py0 = a.px0 = a.Cup = 0;
+  a.Cr = Cr; a.Nr = Nr; a.H2 = H2; a.W2 = W2; a.py0 = py0; a.px0 = px0; a.Cup = Cup;
   const int T = KS * KS;
   if ((size_t)splits * T * Cr * Nr > ws_floats) return hpri_set_error(HPRI_ERR_WORKSPACE, "conv_wgrad_bf16: workspace too small");
   int bc, bn; wgrad_cfg(KS, &bc, &bn);
   dim3 grid((unsigned)splits, (unsigned)(Cr / bc), (unsigned)(Nr / bn));
-  if (KS == 3) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<3, 1, 1>), grid, dim3(256), 0, stream, a);
-  else hipLaunchKernelGGL((conv_wgrad_bf16_kernel<1, 2, 2>), grid, dim3(256), 0, stream, a);
+  if (KS == 3) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<3, 1, 1, HPRI_A_DIRECT>), grid, dim3(256), 0, stream, a);
+  else if (bmode == HPRI_A_S2D) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<1, 2, 2, HPRI_A_S2D>), grid, dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL((conv_wgrad_bf16_kernel<1, 2, 2, HPRI_A_DIRECT>), grid, dim3(256), 0, stream, a);
   HPRI_CHECK_LAUNCH();
   return HPRI_OK;
 }

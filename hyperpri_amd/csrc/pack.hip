@@ -51,9 +51,9 @@ extern "C" int hpri_pack_weight(const float* w, float* wp, int mode, int K, int 
 }
 
 // ---- bf16 panels for conv_fwd_bf16.hip: [chunk][tap][Ncols_pad][32 k] (k contiguous per output column, the order the
-// MFMA B operand wants); same modes 0 (forward) and 1 (data gradient) as the fp32 pack; round-to-nearest-even.
+// MFMA B operand wants); same four modes as the fp32 pack; round-to-nearest-even.
 __global__ void pack_weight_bf16_kernel(const float* __restrict__ w, __bf16* __restrict__ wp, int mode, int K, int Ncols,
-                                        int Ncols_pad, int T, int chunks, int src_d1) {
+                                        int Ncols_pad, int T, int chunks, int src_d1, int Cup) {
   const size_t total = (size_t)chunks * T * Ncols_pad * 32;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
     const int kk = (int)(idx & 31);
@@ -65,23 +65,25 @@ __global__ void pack_weight_bf16_kernel(const float* __restrict__ w, __bf16* __r
     float v = 0.f;
     if (k < K && col < Ncols) {
       if (mode == 0) v = w[((size_t)col * src_d1 + k) * T + t];
-      else v = w[((size_t)k * src_d1 + col) * T + (T - 1 - t)];
+      else if (mode == 1) v = w[((size_t)k * src_d1 + col) * T + (T - 1 - t)];
+      else if (mode == 2) { const int tap = col / Cup, co = col - tap * Cup; v = w[((size_t)k * Cup + co) * 4 + tap]; }
+      else { const int tap = k / Cup, co = k - tap * Cup; v = w[((size_t)col * Cup + co) * 4 + tap]; }
     }
     wp[idx] = (__bf16)v;
   }
 }
 
 extern "C" int hpri_pack_weight_bf16(const float* w, void* wp, int mode, int K, int Ncols, int Ncols_pad, int T,
-                                     int src_d1, hipStream_t stream) {
+                                     int src_d1, int Cup, hipStream_t stream) {
   HPRI_REQUIRE(w && wp, "pack_weight_bf16: null pointer");
-  HPRI_REQUIRE((mode == 0 || mode == 1) && K > 0 && Ncols > 0 && Ncols_pad >= Ncols && Ncols_pad % 64 == 0,
+  HPRI_REQUIRE(mode >= 0 && mode <= 3 && K > 0 && Ncols > 0 && Ncols_pad >= Ncols && Ncols_pad % 64 == 0,
                "pack_weight_bf16: bad arguments");
   const int chunks = hpri_cdiv(K, 32);
   const size_t total = (size_t)chunks * T * Ncols_pad * 32;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(pack_weight_bf16_kernel, dim3(blocks), dim3(256), 0, stream, w, reinterpret_cast<__bf16*>(wp), mode, K,
-                     Ncols, Ncols_pad, T, chunks, src_d1);
+                     Ncols, Ncols_pad, T, chunks, src_d1, Cup);
   HPRI_CHECK_LAUNCH();
   return HPRI_OK;
 }

@@ -249,27 +249,29 @@ def _pack(w: torch.Tensor, mode: int, K: int, ncols: int, T: int, cup: int, d1: 
     return wp, ncols_pad
 
 
-def _pack_bf16(w: torch.Tensor, mode: int, K: int, ncols: int, T: int, d1: int) -> Tuple[torch.Tensor, int]:
+def _pack_bf16(w: torch.Tensor, mode: int, K: int, ncols: int, T: int, d1: int, cup: int = 0) -> Tuple[torch.Tensor, int]:
     ncols_pad = _rup(ncols, 64)
     chunks = (K + 31) // 32
     wp = torch.empty(chunks * T * ncols_pad * 32, dtype=torch.bfloat16, device=w.device)
-    _lib.call("hpri_pack_weight_bf16", _p(w), _p(wp), mode, K, ncols, ncols_pad, T, d1, _stream())
+    _lib.call("hpri_pack_weight_bf16", _p(w), _p(wp), mode, K, ncols, ncols_pad, T, d1, cup, _stream())
     return wp, ncols_pad
 
 
 def _conv_launch_bf16(x: Act, wp: torch.Tensor, bias: Optional[torch.Tensor], y: Act, stats: Optional[torch.Tensor],
                       N: int, H: int, W: int, cin_pad: int, cout: int, cout_pad: int, y_cw: int, ks: int,
-                      accumulate: int = 0, cin_true: int = 0) -> None:
+                      amode: int = A_DIRECT, epi: int = E_DIRECT, accumulate: int = 0,
+                      H2: int = 0, W2: int = 0, py0: int = 0, px0: int = 0, cup: int = 0, cin_true: int = 0) -> None:
     ksplit = ctypes.c_int(); tiles = ctypes.c_int(); wsf = ctypes.c_size_t()
-    _lib.call("hpri_conv_fwd_plan", N, H, W, cin_pad, cout_pad, ks, A_DIRECT, E_DIRECT, ctypes.byref(ksplit), ctypes.byref(tiles),
+    _lib.call("hpri_conv_fwd_plan", N, H, W, cin_pad, cout_pad, ks, amode, epi, ctypes.byref(ksplit), ctypes.byref(tiles),
               ctypes.byref(wsf))
     ws = _ws(wsf.value, x.buf.device) if wsf.value else None
-    tag = f"conv_fwd_bf16<{ks},{'2x2' if cout_pad % 128 == 0 else '4x1'}>"
+    tag = f"conv_fwd_bf16<{ks},{'2x2' if cout_pad % 128 == 0 else '4x1'},{'s2d' if amode else 'direct'},{'d2s' if epi else 'direct'}>"
     if SHAPE_TAGS:
         tag += f" N{N} {H}x{W} K{cin_pad} N{cout}"
     with _timed(tag, 2.0 * N * H * W * (cin_true or cin_pad) * cout * ks * ks):
         _lib.call("hpri_conv_fwd_bf16", x.ptr, x.cs, x.coff, _p(wp), _p(bias), y.ptr, y.cs, y.coff, _p(stats),
-                  N, H, W, cin_pad, cout, cout_pad, y_cw, ks, accumulate, _p(ws), wsf.value, _stream())
+                  N, H, W, cin_pad, cout, cout_pad, y_cw, ks, amode, epi, accumulate, H2, W2, py0, px0, cup,
+                  _p(ws), wsf.value, _stream())
 
 
 def _conv_launch(x: Act, wp: torch.Tensor, bias: Optional[torch.Tensor], y: Act, stats: Optional[torch.Tensor],
@@ -412,10 +414,10 @@ def _wgrad(x: Act, dy: Act, dw: torch.Tensor, accumulate: int, cin: int, cout: i
     tag = f"conv_wgrad{'_bf16' if bf16 else ''}<{ks},{'s2d' if bmode == A_S2D else 'direct'}>"
     if SHAPE_TAGS:
         tag += f" N{N} {H}x{W} C{cin_pad} N{cout}"
-    if bf16 and bmode == A_DIRECT:
+    if bf16:
         with _timed(tag, 2.0 * N * H * W * cin * cout * ks * ks):
             _lib.call("hpri_conv_wgrad_bf16", x.ptr, x.cs, x.coff, cin_pad, dy.ptr, dy.cs, dy.coff, dy_cvalid, _p(ws), ws.numel(),
-                      N, H, W, cin_pad, cout_pad, ks, _stream())
+                      N, H, W, cin_pad, cout_pad, ks, bmode, H2, W2, py0, px0, cup, _stream())
         _lib.call("hpri_wgrad_reduce", _p(ws), _p(dw), N, H, W, cin, cin_pad, cout, cout_pad, ks, dst_mode, cup, accumulate,
                   _stream())
         return
@@ -451,7 +453,7 @@ def maxpool2(tape: Tape, x: Act) -> Act:
 # upsample (ConvTranspose2d k2 s2 | bilinear x2) -> zero-pad -> concat with / multiply by the skip
 # --------------------------------------------------------------------------------------------------
 def _upsample_into(tape: Tape, x1: Act, dst: Act, weight: Optional[torch.Tensor], bias: Optional[torch.Tensor],
-                   need_dx1: bool) -> None:
+                   need_dx1: bool, precision: Optional[str] = None) -> None:
     """Write up(x1), zero-padded to dst's H x W (left = floor(d/2), model_parts.py:73-80), into the view ``dst``.
     ``weight`` given: ConvTranspose2d(k2,s2) as one GEMM per input pixel (Cin -> 4*Cup) whose epilogue scatters the
     2x2 patches (model_parts.py:63-64); ``weight`` None: nn.Upsample(2, 'bilinear', align_corners=True) (:57)."""
@@ -470,9 +472,15 @@ def _upsample_into(tape: Tape, x1: Act, dst: Act, weight: Optional[torch.Tensor]
         cin = weight.shape[0]
         if cin != x1.C or weight.shape[1] != cup:
             raise RuntimeError("hyperpri_amd: Up: ConvTranspose2d channel mismatch")
-        wp, ncols_pad = _pack(weight, 2, cin, 4 * cup, 1, cup, cup)
-        _conv_launch(x1, wp, bias, dst, None, x1.N, x1.H, x1.W, x1.cw, 4 * cup, ncols_pad, 4 * cup, 1,
-                     epi=E_D2S, H2=H2, W2=W2, py0=py0, px0=px0, cup=cup, cin_true=cin)
+        bf16 = (precision or DEFAULT_PRECISION) == "bf16"
+        if bf16:
+            wp, ncols_pad = _pack_bf16(weight, 2, cin, 4 * cup, 1, cup, cup)
+            _conv_launch_bf16(x1, wp, bias, dst, None, x1.N, x1.H, x1.W, x1.cw, 4 * cup, ncols_pad, 4 * cup, 1,
+                              epi=E_D2S, H2=H2, W2=W2, py0=py0, px0=px0, cup=cup, cin_true=cin)
+        else:
+            wp, ncols_pad = _pack(weight, 2, cin, 4 * cup, 1, cup, cup)
+            _conv_launch(x1, wp, bias, dst, None, x1.N, x1.H, x1.W, x1.cw, 4 * cup, ncols_pad, 4 * cup, 1,
+                         epi=E_D2S, H2=H2, W2=W2, py0=py0, px0=px0, cup=cup, cin_true=cin)
         del wp
     else:
         if x1.C != cup:
@@ -502,17 +510,23 @@ def _upsample_into(tape: Tape, x1: Act, dst: Act, weight: Optional[torch.Tensor]
             ws = _ws(nblk.value * 2 * cpart.value + 2 * cup, dev)
             _lib.call("hpri_col_sum", gu.ptr, gu.cs, gu.coff, _p(db), acc_b, _p(ws), ws.numel(), gu.P, cup, _stream())
         dw, acc_w = tp.param_slot(weight)
-        _wgrad(x1, gu, dw, acc_w, cin, 4 * cup, 1, bmode=A_S2D, dst_mode=1, H2=H2, W2=W2, py0=py0, px0=px0, cup=cup)
+        _wgrad(x1, gu, dw, acc_w, cin, 4 * cup, 1, bmode=A_S2D, dst_mode=1, H2=H2, W2=W2, py0=py0, px0=px0, cup=cup,
+               bf16=(precision or DEFAULT_PRECISION) == "bf16")
         if need_dx1:
-            wpd, cols_pad = _pack(weight, 3, 4 * cup, cin, 1, cup, cup)
             gx, acc = tp.grad_slot(x1)
-            _conv_launch(gu, wpd, None, gx, None, x1.N, x1.H, x1.W, 4 * cup, cin, cols_pad, gx.cw, 1,
-                         amode=A_S2D, accumulate=int(acc), H2=H2, W2=W2, py0=py0, px0=px0, cup=cup, cin_true=4 * cup)
+            if (precision or DEFAULT_PRECISION) == "bf16":
+                wpd, cols_pad = _pack_bf16(weight, 3, 4 * cup, cin, 1, cup, cup)
+                _conv_launch_bf16(gu, wpd, None, gx, None, x1.N, x1.H, x1.W, 4 * cup, cin, cols_pad, gx.cw, 1,
+                                  amode=A_S2D, accumulate=int(acc), H2=H2, W2=W2, py0=py0, px0=px0, cup=cup, cin_true=4 * cup)
+            else:
+                wpd, cols_pad = _pack(weight, 3, 4 * cup, cin, 1, cup, cup)
+                _conv_launch(gu, wpd, None, gx, None, x1.N, x1.H, x1.W, 4 * cup, cin, cols_pad, gx.cw, 1,
+                             amode=A_S2D, accumulate=int(acc), H2=H2, W2=W2, py0=py0, px0=px0, cup=cup, cin_true=4 * cup)
     tape.nodes.append(bwd)
 
 
 def up_concat(tape: Tape, x1: Act, skip: Act, weight: Optional[torch.Tensor], bias: Optional[torch.Tensor],
-              need_dx1: bool = True) -> Act:
+              need_dx1: bool = True, precision: Optional[str] = None) -> Act:
     """cat([skip, pad(up(x1))], dim=1): model_parts.py:63-64,73-87 (and models.py:230-239).  One buffer
     [N,H,W,Cskip+Cup]: the skip is copied into channels [0,Cskip), the upsampling kernel writes [Cskip,Cskip+Cup)
     directly; in backward the split is free (channel-slice views of the consumer's input gradient)."""
@@ -527,7 +541,7 @@ def up_concat(tape: Tape, x1: Act, skip: Act, weight: Optional[torch.Tensor], bi
     if cat.cw > cat.C:
         _lib.call("hpri_fill_pad", cat.ptr, cat.cs, cat.coff + cat.C, cat.N, cat.H, cat.W, cat.cw - cat.C, 0, 0, 0, 0, _stream())
     ups = cat.slice(skip.C, cup)
-    _upsample_into(tape, x1, ups, weight, bias, need_dx1)
+    _upsample_into(tape, x1, ups, weight, bias, need_dx1, precision)
     if tape.record:
         def bwd(tp: Tape) -> None:
             g = tp.grads.pop(id(cat), None)
@@ -540,7 +554,7 @@ def up_concat(tape: Tape, x1: Act, skip: Act, weight: Optional[torch.Tensor], bi
 
 
 def up_attention(tape: Tape, x1: Act, skip: Act, weight: Optional[torch.Tensor], bias: Optional[torch.Tensor],
-                 need_dx1: bool = True) -> Act:
+                 need_dx1: bool = True, precision: Optional[str] = None) -> Act:
     """skip * pad(up(x1)) -- the reference's ``use_attention`` branch, model_parts.py:84-85."""
     dev = x1.buf.device
     cup = weight.shape[1] if weight is not None else x1.C
@@ -549,7 +563,7 @@ def up_attention(tape: Tape, x1: Act, skip: Act, weight: Optional[torch.Tensor],
     u = Act.new(skip.N, skip.H, skip.W, cup, dev)
     if u.cw > u.C:
         _lib.call("hpri_fill_pad", u.ptr, u.cs, u.coff + u.C, u.N, u.H, u.W, u.cw - u.C, 0, 0, 0, 0, _stream())
-    _upsample_into(tape, x1, u, weight, bias, need_dx1)
+    _upsample_into(tape, x1, u, weight, bias, need_dx1, precision)
     y = Act.new(skip.N, skip.H, skip.W, cup, dev)
     _lib.call("hpri_mul", skip.ptr, skip.cs, skip.coff, u.ptr, u.cs, u.coff, y.ptr, y.cs, y.coff, y.P, y.cw, 0, _stream())
     if tape.record:

@@ -88,7 +88,8 @@ class Up(nn.Module):
         join = E.up_attention if self.use_attention else E.up_concat
 
         def prog(tape, a, need):
-            return self.conv._ops(tape, join(tape, a[0], a[1], w, b, need_dx1=need[0]))
+            return self.conv._ops(tape, join(tape, a[0], a[1], w, b, need_dx1=need[0],
+                                              precision=getattr(self, "hpri_precision", None)))
         return run(prog, [x1, x2], list(self.parameters()))
 
 

@@ -168,7 +168,7 @@ class CubeNET(torch.nn.Module):
             b4 = None if self.bilinear else self.upsample4.bias
 
             def prog(tape, a, need):
-                cat = E.up_concat(tape, a[0], a[1], w4, b4, need_dx1=need[0])
+                cat = E.up_concat(tape, a[0], a[1], w4, b4, need_dx1=need[0], precision=getattr(self, "hpri_precision", None))
                 return self.upconv4._ops(tape, cat)
             y = run(prog, [y, x1], list(self.upsample4.parameters()) + list(self.upconv4.parameters()))
         logits = self.outc(y)

@@ -149,3 +149,57 @@ def test_conv_bf16_mode_vs_torch_on_rounded_operands(N, Cin, H, W, Cout, ks):
     yd.backward(r.to(DEV))
     _close(xd.grad, xc.grad.numpy(), 1e-4, 3e-4, "bf16 conv dgrad")
     _close(wd.grad, wq.grad.numpy(), 1e-4, 2e-3, "bf16 conv wgrad")
+
+
+def test_up_block_bf16_mode_vs_fixture():
+    """Up (ConvTranspose2d scatter, concat, DoubleConv) with every contraction in bf16 mode: segmentation-level
+    tolerance against the fp32 reference fixture (ConvTranspose2d forward / data / weight gradients on the bf16 kernels)."""
+    import hyperpri_amd as H
+    z = _load("block_up_big")
+    mod = H.Up(64, 32, bilinear=False)
+    mod.load_state_dict(O.synth_state_dict(_shapes(mod), seed0=2400, bn_random=True))
+    mod = H.set_precision(mod.to(DEV), "bf16").train()
+    xs = [torch.from_numpy(z[f"in{i}"]).to(DEV).requires_grad_(True) for i in range(2)]
+    out = mod(*xs)
+    ref = z["out_train"]
+    assert np.abs(out.detach().cpu().numpy() - ref).max() < 0.05 * max(1.0, float(np.abs(ref).max()))
+    (out * torch.from_numpy(z["dout"]).to(DEV)).sum().backward()
+    for i, x in enumerate(xs):
+        r = z[f"din{i}"]
+        assert np.linalg.norm(x.grad.cpu().numpy() - r) <= 0.12 * np.linalg.norm(r)   # two BN layers amplify bf16 rounding
+    for k in ("up.weight", "conv.double_conv.0.weight", "conv.double_conv.3.weight"):
+        r = z["grad/" + k]
+        g = dict(mod.named_parameters())[k].grad.cpu().numpy()
+        assert np.linalg.norm(g - r) <= 0.12 * np.linalg.norm(r), k
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_transposed_conv_concat_vs_torch(prec):
+    """ConvTranspose2d(k2,s2) + right/bottom zero pad + concat (engine.up_concat) against torch on CPU, forward and all
+    gradients.  In bf16 mode the reference uses bf16-rounded operands, so the tolerance stays at fp32-summation level."""
+    from hyperpri_amd import engine as E
+    from hyperpri_amd.autograd import run
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(99)
+    N, Cin, H, W, Cs = 2, 64, 7, 19, 32
+    x1 = torch.randn(N, Cin, H, W, generator=g)
+    sk = torch.randn(N, Cs, 2 * H + 1, 2 * W + 1, generator=g)
+    w = torch.randn(Cin, Cin // 2, 2, 2, generator=g) / (Cin * 4) ** 0.5
+    b = torch.randn(Cin // 2, generator=g)
+    r = torch.randn(N, Cs + Cin // 2, 2 * H + 1, 2 * W + 1, generator=g)
+    rb = (lambda t: t.to(torch.bfloat16).to(torch.float32)) if prec == "bf16" else (lambda t: t.clone())
+    x1c, wc, bc, skc = rb(x1).requires_grad_(True), rb(w).requires_grad_(True), b.clone().requires_grad_(True), sk.clone().requires_grad_(True)
+    up = F.pad(F.conv_transpose2d(x1c, wc, bc, stride=2), [0, 1, 0, 1])
+    yc = torch.cat([skc, up], 1)
+    rr = r.clone()
+    rr[:, Cs:] = rb(r[:, Cs:])            # the gradient reaching the transposed conv is rounded as an operand
+    yc.backward(rr)
+    x1d, skd, wd, bd = (t.to(DEV).requires_grad_(True) for t in (x1, sk, w, b))
+    yd = run(lambda tape, a, need: E.up_concat(tape, a[0], a[1], wd, bd, need_dx1=need[0], precision=prec), [x1d, skd], [wd, bd])
+    _close(yd, yc.detach().numpy(), 1e-4, 2e-4, "convT+cat forward")
+    yd.backward(r.to(DEV))
+    _close(x1d.grad, x1c.grad.numpy(), 1e-4, 3e-4, "convT dgrad")
+    _close(skd.grad, r[:, :Cs].numpy(), 0, 0, "skip gradient is the channel slice")
+    _close(wd.grad, wc.grad.numpy(), 1e-4, 2e-3, "convT wgrad")
+    # the bias gradient is a plain fp32 column sum of the (unrounded) incoming gradient over the un-padded region
+    _close(bd.grad, r[:, Cs:, :2 * H, :2 * W].sum(dim=(0, 2, 3)).numpy(), 1e-4, 1e-3, "convT bias grad")

@@ -52,7 +52,7 @@ def main():
             ws = torch.empty(max(s.value * ks * ks * cr.value * nr.value, 4 * N * H * W * cout_pad), device=dev)
             wpb = torch.empty(((Cin + 31) // 32) * ks * ks * cout_pad * 32, dtype=torch.bfloat16, device=dev)
             if hasattr(lib, "hpri_pack_weight_bf16"):
-                assert lib.hpri_pack_weight_bf16(P(w), P(wpb), 0, Cin, Cout, cout_pad, ks * ks, Cin, st) == 0
+                assert lib.hpri_pack_weight_bf16(P(w), P(wpb), 0, Cin, Cout, cout_pad, ks * ks, Cin, 0, st) == 0
             preps.append((wp, stats, ws, wpb))
         for rnd in range(5):
             for (name, lib), (wp, stats, ws, wpb) in zip(libs, preps):
@@ -65,10 +65,10 @@ def main():
                                                Cout, ks, 0, 0, 0, 0, 0, 0, 0, 0, P(ws), ws.numel(), st)
                     elif mode == "fwd_bf16":
                         rc = lib.hpri_conv_fwd_bf16(P(x), Cin, 0, P(wpb), P(b), P(y), Cout, 0, P(stats), N, H, W, Cin, Cout,
-                                                    cout_pad, Cout, ks, 0, P(ws), ws.numel(), st)
+                                                    cout_pad, Cout, ks, 0, 0, 0, 0, 0, 0, 0, 0, P(ws), ws.numel(), st)
                     elif mode == "wgrad_bf16":
                         rc = lib.hpri_conv_wgrad_bf16(P(x), Cin, 0, Cin, P(y), Cout, 0, Cout, P(ws), ws.numel(), N, H, W, Cin,
-                                                      cout_pad, ks, st)
+                                                      cout_pad, ks, 0, 0, 0, 0, 0, 0, st)
                     else:
                         rc = lib.hpri_conv_wgrad(P(x), Cin, 0, Cin, P(y), Cout, 0, Cout, P(ws), ws.numel(), N, H, W, Cin, cout_pad,
                                                  ks, 0, 0, 0, 0, 0, 0, st)
