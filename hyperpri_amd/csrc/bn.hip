@@ -21,7 +21,20 @@ __global__ void bn_finalize_kernel(const float4* __restrict__ part, int tiles_pe
   double a1 = 0.0, a2 = 0.0, an = 0.0;
   if (c < C) {
     const float4* p = part + (size_t)g * tiles_per_group * Cp + c;
-    for (int t = sl; t < tiles_per_group; t += 32) {
+    int t = sl;
+    for (; t + 96 < tiles_per_group; t += 128) {      // 4 independent loads in flight (latency-bound otherwise)
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = p[(size_t)(t + 32 * u) * Cp];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const double m = v[u].x, n = v[u].z;
+        a1 += n * m;
+        a2 += (double)v[u].y + n * m * m;
+        an += n;
+      }
+    }
+    for (; t < tiles_per_group; t += 32) {
       const float4 v = p[(size_t)t * Cp];
       const double m = v.x, n = v.z;
       a1 += n * m;
@@ -185,7 +198,15 @@ __global__ void col_finalize_kernel(const float* __restrict__ part, int nblk, in
   double a1 = 0.0, a2 = 0.0;
   if (c < C) {
     const float* p = part + (size_t)g * nblk * 2 * Cpart + c;
-    for (int b = sl; b < nblk; b += 32) { a1 += p[(size_t)b * 2 * Cpart]; a2 += p[(size_t)b * 2 * Cpart + Cpart]; }
+    int b = sl;
+    for (; b + 96 < nblk; b += 128) {
+      float u1[4], u2[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { u1[u] = p[(size_t)(b + 32 * u) * 2 * Cpart]; u2[u] = p[(size_t)(b + 32 * u) * 2 * Cpart + Cpart]; }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { a1 += u1[u]; a2 += u2[u]; }
+    }
+    for (; b < nblk; b += 32) { a1 += p[(size_t)b * 2 * Cpart]; a2 += p[(size_t)b * 2 * Cpart + Cpart]; }
   }
   s[0][sl][cl] = a1; s[1][sl][cl] = a2;
   __syncthreads();
