@@ -124,3 +124,51 @@ def test_gradsync_single_rank_matches_plain_gradients():
         sync.remove()
     finally:
         dist.destroy_process_group()
+
+
+def test_inference_mode_and_no_grad_match_eval_forward():
+    """PLTrainer's predict/test paths run under torch.inference_mode() / no_grad (PLTrainer.py:530,626)."""
+    import bench
+    import hyperpri_amd as HP
+    net = HP.UNet(3, 1, bilinear=False).to(DEV)
+    bench.synth_init_(net)
+    x = torch.rand(2, 3, 64, 96, device=DEV)
+    net.train()
+    net(x)                                   # populate running stats
+    net.eval()
+    ref = net(x).detach()
+    with torch.no_grad():
+        a = net(x)
+    with torch.inference_mode():
+        b = net(x)
+    assert torch.equal(a, ref) and torch.equal(b, ref)
+    assert not a.requires_grad and a.is_contiguous() and a.shape == (2, 1, 64, 96)
+
+
+def test_stock_distributed_data_parallel_wraps_the_modules():
+    """Lightning's strategy="ddp" (PLTrainer.py:434-442) wraps the network in torch DistributedDataParallel; with one
+    rank the averaged gradients must equal the plain ones and BN buffers must survive the buffer broadcast."""
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    import bench
+    import hyperpri_amd as HP
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ["MASTER_PORT"] = "29591"
+    net = HP.UNet(3, 1, bilinear=False).to(DEV).train()
+    bench.synth_init_(net)
+    x = torch.rand(2, 3, 64, 96, device=DEV)
+    m = (torch.rand(2, 1, 64, 96, device=DEV) > 0.8).float()
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    _, plain = _step(net, x, m)
+    net.load_state_dict(sd)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        ddp = DDP(net, device_ids=[0])
+        for p in net.parameters():
+            p.grad = None
+        torch.nn.BCEWithLogitsLoss()(ddp(x), m).backward()
+        torch.cuda.synchronize()
+        for p, g in zip(net.parameters(), plain):
+            assert torch.allclose(p.grad, g, rtol=0, atol=0)
+    finally:
+        dist.destroy_process_group()
