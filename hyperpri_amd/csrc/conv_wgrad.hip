@@ -53,46 +53,52 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
   const int s_begin = blockIdx.x * a.strips_per_split;
   const int s_end = min(a.total_strips, s_begin + a.strips_per_split);
 
+  // KS == 1 (Linear / ConvTranspose2d weight gradients: no halo reuse, 128 MFMAs per staged strip) prefetches the next
+  // strip into registers while the current one is being multiplied; KS == 3 has no registers to spare (144 accumulators)
+  // and relies on the second resident workgroup to cover its loads.
+  constexpr bool PREF = (KS == 1);
+  f32x4 xr[NLD_X], yr[NLD_Y];
+#define LOAD_STRIP(st_)                                                                               \
+  {                                                                                                   \
+    int q_ = (st_);                                                                                   \
+    const int sx = q_ % a.strips_x; q_ /= a.strips_x;                                                 \
+    const int sy = q_ % a.strips_y;                                                                   \
+    const int img = q_ / a.strips_y;                                                                  \
+    const int y0 = sy * SH, x0 = sx * SW;                                                             \
+    _Pragma("unroll") for (int p = 0; p < NLD_X; ++p) {                                               \
+      const int f = tid + p * 256;                                                                    \
+      const int pix = f / (BC / 4), c4 = f % (BC / 4);                                                \
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};                                                                 \
+      if (pix < HP) {                                                                                 \
+        const int hy = pix / HW, hx = pix - hy * HW;                                                  \
+        const int iy = y0 + hy - PAD, ix = x0 + hx - PAD;                                             \
+        const int c = c_blk + c4 * 4;                                                                 \
+        if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W && c < a.x_cvalid)                             \
+          v = *reinterpret_cast<const f32x4*>(a.x + ((size_t)(img * a.H + iy) * a.W + ix) * a.x_cs + a.x_coff + c); \
+      }                                                                                               \
+      xr[p] = v;                                                                                      \
+    }                                                                                                 \
+    _Pragma("unroll") for (int p = 0; p < NLD_Y; ++p) {                                               \
+      const int f = tid + p * 256;                                                                    \
+      const int pix = f / (BNW / 4), n4 = f % (BNW / 4);                                              \
+      const int iy = y0 + (pix >> 5), ix = x0 + (pix & 31);                                           \
+      const int n = n_blk + n4 * 4;                                                                   \
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};                                                                 \
+      if (iy < a.H && ix < a.W && n < a.dy_cvalid) {                                                  \
+        if (BMODE == HPRI_A_DIRECT) {                                                                 \
+          v = *reinterpret_cast<const f32x4*>(a.dy + ((size_t)(img * a.H + iy) * a.W + ix) * a.dy_cs + a.dy_coff + n); \
+        } else {                                                                                      \
+          const int tap = n / a.Cup, co = n - tap * a.Cup;                                            \
+          const int yy = 2 * iy + (tap >> 1) + a.py0, xx = 2 * ix + (tap & 1) + a.px0;                \
+          v = *reinterpret_cast<const f32x4*>(a.dy + ((size_t)(img * a.H2 + yy) * a.W2 + xx) * a.dy_cs + a.dy_coff + co); \
+        }                                                                                             \
+      }                                                                                               \
+      yr[p] = v;                                                                                      \
+    }                                                                                                 \
+  }
+  if (PREF && s_begin < s_end) LOAD_STRIP(s_begin)
   for (int st = s_begin; st < s_end; ++st) {
-    int q = st;
-    const int sx = q % a.strips_x; q /= a.strips_x;
-    const int sy = q % a.strips_y;
-    const int img = q / a.strips_y;
-    const int y0 = sy * SH, x0 = sx * SW;
-
-    f32x4 xr[NLD_X], yr[NLD_Y];
-#pragma unroll
-    for (int p = 0; p < NLD_X; ++p) {
-      const int f = tid + p * 256;
-      const int pix = f / (BC / 4), c4 = f % (BC / 4);
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (pix < HP) {
-        const int hy = pix / HW, hx = pix - hy * HW;
-        const int iy = y0 + hy - PAD, ix = x0 + hx - PAD;
-        const int c = c_blk + c4 * 4;
-        if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W && c < a.x_cvalid)
-          v = *reinterpret_cast<const f32x4*>(a.x + ((size_t)(img * a.H + iy) * a.W + ix) * a.x_cs + a.x_coff + c);
-      }
-      xr[p] = v;
-    }
-#pragma unroll
-    for (int p = 0; p < NLD_Y; ++p) {
-      const int f = tid + p * 256;
-      const int pix = f / (BNW / 4), n4 = f % (BNW / 4);
-      const int iy = y0 + (pix >> 5), ix = x0 + (pix & 31);
-      const int n = n_blk + n4 * 4;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (iy < a.H && ix < a.W && n < a.dy_cvalid) {
-        if (BMODE == HPRI_A_DIRECT) {
-          v = *reinterpret_cast<const f32x4*>(a.dy + ((size_t)(img * a.H + iy) * a.W + ix) * a.dy_cs + a.dy_coff + n);
-        } else {
-          const int tap = n / a.Cup, co = n - tap * a.Cup;
-          const int yy = 2 * iy + (tap >> 1) + a.py0, xx = 2 * ix + (tap & 1) + a.px0;
-          v = *reinterpret_cast<const f32x4*>(a.dy + ((size_t)(img * a.H2 + yy) * a.W2 + xx) * a.dy_cs + a.dy_coff + co);
-        }
-      }
-      yr[p] = v;
-    }
+    if (!PREF) LOAD_STRIP(st)
     __syncthreads();   // previous strip's LDS reads are finished
 #pragma unroll
     for (int p = 0; p < NLD_X; ++p) {
@@ -105,6 +111,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
       *reinterpret_cast<f32x4*>(y_lds + f * 4) = yr[p];
     }
     __syncthreads();
+    if (PREF && st + 1 < s_end) LOAD_STRIP(st + 1)    // lands during this strip's MFMAs
 
     // k-step ks covers pixels 2*ks (lanes 0-31) and 2*ks+1 (lanes 32-63) of the 2x32 strip
     const float* xb = x_lds + lh * BC + wc * (CT * 32) + li;
@@ -132,6 +139,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
     }
   }
 
+#undef LOAD_STRIP
   // partial slab: ws[split][t][n][c]; MFMA rows = n (A operand = dY), cols = c (B operand = X) so that
   // lanes store consecutive c -- the order the reduce kernel and the OIHW gradient want
   float* slab = a.ws + (size_t)blockIdx.x * T * a.Cr * a.Nr;
