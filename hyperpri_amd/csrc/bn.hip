@@ -90,6 +90,18 @@ __global__ void bn_eval_prepare_kernel(const float* __restrict__ rm, const float
   }
 }
 
+// eval-mode folding: scale[c] = gamma/sqrt(rv+eps); fbias[c] = (conv_bias[c] - rm[c]) * scale[c] + beta[c]
+__global__ void bn_fold_kernel(const float* __restrict__ rm, const float* __restrict__ rv, const float* __restrict__ gamma,
+                               const float* __restrict__ beta, const float* __restrict__ conv_bias, float eps, int C,
+                               float* __restrict__ scale, float* __restrict__ fbias) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) {
+    const float sc = gamma[c] / sqrtf(rv[c] + eps);
+    scale[c] = sc;
+    fbias[c] = ((conv_bias ? conv_bias[c] : 0.f) - rm[c]) * sc + beta[c];
+  }
+}
+
 // -------------------------------------------------------------------------------------------------
 // y = relu(x*scale + shift)  (float4 over channels; pad channels C..Cw are written as zeros)
 // -------------------------------------------------------------------------------------------------
@@ -324,6 +336,15 @@ extern "C" int hpri_bn_eval_prepare(const float* running_mean, const float* runn
   HPRI_REQUIRE(running_mean && running_var && gamma && beta && mean && invstd && scale && shift, "bn_eval_prepare: null pointer");
   hipLaunchKernelGGL(bn_eval_prepare_kernel, dim3(hpri_cdiv(C, 256)), dim3(256), 0, stream, running_mean, running_var,
                      gamma, beta, eps, C, mean, invstd, scale, shift);
+  HPRI_CHECK_LAUNCH();
+  return HPRI_OK;
+}
+
+extern "C" int hpri_bn_fold(const float* running_mean, const float* running_var, const float* gamma, const float* beta,
+                            const float* conv_bias, float eps, int C, float* scale, float* fbias, hipStream_t stream) {
+  HPRI_REQUIRE(running_mean && running_var && gamma && beta && scale && fbias && C > 0, "bn_fold: bad arguments");
+  hipLaunchKernelGGL(bn_fold_kernel, dim3(hpri_cdiv(C, 256)), dim3(256), 0, stream, running_mean, running_var, gamma, beta,
+                     conv_bias, eps, C, scale, fbias);
   HPRI_CHECK_LAUNCH();
   return HPRI_OK;
 }

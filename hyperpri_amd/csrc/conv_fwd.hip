@@ -33,6 +33,7 @@ struct ConvFwdArgs {
   int Cout_pad;          // multiple of BN
   int y_cw;              // channels written (>= Cout; extra ones get zeros)
   int accumulate;        // y += result instead of y = result
+  int relu;              // epilogue max(.,0): eval-mode conv+BN+ReLU with BN folded into weights and bias
   int H2, W2, py0, px0, Cup;  // S2D / D2S geometry: hi-res image dims, pad offsets, channels per tap
   int ksplit;            // >1: blockIdx.z takes a slice of the K chunks and stores raw partial sums to ws
   float* ws;             // [ksplit][N*H*W][Cout_pad] partial sums (split-K only)
@@ -235,7 +236,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvFwdArgs a) {
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mt][nt][r] += b;
+      for (int r = 0; r < 16; ++r) { acc[mt][nt][r] += b; if (a.relu) acc[mt][nt][r] = fmaxf(acc[mt][nt][r], 0.f); }
   }
 
 #pragma unroll
@@ -519,7 +520,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_bf16_kernel(ConvFwdArgs a) {
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mt][nt][r] += b;
+      for (int r = 0; r < 16; ++r) { acc[mt][nt][r] += b; if (a.relu) acc[mt][nt][r] = fmaxf(acc[mt][nt][r], 0.f); }
   }
 
 #pragma unroll
@@ -611,7 +612,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_bf16_kernel(ConvFwdArgs a) {
 #define SK_PIX 64
 __global__ void splitk_finish_kernel(const float* __restrict__ ws, int ksplit, int Cout_pad, const float* __restrict__ bias,
                                      float* __restrict__ y, int y_cs, int y_coff, float4* __restrict__ stats, int HW,
-                                     long long P, int Cout, int y_cw, int CQ, int accumulate) {
+                                     long long P, int Cout, int y_cw, int CQ, int accumulate, int relu) {
   __shared__ float4 red[256];
   const int rows = 256 / CQ;
   const int cq = threadIdx.x % CQ, pr = threadIdx.x / CQ;
@@ -635,7 +636,7 @@ __global__ void splitk_finish_kernel(const float* __restrict__ ws, int ksplit, i
         v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
       }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) if (c + j >= Cout) v[j] = 0.f;
+      for (int j = 0; j < 4; ++j) { if (relu) v[j] = fmaxf(v[j], 0.f); if (c + j >= Cout) v[j] = 0.f; }
       float* o = y + p * y_cs + y_coff + c;
       if (accumulate) { const float4 old = *reinterpret_cast<const float4*>(o); v[0] += old.x; v[1] += old.y; v[2] += old.z; v[3] += old.w; }
       *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
@@ -786,7 +787,7 @@ extern "C" int hpri_conv_fwd_bf16(const float* x, int x_cs, int x_coff, const vo
   a.x = x; a.x_cs = x_cs; a.x_coff = x_coff; a.wp = reinterpret_cast<const float*>(wp); a.bias = bias;
   a.y = y; a.y_cs = y_cs; a.y_coff = y_coff; a.stats = reinterpret_cast<float4*>(stats);
   a.N = N; a.H = H; a.W = W; a.Cin_pad = Cin_pad; a.Cout = Cout; a.Cout_pad = Cout_pad;
-  a.y_cw = y_cw < Cout ? Cout : y_cw; a.accumulate = accumulate;
+  a.y_cw = y_cw < Cout ? Cout : y_cw; a.accumulate = accumulate & 1; a.relu = (accumulate >> 1) & 1;
   a.H2 = H2; a.W2 = W2; a.py0 = py0; a.px0 = px0; a.Cup = Cup;
   if (epi == HPRI_E_DIRECT) HPRI_REQUIRE(a.y_cw + y_coff <= y_cs, "conv_fwd_bf16: output channels exceed the channel stride");
   if (amode == HPRI_A_S2D || epi == HPRI_E_D2S) {
@@ -820,7 +821,7 @@ extern "C" int hpri_conv_fwd_bf16(const float* x, int x_cs, int x_coff, const vo
   int cq = 1; while (cq < c4 && cq < 64) cq <<= 1;
   dim3 grid((unsigned)hpri_cdiv(H * W, SK_PIX), (unsigned)hpri_cdiv(hpri_cdiv(a.y_cw, 4), cq), (unsigned)N);
   hipLaunchKernelGGL(splitk_finish_kernel, grid, dim3(256), 0, stream, ws, a.ksplit, Cout_pad, bias, y, y_cs, y_coff,
-                     reinterpret_cast<float4*>(stats), H * W, (long long)N * H * W, Cout, a.y_cw, cq, accumulate);
+                     reinterpret_cast<float4*>(stats), H * W, (long long)N * H * W, Cout, a.y_cw, cq, accumulate & 1, a.relu);
   HPRI_CHECK_LAUNCH();
   return HPRI_OK;
 }
@@ -843,7 +844,7 @@ extern "C" int hpri_conv_fwd(const float* x, int x_cs, int x_coff, const float* 
   a.x = x; a.x_cs = x_cs; a.x_coff = x_coff; a.wp = wp; a.bias = bias;
   a.y = y; a.y_cs = y_cs; a.y_coff = y_coff; a.stats = reinterpret_cast<float4*>(stats);
   a.N = N; a.H = H; a.W = W; a.Cin_pad = Cin_pad; a.Cout = Cout; a.Cout_pad = Cout_pad;
-  a.y_cw = y_cw < Cout ? Cout : y_cw; a.accumulate = accumulate;
+  a.y_cw = y_cw < Cout ? Cout : y_cw; a.accumulate = accumulate & 1; a.relu = (accumulate >> 1) & 1;
   a.H2 = H2; a.W2 = W2; a.py0 = py0; a.px0 = px0; a.Cup = Cup;
   a.ksplit = conv_ksplit(N, H, W, Cin_pad, Cout_pad, KS, epi, amode);
   a.ws = ws;
@@ -879,7 +880,7 @@ extern "C" int hpri_conv_fwd(const float* x, int x_cs, int x_coff, const float* 
   int cq = 1; while (cq < c4 && cq < 64) cq <<= 1;
   dim3 grid((unsigned)hpri_cdiv(H * W, SK_PIX), (unsigned)hpri_cdiv(hpri_cdiv(a.y_cw, 4), cq), (unsigned)N);
   hipLaunchKernelGGL(splitk_finish_kernel, grid, dim3(256), 0, stream, ws, a.ksplit, Cout_pad, bias, y, y_cs, y_coff,
-                     reinterpret_cast<float4*>(stats), H * W, (long long)N * H * W, Cout, a.y_cw, cq, accumulate);
+                     reinterpret_cast<float4*>(stats), H * W, (long long)N * H * W, Cout, a.y_cw, cq, accumulate & 1, a.relu);
   HPRI_CHECK_LAUNCH();
   return HPRI_OK;
 }

@@ -9,7 +9,7 @@
 // mode 3: convT data-grad   wp[0][k=tap*Cup+co][col=ci] = Wt[ci][co][tap]
 __global__ void pack_weight_kernel(const float* __restrict__ w, float* __restrict__ wp, int mode,
                                    int K, int Ncols, int Ncols_pad, int T, int chunks, int Cup,
-                                   int src_d0, int src_d1) {
+                                   int src_d0, int src_d1, const float* __restrict__ colscale) {
   // one thread per packed element; layout [chunk][t][kk(32)][Ncols_pad]
   const size_t total = (size_t)chunks * T * 32 * Ncols_pad;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
@@ -25,6 +25,7 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, float* __restric
       else if (mode == 1) v = w[((size_t)k * src_d1 + col) * T + (T - 1 - t)];   // W[n=k][c=col][flip t]
       else if (mode == 2) { const int tap = col / Cup, co = col - tap * Cup; v = w[((size_t)k * Cup + co) * 4 + tap]; }
       else { const int tap = k / Cup, co = k - tap * Cup; v = w[((size_t)col * Cup + co) * 4 + tap]; }
+      if (colscale != nullptr) v *= colscale[col];     // eval-mode BN folded into the conv: w' = w * gamma/sqrt(var+eps)
     }
     wp[idx] = v;
   }
@@ -45,7 +46,23 @@ extern "C" int hpri_pack_weight(const float* w, float* wp, int mode, int K, int 
   int blocks = (int)((total + 255) / 256);
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, stream, w, wp, mode, K, Ncols, Ncols_pad, T,
-                     chunks, Cup, src_d0, src_d1);
+                     chunks, Cup, src_d0, src_d1, (const float*)nullptr);
+  HPRI_CHECK_LAUNCH();
+  return HPRI_OK;
+}
+
+// Forward pack (mode 0) with a per-output-channel scale: the eval-mode BatchNorm of a conv->BN->ReLU stage folded into
+// the conv (PLTrainer's predict/validate/test paths run the modules in eval mode, PLTrainer.py:142-162).
+extern "C" int hpri_pack_weight_scaled(const float* w, float* wp, const float* colscale, int K, int Ncols, int Ncols_pad,
+                                       int T, int src_d1, hipStream_t stream) {
+  HPRI_REQUIRE(w && wp && colscale, "pack_weight_scaled: null pointer");
+  HPRI_REQUIRE(K > 0 && Ncols > 0 && Ncols_pad >= Ncols && Ncols_pad % 64 == 0, "pack_weight_scaled: bad arguments");
+  const int chunks = hpri_cdiv(K, 32);
+  const size_t total = (size_t)chunks * T * 32 * Ncols_pad;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, stream, w, wp, 0, K, Ncols, Ncols_pad, T, chunks, 0, 0,
+                     src_d1, colscale);
   HPRI_CHECK_LAUNCH();
   return HPRI_OK;
 }

@@ -307,6 +307,8 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
     if cin != x.C:
         raise RuntimeError(f"hyperpri_amd: conv expects {cin} input channels, got {x.C}")
     cin_pad = x.cw
+    if bn is not None and not train and not tape.record and (precision or DEFAULT_PRECISION) == "fp32" and FOLD_EVAL_BN:
+        return _conv_folded_eval(x, weight, bias, bn, ks, cin, cout, relu)
     prec = precision or DEFAULT_PRECISION
     if prec not in PRECISIONS:
         raise RuntimeError(f"hyperpri_amd: unknown precision {prec!r}; choose from {PRECISIONS}")
@@ -398,6 +400,28 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
                              cin_true=cout)
 
     tape.nodes.append(bwd)
+    return y
+
+
+FOLD_EVAL_BN = True   # inference only (no tape): conv + eval-mode BN + ReLU as ONE kernel with BN folded into w and b
+
+
+def _conv_folded_eval(x: Act, weight: torch.Tensor, bias: Optional[torch.Tensor], bn: BNRef, ks: int, cin: int, cout: int,
+                      relu: bool) -> Act:
+    """Eval-mode Conv -> BatchNorm -> ReLU (running statistics) without the normalise pass: w' = w*gamma/sqrt(var+eps),
+    b' = (b-mean)*gamma/sqrt(var+eps)+beta, ReLU in the conv epilogue.  Used when nothing is recorded for backward
+    (torch.no_grad / inference_mode: PLTrainer.py:530,626)."""
+    dev = x.buf.device
+    T = ks * ks
+    fold = torch.empty(2 * cout, dtype=torch.float32, device=dev)
+    scale, fbias = fold[:cout], fold[cout:]
+    _lib.call("hpri_bn_fold", _p(bn.running_mean), _p(bn.running_var), _p(bn.weight), _p(bn.bias), _p(bias), bn.eps, cout,
+              _p(scale), _p(fbias), _stream())
+    cout_pad = _rup(cout, 64)
+    wp = torch.empty(_lib.load().hpri_packed_weight_floats(cin, cout_pad, T), dtype=torch.float32, device=dev)
+    _lib.call("hpri_pack_weight_scaled", _p(weight), _p(wp), _p(scale), cin, cout, cout_pad, T, cin, _stream())
+    y = Act.new(x.N, x.H, x.W, cout, dev)
+    _conv_launch(x, wp, fbias, y, None, x.N, x.H, x.W, x.cw, cout, cout_pad, y.cw, ks, accumulate=2 if relu else 0, cin_true=cin)
     return y
 
 

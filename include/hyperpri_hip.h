@@ -51,6 +51,14 @@ size_t hpri_packed_weight_floats(int K, int Ncols_pad, int T);
 int hpri_pack_weight(const float* w, float* wp, int mode, int K, int Ncols, int Ncols_pad, int T, int Cup,
                      int src_d0, int src_d1, hipStream_t stream);
 
+/* eval-mode conv->BN->ReLU folded into one conv (predict / validate / test paths, PLTrainer.py:142-162, 530-532):
+ * hpri_bn_fold gives scale = gamma/sqrt(var+eps) and the folded bias; hpri_pack_weight_scaled packs w*scale; bit 1 of
+ * hpri_conv_fwd's `accumulate` argument (value 2) turns on the ReLU epilogue. */
+int hpri_bn_fold(const float* running_mean, const float* running_var, const float* gamma, const float* beta,
+                 const float* conv_bias, float eps, int C, float* scale, float* fbias, hipStream_t stream);
+int hpri_pack_weight_scaled(const float* w, float* wp, const float* colscale, int K, int Ncols, int Ncols_pad, int T,
+                            int src_d1, hipStream_t stream);
+
 /* ---- implicit-GEMM convolution, fp32 MFMA (conv_fwd.hip) ----------------------------------------
  * Replaces F.conv2d / F.conv3d / F.linear / F.conv_transpose2d forward and their data gradients
  * (model_parts.py:22,25,63,96; models.py:108,169,177,198).  hpri_conv_fwd_plan (host only) returns the split-K

@@ -172,3 +172,33 @@ def test_stock_distributed_data_parallel_wraps_the_modules():
             assert torch.allclose(p.grad, g, rtol=0, atol=0)
     finally:
         dist.destroy_process_group()
+
+
+def test_eval_bn_folding_matches_unfused_eval():
+    """Inference (no tape) folds eval-mode BN into the conv weights/bias with the ReLU in the conv epilogue; it must agree
+    with the unfused eval path (conv -> normalise+ReLU pass) and with it the reference's eval logits (golden tests)."""
+    import bench
+    import hyperpri_amd as HP
+    from hyperpri_amd import engine
+    net = HP.CubeNET(6, 1, first_depth=64, bilinear=False).to(DEV)
+    bench.synth_init_(net)
+    x = torch.rand(2, 1, 6, 76, 121, device=DEV)
+    net.train()
+    with torch.no_grad():
+        for _ in range(3):
+            net(x * (1.0 + 0.1 * _))        # non-trivial running statistics
+    net.eval()
+    try:
+        engine.FOLD_EVAL_BN = False
+        with torch.no_grad():
+            ref = net(x)
+        engine.FOLD_EVAL_BN = True
+        with torch.no_grad():
+            fold = net(x)
+    finally:
+        engine.FOLD_EVAL_BN = True
+    assert (ref - fold).abs().max() < 2e-5
+    # with a tape (requires_grad input / training of frozen-BN nets) the unfused path is used and gradients flow
+    xg = x.clone().requires_grad_(True)
+    net(xg).sum().backward()
+    assert xg.grad is not None and torch.isfinite(xg.grad).all()
