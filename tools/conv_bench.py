@@ -77,6 +77,21 @@ def main():
                 torch.cuda.synchronize()
                 if rnd > 0:
                     res.setdefault(name, []).append(e0.elapsed_time(e1) / reps)
+        if os.environ.get("CHECK") and mode in ("fwd", "fwd_bf16"):
+            outs = []
+            for (name, lib), (wp, stats, ws, wpb) in zip(libs, preps):
+                yy = torch.zeros_like(y)
+                if mode == "fwd":
+                    lib.hpri_conv_fwd(P(x), Cin, 0, P(wp), P(b), P(yy), Cout, 0, P(stats), N, H, W, Cin, Cout, cout_pad,
+                                      Cout, ks, 0, 0, 0, 0, 0, 0, 0, 0, P(ws), ws.numel(), st)
+                else:
+                    lib.hpri_conv_fwd_bf16(P(x), Cin, 0, P(wpb), P(b), P(yy), Cout, 0, P(stats), N, H, W, Cin, Cout, cout_pad,
+                                           Cout, ks, 0, 0, 0, 0, 0, 0, 0, 0, P(ws), ws.numel(), st)
+                torch.cuda.synchronize()
+                outs.append((yy, stats.clone()))
+            for (name, _), (yy, stt) in zip(libs[1:], outs[1:]):
+                print(f"   check {name}: max|dy| = {float((yy - outs[0][0]).abs().max()):.3e}, max|dstats| = "
+                      f"{float((stt - outs[0][1]).abs().max()):.3e}")
         line = f"{mode} N{N} {H}x{W} {Cin}->{Cout} k{ks}: "
         for name, _ in libs:
             ms = sorted(res[name])
