@@ -341,7 +341,11 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvFwdArgs a) {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
-template <int KS, int WM, int WN, int AMODE, int EPI>
+// SPLIT = 1 is precision mode "bf16x3": every operand is carried as hi = bf16(x) and lo = bf16(x - hi) (16 mantissa
+// bits) and each k16-step issues three MFMAs, hi*hi + hi*lo + lo*hi, into the same fp32 accumulator -- ~4e-5 on the
+// logits instead of bf16's 2e-2, i.e. inside the reference's 1e-3 contract, at 3 bf16 MFMAs per product instead of
+// one 16x slower fp32 MFMA.  Stage = one tap (two planes) instead of one kernel row.
+template <int KS, int WM, int WN, int AMODE, int EPI, int SPLIT>
 __global__ __launch_bounds__(256, 2) void conv_fwd_bf16_kernel(ConvFwdArgs a) {
   constexpr int T = KS * KS, PAD = KS / 2;
   constexpr int TPIX = 64 * WM;
@@ -349,10 +353,14 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_bf16_kernel(ConvFwdArgs a) {
   constexpr int BN = 64 * WN;
   constexpr int CS = 40;                          // halves per staged pixel / per staged weight row (32 + 8 pad)
   constexpr int NLD_A = (MAXHP * 8 + 255) / 256;  // float4 global loads per thread per A chunk
-  constexpr int NLD_B = (KS * BN * 4) / 256;      // 16-byte global loads per thread per B stage (KS taps)
-  __shared__ __attribute__((aligned(16))) __bf16 smem_h[MAXHP * CS + 2 * KS * BN * CS];
+  constexpr int TS = SPLIT ? 1 : KS;              // taps per stage
+  constexpr int NPL = SPLIT ? 2 : 1;              // operand planes (hi, lo)
+  constexpr int SR = TS * NPL;                    // [BN][32] row blocks per B stage
+  constexpr int NST = SPLIT ? T : KS;             // stages per 32-channel chunk
+  constexpr int NLD_B = (SR * BN * 4) / 256;      // 16-byte global loads per thread per B stage
+  __shared__ __attribute__((aligned(16))) __bf16 smem_h[NPL * MAXHP * CS + 2 * SR * BN * CS];
   __bf16* a_lds = smem_h;
-  __bf16* b_lds = smem_h + MAXHP * CS;
+  __bf16* b_lds = smem_h + NPL * MAXHP * CS;
   float* smem = reinterpret_cast<float*>(smem_h);  // the statistics epilogue reuses the staging area as floats
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -387,7 +395,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_bf16_kernel(ConvFwdArgs a) {
   const int cps = (nchunks_all + a.ksplit - 1) / a.ksplit;
   const int chunk0 = blockIdx.z * cps;
   const int nchunks = min(nchunks_all, chunk0 + cps);
-  const int S0 = chunk0 * KS, S = nchunks * KS;          // stage = (chunk, kernel row)
+  const int S0 = chunk0 * NST, S = nchunks * NST;        // stage = (chunk, kernel row) or (chunk, tap) when SPLIT
 
   // ---- B stages: KS taps x BN rows x 64 bytes, contiguous per tap in the packed tensor ----
   const __bf16* wpk = reinterpret_cast<const __bf16*>(a.wp);
@@ -402,13 +410,13 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_bf16_kernel(ConvFwdArgs a) {
   f32x4 breg[NLD_B];
 #define LOAD_STAGE(s_)                                                                               \
   {                                                                                                  \
-    const __bf16* pb_ = wpk + (size_t)(s_) * KS * a.Cout_pad * 32;                                   \
+    const __bf16* pb_ = wpk + (size_t)(s_) * SR * a.Cout_pad * 32;                                   \
     _Pragma("unroll") for (int p = 0; p < NLD_B; ++p)                                                \
         breg[p] = *reinterpret_cast<const f32x4*>(pb_ + boff[p]);                                    \
   }
 #define STORE_STAGE(buf_)                                                                            \
   _Pragma("unroll") for (int p = 0; p < NLD_B; ++p)                                                  \
-      *reinterpret_cast<f32x4*>(b_lds + (buf_) * KS * BN * CS + blds[p]) = breg[p];
+      *reinterpret_cast<f32x4*>(b_lds + (buf_) * SR * BN * CS + blds[p]) = breg[p];
 
   // ---- A halo: fp32 in HBM -> registers -> bf16 in LDS ----
   const float* ximg = a.x + (size_t)img * (AMODE == HPRI_A_DIRECT ? (size_t)a.H * a.W : (size_t)a.H2 * a.W2) * a.x_cs;
@@ -454,8 +462,14 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_bf16_kernel(ConvFwdArgs a) {
 #define STORE_A()                                                                                    \
   _Pragma("unroll") for (int p = 0; p < NLD_A; ++p) {                                                \
     const int f = tid + p * 256;                                                                     \
-    if ((f >> 3) < HP)                                                                               \
-      *reinterpret_cast<bf16x4*>(a_lds + (f >> 3) * CS + (f & 7) * 4) = __builtin_convertvector(areg[p], bf16x4); \
+    if ((f >> 3) < HP) {                                                                             \
+      const bf16x4 hi_ = __builtin_convertvector(areg[p], bf16x4);                                   \
+      *reinterpret_cast<bf16x4*>(a_lds + (f >> 3) * CS + (f & 7) * 4) = hi_;                         \
+      if (SPLIT) {                                                                                   \
+        const f32x4 rest_ = areg[p] - __builtin_convertvector(hi_, f32x4);                           \
+        *reinterpret_cast<bf16x4*>(a_lds + MAXHP * CS + (f >> 3) * CS + (f & 7) * 4) = __builtin_convertvector(rest_, bf16x4); \
+      }                                                                                              \
+    }                                                                                                \
   }
 
   const int a_base = ((wm * 2 * RW + (li >> twl)) * HW + (li & (TW - 1))) * CS + lh * 8;
@@ -465,32 +479,59 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_bf16_kernel(ConvFwdArgs a) {
   LOAD_STAGE(S0)
   LOAD_A(chunk0 * 32)
   for (int s = S0; s < S; ++s) {
-    const int chunk = s / KS, dy = s - chunk * KS;
-    if (dy == 0) {
+    const int chunk = s / NST, st = s - chunk * NST;         // st = kernel row, or tap when SPLIT
+    if (st == 0) {
       __syncthreads();
       STORE_A()
     }
     STORE_STAGE(s & 1)
     __syncthreads();
     if (s + 1 < S) { LOAD_STAGE(s + 1) }
-    if (dy == KS - 1 && chunk + 1 < nchunks) { LOAD_A((chunk + 1) * 32) }
+    if (st == NST - 1 && chunk + 1 < nchunks) { LOAD_A((chunk + 1) * 32) }
 
-    const __bf16* ap = a_lds + a_base + dy * HW * CS;
-    const __bf16* bp = b_lds + (s & 1) * KS * BN * CS + b_base;
+    const __bf16* bp = b_lds + (s & 1) * SR * BN * CS + b_base;
+    if (!SPLIT) {
+      const __bf16* ap = a_lds + a_base + st * HW * CS;
 #pragma unroll
-    for (int dx = 0; dx < KS; ++dx) {
+      for (int dx = 0; dx < KS; ++dx) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          bf16x8 af[2], bf[2];
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt) af[mt] = *reinterpret_cast<const bf16x8*>(ap + mt * a_mt + dx * CS + kk * 16);
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) bf[nt] = *reinterpret_cast<const bf16x8*>(bp + (dx * BN + nt * 32) * CS + kk * 16);
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mt], bf[nt], acc[mt][nt], 0, 0, 0);
+        }
+      }
+    } else {
+      const int dy = st / KS, dx = st - dy * KS;
+      const __bf16* ap = a_lds + a_base + (dy * HW + dx) * CS;
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
-        bf16x8 af[2], bf[2];
+        bf16x8 ah[2], al[2], bh[2], bl[2];
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) af[mt] = *reinterpret_cast<const bf16x8*>(ap + mt * a_mt + dx * CS + kk * 16);
+        for (int mt = 0; mt < 2; ++mt) {
+          ah[mt] = *reinterpret_cast<const bf16x8*>(ap + mt * a_mt + kk * 16);
+          al[mt] = *reinterpret_cast<const bf16x8*>(ap + MAXHP * CS + mt * a_mt + kk * 16);
+        }
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) bf[nt] = *reinterpret_cast<const bf16x8*>(bp + (dx * BN + nt * 32) * CS + kk * 16);
+        for (int nt = 0; nt < 2; ++nt) {
+          bh[nt] = *reinterpret_cast<const bf16x8*>(bp + (nt * 32) * CS + kk * 16);
+          bl[nt] = *reinterpret_cast<const bf16x8*>(bp + (BN + nt * 32) * CS + kk * 16);
+        }
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-          for (int nt = 0; nt < 2; ++nt)
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mt], bf[nt], acc[mt][nt], 0, 0, 0);
+          for (int nt = 0; nt < 2; ++nt) {
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+          }
       }
     }
   }
@@ -763,7 +804,7 @@ extern "C" int hpri_conv_fwd_plan(int N, int H, int W, int Cin_pad, int Cout_pad
   return HPRI_OK;
 }
 
-template <int KS, int WM, int WN, int AMODE, int EPI>
+template <int KS, int WM, int WN, int AMODE, int EPI, int SPLIT>
 static int launch_conv_bf16(const ConvFwdArgs& a0, hipStream_t stream) {
   ConvFwdArgs a = a0;
   constexpr int BN = 64 * WN;
@@ -771,7 +812,7 @@ static int launch_conv_bf16(const ConvFwdArgs& a0, hipStream_t stream) {
   a.nseg = sg.nseg; a.tiles_img = sg.tiles_img;
   for (int k = 0; k < HPRI_MAXSEG; ++k) { a.seg_twl[k] = sg.twl[k]; a.seg_xbeg[k] = sg.xbeg[k]; a.seg_ntx[k] = sg.ntx[k]; a.seg_first[k] = sg.first[k]; }
   dim3 grid((unsigned)(a.N * a.tiles_img), (unsigned)(a.Cout_pad / BN), (unsigned)a.ksplit);
-  hipLaunchKernelGGL((conv_fwd_bf16_kernel<KS, WM, WN, AMODE, EPI>), grid, dim3(256), 0, stream, a);
+  hipLaunchKernelGGL((conv_fwd_bf16_kernel<KS, WM, WN, AMODE, EPI, SPLIT>), grid, dim3(256), 0, stream, a);
   HPRI_CHECK_LAUNCH();
   return HPRI_OK;
 }
@@ -781,7 +822,7 @@ extern "C" int hpri_conv_fwd_bf16(const float* x, int x_cs, int x_coff, const vo
                                   float* y, int y_cs, int y_coff, float* stats,
                                   int N, int H, int W, int Cin_pad, int Cout, int Cout_pad, int y_cw,
                                   int KS, int amode, int epi, int accumulate, int H2, int W2, int py0, int px0, int Cup,
-                                  float* ws, size_t ws_floats, hipStream_t stream) {
+                                  int split, float* ws, size_t ws_floats, hipStream_t stream) {
   HPRI_REQUIRE(x && wp && y, "conv_fwd_bf16: null pointer");
   HPRI_REQUIRE(N > 0 && H > 0 && W > 0, "conv_fwd_bf16: empty image");
   HPRI_REQUIRE(Cin_pad > 0 && Cin_pad % 8 == 0, "conv_fwd_bf16: Cin_pad must be a positive multiple of 8");
@@ -817,7 +858,8 @@ extern "C" int hpri_conv_fwd_bf16(const float* x, int x_cs, int x_coff, const vo
   int wm, wn; conv_cfg(Cout_pad, &wm, &wn);
   int rc;
 #define HPRI_DISPATCH_B(KS_, AM_, EP_)                                                      \
-  rc = (wm == 2) ? launch_conv_bf16<KS_, 2, 2, AM_, EP_>(a, stream) : launch_conv_bf16<KS_, 4, 1, AM_, EP_>(a, stream)
+  rc = split ? ((wm == 2) ? launch_conv_bf16<KS_, 2, 2, AM_, EP_, 1>(a, stream) : launch_conv_bf16<KS_, 4, 1, AM_, EP_, 1>(a, stream)) \
+             : ((wm == 2) ? launch_conv_bf16<KS_, 2, 2, AM_, EP_, 0>(a, stream) : launch_conv_bf16<KS_, 4, 1, AM_, EP_, 0>(a, stream))
   if (KS == 3) { HPRI_DISPATCH_B(3, HPRI_A_DIRECT, HPRI_E_DIRECT); }
   else if (amode == HPRI_A_S2D) { HPRI_DISPATCH_B(1, HPRI_A_S2D, HPRI_E_DIRECT); }
   else if (epi == HPRI_E_D2S) { HPRI_DISPATCH_B(1, HPRI_A_DIRECT, HPRI_E_D2S); }

@@ -174,21 +174,24 @@ __device__ __forceinline__ bf16x8 tr_frag(const __bf16* p, int pitch4) {
   return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-template <int KS, int CT, int NT, int BMODE>
+// SPLIT = 1 (precision mode "bf16x3"): X and dY are staged as two bf16 planes (hi, lo) and every k16-step issues
+// dYl*Xh + dYh*Xl + dYh*Xh.
+template <int KS, int CT, int NT, int BMODE, int SPLIT>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradArgs a) {
   constexpr int T = KS * KS, PAD = KS / 2;
   // one staged unit = SQ vertically adjacent 2x32 strips (SQ*64 pixels): the bf16 MFMAs retire so fast that the
   // staging + barrier cost must be amortised over more pixels than in the fp32 kernel
-  constexpr int SQ = (KS == 3) ? 2 : 1;
+  constexpr int SQ = (KS == 3 && !SPLIT) ? 2 : 1;
+  constexpr int NPL = SPLIT ? 2 : 1;
   constexpr int SH = 2 * SQ, SW = 32, HH = SH + KS - 1, HW = SW + KS - 1, HP = HH * HW, NPIX = SH * SW;
   constexpr int BC = 64 * CT, BNW = 64 * NT;
   constexpr int PX = BC + 32, PY = BNW + 32;      // halves per staged pixel: data + 32 pad, i.e. a pitch of 48 / 80 dwords
                                                   // = 16 (mod 32): the 4 pixel rows of a transposed read hit disjoint banks
   constexpr int NLD_X = (HP * (BC / 4) + 255) / 256;
   constexpr int NLD_Y = (NPIX * (BNW / 4)) / 256;
-  __shared__ __attribute__((aligned(16))) __bf16 smem[HP * PX + NPIX * PY];
+  __shared__ __attribute__((aligned(16))) __bf16 smem[NPL * (HP * PX + NPIX * PY)];
   __bf16* x_lds = smem;
-  __bf16* y_lds = smem + HP * PX;
+  __bf16* y_lds = smem + NPL * HP * PX;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wc = wave >> 1, wn = wave & 1;
@@ -224,7 +227,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradArgs a) {
     const int img = q / units_y;
     const int y0 = sy * SH, x0 = sx * SW;
 
-    bf16x4 xr[NLD_X], yr[NLD_Y];               // converted to bf16 right after the load: half the staging registers
+    bf16x4 xr[NPL][NLD_X], yr[NPL][NLD_Y];     // converted to bf16 right after the load: half the staging registers
 #pragma unroll
     for (int p = 0; p < NLD_X; ++p) {
       const int f = tid + p * 256;
@@ -237,7 +240,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradArgs a) {
         if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W && c < a.x_cvalid)
           v = *reinterpret_cast<const f32x4*>(a.x + ((size_t)(img * a.H + iy) * a.W + ix) * a.x_cs + a.x_coff + c);
       }
-      xr[p] = __builtin_convertvector(v, bf16x4);
+      xr[0][p] = __builtin_convertvector(v, bf16x4);
+      if (SPLIT) xr[NPL - 1][p] = __builtin_convertvector(v - __builtin_convertvector(xr[0][p], f32x4), bf16x4);
     }
 #pragma unroll
     for (int p = 0; p < NLD_Y; ++p) {
@@ -255,20 +259,25 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradArgs a) {
           v = *reinterpret_cast<const f32x4*>(a.dy + ((size_t)(img * a.H2 + yy) * a.W2 + xx) * a.dy_cs + a.dy_coff + co);
         }
       }
-      yr[p] = __builtin_convertvector(v, bf16x4);
+      yr[0][p] = __builtin_convertvector(v, bf16x4);
+      if (SPLIT) yr[NPL - 1][p] = __builtin_convertvector(v - __builtin_convertvector(yr[0][p], f32x4), bf16x4);
     }
     __syncthreads();   // previous unit's LDS reads are finished
 #pragma unroll
     for (int p = 0; p < NLD_X; ++p) {
       const int f = tid + p * 256;
       const int pix = f / (BC / 4), c4 = f % (BC / 4);
-      if (pix < HP) *reinterpret_cast<bf16x4*>(x_lds + pix * PX + c4 * 4) = xr[p];
+      if (pix < HP) {
+        *reinterpret_cast<bf16x4*>(x_lds + pix * PX + c4 * 4) = xr[0][p];
+        if (SPLIT) *reinterpret_cast<bf16x4*>(x_lds + HP * PX + pix * PX + c4 * 4) = xr[NPL - 1][p];
+      }
     }
 #pragma unroll
     for (int p = 0; p < NLD_Y; ++p) {
       const int f = tid + p * 256;
       const int pix = f / (BNW / 4), n4 = f % (BNW / 4);
-      *reinterpret_cast<bf16x4*>(y_lds + pix * PY + n4 * 4) = yr[p];
+      *reinterpret_cast<bf16x4*>(y_lds + pix * PY + n4 * 4) = yr[0][p];
+      if (SPLIT) *reinterpret_cast<bf16x4*>(y_lds + NPIX * PY + pix * PY + n4 * 4) = yr[NPL - 1][p];
     }
     __syncthreads();
 
@@ -276,20 +285,31 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradArgs a) {
 #pragma unroll
     for (int ks = 0; ks < NPIX / 16; ++ks) {
       const int py = ks >> 1, pxo = 16 * (ks & 1);
-      bf16x8 af[NT];
+      bf16x8 af[NT], afl[NT];
 #pragma unroll
-      for (int j = 0; j < NT; ++j) af[j] = tr_frag(yb + (ks * 16) * PY + j * 32, 4 * PY);
+      for (int j = 0; j < NT; ++j) {
+        af[j] = tr_frag(yb + (ks * 16) * PY + j * 32, 4 * PY);
+        if (SPLIT) afl[j] = tr_frag(yb + NPIX * PY + (ks * 16) * PY + j * 32, 4 * PY);
+      }
 #pragma unroll
       for (int t = 0; t < T; ++t) {
         const int dy = t / KS, dx = t - dy * KS;
-        bf16x8 bfr[CT];
+        bf16x8 bfr[CT], bfl[CT];
 #pragma unroll
-        for (int i = 0; i < CT; ++i) bfr[i] = tr_frag(xb + ((py + dy) * HW + pxo + dx) * PX + i * 32, 4 * PX);
+        for (int i = 0; i < CT; ++i) {
+          bfr[i] = tr_frag(xb + ((py + dy) * HW + pxo + dx) * PX + i * 32, 4 * PX);
+          if (SPLIT) bfl[i] = tr_frag(xb + HP * PX + ((py + dy) * HW + pxo + dx) * PX + i * 32, 4 * PX);
+        }
 #pragma unroll
         for (int i = 0; i < CT; ++i)
 #pragma unroll
-          for (int j = 0; j < NT; ++j)
+          for (int j = 0; j < NT; ++j) {
+            if (SPLIT) {
+              acc[t][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afl[j], bfr[i], acc[t][i][j], 0, 0, 0);
+              acc[t][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[j], bfl[i], acc[t][i][j], 0, 0, 0);
+            }
             acc[t][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[j], bfr[i], acc[t][i][j], 0, 0, 0);
+          }
       }
     }
   }
@@ -413,7 +433,7 @@ extern "C" int hpri_conv_wgrad_bf16(const float* x, int x_cs, int x_coff, int x_
                                     const float* dy, int dy_cs, int dy_coff, int dy_cvalid,
                                     float* ws, size_t ws_floats,
                                     int N, int H, int W, int Cin_pad, int Cout_pad, int KS, int bmode,
-                                    int H2, int W2, int py0, int px0, int Cup, hipStream_t stream) {
+                                    int H2, int W2, int py0, int px0, int Cup, int split, hipStream_t stream) {
   HPRI_REQUIRE(x && dy && ws, "conv_wgrad_bf16: null pointer");
   HPRI_REQUIRE(KS == 1 || KS == 3, "conv_wgrad_bf16: kernel size must be 1 or 3");
   HPRI_REQUIRE(x_cs % 4 == 0 && x_coff % 4 == 0 && dy_cs % 4 == 0 && dy_coff % 4 == 0 && x_cvalid % 4 == 0 && dy_cvalid % 4 == 0,
@@ -437,9 +457,15 @@ extern "C" int hpri_conv_wgrad_bf16(const float* x, int x_cs, int x_coff, int x_
   if ((size_t)splits * T * Cr * Nr > ws_floats) return hpri_set_error(HPRI_ERR_WORKSPACE, "conv_wgrad_bf16: workspace too small");
   int bc, bn; wgrad_cfg(KS, &bc, &bn);
   dim3 grid((unsigned)splits, (unsigned)(Cr / bc), (unsigned)(Nr / bn));
-  if (KS == 3) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<3, 1, 1, HPRI_A_DIRECT>), grid, dim3(256), 0, stream, a);
-  else if (bmode == HPRI_A_S2D) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<1, 2, 2, HPRI_A_S2D>), grid, dim3(256), 0, stream, a);
-  else hipLaunchKernelGGL((conv_wgrad_bf16_kernel<1, 2, 2, HPRI_A_DIRECT>), grid, dim3(256), 0, stream, a);
+  if (split) {
+    if (KS == 3) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<3, 1, 1, HPRI_A_DIRECT, 1>), grid, dim3(256), 0, stream, a);
+    else if (bmode == HPRI_A_S2D) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<1, 2, 2, HPRI_A_S2D, 1>), grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((conv_wgrad_bf16_kernel<1, 2, 2, HPRI_A_DIRECT, 1>), grid, dim3(256), 0, stream, a);
+  } else {
+    if (KS == 3) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<3, 1, 1, HPRI_A_DIRECT, 0>), grid, dim3(256), 0, stream, a);
+    else if (bmode == HPRI_A_S2D) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<1, 2, 2, HPRI_A_S2D, 0>), grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((conv_wgrad_bf16_kernel<1, 2, 2, HPRI_A_DIRECT, 0>), grid, dim3(256), 0, stream, a);
+  }
   HPRI_CHECK_LAUNCH();
   return HPRI_OK;
 }

@@ -69,8 +69,9 @@ extern "C" int hpri_pack_weight_scaled(const float* w, float* wp, const float* c
 
 // ---- bf16 panels for conv_fwd_bf16.hip: [chunk][tap][Ncols_pad][32 k] (k contiguous per output column, the order the
 // MFMA B operand wants); same four modes as the fp32 pack; round-to-nearest-even.
+// split = 1 (mode "bf16x3"): two planes per tap, [chunk][tap][plane][Ncols_pad][32]: hi = bf16(w), lo = bf16(w - hi)
 __global__ void pack_weight_bf16_kernel(const float* __restrict__ w, __bf16* __restrict__ wp, int mode, int K, int Ncols,
-                                        int Ncols_pad, int T, int chunks, int src_d1, int Cup) {
+                                        int Ncols_pad, int T, int chunks, int src_d1, int Cup, int split) {
   const size_t total = (size_t)chunks * T * Ncols_pad * 32;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
     const int kk = (int)(idx & 31);
@@ -86,12 +87,20 @@ __global__ void pack_weight_bf16_kernel(const float* __restrict__ w, __bf16* __r
       else if (mode == 2) { const int tap = col / Cup, co = col - tap * Cup; v = w[((size_t)k * Cup + co) * 4 + tap]; }
       else { const int tap = k / Cup, co = k - tap * Cup; v = w[((size_t)col * Cup + co) * 4 + tap]; }
     }
-    wp[idx] = (__bf16)v;
+    if (!split) {
+      wp[idx] = (__bf16)v;
+    } else {
+      const size_t plane = (size_t)Ncols_pad * 32;
+      const size_t o = ((size_t)(chunk * T + t) * 2) * plane + (size_t)col * 32 + kk;
+      const __bf16 hi = (__bf16)v;
+      wp[o] = hi;
+      wp[o + plane] = (__bf16)(v - (float)hi);
+    }
   }
 }
 
 extern "C" int hpri_pack_weight_bf16(const float* w, void* wp, int mode, int K, int Ncols, int Ncols_pad, int T,
-                                     int src_d1, int Cup, hipStream_t stream) {
+                                     int src_d1, int Cup, int split, hipStream_t stream) {
   HPRI_REQUIRE(w && wp, "pack_weight_bf16: null pointer");
   HPRI_REQUIRE(mode >= 0 && mode <= 3 && K > 0 && Ncols > 0 && Ncols_pad >= Ncols && Ncols_pad % 64 == 0,
                "pack_weight_bf16: bad arguments");
@@ -100,7 +109,7 @@ extern "C" int hpri_pack_weight_bf16(const float* w, void* wp, int mode, int K, 
   int blocks = (int)((total + 255) / 256);
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(pack_weight_bf16_kernel, dim3(blocks), dim3(256), 0, stream, w, reinterpret_cast<__bf16*>(wp), mode, K,
-                     Ncols, Ncols_pad, T, chunks, src_d1, Cup);
+                     Ncols, Ncols_pad, T, chunks, src_d1, Cup, split);
   HPRI_CHECK_LAUNCH();
   return HPRI_OK;
 }

@@ -22,9 +22,12 @@ E_DIRECT, E_D2S = 0, 1
 #   "fp32" (default) -- exact fp32 on v_mfma_f32_32x32x2_f32: the mode every 1e-3-logit parity claim refers to
 #   "bf16"           -- conv / linear operands (forward, data gradient, weight gradient) rounded to bf16,
 #                       v_mfma_f32_32x32x16_bf16 with fp32 accumulate (BASELINE.json config C5); activations in HBM,
-#                       BN, pooling, ConvTranspose2d and the 1x1 output conv stay fp32.
+#                       BN, pooling and the 1x1 output conv stay fp32.
+#   "bf16x3"         -- every contraction operand carried as bf16 hi + bf16 lo (16 mantissa bits), three bf16 MFMAs per
+#                       product (hi*hi + hi*lo + lo*hi), fp32 accumulate: ~4e-5 on the logits, i.e. INSIDE the 1e-3
+#                       contract, on the 16x faster pipe.
 #                       Dice/IoU-level parity only (bf16 operands move logits by ~2e-2).
-PRECISIONS = ("fp32", "bf16")
+PRECISIONS = ("fp32", "bf16", "bf16x3")
 DEFAULT_PRECISION = os.environ.get("HPRI_PRECISION", "fp32")
 
 
@@ -249,28 +252,30 @@ def _pack(w: torch.Tensor, mode: int, K: int, ncols: int, T: int, cup: int, d1: 
     return wp, ncols_pad
 
 
-def _pack_bf16(w: torch.Tensor, mode: int, K: int, ncols: int, T: int, d1: int, cup: int = 0) -> Tuple[torch.Tensor, int]:
+def _pack_bf16(w: torch.Tensor, mode: int, K: int, ncols: int, T: int, d1: int, cup: int = 0,
+               split: int = 0) -> Tuple[torch.Tensor, int]:
     ncols_pad = _rup(ncols, 64)
     chunks = (K + 31) // 32
-    wp = torch.empty(chunks * T * ncols_pad * 32, dtype=torch.bfloat16, device=w.device)
-    _lib.call("hpri_pack_weight_bf16", _p(w), _p(wp), mode, K, ncols, ncols_pad, T, d1, cup, _stream())
+    wp = torch.empty(chunks * T * ncols_pad * 32 * (2 if split else 1), dtype=torch.bfloat16, device=w.device)
+    _lib.call("hpri_pack_weight_bf16", _p(w), _p(wp), mode, K, ncols, ncols_pad, T, d1, cup, split, _stream())
     return wp, ncols_pad
 
 
 def _conv_launch_bf16(x: Act, wp: torch.Tensor, bias: Optional[torch.Tensor], y: Act, stats: Optional[torch.Tensor],
                       N: int, H: int, W: int, cin_pad: int, cout: int, cout_pad: int, y_cw: int, ks: int,
                       amode: int = A_DIRECT, epi: int = E_DIRECT, accumulate: int = 0,
-                      H2: int = 0, W2: int = 0, py0: int = 0, px0: int = 0, cup: int = 0, cin_true: int = 0) -> None:
+                      H2: int = 0, W2: int = 0, py0: int = 0, px0: int = 0, cup: int = 0, cin_true: int = 0,
+                      split: int = 0) -> None:
     ksplit = ctypes.c_int(); tiles = ctypes.c_int(); wsf = ctypes.c_size_t()
     _lib.call("hpri_conv_fwd_plan", N, H, W, cin_pad, cout_pad, ks, amode, epi, ctypes.byref(ksplit), ctypes.byref(tiles),
               ctypes.byref(wsf))
     ws = _ws(wsf.value, x.buf.device) if wsf.value else None
-    tag = f"conv_fwd_bf16<{ks},{'2x2' if cout_pad % 128 == 0 else '4x1'},{'s2d' if amode else 'direct'},{'d2s' if epi else 'direct'}>"
+    tag = f"conv_fwd_{'bf16x3' if split else 'bf16'}<{ks},{'2x2' if cout_pad % 128 == 0 else '4x1'},{'s2d' if amode else 'direct'},{'d2s' if epi else 'direct'}>"
     if SHAPE_TAGS:
         tag += f" N{N} {H}x{W} K{cin_pad} N{cout}"
     with _timed(tag, 2.0 * N * H * W * (cin_true or cin_pad) * cout * ks * ks):
         _lib.call("hpri_conv_fwd_bf16", x.ptr, x.cs, x.coff, _p(wp), _p(bias), y.ptr, y.cs, y.coff, _p(stats),
-                  N, H, W, cin_pad, cout, cout_pad, y_cw, ks, amode, epi, accumulate, H2, W2, py0, px0, cup,
+                  N, H, W, cin_pad, cout, cout_pad, y_cw, ks, amode, epi, accumulate, H2, W2, py0, px0, cup, split,
                   _p(ws), wsf.value, _stream())
 
 
@@ -312,8 +317,10 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
     prec = precision or DEFAULT_PRECISION
     if prec not in PRECISIONS:
         raise RuntimeError(f"hyperpri_amd: unknown precision {prec!r}; choose from {PRECISIONS}")
-    if prec == "bf16":
-        wp, cout_pad = _pack_bf16(weight, 0, cin, cout, T, cin)
+    lowp = prec in ("bf16", "bf16x3")
+    split = int(prec == "bf16x3")
+    if lowp:
+        wp, cout_pad = _pack_bf16(weight, 0, cin, cout, T, cin, split=split)
     else:
         wp, cout_pad = _pack(weight, 0, cin, cout, T, 0, cin)
     yr = Act.new(x.N, x.H, x.W, cout, dev)
@@ -326,8 +333,8 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
                   ctypes.byref(tl), ctypes.byref(wsf))
         tiles = tl.value
         stats = torch.empty(tiles * cout_pad * 4, dtype=torch.float32, device=dev)
-    if prec == "bf16":
-        _conv_launch_bf16(x, wp, bias, yr, stats, x.N, x.H, x.W, cin_pad, cout, cout_pad, yr.cw, ks, cin_true=cin)
+    if lowp:
+        _conv_launch_bf16(x, wp, bias, yr, stats, x.N, x.H, x.W, cin_pad, cout, cout_pad, yr.cw, ks, cin_true=cin, split=split)
     else:
         _conv_launch(x, wp, bias, yr, stats, x.N, x.H, x.W, cin_pad, cout, cout_pad, yr.cw, ks, cin_true=cin)
     del wp
@@ -382,18 +389,18 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
             main, side = torch.cuda.current_stream(dev), _side(dev)
             side.wait_stream(main)                      # dyr (and everything before it) is ready
             with torch.cuda.stream(side):
-                _wgrad(x, dyr, dw, acc_w, cin, cout, ks, bf16=(prec == "bf16"))
+                _wgrad(x, dyr, dw, acc_w, cin, cout, ks, bf16=lowp, split=split)
             for t in (x.buf, dyr.buf, dw):               # keep the caching allocator from recycling them early
                 t.record_stream(side)
             tp.used_side = True
         else:
-            _wgrad(x, dyr, dw, acc_w, cin, cout, ks, bf16=(prec == "bf16"))
+            _wgrad(x, dyr, dw, acc_w, cin, cout, ks, bf16=lowp, split=split)
         if need_dx:
             gx, acc = tp.grad_slot(x)
-            if prec == "bf16":
-                wpd, cin_cols_pad = _pack_bf16(weight, 1, cout, cin, T, cin)
+            if lowp:
+                wpd, cin_cols_pad = _pack_bf16(weight, 1, cout, cin, T, cin, split=split)
                 _conv_launch_bf16(dyr, wpd, None, gx, None, x.N, x.H, x.W, dyr.cw, cin, cin_cols_pad, gx.cw, ks,
-                                  accumulate=int(acc), cin_true=cout)
+                                  accumulate=int(acc), cin_true=cout, split=split)
             else:
                 wpd, cin_cols_pad = _pack(weight, 1, cout, cin, T, 0, cin)
                 _conv_launch(dyr, wpd, None, gx, None, x.N, x.H, x.W, dyr.cw, cin, cin_cols_pad, gx.cw, ks, accumulate=int(acc),
@@ -427,7 +434,8 @@ def _conv_folded_eval(x: Act, weight: torch.Tensor, bias: Optional[torch.Tensor]
 
 def _wgrad(x: Act, dy: Act, dw: torch.Tensor, accumulate: int, cin: int, cout: int, ks: int,
            bmode: int = A_DIRECT, dst_mode: int = 0, N: int = 0, H: int = 0, W: int = 0,
-           H2: int = 0, W2: int = 0, py0: int = 0, px0: int = 0, cup: int = 0, bf16: bool = False) -> None:
+           H2: int = 0, W2: int = 0, py0: int = 0, px0: int = 0, cup: int = 0, bf16: bool = False,
+           split: int = 0) -> None:
     N, H, W = (N or x.N), (H or x.H), (W or x.W)
     cin_pad = x.cw
     cout_pad = _rup(cout, 64)
@@ -435,13 +443,13 @@ def _wgrad(x: Act, dy: Act, dw: torch.Tensor, accumulate: int, cin: int, cout: i
     _lib.call("hpri_wgrad_plan", N, H, W, cin_pad, cout_pad, ks, ctypes.byref(splits), ctypes.byref(cr), ctypes.byref(nr))
     ws = _ws(splits.value * ks * ks * cr.value * nr.value, x.buf.device)
     dy_cvalid = (4 * cup) if bmode == A_S2D else dy.cw
-    tag = f"conv_wgrad{'_bf16' if bf16 else ''}<{ks},{'s2d' if bmode == A_S2D else 'direct'}>"
+    tag = f"conv_wgrad{('_bf16x3' if split else '_bf16') if bf16 else ''}<{ks},{'s2d' if bmode == A_S2D else 'direct'}>"
     if SHAPE_TAGS:
         tag += f" N{N} {H}x{W} C{cin_pad} N{cout}"
     if bf16:
         with _timed(tag, 2.0 * N * H * W * cin * cout * ks * ks):
             _lib.call("hpri_conv_wgrad_bf16", x.ptr, x.cs, x.coff, cin_pad, dy.ptr, dy.cs, dy.coff, dy_cvalid, _p(ws), ws.numel(),
-                      N, H, W, cin_pad, cout_pad, ks, bmode, H2, W2, py0, px0, cup, _stream())
+                      N, H, W, cin_pad, cout_pad, ks, bmode, H2, W2, py0, px0, cup, split, _stream())
         _lib.call("hpri_wgrad_reduce", _p(ws), _p(dw), N, H, W, cin, cin_pad, cout, cout_pad, ks, dst_mode, cup, accumulate,
                   _stream())
         return
@@ -496,11 +504,13 @@ def _upsample_into(tape: Tape, x1: Act, dst: Act, weight: Optional[torch.Tensor]
         cin = weight.shape[0]
         if cin != x1.C or weight.shape[1] != cup:
             raise RuntimeError("hyperpri_amd: Up: ConvTranspose2d channel mismatch")
-        bf16 = (precision or DEFAULT_PRECISION) == "bf16"
+        uprec = precision or DEFAULT_PRECISION
+        bf16 = uprec in ("bf16", "bf16x3")
+        usplit = int(uprec == "bf16x3")
         if bf16:
-            wp, ncols_pad = _pack_bf16(weight, 2, cin, 4 * cup, 1, cup, cup)
+            wp, ncols_pad = _pack_bf16(weight, 2, cin, 4 * cup, 1, cup, cup, split=usplit)
             _conv_launch_bf16(x1, wp, bias, dst, None, x1.N, x1.H, x1.W, x1.cw, 4 * cup, ncols_pad, 4 * cup, 1,
-                              epi=E_D2S, H2=H2, W2=W2, py0=py0, px0=px0, cup=cup, cin_true=cin)
+                              epi=E_D2S, H2=H2, W2=W2, py0=py0, px0=px0, cup=cup, cin_true=cin, split=usplit)
         else:
             wp, ncols_pad = _pack(weight, 2, cin, 4 * cup, 1, cup, cup)
             _conv_launch(x1, wp, bias, dst, None, x1.N, x1.H, x1.W, x1.cw, 4 * cup, ncols_pad, 4 * cup, 1,
@@ -534,14 +544,16 @@ def _upsample_into(tape: Tape, x1: Act, dst: Act, weight: Optional[torch.Tensor]
             ws = _ws(nblk.value * 2 * cpart.value + 2 * cup, dev)
             _lib.call("hpri_col_sum", gu.ptr, gu.cs, gu.coff, _p(db), acc_b, _p(ws), ws.numel(), gu.P, cup, _stream())
         dw, acc_w = tp.param_slot(weight)
+        bprec = precision or DEFAULT_PRECISION
         _wgrad(x1, gu, dw, acc_w, cin, 4 * cup, 1, bmode=A_S2D, dst_mode=1, H2=H2, W2=W2, py0=py0, px0=px0, cup=cup,
-               bf16=(precision or DEFAULT_PRECISION) == "bf16")
+               bf16=bprec in ("bf16", "bf16x3"), split=int(bprec == "bf16x3"))
         if need_dx1:
             gx, acc = tp.grad_slot(x1)
-            if (precision or DEFAULT_PRECISION) == "bf16":
-                wpd, cols_pad = _pack_bf16(weight, 3, 4 * cup, cin, 1, cup, cup)
+            if bprec in ("bf16", "bf16x3"):
+                wpd, cols_pad = _pack_bf16(weight, 3, 4 * cup, cin, 1, cup, cup, split=int(bprec == "bf16x3"))
                 _conv_launch_bf16(gu, wpd, None, gx, None, x1.N, x1.H, x1.W, 4 * cup, cin, cols_pad, gx.cw, 1,
-                                  amode=A_S2D, accumulate=int(acc), H2=H2, W2=W2, py0=py0, px0=px0, cup=cup, cin_true=4 * cup)
+                                  amode=A_S2D, accumulate=int(acc), H2=H2, W2=W2, py0=py0, px0=px0, cup=cup, cin_true=4 * cup,
+                                  split=int(bprec == "bf16x3"))
             else:
                 wpd, cols_pad = _pack(weight, 3, 4 * cup, cin, 1, cup, cup)
                 _conv_launch(gu, wpd, None, gx, None, x1.N, x1.H, x1.W, 4 * cup, cin, cols_pad, gx.cw, 1,

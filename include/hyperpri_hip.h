@@ -73,13 +73,15 @@ int hpri_conv_fwd(const float* x, int x_cs, int x_coff, const float* wp, const f
 
 /* bf16-operand variants (precision mode "bf16", BASELINE.json config C5): operands rounded to bf16 while staged into
  * LDS, v_mfma_f32_32x32x16_bf16 with fp32 accumulate, fp32 activations in HBM.  Same modes, plan, workspace and
- * statistics contract as hpri_conv_fwd / hpri_pack_weight. */
+ * statistics contract as hpri_conv_fwd / hpri_pack_weight.  split = 1 (precision mode "bf16x3"): operands carried as
+ * bf16 hi + bf16 lo (16 mantissa bits), three MFMAs per product (hi*hi + hi*lo + lo*hi); the packed weights then hold
+ * two planes (twice the size). */
 int hpri_pack_weight_bf16(const float* w, void* wp, int mode, int K, int Ncols, int Ncols_pad, int T, int src_d1,
-                          int Cup, hipStream_t stream);
+                          int Cup, int split, hipStream_t stream);
 int hpri_conv_fwd_bf16(const float* x, int x_cs, int x_coff, const void* wp, const float* bias, float* y, int y_cs,
                        int y_coff, float* stats, int N, int H, int W, int Cin_pad, int Cout, int Cout_pad, int y_cw,
-                       int KS, int amode, int epi, int accumulate, int H2, int W2, int py0, int px0, int Cup, float* ws,
-                       size_t ws_floats, hipStream_t stream);
+                       int KS, int amode, int epi, int accumulate, int H2, int W2, int py0, int px0, int Cup, int split,
+                       float* ws, size_t ws_floats, hipStream_t stream);
 
 /* ---- weight gradients, fp32 MFMA, deterministic split-K (conv_wgrad.hip) --------------------------
  * Replaces the wgrad half of autograd for the same layers.  dst_mode 0 writes OIHW / (out,in),
@@ -90,7 +92,7 @@ int hpri_conv_wgrad(const float* x, int x_cs, int x_coff, int x_cvalid, const fl
                     int bmode, int H2, int W2, int py0, int px0, int Cup, hipStream_t stream);
 int hpri_conv_wgrad_bf16(const float* x, int x_cs, int x_coff, int x_cvalid, const float* dy, int dy_cs, int dy_coff,
                          int dy_cvalid, float* ws, size_t ws_floats, int N, int H, int W, int Cin_pad, int Cout_pad,
-                         int KS, int bmode, int H2, int W2, int py0, int px0, int Cup, hipStream_t stream);
+                         int KS, int bmode, int H2, int W2, int py0, int px0, int Cup, int split, hipStream_t stream);
 int hpri_wgrad_reduce(const float* ws, float* dw, int N, int H, int W, int Cin, int Cin_pad, int Cout, int Cout_pad,
                       int KS, int dst_mode, int Cup, int accumulate, hipStream_t stream);
 

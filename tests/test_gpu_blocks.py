@@ -203,3 +203,29 @@ def test_transposed_conv_concat_vs_torch(prec):
     _close(wd.grad, wc.grad.numpy(), 1e-4, 2e-3, "convT wgrad")
     # the bias gradient is a plain fp32 column sum of the (unrounded) incoming gradient over the un-padded region
     _close(bd.grad, r[:, Cs:, :2 * H, :2 * W].sum(dim=(0, 2, 3)).numpy(), 1e-4, 1e-3, "convT bias grad")
+
+
+@pytest.mark.parametrize("N,Cin,H,W,Cout,ks", [(2, 5, 9, 11, 7, 3), (1, 64, 20, 70, 128, 3), (2, 40, 13, 37, 64, 3),
+                                               (1, 24, 5, 33, 200, 1), (1, 512, 38, 60, 512, 3)])
+def test_conv_bf16x3_mode_vs_exact(N, Cin, H, W, Cout, ks):
+    """precision="bf16x3": operands carried as bf16 hi + bf16 lo (16 mantissa bits), hi*hi + hi*lo + lo*hi on the bf16
+    pipe.  Against the EXACT fp32 torch conv: relative error of a product ~2^-16, i.e. ~1e-5 of the output scale."""
+    from hyperpri_amd import engine as E
+    from hyperpri_amd.autograd import run
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(N * 1000 + Cin + H)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, ks, ks, generator=g) / (Cin * ks * ks) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    r = torch.randn(N, Cout, H, W, generator=g)
+    xc, wc = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yc = F.conv2d(xc.double(), wc.double(), b.double(), padding=ks // 2)
+    yc.backward(r.double())
+    xd, wd, bd = (t.to(DEV).requires_grad_(True) for t in (x, w, b))
+    yd = run(lambda tape, a, need: E.conv_bn_relu(tape, a[0], wd, bd, None, True, ks, need_dx=need[0], precision="bf16x3"),
+             [xd], [wd, bd])
+    sc = float(yc.detach().abs().max())
+    assert float((yd.detach().cpu().double() - yc.detach()).abs().max()) < 1e-4 * sc
+    yd.backward(r.to(DEV))
+    assert float((xd.grad.cpu().double() - xc.grad).abs().max()) < 1e-4 * float(xc.grad.abs().max())
+    assert float((wd.grad.cpu().double() - wc.grad).abs().max()) < 1e-4 * float(wc.grad.abs().max())

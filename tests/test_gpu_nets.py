@@ -215,3 +215,60 @@ def test_full_size_cubenet128_bf16_vs_fp32_mode():
     _, d16, i16 = O.seg_metrics(l16, mask.cpu())
     assert abs(d32 - d16) < 2e-3 and abs(i32 - i16) < 2e-3
     assert ((g32 - g16).abs() <= 0.1 * g32 + 1e-6).all()
+
+
+X3_CASES = [c for c in CASES if c[0] in ("net_unet3_tiny", "net_cubenet64_tiny", "net_cubenet128_tiny", "net_spectral_f50")]
+
+
+@pytest.mark.parametrize("name,xseed,xshape,mseed,thr", X3_CASES, ids=[c[0] for c in X3_CASES])
+def test_tiny_net_bf16x3_mode_meets_the_fp32_contract(name, xseed, xshape, mseed, thr):
+    """precision="bf16x3" is held to the SAME bar as the exact fp32 path: logits within 1e-3 of the reference fixture,
+    loss within 1e-5, Dice/IoU equal to 4 dp."""
+    import hyperpri_amd as H
+    z = _load(name)
+    net = _mk(name)
+    shapes = OrderedDict((k, tuple(v.shape)) for k, v in net.state_dict().items())
+    net.load_state_dict(O.synth_state_dict(shapes))
+    net = H.set_precision(net.to(DEV), "bf16x3").train()
+    x = _u(xseed, xshape).to(DEV)
+    mask = (_u(mseed, (xshape[0], 1) + tuple(xshape[-2:])) > thr).float().to(DEV)
+    logits = net(x)
+    loss = torch.nn.BCEWithLogitsLoss()(logits, mask)
+    loss.backward()
+    lg = logits.detach().cpu()
+    assert np.abs(lg.numpy() - z["logits"]).max() < 1e-3
+    assert abs(float(loss.detach()) - float(z["loss"])) < 1e-5
+    acc, dice, iou = O.seg_metrics(lg, mask.cpu())
+    assert round(dice, 4) == round(float(z["dice"]), 4) and round(iou, 4) == round(float(z["iou"]), 4)
+    names = list(z["grad_names"])
+    grads = OrderedDict((k, p.grad) for k, p in net.named_parameters())
+    for i, k in enumerate(names):
+        g = float(grads[k].detach().double().norm())
+        ref = z["grad_l2"][i]
+        assert abs(g - ref) <= 5e-3 * ref + 2e-6, (k, g, ref)
+
+
+def test_full_size_cubenet64_bf16x3_vs_golden():
+    """BASELINE config C2 at full size in mode bf16x3 against the fixture captured from the reference modules."""
+    import hyperpri_amd as H
+    z = _load("net_cubenet64_full")
+    net = H.CubeNET(238, 1, first_depth=64, bilinear=False)
+    shapes = OrderedDict((k, tuple(v.shape)) for k, v in net.state_dict().items())
+    net.load_state_dict(O.synth_state_dict(shapes))
+    net = H.set_precision(net.to(DEV), "bf16x3").train()
+    x = _u(1234, (1, 1, 238, 608, 968))
+    mask = (_u(4321, (1, 1, 608, 968)) > 0.9).float()
+    logits = net(x.to(DEV))
+    loss = torch.nn.BCEWithLogitsLoss()(logits, mask.to(DEV))
+    loss.backward()
+    lg = logits.detach().cpu()
+    stride = int(z["stride"])
+    assert np.abs(lg.reshape(-1)[::stride].numpy() - z["logits_sub"]).max() < 1e-3
+    assert abs(float(loss.detach()) - float(z["loss"])) < 1e-5
+    acc, dice, iou = O.seg_metrics(lg, mask)
+    assert round(dice, 4) == round(float(z["dice"]), 4) and round(iou, 4) == round(float(z["iou"]), 4)
+    grads = OrderedDict((k, p.grad) for k, p in net.named_parameters())
+    for i, k in enumerate(list(z["grad_names"])):
+        g = float(grads[k].detach().double().norm())
+        ref = z["grad_l2"][i]
+        assert abs(g - ref) <= 1e-2 * ref + 1e-5, (k, g, ref)

@@ -11,6 +11,7 @@ import torch  # noqa: E402
 from hyperpri_amd import _lib  # noqa: E402
 
 import json
+SPLIT = int(os.environ.get("SPLIT", "0"))
 SHAPES = json.loads(os.environ["SHAPES"]) if "SHAPES" in os.environ else [  # N, H, W, Cin, Cout, ks
     (2, 304, 484, 128, 128, 3),
     (2, 608, 968, 64, 64, 3),
@@ -50,9 +51,9 @@ def main():
             s, cr, nr = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
             lib.hpri_wgrad_plan(N, H, W, Cin, cout_pad, ks, ctypes.byref(s), ctypes.byref(cr), ctypes.byref(nr))
             ws = torch.empty(max(s.value * ks * ks * cr.value * nr.value, 4 * N * H * W * cout_pad), device=dev)
-            wpb = torch.empty(((Cin + 31) // 32) * ks * ks * cout_pad * 32, dtype=torch.bfloat16, device=dev)
+            wpb = torch.empty(((Cin + 31) // 32) * ks * ks * cout_pad * 32 * 2, dtype=torch.bfloat16, device=dev)
             if hasattr(lib, "hpri_pack_weight_bf16"):
-                assert lib.hpri_pack_weight_bf16(P(w), P(wpb), 0, Cin, Cout, cout_pad, ks * ks, Cin, 0, st) == 0
+                assert lib.hpri_pack_weight_bf16(P(w), P(wpb), 0, Cin, Cout, cout_pad, ks * ks, Cin, 0, SPLIT, st) == 0
             preps.append((wp, stats, ws, wpb))
         for rnd in range(5):
             for (name, lib), (wp, stats, ws, wpb) in zip(libs, preps):
@@ -62,13 +63,13 @@ def main():
                 for _ in range(reps):
                     if mode == "fwd":
                         rc = lib.hpri_conv_fwd(P(x), Cin, 0, P(wp), P(b), P(y), Cout, 0, P(stats), N, H, W, Cin, Cout, cout_pad,
-                                               Cout, ks, 0, 0, 0, 0, 0, 0, 0, 0, P(ws), ws.numel(), st)
+                                               Cout, ks, 0, 0, 0, 0, 0, 0, 0, 0, SPLIT, P(ws), ws.numel(), st)
                     elif mode == "fwd_bf16":
                         rc = lib.hpri_conv_fwd_bf16(P(x), Cin, 0, P(wpb), P(b), P(y), Cout, 0, P(stats), N, H, W, Cin, Cout,
-                                                    cout_pad, Cout, ks, 0, 0, 0, 0, 0, 0, 0, 0, P(ws), ws.numel(), st)
+                                                    cout_pad, Cout, ks, 0, 0, 0, 0, 0, 0, 0, 0, SPLIT, P(ws), ws.numel(), st)
                     elif mode == "wgrad_bf16":
                         rc = lib.hpri_conv_wgrad_bf16(P(x), Cin, 0, Cin, P(y), Cout, 0, Cout, P(ws), ws.numel(), N, H, W, Cin,
-                                                      cout_pad, ks, 0, 0, 0, 0, 0, 0, st)
+                                                      cout_pad, ks, 0, 0, 0, 0, 0, 0, SPLIT, st)
                     else:
                         rc = lib.hpri_conv_wgrad(P(x), Cin, 0, Cin, P(y), Cout, 0, Cout, P(ws), ws.numel(), N, H, W, Cin, cout_pad,
                                                  ks, 0, 0, 0, 0, 0, 0, st)
@@ -86,7 +87,7 @@ def main():
                                       Cout, ks, 0, 0, 0, 0, 0, 0, 0, 0, P(ws), ws.numel(), st)
                 else:
                     lib.hpri_conv_fwd_bf16(P(x), Cin, 0, P(wpb), P(b), P(yy), Cout, 0, P(stats), N, H, W, Cin, Cout, cout_pad,
-                                           Cout, ks, 0, 0, 0, 0, 0, 0, 0, 0, P(ws), ws.numel(), st)
+                                           Cout, ks, 0, 0, 0, 0, 0, 0, 0, 0, SPLIT, P(ws), ws.numel(), st)
                 torch.cuda.synchronize()
                 outs.append((yy, stats.clone()))
             for (name, _), (yy, stt) in zip(libs[1:], outs[1:]):
