@@ -132,7 +132,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="skip the per-kernel HIP-event pass")
     ap.add_argument("--bf16-steps", type=int, default=5,
-                    help="extra steps in precision mode bf16 (reported as 'bf16_mode', never as 'value'); 0 = skip")
+                    help="extra steps in each of the precision modes bf16x3 and bf16 (reported as 'bf16x3_mode' / "
+                         "'bf16_mode', never as 'value'); 0 = skip")
     ap.add_argument("--force-sync", action="store_true",
                     help="rehearsal: run the RCCL GradSync path (process group, hooks, all-reduce) even with one rank")
     args = ap.parse_args()
@@ -193,10 +194,9 @@ def main():
         dt = float(t.item())
     loss_val = float(loss.detach())
 
-    # ---- secondary line: the same workload in precision mode "bf16" (config C5's arithmetic; Dice-level parity only) ----
-    bf16_mode = None
-    if args.bf16_steps > 0:
-        HP.set_precision(net, "bf16")
+    # ---- secondary lines: the same workload in the other precision modes (never the headline) ----
+    def timed_mode(mode):
+        HP.set_precision(net, mode)
         for _ in range(2):
             step()
         fence()
@@ -209,12 +209,23 @@ def main():
             t = torch.tensor([dtb], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dtb = float(t.item())
-        bf16_mode = {"value": round(world * BATCH * args.bf16_steps / dtb, 4), "unit": "cubes/s", "steps": args.bf16_steps,
-                     "ms_per_step": round(dtb / args.bf16_steps * 1e3, 3), "loss": round(float(lossb.detach()), 6),
-                     "dtype": "bf16 operands / f32 accumulate (v_mfma_f32_32x32x16_bf16); activations, BN, pooling, convT f32",
-                     "parity": "Dice/IoU level only (max |dlogit| 4.0e-2, <=0.35 % sign flips, |dDice| <= 1.5e-4 vs the fp32 oracle: "
-                               "profiles/r01_bf16_dice_parity.json); NOT the headline value"}
         HP.set_precision(net, "fp32")
+        return {"value": round(world * BATCH * args.bf16_steps / dtb, 4), "unit": "cubes/s", "steps": args.bf16_steps,
+                "ms_per_step": round(dtb / args.bf16_steps * 1e3, 3), "loss": round(float(lossb.detach()), 6)}
+
+    bf16_mode = bf16x3_mode = None
+    if args.bf16_steps > 0:
+        bf16x3_mode = timed_mode("bf16x3")
+        bf16x3_mode.update({
+            "dtype": "bf16 hi+lo operands (16 mantissa bits), 3 x v_mfma_f32_32x32x16_bf16 per product, f32 accumulate",
+            "parity": "meets the fp32 contract on every fixture: full-size logits within 1e-3 of the reference, Dice/IoU equal "
+                      "to 4 dp on all 42 held-out comparisons, max |dlogit| 7.8e-5 (profiles/r01_bf16x3_dice_parity.json); "
+                      "reported separately because BASELINE config C2 names fp32"})
+        bf16_mode = timed_mode("bf16")
+        bf16_mode.update({
+            "dtype": "bf16 operands / f32 accumulate (v_mfma_f32_32x32x16_bf16); activations, BN, pooling f32",
+            "parity": "Dice/IoU level only (max |dlogit| 4.0e-2, <=0.35 % sign flips, |dDice| <= 1.5e-4 vs the fp32 oracle: "
+                      "profiles/r01_bf16_dice_parity.json); NOT the headline value"})
 
     roofline = None
     if rank == 0 and not args.no_roofline:
@@ -254,7 +265,7 @@ def main():
                        "global_batch": world * BATCH, "parallelism": f"dp{world}"},
             "loss": round(loss_val, 6),
             "model_tflops": round(value * GFLOP_PER_CUBE / 1e3 / world, 2),
-            "roofline": roofline, "cpu_baseline": cpu, "bf16_mode": bf16_mode,
+            "roofline": roofline, "cpu_baseline": cpu, "bf16x3_mode": bf16x3_mode, "bf16_mode": bf16_mode,
         }
         print(json.dumps(out), flush=True)
     if use_pg:

@@ -47,7 +47,7 @@ def main():
             nfl = lib.hpri_packed_weight_floats(Cin, cout_pad, ks * ks)
             wp = torch.empty(nfl, device=dev)
             assert lib.hpri_pack_weight(P(w), P(wp), 0, Cin, Cout, cout_pad, ks * ks, 0, 0, Cin, st) == 0
-            stats = torch.empty((N * ((H + 3) // 4) * ((W + 31) // 32) + 64) * cout_pad * 4, device=dev)
+            stats = torch.empty((N * ((H * W + 15) // 16) + 64) * cout_pad * 4, device=dev)   # >= any plan's stat_tiles
             s, cr, nr = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
             lib.hpri_wgrad_plan(N, H, W, Cin, cout_pad, ks, ctypes.byref(s), ctypes.byref(cr), ctypes.byref(nr))
             ws = torch.empty(max(s.value * ks * ks * cr.value * nr.value, 4 * N * H * W * cout_pad), device=dev)
