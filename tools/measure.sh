@@ -5,7 +5,7 @@ set -o pipefail
 R=${GRAFT_REPO_ROOT:-/root/repo}
 TAG=${1:-r01}
 OUT=$R/gpurun_out/$TAG
-mkdir -p $OUT
+rm -rf $OUT; mkdir -p $OUT   # NB: gpurun merges into the local gpurun_out/ -- remove the local copy of the tag dir before a re-run
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 500 python3 $R/bench.py > $OUT/bench.json 2> $OUT/bench.err || exit 1
 tail -1 $OUT/bench.json | cut -c1-600
