@@ -154,6 +154,35 @@ int hpri_mul(const float* a, int a_cs, int a_coff, const float* b, int b_cs, int
 int hpri_synth_fill(float* dst, long long n, unsigned long long seed, int mode, float thr, float scale,
                     hipStream_t stream);
 
+/* ---- the caller-side tail of a step (step.hip) ---------------------------------
+ * What RootLightningModel does with the logits once the network returns them:
+ *   hpri_bce_logits_fwd / _bwd   nn.BCEWithLogitsLoss() mean, `loss = self.f_criterion(pred, batch['mask'])`
+ *                                (PLTrainer.py:86,109,131; params_HyperPRI.py:60) and its gradient
+ *                                dlogits = (sigmoid(x) - y) * grad_out / n; `loss` and `grad_out` are device scalars.
+ *   hpri_seg_counts              `seg = torch.sigmoid(pred.detach()) > threshold` and the TP/FP/FN/TN counts that
+ *                                Accuracy / JaccardIndex / Dice (PLTrainer.py:62-68,88-91) reduce to;
+ *                                counts[4] (int64: TP, FP, FN, TN) are accumulated, so one buffer serves an epoch.
+ *   hpri_pr_curve_hist           PrecisionRecallCurve('binary', thresholds=500) (PLTrainer.py:542-543; torchmetrics
+ *                                1.2.0 binned update): hist[2][T+1] int64, bin = #{k : thresholds[k] <= p}, accumulated.
+ *   hpri_adam_step / hpri_sgd_step  optim.Adam / optim.SGD over every parameter tensor (PLTrainer.py:171-181):
+ *                                host arrays of device pointers + element counts; `grad_scale` (nullable device
+ *                                scalar) multiplies the gradients first (1/world_size after a sum all-reduce). */
+size_t hpri_bce_workspace_doubles(long long n);
+int hpri_bce_logits_fwd(const float* logits, const float* target, long long n, float* loss, double* workspace,
+                        size_t ws_doubles, hipStream_t stream);
+int hpri_bce_logits_bwd(const float* logits, const float* target, long long n, const float* grad_out, float* dlogits,
+                        hipStream_t stream);
+int hpri_seg_counts(const float* pred, const float* target, long long n, float threshold, int is_logits,
+                    long long* counts, hipStream_t stream);
+int hpri_pr_curve_hist(const float* pred, const float* target, long long n, const float* thresholds, int T,
+                       int is_logits, long long* hist, hipStream_t stream);
+int hpri_adam_step(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                   const long long* numel, int ntensors, float lr, float beta1, float beta2, float eps,
+                   float weight_decay, int step, const float* grad_scale, hipStream_t stream);
+int hpri_sgd_step(float* const* params, const float* const* grads, float* const* momentum_buf, const long long* numel,
+                  int ntensors, float lr, float momentum, float weight_decay, int first_step, const float* grad_scale,
+                  hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -357,3 +357,63 @@ def train_step(forward, sd: SD, x: Tensor, mask: Tensor, **kw):
     loss = bce_with_logits(logits, mask)
     loss.backward()
     return logits.detach(), float(loss.detach()), OrderedDict((k, t.grad) for k, t in leaves.items())
+
+
+# --------------------------------------------------------------------------------------------
+# caller-side tail of a step: counts, binned PR curve, optimizer
+# --------------------------------------------------------------------------------------------
+def seg_counts(pred: Tensor, mask: Tensor, thr: float = 0.5, is_logits: bool = True) -> Tuple[int, int, int, int]:
+    """(TP, FP, FN, TN) of ``torch.sigmoid(pred) > thr`` in fp32, as PLTrainer.py:88 evaluates it, against
+    ``mask.to(torch.int32)`` (PLTrainer.py:80)."""
+    p = torch.sigmoid(pred.detach().float()) if is_logits else pred.detach().float()
+    seg = (p > thr).flatten()
+    m = (mask.to(torch.int32) != 0).flatten()
+    return (int((seg & m).sum()), int((seg & ~m).sum()), int((~seg & m).sum()), int((~seg & ~m).sum()))
+
+
+def pr_curve_binned(probs: Tensor, target: Tensor, thresholds: int = 500):
+    """torchmetrics 1.2.0 ``PrecisionRecallCurve('binary', thresholds=T)`` (PLTrainer.py:542-543; torchmetrics is a
+    pinned dependency, environment.yml:31, NOT installed here -> restated from its published algorithm, parity
+    unpinned): thresholds = linspace(0, 1, T); per threshold the confusion matrix of (probs >= t) vs target;
+    precision = tp/(tp+fp), recall = tp/(tp+fn) with 0 where the denominator is 0; a final (1, 0) point appended.
+    Returns (precision[T+1], recall[T+1], thresholds[T], tp[T], fp[T], fn[T])."""
+    thr = torch.linspace(0, 1, thresholds, dtype=torch.float32)
+    p = probs.detach().float().flatten()
+    t = (target.flatten().to(torch.int32) != 0)
+    tp = torch.empty(thresholds, dtype=torch.int64)
+    fp = torch.empty(thresholds, dtype=torch.int64)
+    for k in range(thresholds):
+        ge = p >= thr[k]
+        tp[k] = int((ge & t).sum())
+        fp[k] = int((ge & ~t).sum())
+    fn = int(t.sum()) - tp
+
+    def safe_div(a, b):
+        b = torch.where(b == 0, torch.ones_like(b), b)
+        return a / b
+
+    tpf, fpf, fnf = tp.float(), fp.float(), fn.float()
+    precision = torch.cat([safe_div(tpf, tpf + fpf), torch.ones(1)])
+    recall = torch.cat([safe_div(tpf, tpf + fnf), torch.zeros(1)])
+    return precision, recall, thr, tp, fp, fn
+
+
+def best_dice_threshold(precision: Tensor, recall: Tensor, thresholds: Tensor):
+    """PLTrainer.py:546-556: crop 1 % at both ends, Dice = 2PR/(P+R), arg-max, threshold rounded to 2 decimals."""
+    crop = int(len(precision) // 100)
+    p, r, t = precision[crop:-crop], recall[crop:-crop], thresholds[crop:-crop]
+    dice = 2 * p * r / (p + r)
+    i = int(torch.argmax(dice))
+    return float(torch.round(t[i].to(torch.float), decimals=2)), float(p[i]), float(r[i])
+
+
+def optimizer_steps(kind: str, params, grads_per_step, **hyper):
+    """Run ``torch.optim.Adam`` / ``torch.optim.SGD`` (the optimizers PLTrainer.py:171-181 constructs) on CPU copies of
+    ``params`` with the given per-step gradient lists; returns the updated tensors."""
+    ps = [torch.nn.Parameter(p.detach().clone().float()) for p in params]
+    opt = (torch.optim.Adam if kind.lower() == "adam" else torch.optim.SGD)(ps, **hyper)
+    for grads in grads_per_step:
+        for p, g in zip(ps, grads):
+            p.grad = None if g is None else g.detach().clone().float()
+        opt.step()
+    return [p.detach() for p in ps]
