@@ -20,7 +20,10 @@ def _as4d(t: torch.Tensor) -> torch.Tensor:
     if t.dim() == 5:           # CubeNET cube (N,1,D,H,W) -> (N,D,H,W); dataset.py:269-271
         if t.shape[1] != 1:
             raise RuntimeError("hyperpri_amd: 5-D input must be (N,1,D,H,W)")
-        return t.reshape(t.shape[0], t.shape[2], t.shape[3], t.shape[4])
+        r = t.reshape(t.shape[0], t.shape[2], t.shape[3], t.shape[4])
+        if getattr(t, "_hpri_zero_padded", False):      # ingest.py cubes: keep the zero-copy channels-last marker
+            r._hpri_zero_padded = True
+        return r
     if t.dim() != 4:
         raise RuntimeError(f"hyperpri_amd: expected a 4-D or 5-D tensor, got shape {tuple(t.shape)}")
     return t

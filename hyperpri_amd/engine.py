@@ -97,7 +97,9 @@ class Act:
         N, C, H, W = t.shape
         st = t.stride()
         cs = st[3] if W > 1 else (st[2] if H > 1 else C)
-        if (C % 8 == 0 and st[1] == 1 and cs >= C and cs % 4 == 0 and (W == 1 or st[3] == cs)
+        # C % 8 != 0 is only zero-copy for tensors the ingest path built (ingest.py): it guarantees zero pad channels
+        padded_ok = C % 8 == 0 or (getattr(t, "_hpri_zero_padded", False) and cs >= _rup(C, 8))
+        if (padded_ok and st[1] == 1 and cs >= C and cs % 4 == 0 and (W == 1 or st[3] == cs)
                 and (H == 1 or st[2] == W * cs) and (N == 1 or st[0] == H * W * cs)
                 and t.data_ptr() % 16 == 0):
             a = Act(t, N, H, W, C, cs, 0)

@@ -183,6 +183,16 @@ int hpri_sgd_step(float* const* params, const float* const* grads, float* const*
                   int ntensors, float lr, float momentum, float weight_decay, int first_step, const float* grad_scale,
                   hipStream_t stream);
 
+/* ---- ingest fast path (ingest.hip) ---------------------------------------------------
+ * `HyperpriDataset.__getitem__` (dataset.py:261-271) loads an ENVI cube as (H, W, B), moves the band axis to the
+ * front on the host and slices [hsi_lo:hsi_hi].  These two take the (H, W, B) array as it is:
+ *   hpri_hwb_ingest  device (H,W,B) f32/f16 -> zero-padded channels-last fp32 [P][dst_cs], bands [lo, lo+C)
+ *   hpri_hwb_h2d     host (pinned) fp32 (H,W,B) -> the same layout directly, as one async 2-D H2D copy
+ *                    (pad channels must have been zeroed once by the caller). */
+int hpri_hwb_ingest(const void* src, int src_dtype, float* dst, long long P, int B, int lo, int C, int dst_cs,
+                    int dst_cw, hipStream_t stream);
+int hpri_hwb_h2d(const float* host_src, float* dst, long long P, int B, int lo, int C, int dst_cs, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

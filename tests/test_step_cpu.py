@@ -146,3 +146,19 @@ def test_trainer_fails_loudly_on_cpu_tensors():
     p = torch.nn.Parameter(torch.zeros(4)); p.grad = torch.ones(4)
     with pytest.raises(RuntimeError):
         FusedAdam([p]).step()
+
+
+def test_ingest_entry_points_reject_bad_arguments():
+    from hyperpri_amd import _lib
+    from hyperpri_amd.ingest import CubeStager, from_hwb
+    lib = _lib.load()
+    null, one = ctypes.c_void_p(0), ctypes.c_void_p(16)
+    assert lib.hpri_hwb_ingest(null, 0, null, 10, 8, 0, 8, 8, 8, null) == -1
+    assert lib.hpri_hwb_ingest(one, 0, one, 10, 8, 4, 8, 8, 8, null) == -1 and b"band range" in lib.hpri_last_error()
+    assert lib.hpri_hwb_ingest(one, 0, one, 10, 8, 0, 6, 6, 6, null) == -1      # destination stride not a multiple of 4
+    assert lib.hpri_hwb_ingest(one, 2, one, 10, 8, 0, 8, 8, 8, null) == -1      # unknown dtype
+    assert lib.hpri_hwb_h2d(null, null, 10, 8, 0, 8, 8, null) == -1
+    with pytest.raises(RuntimeError):
+        CubeStager(1, 4, 4, 8, device="cpu")
+    with pytest.raises(RuntimeError):
+        from_hwb(torch.zeros(1, 4, 4, 8))
