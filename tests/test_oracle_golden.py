@@ -98,7 +98,12 @@ NETS = [
     ("net_spectral_tiny", lambda: O.spectral_shapes(10, 1, 4), O.spectral_forward, {}, 1237, (3, 10, 7, 9), 4322),
     ("net_spectral_f48", lambda: O.spectral_shapes(22, 1, 48), O.spectral_forward, {}, 1238, (2, 22, 12, 20), 4323),
     ("net_spectral_f50", lambda: O.spectral_shapes(22, 1, 50), O.spectral_forward, {}, 1242, (2, 22, 9, 14), 4324),
+    # the BASELINE configs' exact channel widths at reduced spatial size (tests/golden/make_golden_widths.py)
+    ("net_spectral1650_small", lambda: O.spectral_shapes(238, 1, 1650), O.spectral_forward, {}, 1250, (2, 238, 16, 24), 4330),
+    ("net_cubenet128_300_small", lambda: O.cubenet_shapes(300, 1, 128), O.cubenet_forward, dict(first_depth=128), 1251,
+     (2, 1, 300, 32, 48), 4331),
 ]
+MASK_THR = {"net_spectral1650_small": 0.8, "net_cubenet128_300_small": 0.9}
 
 
 @pytest.mark.parametrize("name,shapes,fwd,kw,xseed,xshape,mseed", NETS, ids=[n[0] for n in NETS])
@@ -106,7 +111,7 @@ def test_tiny_net(name, shapes, fwd, kw, xseed, xshape, mseed):
     z = _load(name)
     sd = O.synth_state_dict(shapes())
     x = _u(xseed, xshape)
-    thr = 0.9 if "spectral" not in name else 0.7
+    thr = MASK_THR.get(name, 0.9 if "spectral" not in name else 0.7)
     mask = (_u(mseed, (xshape[0], 1) + tuple(xshape[-2:])) > thr).float()
     logits, loss, grads = O.train_step(fwd, sd, x, mask, **kw)
     np.testing.assert_allclose(logits.numpy(), z["logits"], rtol=1e-4, atol=2e-6)
