@@ -19,6 +19,7 @@
 // Epilogue: + bias, NHWC store (or 2x2 scatter), optional accumulate, optional per-tile BatchNorm
 // partial statistics (mean, M2, count) for the training-mode BN that follows every conv in the model.
 #include "common.h"
+#include <stdlib.h>
 
 #define HPRI_MAXSEG 4
 struct ConvFwdArgs {
@@ -40,11 +41,29 @@ struct ConvFwdArgs {
   // Tile segments: the image width is cut into column bands of tile width 32, 16, 8 or 4 (tile height grows as the
   // width shrinks, pixels per tile stay constant) so that W = 484 / 242 / 121 does not round up to 512 / 256 / 128.
   int nseg, tiles_img;
+  int nbx;               // >0: XCD-aware 1-D grid (see conv_block_ids); = number of output-channel blocks
   int seg_twl[HPRI_MAXSEG];    // log2(tile width)
   int seg_xbeg[HPRI_MAXSEG];   // first column of the band
   int seg_ntx[HPRI_MAXSEG];    // tiles per row of the band
   int seg_first[HPRI_MAXSEG];  // index (within one image) of the band's first tile
 };
+
+// Block -> (pixel tile, output-channel block).  Legacy: grid (tiles, NB): channel blocks of one pixel tile are a whole
+// grid row apart, so with many channel blocks and activations far larger than L2 (SpectralUNET, F = 1650: 13 blocks,
+// 2.8 GB) every block re-reads its input tile from HBM.  nbx > 0: 1-D grid; workgroups go round-robin over the 8 XCDs
+// in launch order, so id%8 picks the XCD and consecutive ids on one XCD walk the channel blocks of ONE pixel tile:
+// the tile is fetched from HBM once and served to the other NB-1 blocks by that XCD's L2.
+__device__ __forceinline__ bool conv_block_ids(const ConvFwdArgs& a, int& bx, int& nb) {
+  bx = blockIdx.x; nb = blockIdx.y;
+  if (a.nbx > 0) {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    nb = j % a.nbx;
+    bx = (j / a.nbx) * 8 + xcd;
+    if (bx >= a.N * a.tiles_img) return false;
+  }
+  return true;
+}
+
 
 template <int KS, int WM, int WN, int AMODE, int EPI>
 __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvFwdArgs a) {
@@ -63,11 +82,12 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvFwdArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
   const int wm = wave / WN, wn = wave % WN;
-  const int nb = blockIdx.y;
+  int bx, nb;
+  if (!conv_block_ids(a, bx, nb)) return;
 
   // ---- which tile: image, column band (tile kind), position ----
-  const int img = blockIdx.x / a.tiles_img;
-  const int tin = blockIdx.x - img * a.tiles_img;
+  const int img = bx / a.tiles_img;
+  const int tin = bx - img * a.tiles_img;
   int seg = 0;
 #pragma unroll
   for (int k = 1; k < HPRI_MAXSEG; ++k)
@@ -321,7 +341,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvFwdArgs a) {
         if (pass == 0) mean[nt] = t / cnt;
         else if (wm == 0 && lh == 0) {
           const int n = nb * BN + wn * 64 + nt * 32 + li;
-          a.stats[(size_t)blockIdx.x * a.Cout_pad + n] = make_float4(mean[nt], t, cnt, 0.f);
+          a.stats[(size_t)bx * a.Cout_pad + n] = make_float4(mean[nt], t, cnt, 0.f);
         }
       }
       __syncthreads();
@@ -366,10 +386,11 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_bf16_kernel(ConvFwdArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
   const int wm = wave / WN, wn = wave % WN;
-  const int nb = blockIdx.y;
+  int bx, nb;
+  if (!conv_block_ids(a, bx, nb)) return;
 
-  const int img = blockIdx.x / a.tiles_img;
-  const int tin = blockIdx.x - img * a.tiles_img;
+  const int img = bx / a.tiles_img;
+  const int tin = bx - img * a.tiles_img;
   int seg = 0;
 #pragma unroll
   for (int k = 1; k < HPRI_MAXSEG; ++k)
@@ -646,7 +667,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_bf16_kernel(ConvFwdArgs a) {
         if (pass == 0) mean[nt] = t / cnt;
         else if (wm == 0 && lh == 0) {
           const int n = nb * BN + wn * 64 + nt * 32 + li;
-          a.stats[(size_t)blockIdx.x * a.Cout_pad + n] = make_float4(mean[nt], t, cnt, 0.f);
+          a.stats[(size_t)bx * a.Cout_pad + n] = make_float4(mean[nt], t, cnt, 0.f);
         }
       }
       __syncthreads();
@@ -757,6 +778,10 @@ static ConvSegs conv_segments(int H, int W, int wm) {
   return r;
 }
 
+// Channel-block count from which the XCD-aware 1-D grid is used (conv_block_ids).  Default 9: only shapes with more
+// channel blocks than any CubeNET / UNet layer has (SpectralUNET's 13 and 26); option "conv_nbx_min" (api.cpp).
+static int conv_nbx_min() { return hpri_option(0); }
+
 template <int KS, int WM, int WN, int AMODE, int EPI>
 static int launch_conv(const ConvFwdArgs& a0, hipStream_t stream) {
   ConvFwdArgs a = a0;
@@ -764,7 +789,10 @@ static int launch_conv(const ConvFwdArgs& a0, hipStream_t stream) {
   const ConvSegs sg = conv_segments(a.H, a.W, WM);
   a.nseg = sg.nseg; a.tiles_img = sg.tiles_img;
   for (int k = 0; k < HPRI_MAXSEG; ++k) { a.seg_twl[k] = sg.twl[k]; a.seg_xbeg[k] = sg.xbeg[k]; a.seg_ntx[k] = sg.ntx[k]; a.seg_first[k] = sg.first[k]; }
-  dim3 grid((unsigned)(a.N * a.tiles_img), (unsigned)(a.Cout_pad / BN), (unsigned)a.ksplit);
+  const int NB = a.Cout_pad / BN, tiles = a.N * a.tiles_img;
+  a.nbx = (NB >= conv_nbx_min()) ? NB : 0;
+  dim3 grid((unsigned)tiles, (unsigned)NB, (unsigned)a.ksplit);
+  if (a.nbx > 0) grid = dim3((unsigned)(hpri_cdiv(tiles, 8) * 8 * NB), 1u, (unsigned)a.ksplit);
   hipLaunchKernelGGL((conv_fwd_kernel<KS, WM, WN, AMODE, EPI>), grid, dim3(256), 0, stream, a);
   HPRI_CHECK_LAUNCH();
   return HPRI_OK;
@@ -811,7 +839,10 @@ static int launch_conv_bf16(const ConvFwdArgs& a0, hipStream_t stream) {
   const ConvSegs sg = conv_segments(a.H, a.W, WM);
   a.nseg = sg.nseg; a.tiles_img = sg.tiles_img;
   for (int k = 0; k < HPRI_MAXSEG; ++k) { a.seg_twl[k] = sg.twl[k]; a.seg_xbeg[k] = sg.xbeg[k]; a.seg_ntx[k] = sg.ntx[k]; a.seg_first[k] = sg.first[k]; }
-  dim3 grid((unsigned)(a.N * a.tiles_img), (unsigned)(a.Cout_pad / BN), (unsigned)a.ksplit);
+  const int NB = a.Cout_pad / BN, tiles = a.N * a.tiles_img;
+  a.nbx = (NB >= conv_nbx_min()) ? NB : 0;
+  dim3 grid((unsigned)tiles, (unsigned)NB, (unsigned)a.ksplit);
+  if (a.nbx > 0) grid = dim3((unsigned)(hpri_cdiv(tiles, 8) * 8 * NB), 1u, (unsigned)a.ksplit);
   hipLaunchKernelGGL((conv_fwd_bf16_kernel<KS, WM, WN, AMODE, EPI, SPLIT>), grid, dim3(256), 0, stream, a);
   HPRI_CHECK_LAUNCH();
   return HPRI_OK;

@@ -13,6 +13,7 @@
 // channels) are staged in LDS as [pixel][channel]; MFMA lanes index the channel, so every ds_read_b32 is
 // 32 consecutive dwords (conflict-free) and the NHWC global loads are full 128-byte lines.
 #include "common.h"
+#include <stdlib.h>
 
 struct WgradArgs {
   const float* x; int x_cs; int x_coff; int x_cvalid;   // conv input (NHWC), readable channels
@@ -22,7 +23,26 @@ struct WgradArgs {
   int strips_x, strips_y, total_strips, strips_per_split;
   int Cr, Nr;            // padded slab dims (gridDim.y*BC, gridDim.z*BNW)
   int H2, W2, py0, px0, Cup;  // S2D geometry for dY (convT): hi-res dims, pad offsets, channels per tap
+  int splits;            // pixel splits (= slabs)
+  int xcd_tiles;         // >0: XCD-aware 1-D grid (wgrad_block_ids); = cblk * nblk
+  int cblk;              // channel blocks along C (for the 1-D grid decode)
 };
+
+// Block -> (pixel split, C block, N block).  Legacy grid (splits, cblk, nblk).  With many (C, N) tiles (SpectralUNET:
+// 13 x 13 and 26 x 13 tiles of 128 x 128) every tile streams the whole X and dY from HBM.  xcd_tiles > 0: 1-D grid of
+// 8k * tiles workgroups; they go round-robin over the 8 XCDs in launch order, so id%8 picks the XCD; each XCD owns the
+// pixel splits = xcd (mod 8) and walks the (C, N) tiles of one split back to back (C fastest): the ~64 workgroups
+// resident on an XCD read the SAME pixel strips, which its L2 then serves 5-13 times.
+__device__ __forceinline__ void wgrad_block_ids(const WgradArgs& a, int& split, int& cb, int& nb) {
+  split = blockIdx.x; cb = blockIdx.y; nb = blockIdx.z;
+  if (a.xcd_tiles > 0) {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int tile = j % a.xcd_tiles;
+    split = (j / a.xcd_tiles) * 8 + xcd;
+    cb = tile % a.cblk;
+    nb = tile / a.cblk;
+  }
+}
 
 template <int KS, int CT, int NT, int BMODE>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
@@ -38,7 +58,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
   const int wc = wave >> 1, wn = wave & 1;
-  const int c_blk = blockIdx.y * BC, n_blk = blockIdx.z * BNW;
+  int split_id, cb_id, nb_id;
+  wgrad_block_ids(a, split_id, cb_id, nb_id);
+  const int c_blk = cb_id * BC, n_blk = nb_id * BNW;
 
   f32x16 acc[T][CT][NT];
 #pragma unroll
@@ -50,7 +72,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][i][j][r] = 0.f;
 
-  const int s_begin = blockIdx.x * a.strips_per_split;
+  const int s_begin = split_id * a.strips_per_split;
   const int s_end = min(a.total_strips, s_begin + a.strips_per_split);
 
   // KS == 1 (Linear / ConvTranspose2d weight gradients: no halo reuse, 128 MFMAs per staged strip) prefetches the next
@@ -142,7 +164,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
 #undef LOAD_STRIP
   // partial slab: ws[split][t][n][c]; MFMA rows = n (A operand = dY), cols = c (B operand = X) so that
   // lanes store consecutive c -- the order the reduce kernel and the OIHW gradient want
-  float* slab = a.ws + (size_t)blockIdx.x * T * a.Cr * a.Nr;
+  float* slab = a.ws + (size_t)split_id * T * a.Cr * a.Nr;
 #pragma unroll
   for (int t = 0; t < T; ++t)
 #pragma unroll
@@ -195,7 +217,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wc = wave >> 1, wn = wave & 1;
-  const int c_blk = blockIdx.y * BC, n_blk = blockIdx.z * BNW;
+  int split_id, cb_id, nb_id;
+  wgrad_block_ids(a, split_id, cb_id, nb_id);
+  const int c_blk = cb_id * BC, n_blk = nb_id * BNW;
   // transposed-read lane roles: 16-lane group = (k half h, channel half g); lane i of the group addresses pixel row
   // q = i>>2, channel quad p = i&3 and receives channel i of the block
   const int lg = (lane >> 4) & 1, lh = lane >> 5, lq = (lane >> 2) & 3, lp = lane & 3;
@@ -214,8 +238,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradArgs a) {
   // strips_y counts 2-row strips; this kernel walks them SQ at a time: unit = (img, unit row, strip column)
   const int units_y = (a.strips_y + SQ - 1) / SQ;
   const int total_units = a.N * units_y * a.strips_x;
-  const int units_per_split = (total_units + gridDim.x - 1) / gridDim.x;
-  const int u_begin = blockIdx.x * units_per_split;
+  const int units_per_split = (total_units + a.splits - 1) / a.splits;
+  const int u_begin = split_id * units_per_split;
   const int u_end = min(total_units, u_begin + units_per_split);
   const __bf16* xb = x_lds + (lh * 8 + lq) * PX + wc * (CT * 32) + lg * 16 + lp * 4;
   const __bf16* yb = y_lds + (lh * 8 + lq) * PY + wn * (NT * 32) + lg * 16 + lp * 4;
@@ -315,7 +339,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradArgs a) {
   }
 
   // partial slab ws[split][t][n][c]: MFMA rows = n (A operand = dY), cols = c (B operand = X)
-  float* slab = a.ws + (size_t)blockIdx.x * T * a.Cr * a.Nr;
+  float* slab = a.ws + (size_t)split_id * T * a.Cr * a.Nr;
 #pragma unroll
   for (int t = 0; t < T; ++t)
 #pragma unroll
@@ -372,6 +396,14 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restr
   }
 }
 
+// XCD-aware grid (wgrad_block_ids) from this many (C, N) tiles on: at least two XCDs' worth of resident workgroups,
+// and enough pixel strips that 8k splits still amortise the slab write.  Options "wgrad_xcd_min_tiles" (0 = never) and
+// "wgrad_xcd_min_strips" (api.cpp).
+static bool wgrad_xcd(int tiles, int total_strips) {
+  const int v = hpri_option(1);
+  return v > 0 && tiles >= v && total_strips >= hpri_option(2);
+}
+
 static inline void wgrad_cfg(int KS, int* bc, int* bn) {
   if (KS == 3) { *bc = 64; *bn = 64; } else { *bc = 128; *bn = 128; }
 }
@@ -383,12 +415,23 @@ extern "C" int hpri_wgrad_plan(int N, int H, int W, int Cin_pad, int Cout_pad, i
   int bc, bn; wgrad_cfg(KS, &bc, &bn);
   const int cblk = hpri_cdiv(Cin_pad, bc), nblk = hpri_cdiv(Cout_pad, bn);
   const int total = N * hpri_cdiv(H, 2) * hpri_cdiv(W, 32);
+  *Cr = cblk * bc; *Nr = nblk * bn;
+  if (wgrad_xcd(cblk * nblk, total)) {            // 8k splits, k such that the grid is close to whole rounds of 512
+    const int tiles = cblk * nblk;
+    int best = 1; double best_eff = 0.0;
+    for (int k = 1; k <= 4; ++k) {
+      const double rounds = 8.0 * k * tiles / 512.0, eff = rounds / (double)((long long)(rounds + 0.999999));
+      if (eff > best_eff + 1e-9) { best_eff = eff; best = k; }
+    }
+    *splits = 8 * best;
+    return HPRI_OK;
+  }
   int s = hpri_cdiv(512, cblk * nblk);           // one round of 256 CUs x 2 resident workgroups
   if (s > total) s = total;
   if (s < 1) s = 1;
   const int per = hpri_cdiv(total, s);
   s = hpri_cdiv(total, per);
-  *splits = s; *Cr = cblk * bc; *Nr = nblk * bn;
+  *splits = s;
   return HPRI_OK;
 }
 
@@ -421,6 +464,11 @@ extern "C" int hpri_conv_wgrad(const float* x, int x_cs, int x_coff, int x_cvali
   if ((size_t)splits * T * Cr * Nr > ws_floats) return hpri_set_error(HPRI_ERR_WORKSPACE, "conv_wgrad: workspace too small");
   int bc, bn; wgrad_cfg(KS, &bc, &bn);
   dim3 grid((unsigned)splits, (unsigned)(Cr / bc), (unsigned)(Nr / bn));
+  a.splits = splits; a.cblk = Cr / bc; a.xcd_tiles = 0;
+  if (wgrad_xcd((Cr / bc) * (Nr / bn), a.total_strips)) {
+    a.xcd_tiles = (Cr / bc) * (Nr / bn);
+    grid = dim3((unsigned)(splits * a.xcd_tiles), 1u, 1u);
+  }
   if (KS == 3) hipLaunchKernelGGL((conv_wgrad_kernel<3, 1, 1, HPRI_A_DIRECT>), grid, dim3(256), 0, stream, a);
   else if (bmode == HPRI_A_S2D) hipLaunchKernelGGL((conv_wgrad_kernel<1, 2, 2, HPRI_A_S2D>), grid, dim3(256), 0, stream, a);
   else hipLaunchKernelGGL((conv_wgrad_kernel<1, 2, 2, HPRI_A_DIRECT>), grid, dim3(256), 0, stream, a);
@@ -457,6 +505,11 @@ extern "C" int hpri_conv_wgrad_bf16(const float* x, int x_cs, int x_coff, int x_
   if ((size_t)splits * T * Cr * Nr > ws_floats) return hpri_set_error(HPRI_ERR_WORKSPACE, "conv_wgrad_bf16: workspace too small");
   int bc, bn; wgrad_cfg(KS, &bc, &bn);
   dim3 grid((unsigned)splits, (unsigned)(Cr / bc), (unsigned)(Nr / bn));
+  a.splits = splits; a.cblk = Cr / bc; a.xcd_tiles = 0;
+  if (wgrad_xcd((Cr / bc) * (Nr / bn), a.total_strips)) {
+    a.xcd_tiles = (Cr / bc) * (Nr / bn);
+    grid = dim3((unsigned)(splits * a.xcd_tiles), 1u, 1u);
+  }
   if (split) {
     if (KS == 3) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<3, 1, 1, HPRI_A_DIRECT, 1>), grid, dim3(256), 0, stream, a);
     else if (bmode == HPRI_A_S2D) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<1, 2, 2, HPRI_A_S2D, 1>), grid, dim3(256), 0, stream, a);

@@ -202,3 +202,50 @@ def test_eval_bn_folding_matches_unfused_eval():
     xg = x.clone().requires_grad_(True)
     net(xg).sum().backward()
     assert xg.grad is not None and torch.isfinite(xg.grad).all()
+
+
+def test_xcd_aware_grids_only_reorder_work():
+    """The XCD-aware 1-D grids used for SpectralUNET-sized layers, forced onto a small UNet: the conv
+    kernels must give bit-identical outputs (pure block re-ordering), the weight-gradient kernels the same sums in a
+    different (still fixed) order."""
+    from collections import OrderedDict
+    import numpy as np
+    import hyperpri_amd as HP
+    from hyperpri_amd import _lib
+    from oracle import hyperpri_oracle as O
+
+    def _u(seed, shape):
+        return torch.from_numpy(O._u(seed, int(np.prod(shape))).reshape(shape).copy())
+    lib = _lib.load()
+    names = (b"conv_nbx_min", b"wgrad_xcd_min_tiles", b"wgrad_xcd_min_strips")
+    saved = [lib.hpri_get_option(n) for n in names]
+    net = HP.UNet(3, 1, bilinear=False)
+    shapes = OrderedDict((k, tuple(v.shape)) for k, v in net.state_dict().items())
+    net.load_state_dict(O.synth_state_dict(shapes))
+    net = net.to(DEV).train()
+    x = _u(1234, (2, 3, 40, 72)).to(DEV)
+    mask = (_u(4321, (2, 1, 40, 72)) > 0.9).float().to(DEV)
+
+    def run():
+        for p in net.parameters():
+            p.grad = None
+        for m in net.modules():
+            if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+                m.reset_running_stats()
+        logits = net(x)
+        torch.nn.BCEWithLogitsLoss()(logits, mask).backward()
+        return logits.detach().clone(), [p.grad.clone() for p in net.parameters()]
+    try:
+        l0, g0 = run()
+        for n in names:
+            assert lib.hpri_set_option(n, 1) == 0
+        l1, g1 = run()
+        l2, g2 = run()
+    finally:
+        for n, v in zip(names, saved):
+            lib.hpri_set_option(n, v)
+    assert torch.equal(l0, l1)
+    for a, b, c in zip(g0, g1, g2):
+        assert torch.equal(b, c)                                    # still run-to-run deterministic
+        assert float((a - b).abs().max()) <= 1e-4 * float(a.abs().max()) + 1e-9
+    assert lib.hpri_set_option(b"no_such_option", 1) == -1

@@ -45,6 +45,18 @@ def main():
         return loss
     loss = step()
     torch.cuda.synchronize()
+    if os.environ.get("EVENTS"):            # per-kernel HIP-event table (serialises launches a little)
+        engine.SHAPE_TAGS = True
+        engine.enable_event_log(True)
+        step()
+        torch.cuda.synchronize()
+        rows = engine.event_log_summary()
+        engine.enable_event_log(False)
+        tot = 0.0
+        for k, v in sorted(rows.items(), key=lambda kv: -kv[1]["total_ms"]):
+            tot += v["total_ms"]
+            print(f"{k:90s} n={v['launches']:3d} {v['total_ms']:9.3f} ms {v['tflops']:7.1f} TF")
+        print("sum of timed kernels", round(tot, 2), "ms")
     t0 = time.perf_counter()
     for _ in range(steps):
         loss = step()
