@@ -244,48 +244,57 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradArgs a) {
   const __bf16* xb = x_lds + (lh * 8 + lq) * PX + wc * (CT * 32) + lg * 16 + lp * 4;
   const __bf16* yb = y_lds + (lh * 8 + lq) * PY + wn * (NT * 32) + lg * 16 + lp * 4;
 
+  // The unit's global loads are converted to bf16 at once (half the staging registers).  KS == 1 (64 accumulators)
+  // fetches the NEXT unit while the current one is multiplied; the 3x3 kernels (144 accumulators) have no registers for
+  // that -- measured: prefetch + one strip per unit 20.6 ms/step vs 19.3 without (124 spills with two strips).
+  constexpr bool PREF = (KS == 1);
+  bf16x4 xr[NPL][NLD_X], yr[NPL][NLD_Y];
+#define LOAD_UNIT(st_)                                                                               \
+  {                                                                                                  \
+    int q = (st_);                                                                                   \
+    const int sx = q % a.strips_x; q /= a.strips_x;                                                  \
+    const int sy = q % units_y;                                                                      \
+    const int img = q / units_y;                                                                     \
+    const int y0 = sy * SH, x0 = sx * SW;                                                            \
+                                                                                                     \
+_Pragma("unroll")                                                                                    \
+    for (int p = 0; p < NLD_X; ++p) {                                                                \
+      const int f = tid + p * 256;                                                                   \
+      const int pix = f / (BC / 4), c4 = f % (BC / 4);                                               \
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};                                                                \
+      if (pix < HP) {                                                                                \
+        const int hy = pix / HW, hx = pix - hy * HW;                                                 \
+        const int iy = y0 + hy - PAD, ix = x0 + hx - PAD;                                            \
+        const int c = c_blk + c4 * 4;                                                                \
+        if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W && c < a.x_cvalid)                            \
+          v = *reinterpret_cast<const f32x4*>(a.x + ((size_t)(img * a.H + iy) * a.W + ix) * a.x_cs + a.x_coff + c);\
+      }                                                                                              \
+      xr[0][p] = __builtin_convertvector(v, bf16x4);                                                 \
+      if (SPLIT) xr[NPL - 1][p] = __builtin_convertvector(v - __builtin_convertvector(xr[0][p], f32x4), bf16x4);\
+    }                                                                                                \
+_Pragma("unroll")                                                                                    \
+    for (int p = 0; p < NLD_Y; ++p) {                                                                \
+      const int f = tid + p * 256;                                                                   \
+      const int pix = f / (BNW / 4), n4 = f % (BNW / 4);                                             \
+      const int iy = y0 + (pix >> 5), ix = x0 + (pix & 31);                                          \
+      const int n = n_blk + n4 * 4;                                                                  \
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};                                                                \
+      if (iy < a.H && ix < a.W && n < a.dy_cvalid) {                                                 \
+        if (BMODE == HPRI_A_DIRECT) {                                                                \
+          v = *reinterpret_cast<const f32x4*>(a.dy + ((size_t)(img * a.H + iy) * a.W + ix) * a.dy_cs + a.dy_coff + n);\
+        } else {                                                                                     \
+          const int tap = n / a.Cup, co = n - tap * a.Cup;                                           \
+          const int yy = 2 * iy + (tap >> 1) + a.py0, xx = 2 * ix + (tap & 1) + a.px0;               \
+          v = *reinterpret_cast<const f32x4*>(a.dy + ((size_t)(img * a.H2 + yy) * a.W2 + xx) * a.dy_cs + a.dy_coff + co);\
+        }                                                                                            \
+      }                                                                                              \
+      yr[0][p] = __builtin_convertvector(v, bf16x4);                                                 \
+      if (SPLIT) yr[NPL - 1][p] = __builtin_convertvector(v - __builtin_convertvector(yr[0][p], f32x4), bf16x4);\
+    }                                                                                                \
+  }
+  if (PREF && u_begin < u_end) LOAD_UNIT(u_begin)
   for (int st = u_begin; st < u_end; ++st) {
-    int q = st;
-    const int sx = q % a.strips_x; q /= a.strips_x;
-    const int sy = q % units_y;
-    const int img = q / units_y;
-    const int y0 = sy * SH, x0 = sx * SW;
-
-    bf16x4 xr[NPL][NLD_X], yr[NPL][NLD_Y];     // converted to bf16 right after the load: half the staging registers
-#pragma unroll
-    for (int p = 0; p < NLD_X; ++p) {
-      const int f = tid + p * 256;
-      const int pix = f / (BC / 4), c4 = f % (BC / 4);
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (pix < HP) {
-        const int hy = pix / HW, hx = pix - hy * HW;
-        const int iy = y0 + hy - PAD, ix = x0 + hx - PAD;
-        const int c = c_blk + c4 * 4;
-        if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W && c < a.x_cvalid)
-          v = *reinterpret_cast<const f32x4*>(a.x + ((size_t)(img * a.H + iy) * a.W + ix) * a.x_cs + a.x_coff + c);
-      }
-      xr[0][p] = __builtin_convertvector(v, bf16x4);
-      if (SPLIT) xr[NPL - 1][p] = __builtin_convertvector(v - __builtin_convertvector(xr[0][p], f32x4), bf16x4);
-    }
-#pragma unroll
-    for (int p = 0; p < NLD_Y; ++p) {
-      const int f = tid + p * 256;
-      const int pix = f / (BNW / 4), n4 = f % (BNW / 4);
-      const int iy = y0 + (pix >> 5), ix = x0 + (pix & 31);
-      const int n = n_blk + n4 * 4;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (iy < a.H && ix < a.W && n < a.dy_cvalid) {
-        if (BMODE == HPRI_A_DIRECT) {
-          v = *reinterpret_cast<const f32x4*>(a.dy + ((size_t)(img * a.H + iy) * a.W + ix) * a.dy_cs + a.dy_coff + n);
-        } else {   // S2D (ConvTranspose2d): column n = tap*Cup + co lives at hi-res pixel (2*iy + t_y + py0, 2*ix + t_x + px0)
-          const int tap = n / a.Cup, co = n - tap * a.Cup;
-          const int yy = 2 * iy + (tap >> 1) + a.py0, xx = 2 * ix + (tap & 1) + a.px0;
-          v = *reinterpret_cast<const f32x4*>(a.dy + ((size_t)(img * a.H2 + yy) * a.W2 + xx) * a.dy_cs + a.dy_coff + co);
-        }
-      }
-      yr[0][p] = __builtin_convertvector(v, bf16x4);
-      if (SPLIT) yr[NPL - 1][p] = __builtin_convertvector(v - __builtin_convertvector(yr[0][p], f32x4), bf16x4);
-    }
+    if (!PREF) LOAD_UNIT(st)
     __syncthreads();   // previous unit's LDS reads are finished
 #pragma unroll
     for (int p = 0; p < NLD_X; ++p) {
@@ -304,6 +313,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradArgs a) {
       if (SPLIT) *reinterpret_cast<bf16x4*>(y_lds + NPIX * PY + pix * PY + n4 * 4) = yr[NPL - 1][p];
     }
     __syncthreads();
+    if (PREF && st + 1 < u_end) LOAD_UNIT(st + 1)
 
     // NPIX/16 k16-steps: unit pixels 16*ks .. 16*ks+15 (row ks>>1, columns 16*(ks&1) ..)
 #pragma unroll
@@ -338,6 +348,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradArgs a) {
     }
   }
 
+#undef LOAD_UNIT
   // partial slab ws[split][t][n][c]: MFMA rows = n (A operand = dY), cols = c (B operand = X)
   float* slab = a.ws + (size_t)split_id * T * a.Cr * a.Nr;
 #pragma unroll
