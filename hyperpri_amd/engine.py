@@ -325,8 +325,12 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
         wp, cout_pad = _pack_bf16(weight, 0, cin, cout, T, cin, split=split)
     else:
         wp, cout_pad = _pack(weight, 0, cin, cout, T, 0, cin)
-    yr = Act.new(x.N, x.H, x.W, cout, dev)
     use_batch = bn is not None and train
+    if use_batch and (x.N * x.H * x.W) // max(groups, 1) <= 1:
+        # torch.nn.functional.batch_norm's own check (_verify_batch_size): same error, same message
+        raise ValueError("Expected more than 1 value per channel when training, got input size "
+                         f"torch.Size([{x.N // max(groups, 1)}, {cout}, {x.H}, {x.W}])")
+    yr = Act.new(x.N, x.H, x.W, cout, dev)
     stats = None
     tiles = 0
     if use_batch:
