@@ -13,7 +13,8 @@
 __global__ void bn_finalize_kernel(const float4* __restrict__ part, int tiles_per_group, int Cp, int C,
                                    const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                    float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ var_unbiased,
-                                   float* __restrict__ scale, float* __restrict__ shift) {
+                                   float* __restrict__ scale, float* __restrict__ shift, float momentum,
+                                   float* __restrict__ rm, float* __restrict__ rv, long long* __restrict__ nbt) {
   // block = 32 slices x 32 channels (1024 threads); grid = (ceil(C/32), G)
   __shared__ double s1[32][32], s2[32][32], sn[32][32];
   const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
@@ -58,6 +59,11 @@ __global__ void bn_finalize_kernel(const float4* __restrict__ part, int tiles_pe
     const float sc = gamma[c] * (float)is;
     scale[o] = sc;
     shift[o] = beta[c] - (float)mu * sc;
+    if (rm != nullptr) {   // one group only: the running-stat update rides along (G > 1 needs the groups in order)
+      rm[c] = (1.f - momentum) * rm[c] + momentum * mean[o];
+      rv[c] = (1.f - momentum) * rv[c] + momentum * var_unbiased[o];
+      if (c == 0 && nbt != nullptr) *nbt += 1;
+    }
   }
 }
 
@@ -203,7 +209,8 @@ __global__ void col_reduce_kernel(const float* __restrict__ dy, int dy_cs, int d
 }
 
 // stage 2: sums[g][k][c] = sum over blocks (double accumulation, fixed order); k in {0,1}
-__global__ void col_finalize_kernel(const float* __restrict__ part, int nblk, int Cpart, int C, float* __restrict__ sums) {
+__global__ void col_finalize_kernel(const float* __restrict__ part, int nblk, int Cpart, int C, float* __restrict__ sums,
+                                    float* __restrict__ out1, float* __restrict__ out2, int accumulate) {
   __shared__ double s[2][32][32];
   const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cl, g = blockIdx.y;
@@ -227,6 +234,9 @@ __global__ void col_finalize_kernel(const float* __restrict__ part, int nblk, in
     for (int k = 0; k < 32; ++k) { t1 += s[0][k][cl]; t2 += s[1][k][cl]; }
     sums[((size_t)g * 2) * C + c] = (float)t1;
     sums[((size_t)g * 2 + 1) * C + c] = (float)t2;
+    // one group only: the parameter gradients ride along (out1 (+)= first sum, out2 (+)= second sum)
+    if (out1 != nullptr) out1[c] = accumulate ? out1[c] + (float)t1 : (float)t1;
+    if (out2 != nullptr) out2[c] = accumulate ? out2[c] + (float)t2 : (float)t2;
   }
 }
 
@@ -318,11 +328,14 @@ extern "C" int hpri_bn_finalize(const float* partials, int tiles_per_group, int 
                                 hipStream_t stream) {
   HPRI_REQUIRE(partials && gamma && beta && mean && invstd && var_unbiased && scale && shift, "bn_finalize: null pointer");
   HPRI_REQUIRE(tiles_per_group > 0 && G > 0 && C > 0 && Cp >= C, "bn_finalize: bad sizes");
+  const bool running = running_mean != nullptr && running_var != nullptr;
+  const bool fused = running && G == 1;
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(hpri_cdiv(C, 32), G), dim3(1024), 0, stream,
                      reinterpret_cast<const float4*>(partials), tiles_per_group, Cp, C, gamma, beta, eps, mean, invstd,
-                     var_unbiased, scale, shift);
+                     var_unbiased, scale, shift, momentum, fused ? running_mean : nullptr, fused ? running_var : nullptr,
+                     fused ? num_batches_tracked : nullptr);
   HPRI_CHECK_LAUNCH();
-  if (running_mean != nullptr && running_var != nullptr) {
+  if (running && !fused) {
     hipLaunchKernelGGL(bn_update_running_kernel, dim3(hpri_cdiv(C, 256)), dim3(256), 0, stream, mean, var_unbiased, G, C,
                        momentum, running_mean, running_var, num_batches_tracked);
     HPRI_CHECK_LAUNCH();
@@ -406,9 +419,11 @@ extern "C" int hpri_bn_relu_bwd(const float* dy, int dy_cs, int dy_coff, const f
   hipLaunchKernelGGL((col_reduce_kernel<0>), dim3(nblk, ycols, G), dim3(256), 0, stream, dy, dy_cs, dy_coff, x,
                      x_cs, x_coff, mean, invstd, scale, shift, pix_per_group, C, cq, relu, part, Cpart);
   HPRI_CHECK_LAUNCH();
-  hipLaunchKernelGGL(col_finalize_kernel, dim3(hpri_cdiv(C, 32), G), dim3(1024), 0, stream, part, nblk, Cpart, C, sums);
+  const bool pg = dgamma != nullptr && dbeta != nullptr;
+  hipLaunchKernelGGL(col_finalize_kernel, dim3(hpri_cdiv(C, 32), G), dim3(1024), 0, stream, part, nblk, Cpart, C, sums,
+                     (pg && G == 1) ? dbeta : nullptr, (pg && G == 1) ? dgamma : nullptr, accumulate_param_grads);
   HPRI_CHECK_LAUNCH();
-  if (dgamma != nullptr && dbeta != nullptr) {
+  if (pg && G > 1) {
     hipLaunchKernelGGL(bn_param_grad_kernel, dim3(hpri_cdiv(C, 256)), dim3(256), 0, stream, sums, G, C, dgamma, dbeta,
                        accumulate_param_grads);
     HPRI_CHECK_LAUNCH();
@@ -421,12 +436,14 @@ extern "C" int hpri_bn_relu_bwd(const float* dy, int dy_cs, int dy_coff, const f
                      use_batch_stats, dbias != nullptr ? dxpart : nullptr, Cpart);
   HPRI_CHECK_LAUNCH();
   if (dbias != nullptr) {
-    hipLaunchKernelGGL(col_finalize_kernel, dim3(hpri_cdiv(C, 32), G), dim3(1024), 0, stream, dxpart, nblk, Cpart, C, dxsums);
+    hipLaunchKernelGGL(col_finalize_kernel, dim3(hpri_cdiv(C, 32), G), dim3(1024), 0, stream, dxpart, nblk, Cpart, C, dxsums,
+                       G == 1 ? dbias : nullptr, (float*)nullptr, accumulate_dbias);
     HPRI_CHECK_LAUNCH();
-    // dxsums[g][0][c] = per-group column sums; "dbeta" path of the param-grad kernel adds the groups
-    hipLaunchKernelGGL(bn_param_grad_kernel, dim3(hpri_cdiv(C, 256)), dim3(256), 0, stream, dxsums, G, C, nullptr, dbias,
-                       accumulate_dbias);
-    HPRI_CHECK_LAUNCH();
+    if (G > 1) {   // dxsums[g][0][c] = per-group column sums; "dbeta" path of the param-grad kernel adds the groups
+      hipLaunchKernelGGL(bn_param_grad_kernel, dim3(hpri_cdiv(C, 256)), dim3(256), 0, stream, dxsums, G, C, nullptr, dbias,
+                         accumulate_dbias);
+      HPRI_CHECK_LAUNCH();
+    }
   }
   return HPRI_OK;
 }
@@ -447,10 +464,9 @@ extern "C" int hpri_col_sum(const float* src, int cs, int coff, float* out, int 
   hipLaunchKernelGGL((col_reduce_kernel<1>), dim3(nblk, hpri_cdiv(c4, cq), 1), dim3(256), 0, stream, src, cs, coff, nullptr, 0,
                      0, nullptr, nullptr, nullptr, nullptr, P, C, cq, 0, part, Cpart);
   HPRI_CHECK_LAUNCH();
-  hipLaunchKernelGGL(col_finalize_kernel, dim3(hpri_cdiv(C, 32), 1), dim3(1024), 0, stream, part, nblk, Cpart, C, sums);
-  HPRI_CHECK_LAUNCH();
-  // sums[0][c] holds the column sums; reuse the param-grad kernel's "dbeta" path
-  hipLaunchKernelGGL(bn_param_grad_kernel, dim3(hpri_cdiv(C, 256)), dim3(256), 0, stream, sums, 1, C, nullptr, out, accumulate);
+  // sums[0][c] holds the column sums; the finalize kernel writes (or accumulates) them into `out` on the way
+  hipLaunchKernelGGL(col_finalize_kernel, dim3(hpri_cdiv(C, 32), 1), dim3(1024), 0, stream, part, nblk, Cpart, C, sums, out,
+                     (float*)nullptr, accumulate);
   HPRI_CHECK_LAUNCH();
   return HPRI_OK;
 }
