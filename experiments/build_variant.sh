@@ -6,7 +6,7 @@ NAME=$1; SRC=$2; shift 2
 OUT=experiments/build_$NAME; mkdir -p $OUT
 C=hyperpri_amd/csrc
 WG=${WGRAD_SRC:-$C/conv_wgrad.hip}
-for f in api.cpp pack.hip bn.hip elementwise.hip; do
+for f in api.cpp pack.hip bn.hip elementwise.hip step.hip ingest.hip; do
   [ -f $OUT/${f%.*}.o ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -x hip -c $C/$f -I $C -o $OUT/${f%.*}.o &
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -x hip -c $SRC -I $C "$@" -o $OUT/conv_fwd.o &

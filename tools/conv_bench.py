@@ -63,7 +63,7 @@ def main():
                 for _ in range(reps):
                     if mode == "fwd":
                         rc = lib.hpri_conv_fwd(P(x), Cin, 0, P(wp), P(b), P(y), Cout, 0, P(stats), N, H, W, Cin, Cout, cout_pad,
-                                               Cout, ks, 0, 0, 0, 0, 0, 0, 0, 0, SPLIT, P(ws), ws.numel(), st)
+                                               Cout, ks, 0, 0, 0, 0, 0, 0, 0, 0, P(ws), ws.numel(), st)
                     elif mode == "fwd_bf16":
                         rc = lib.hpri_conv_fwd_bf16(P(x), Cin, 0, P(wpb), P(b), P(y), Cout, 0, P(stats), N, H, W, Cin, Cout,
                                                     cout_pad, Cout, ks, 0, 0, 0, 0, 0, 0, 0, 0, SPLIT, P(ws), ws.numel(), st)
