@@ -377,8 +377,9 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_bf16_kernel(ConvFwdArgs a) {
   constexpr int NPL = SPLIT ? 2 : 1;              // operand planes (hi, lo)
   constexpr int SR = TS * NPL;                    // [BN][32] row blocks per B stage
   constexpr int NST = SPLIT ? T : KS;             // stages per 32-channel chunk
-  constexpr int NLD_B = (SR * BN * 4) / 256;      // 16-byte global loads per thread per B stage
-  __shared__ __attribute__((aligned(16))) __bf16 smem_h[NPL * MAXHP * CS + 2 * SR * BN * CS];
+  constexpr int BS = 32;                          // halves per staged weight row: 64 bytes, unpadded, XOR-swizzled
+  constexpr int NLD_B = (SR * BN) / 64;           // LDS-DMA instructions per wave per B stage (1 KB = 16 rows each)
+  __shared__ __attribute__((aligned(16))) __bf16 smem_h[NPL * MAXHP * CS + 2 * SR * BN * BS];
   __bf16* a_lds = smem_h;
   __bf16* b_lds = smem_h + NPL * MAXHP * CS;
   float* smem = reinterpret_cast<float*>(smem_h);  // the statistics epilogue reuses the staging area as floats
@@ -418,26 +419,29 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_bf16_kernel(ConvFwdArgs a) {
   const int nchunks = min(nchunks_all, chunk0 + cps);
   const int S0 = chunk0 * NST, S = nchunks * NST;        // stage = (chunk, kernel row) or (chunk, tap) when SPLIT
 
-  // ---- B stages: KS taps x BN rows x 64 bytes, contiguous per tap in the packed tensor ----
+  // ---- B stages: SR row blocks (taps x planes) of BN rows x 64 bytes, contiguous per row block in the packed tensor.
+  // LDS-DMA (global_load_lds_dwordx4): no VGPR staging, no ds_write.  A wave instruction fills 1 KB = 16 rows; lane l
+  // lands on 16-byte slot l&3 of row l>>2.  Rows are unpadded (64-byte pitch), so the four 16-byte segments of a row are
+  // XOR-swizzled with (row>>1)&3 to keep the ds_read_b128 of 16 consecutive rows conflict-free; the DMA cannot permute,
+  // but every lane chooses WHICH global segment it fetches, which is the same thing.
   const __bf16* wpk = reinterpret_cast<const __bf16*>(a.wp);
-  int boff[NLD_B], blds[NLD_B];
+  int goff[NLD_B];
 #pragma unroll
   for (int p = 0; p < NLD_B; ++p) {
-    const int f = tid + p * 256;
-    const int tap = f / (BN * 4), n = (f >> 2) % BN, q = f & 3;
-    boff[p] = (tap * a.Cout_pad + nb * BN + n) * 32 + q * 8;   // halves, relative to the stage's first tap
-    blds[p] = (tap * BN + n) * CS + q * 8;
+    const int R = (p * 4 + wave) * 16 + (lane >> 2);          // row within the stage
+    const int rb = R / BN, n = R % BN;
+    const int ls = (lane & 3) ^ ((n >> 1) & 3);               // logical segment stored at physical slot lane&3
+    goff[p] = (rb * a.Cout_pad + nb * BN + n) * 32 + ls * 8;  // halves, relative to the stage's first row block
   }
-  f32x4 breg[NLD_B];
 #define LOAD_STAGE(s_)                                                                               \
   {                                                                                                  \
     const __bf16* pb_ = wpk + (size_t)(s_) * SR * a.Cout_pad * 32;                                   \
+    __bf16* lb_ = b_lds + ((s_) & 1) * SR * BN * BS;                                                 \
     _Pragma("unroll") for (int p = 0; p < NLD_B; ++p)                                                \
-        breg[p] = *reinterpret_cast<const f32x4*>(pb_ + boff[p]);                                    \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pb_ + goff[p]),           \
+                                         (__attribute__((address_space(3))) void*)(lb_ + (p * 4 + wave) * 512), 16, 0, 0); \
   }
-#define STORE_STAGE(buf_)                                                                            \
-  _Pragma("unroll") for (int p = 0; p < NLD_B; ++p)                                                  \
-      *reinterpret_cast<f32x4*>(b_lds + (buf_) * SR * BN * CS + blds[p]) = breg[p];
+#define STORE_STAGE(buf_)
 
   // ---- A halo: fp32 in HBM -> registers -> bf16 in LDS ----
   const float* ximg = a.x + (size_t)img * (AMODE == HPRI_A_DIRECT ? (size_t)a.H * a.W : (size_t)a.H2 * a.W2) * a.x_cs;
@@ -495,7 +499,8 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_bf16_kernel(ConvFwdArgs a) {
 
   const int a_base = ((wm * 2 * RW + (li >> twl)) * HW + (li & (TW - 1))) * CS + lh * 8;
   const int a_mt = RW * HW * CS;
-  const int b_base = (wn * 64 + li) * CS + lh * 8;
+  const int b_base = (wn * 64 + li) * BS;
+  const int bsw0 = ((0 + lh) ^ ((li >> 1) & 3)) * 8, bsw1 = ((2 + lh) ^ ((li >> 1) & 3)) * 8;   // swizzled k16-step offsets
 
   LOAD_STAGE(S0)
   LOAD_A(chunk0 * 32)
@@ -510,7 +515,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_bf16_kernel(ConvFwdArgs a) {
     if (s + 1 < S) { LOAD_STAGE(s + 1) }
     if (st == NST - 1 && chunk + 1 < nchunks) { LOAD_A((chunk + 1) * 32) }
 
-    const __bf16* bp = b_lds + (s & 1) * SR * BN * CS + b_base;
+    const __bf16* bp = b_lds + (s & 1) * SR * BN * BS + b_base;
     if (!SPLIT) {
       const __bf16* ap = a_lds + a_base + st * HW * CS;
 #pragma unroll
@@ -521,7 +526,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_bf16_kernel(ConvFwdArgs a) {
 #pragma unroll
           for (int mt = 0; mt < 2; ++mt) af[mt] = *reinterpret_cast<const bf16x8*>(ap + mt * a_mt + dx * CS + kk * 16);
 #pragma unroll
-          for (int nt = 0; nt < 2; ++nt) bf[nt] = *reinterpret_cast<const bf16x8*>(bp + (dx * BN + nt * 32) * CS + kk * 16);
+          for (int nt = 0; nt < 2; ++nt) bf[nt] = *reinterpret_cast<const bf16x8*>(bp + (dx * BN + nt * 32) * BS + (kk ? bsw1 : bsw0));
 #pragma unroll
           for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -542,8 +547,8 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_bf16_kernel(ConvFwdArgs a) {
         }
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
-          bh[nt] = *reinterpret_cast<const bf16x8*>(bp + (nt * 32) * CS + kk * 16);
-          bl[nt] = *reinterpret_cast<const bf16x8*>(bp + (BN + nt * 32) * CS + kk * 16);
+          bh[nt] = *reinterpret_cast<const bf16x8*>(bp + (nt * 32) * BS + (kk ? bsw1 : bsw0));
+          bl[nt] = *reinterpret_cast<const bf16x8*>(bp + (BN + nt * 32) * BS + (kk ? bsw1 : bsw0));
         }
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
