@@ -117,14 +117,6 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvFwdArgs a) {
 
   // ---- B panels: per-thread offsets computed once; per panel only the panel base moves ----
   const float* wpanel = a.wp + (size_t)nb * BN;
-  int boff[NLD_B], blds[NLD_B];
-#pragma unroll
-  for (int p = 0; p < NLD_B; ++p) {
-    const int f = tid + p * 256;
-    const int row = f / (BN / 4), c4 = f % (BN / 4);
-    boff[p] = row * a.Cout_pad + c4 * 4;
-    blds[p] = row * BN + c4 * 4;
-  }
   // LDS-DMA: panel s goes straight from global memory into LDS buffer s&1 (no VGPR staging, no ds_write); wave w's
   // p-th instruction fills floats [(p*4+w)*256, +256) of the panel, lane l the 4 floats at +4*l
   int goff[NLD_B];
