@@ -742,12 +742,8 @@ __global__ void splitk_finish_kernel(const float* __restrict__ ws, int ksplit, i
 }
 
 // Tile-shape choice shared by the launcher and the sizing query.
-// Workgroup shape: 2x2 waves (128 px x 128 ch) when the output channels allow it, else 4x1 (256 px x 64 ch).
-// prec: 0 fp32, 1 bf16, 2 bf16x3.  The plain bf16 kernel always takes 4x1: its 51 KB of LDS and 168 VGPRs let THREE
-// workgroups share a CU, which beats the wider tile on every layer (measured +4..17 %); the waves of a workgroup leave
-// each barrier in phase, so only other workgroups can fill the matrix pipe while one is reading its fragments.
-static inline void conv_cfg(int Cout_pad, int* wm, int* wn, int prec = 0) {
-  if (Cout_pad % 128 == 0 && prec != 1) { *wm = 2; *wn = 2; } else { *wm = 4; *wn = 1; }
+static inline void conv_cfg(int Cout_pad, int* wm, int* wn) {
+  *wm = 4; *wn = 1;   // experiment r6: 256 px x 64 ch tiles everywhere
 }
 
 // Cut the image width into column bands of tile width 32 / 16 / 8 / 4 (host only).  Candidates: plain 32-wide
@@ -801,9 +797,9 @@ static int launch_conv(const ConvFwdArgs& a0, hipStream_t stream) {
 
 // Split-K plan (host only).  A layer whose natural grid leaves CUs idle or badly balanced (38x60 and 76x121 levels)
 // is cut along K so that the number of equal-sized workgroups per CU is close to an integer.
-static inline int conv_ksplit(int N, int H, int W, int Cin_pad, int Cout_pad, int KS, int epi, int amode, int prec = 0) {
+static inline int conv_ksplit(int N, int H, int W, int Cin_pad, int Cout_pad, int KS, int epi, int amode) {
   if (epi != HPRI_E_DIRECT) return 1;
-  int wm, wn; conv_cfg(Cout_pad, &wm, &wn, prec);
+  int wm, wn; conv_cfg(Cout_pad, &wm, &wn);
   const long long blocks = (long long)N * conv_segments(H, W, wm).tiles_img * (Cout_pad / (64 * wn));
   const int nchunks = hpri_cdiv(Cin_pad, 32);
   if (blocks >= 2048) return 1;                       // >= 8 workgroups per CU: balance is already fine
@@ -818,30 +814,19 @@ static inline int conv_ksplit(int N, int H, int W, int Cin_pad, int Cout_pad, in
   return best;
 }
 
-static int conv_plan(int N, int H, int W, int Cin_pad, int Cout_pad, int KS, int amode, int epi, int prec,
-                     int* ksplit, int* stat_tiles, size_t* ws_floats) {
-  const int k = conv_ksplit(N, H, W, Cin_pad, Cout_pad, KS, epi, amode, prec);
+extern "C" int hpri_conv_fwd_plan(int N, int H, int W, int Cin_pad, int Cout_pad, int KS, int amode, int epi,
+                                  int* ksplit, int* stat_tiles, size_t* ws_floats) {
+  const int k = conv_ksplit(N, H, W, Cin_pad, Cout_pad, KS, epi, amode);
   *ksplit = k;
   if (k > 1) {
     *stat_tiles = N * hpri_cdiv(H * W, SK_PIX);
     *ws_floats = (size_t)k * N * H * W * Cout_pad;
   } else {
-    int wm, wn; conv_cfg(Cout_pad, &wm, &wn, prec);
+    int wm, wn; conv_cfg(Cout_pad, &wm, &wn);
     *stat_tiles = N * conv_segments(H, W, wm).tiles_img;
     *ws_floats = 0;
   }
   return HPRI_OK;
-}
-
-extern "C" int hpri_conv_fwd_plan(int N, int H, int W, int Cin_pad, int Cout_pad, int KS, int amode, int epi,
-                                  int* ksplit, int* stat_tiles, size_t* ws_floats) {
-  return conv_plan(N, H, W, Cin_pad, Cout_pad, KS, amode, epi, 0, ksplit, stat_tiles, ws_floats);
-}
-
-// the same query for hpri_conv_fwd_bf16 (split = 0: bf16, 1: bf16x3), whose workgroup shapes differ
-extern "C" int hpri_conv_fwd_bf16_plan(int N, int H, int W, int Cin_pad, int Cout_pad, int KS, int amode, int epi,
-                                       int split, int* ksplit, int* stat_tiles, size_t* ws_floats) {
-  return conv_plan(N, H, W, Cin_pad, Cout_pad, KS, amode, epi, split ? 2 : 1, ksplit, stat_tiles, ws_floats);
 }
 
 template <int KS, int WM, int WN, int AMODE, int EPI, int SPLIT>
@@ -890,7 +875,7 @@ extern "C" int hpri_conv_fwd_bf16(const float* x, int x_cs, int x_coff, const vo
     if (epi == HPRI_E_D2S) HPRI_REQUIRE(Cout == 4 * Cup, "conv_fwd_bf16: D2S needs Cout == 4*Cup");
     HPRI_REQUIRE(!(amode == HPRI_A_S2D && epi == HPRI_E_D2S), "conv_fwd_bf16: S2D and D2S are exclusive");
   }
-  a.ksplit = conv_ksplit(N, H, W, Cin_pad, Cout_pad, KS, epi, amode, split ? 2 : 1);
+  a.ksplit = conv_ksplit(N, H, W, Cin_pad, Cout_pad, KS, epi, amode);
   a.ws = ws;
   if (a.ksplit > 1) {
     if (ws == nullptr || (size_t)a.ksplit * N * H * W * Cout_pad > ws_floats)
@@ -898,7 +883,7 @@ extern "C" int hpri_conv_fwd_bf16(const float* x, int x_cs, int x_coff, const vo
     a.stats = nullptr;
     a.accumulate = 0;
   }
-  int wm, wn; conv_cfg(Cout_pad, &wm, &wn, split ? 2 : 1);
+  int wm, wn; conv_cfg(Cout_pad, &wm, &wn);
   int rc;
 #define HPRI_DISPATCH_B(KS_, AM_, EP_)                                                      \
   rc = split ? ((wm == 2) ? launch_conv_bf16<KS_, 2, 2, AM_, EP_, 1>(a, stream) : launch_conv_bf16<KS_, 4, 1, AM_, EP_, 1>(a, stream)) \

@@ -269,10 +269,10 @@ def _conv_launch_bf16(x: Act, wp: torch.Tensor, bias: Optional[torch.Tensor], y:
                       H2: int = 0, W2: int = 0, py0: int = 0, px0: int = 0, cup: int = 0, cin_true: int = 0,
                       split: int = 0) -> None:
     ksplit = ctypes.c_int(); tiles = ctypes.c_int(); wsf = ctypes.c_size_t()
-    _lib.call("hpri_conv_fwd_plan", N, H, W, cin_pad, cout_pad, ks, amode, epi, ctypes.byref(ksplit), ctypes.byref(tiles),
-              ctypes.byref(wsf))
+    _lib.call("hpri_conv_fwd_bf16_plan", N, H, W, cin_pad, cout_pad, ks, amode, epi, split, ctypes.byref(ksplit),
+              ctypes.byref(tiles), ctypes.byref(wsf))
     ws = _ws(wsf.value, x.buf.device) if wsf.value else None
-    tag = f"conv_fwd_{'bf16x3' if split else 'bf16'}<{ks},{'2x2' if cout_pad % 128 == 0 else '4x1'},{'s2d' if amode else 'direct'},{'d2s' if epi else 'direct'}>"
+    tag = f"conv_fwd_{'bf16x3' if split else 'bf16'}<{ks},{'2x2' if (cout_pad % 128 == 0 and split) else '4x1'},{'s2d' if amode else 'direct'},{'d2s' if epi else 'direct'}>"
     if SHAPE_TAGS:
         tag += f" N{N} {H}x{W} K{cin_pad} N{cout}"
     with _timed(tag, 2.0 * N * H * W * (cin_true or cin_pad) * cout * ks * ks):
@@ -335,8 +335,12 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
     tiles = 0
     if use_batch:
         ksp = ctypes.c_int(); tl = ctypes.c_int(); wsf = ctypes.c_size_t()
-        _lib.call("hpri_conv_fwd_plan", x.N, x.H, x.W, cin_pad, cout_pad, ks, A_DIRECT, E_DIRECT, ctypes.byref(ksp),
-                  ctypes.byref(tl), ctypes.byref(wsf))
+        if lowp:
+            _lib.call("hpri_conv_fwd_bf16_plan", x.N, x.H, x.W, cin_pad, cout_pad, ks, A_DIRECT, E_DIRECT, split,
+                      ctypes.byref(ksp), ctypes.byref(tl), ctypes.byref(wsf))
+        else:
+            _lib.call("hpri_conv_fwd_plan", x.N, x.H, x.W, cin_pad, cout_pad, ks, A_DIRECT, E_DIRECT, ctypes.byref(ksp),
+                      ctypes.byref(tl), ctypes.byref(wsf))
         tiles = tl.value
         stats = torch.empty(tiles * cout_pad * 4, dtype=torch.float32, device=dev)
     if lowp:

@@ -81,6 +81,8 @@ int hpri_conv_fwd(const float* x, int x_cs, int x_coff, const float* wp, const f
  * statistics contract as hpri_conv_fwd / hpri_pack_weight.  split = 1 (precision mode "bf16x3"): operands carried as
  * bf16 hi + bf16 lo (16 mantissa bits), three MFMAs per product (hi*hi + hi*lo + lo*hi); the packed weights then hold
  * two planes (twice the size). */
+int hpri_conv_fwd_bf16_plan(int N, int H, int W, int Cin_pad, int Cout_pad, int KS, int amode, int epi, int split,
+                            int* ksplit, int* stat_tiles, size_t* ws_floats);
 int hpri_pack_weight_bf16(const float* w, void* wp, int mode, int K, int Ncols, int Ncols_pad, int T, int src_d1,
                           int Cup, int split, hipStream_t stream);
 int hpri_conv_fwd_bf16(const float* x, int x_cs, int x_coff, const void* wp, const float* bias, float* y, int y_cs,
