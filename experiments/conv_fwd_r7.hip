@@ -371,9 +371,6 @@ __global__ __launch_bounds__(256, ((WM == 4 && !SPLIT) || (WM == 2 && SPLIT)) ? 
   constexpr int NST = SPLIT ? T : KS;             // stages per 32-channel chunk
   constexpr int BS = 32;                          // halves per staged weight row: 64 bytes, unpadded, XOR-swizzled
   constexpr int NLD_B = (SR * BN) / 64;           // LDS-DMA instructions per wave per B stage (1 KB = 16 rows each)
-  // Stage buffers.  The 2x2 split kernel keeps ONE: 48.6 KB of LDS then lets three workgroups share a CU, and a third
-  // workgroup hides more than prefetching the next stage inside the workgroup did (measured +5..16 %; a three-buffer
-  // ring with two stages in flight measured 0 %).
   constexpr int NBUF = (SPLIT && WM == 2) ? 1 : 2;
   __shared__ __attribute__((aligned(16))) __bf16 smem_h[NPL * MAXHP * CS + NBUF * SR * BN * BS];
   __bf16* a_lds = smem_h;
