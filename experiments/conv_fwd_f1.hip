@@ -75,8 +75,6 @@ __global__ __launch_bounds__(256, (WM == 2) ? 3 : 2) void conv_fwd_kernel(ConvFw
   constexpr int CS = 36;                         // dwords per staged pixel (32 channels + 4 pad)
   constexpr int NLD_A = (MAXHP * 8 + 255) / 256; // float4 loads per thread per A chunk
   constexpr int NLD_B = (32 * BN / 4) / 256;     // float4 loads per thread per B panel
-  // Panel buffers.  The 2x2 shape keeps ONE (45 KB of LDS, 168 VGPRs): three workgroups then share a CU, and a third
-  // workgroup covers the panel's DMA latency better than the double buffer inside the workgroup did (+1..4 %, bit-identical).
   constexpr int NBUF = (WM == 2) ? 1 : 2;
   __shared__ __attribute__((aligned(16))) float smem[MAXHP * CS + NBUF * 32 * BN];
   float* a_lds = smem;

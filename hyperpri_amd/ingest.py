@@ -59,6 +59,11 @@ class CubeStager:
         self._dev = [torch.zeros((batch, height, width, self.cs), dtype=torch.float32, device=self.device)
                      for _ in range(slots)]
         self._stream = torch.cuda.Stream(device=self.device)
+        # the zero fill above runs on the caller's stream: the copy stream must not overtake it (it would be zeroed
+        # AFTER the first cube landed), and the caching allocator must know both streams use these buffers
+        self._stream.wait_stream(torch.cuda.current_stream(self.device))
+        for t in self._dev + (self._raw or []):
+            t.record_stream(self._stream)
         self._ready: List[Optional[torch.cuda.Event]] = [None] * slots
         self._consumed: List[Optional[torch.cuda.Event]] = [None] * slots
         self._next = 0
