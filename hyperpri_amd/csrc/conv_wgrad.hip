@@ -198,14 +198,18 @@ __device__ __forceinline__ bf16x8 tr_frag(const __bf16* p, int pitch4) {
 
 // SPLIT = 1 (precision mode "bf16x3"): X and dY are staged as two bf16 planes (hi, lo) and every k16-step issues
 // dYl*Xh + dYh*Xl + dYh*Xh.
-template <int KS, int CT, int NT, int BMODE, int SPLIT>
-__global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradArgs a) {
-  constexpr int T = KS * KS, PAD = KS / 2;
+// KR = kernel rows per workgroup.  KR == KS: all taps in one workgroup (144 accumulators for 3x3: two workgroups per CU
+// and no registers left to prefetch).  KR == 1: blockIdx picks ONE kernel row (3 taps, 48 accumulators, a 2-row input
+// strip without vertical halo): 50.7 KB of LDS and ~160 VGPRs, i.e. THREE workgroups per CU plus a register prefetch of
+// the next unit -- the 3x3 bf16 kernels were waiting for their global loads two thirds of the time.
+template <int KS, int CT, int NT, int BMODE, int SPLIT, int KR>
+__global__ __launch_bounds__(256, (KS == 3 && KR == 1) ? 3 : 2) void conv_wgrad_bf16_kernel(WgradArgs a) {
+  constexpr int T = KR * KS, PAD = KS / 2, RS = KS / KR;   // T: taps of THIS workgroup; RS: kernel-row groups
   // one staged unit = SQ vertically adjacent 2x32 strips (SQ*64 pixels): the bf16 MFMAs retire so fast that the
   // staging + barrier cost must be amortised over more pixels than in the fp32 kernel
   constexpr int SQ = (KS == 3 && !SPLIT) ? 2 : 1;
   constexpr int NPL = SPLIT ? 2 : 1;
-  constexpr int SH = 2 * SQ, SW = 32, HH = SH + KS - 1, HW = SW + KS - 1, HP = HH * HW, NPIX = SH * SW;
+  constexpr int SH = 2 * SQ, SW = 32, HH = SH + KR - 1, HW = SW + KS - 1, HP = HH * HW, NPIX = SH * SW;
   constexpr int BC = 64 * CT, BNW = 64 * NT;
   constexpr int PX = BC + 32, PY = BNW + 32;      // halves per staged pixel: data + 32 pad, i.e. a pitch of 48 / 80 dwords
                                                   // = 16 (mod 32): the 4 pixel rows of a transposed read hit disjoint banks
@@ -219,6 +223,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradArgs a) {
   const int wc = wave >> 1, wn = wave & 1;
   int split_id, cb_id, nb_id;
   wgrad_block_ids(a, split_id, cb_id, nb_id);
+  const int r0 = (RS > 1) ? nb_id % RS : 0;        // first kernel row of this workgroup
+  if (RS > 1) nb_id /= RS;
   const int c_blk = cb_id * BC, n_blk = nb_id * BNW;
   // transposed-read lane roles: 16-lane group = (k half h, channel half g); lane i of the group addresses pixel row
   // q = i>>2, channel quad p = i&3 and receives channel i of the block
@@ -244,10 +250,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradArgs a) {
   const __bf16* xb = x_lds + (lh * 8 + lq) * PX + wc * (CT * 32) + lg * 16 + lp * 4;
   const __bf16* yb = y_lds + (lh * 8 + lq) * PY + wn * (NT * 32) + lg * 16 + lp * 4;
 
-  // The unit's global loads are converted to bf16 at once (half the staging registers).  KS == 1 (64 accumulators)
-  // fetches the NEXT unit while the current one is multiplied; the 3x3 kernels (144 accumulators) have no registers for
-  // that -- measured: prefetch + one strip per unit 20.6 ms/step vs 19.3 without (124 spills with two strips).
-  constexpr bool PREF = (KS == 1);
+  // The unit's global loads are converted to bf16 at once (half the staging registers).  KS == 1 (64 accumulators) and
+  // the one-kernel-row 3x3 form (48) fetch the NEXT unit while the current one is multiplied; with all nine taps in one
+  // workgroup (144 accumulators) there are no registers for that (measured: 124 spills, or -6 %).
+  constexpr bool PREF = (KS == 1) || (KR < KS);
   bf16x4 xr[NPL][NLD_X], yr[NPL][NLD_Y];
 #define LOAD_UNIT(st_)                                                                               \
   {                                                                                                  \
@@ -264,7 +270,7 @@ _Pragma("unroll")                                                               
       f32x4 v = {0.f, 0.f, 0.f, 0.f};                                                                \
       if (pix < HP) {                                                                                \
         const int hy = pix / HW, hx = pix - hy * HW;                                                 \
-        const int iy = y0 + hy - PAD, ix = x0 + hx - PAD;                                            \
+        const int iy = y0 + hy - PAD + r0, ix = x0 + hx - PAD;                                       \
         const int c = c_blk + c4 * 4;                                                                \
         if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W && c < a.x_cvalid)                            \
           v = *reinterpret_cast<const f32x4*>(a.x + ((size_t)(img * a.H + iy) * a.W + ix) * a.x_cs + a.x_coff + c);\
@@ -350,7 +356,7 @@ _Pragma("unroll")                                                               
 
 #undef LOAD_UNIT
   // partial slab ws[split][t][n][c]: MFMA rows = n (A operand = dY), cols = c (B operand = X)
-  float* slab = a.ws + (size_t)split_id * T * a.Cr * a.Nr;
+  float* slab = a.ws + (size_t)split_id * (KS * KS) * a.Cr * a.Nr;
 #pragma unroll
   for (int t = 0; t < T; ++t)
 #pragma unroll
@@ -361,7 +367,7 @@ _Pragma("unroll")                                                               
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int n = n_blk + wn * (NT * 32) + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          slab[((size_t)t * a.Nr + n) * a.Cr + c] = acc[t][i][j][r];
+          slab[((size_t)(r0 * KS + t) * a.Nr + n) * a.Cr + c] = acc[t][i][j][r];
         }
       }
 }
@@ -521,14 +527,20 @@ extern "C" int hpri_conv_wgrad_bf16(const float* x, int x_cs, int x_coff, int x_
     a.xcd_tiles = (Cr / bc) * (Nr / bn);
     grid = dim3((unsigned)(splits * a.xcd_tiles), 1u, 1u);
   }
+  if (KS == 3 && split) {   // one kernel row per workgroup: the (C, N) tile index carries the row (z = nblk * 3 + row).
+    // Only the split form: measured 29.2 -> 25.7 ms/step for bf16x3, but 18.7 -> 21.1 for plain bf16, whose nine-tap
+    // workgroup already stages two strips per unit and has a third of the MFMA work per staged byte.
+    if (a.xcd_tiles > 0) { a.xcd_tiles *= 3; grid = dim3((unsigned)(splits * a.xcd_tiles), 1u, 1u); }
+    else grid.z *= 3;
+  }
   if (split) {
-    if (KS == 3) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<3, 1, 1, HPRI_A_DIRECT, 1>), grid, dim3(256), 0, stream, a);
-    else if (bmode == HPRI_A_S2D) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<1, 2, 2, HPRI_A_S2D, 1>), grid, dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL((conv_wgrad_bf16_kernel<1, 2, 2, HPRI_A_DIRECT, 1>), grid, dim3(256), 0, stream, a);
+    if (KS == 3) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<3, 1, 1, HPRI_A_DIRECT, 1, 1>), grid, dim3(256), 0, stream, a);
+    else if (bmode == HPRI_A_S2D) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<1, 2, 2, HPRI_A_S2D, 1, 1>), grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((conv_wgrad_bf16_kernel<1, 2, 2, HPRI_A_DIRECT, 1, 1>), grid, dim3(256), 0, stream, a);
   } else {
-    if (KS == 3) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<3, 1, 1, HPRI_A_DIRECT, 0>), grid, dim3(256), 0, stream, a);
-    else if (bmode == HPRI_A_S2D) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<1, 2, 2, HPRI_A_S2D, 0>), grid, dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL((conv_wgrad_bf16_kernel<1, 2, 2, HPRI_A_DIRECT, 0>), grid, dim3(256), 0, stream, a);
+    if (KS == 3) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<3, 1, 1, HPRI_A_DIRECT, 0, 3>), grid, dim3(256), 0, stream, a);
+    else if (bmode == HPRI_A_S2D) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<1, 2, 2, HPRI_A_S2D, 0, 1>), grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((conv_wgrad_bf16_kernel<1, 2, 2, HPRI_A_DIRECT, 0, 1>), grid, dim3(256), 0, stream, a);
   }
   HPRI_CHECK_LAUNCH();
   return HPRI_OK;
