@@ -35,6 +35,40 @@ __global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, float* __rest
   }
 }
 
+// The same for 16-byte aligned problems (P % 4 == 0, 16-byte aligned bases, cs/coff/Cw multiples of 4), which is what
+// the 560 MB cubes are: a 64 channel x 128 pixel tile, float4 reads along the pixels (512-byte runs per channel row),
+// float4 writes along the channels (256-byte runs per pixel).
+__global__ __launch_bounds__(256) void nchw_to_nhwc_v4_kernel(const float* __restrict__ src, float* __restrict__ dst, int C,
+                                                              long long P, int cs, int coff, int Cw) {
+  __shared__ float tile[128][65];                    // [pixel][channel], pitch 65: conflict-free scalar transposition
+  const int n = blockIdx.z;
+  const long long p0 = (long long)blockIdx.x * 128;
+  const int c0 = blockIdx.y * 64;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 pixel quads x 8 channel rows
+#pragma unroll
+  for (int r = ty; r < 64; r += 8) {
+    const int c = c0 + r;
+    const long long p = p0 + tx * 4;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (c < C && p < P) v = *reinterpret_cast<const f32x4*>(src + ((long long)n * C + c) * P + p);
+    const int rc = (r + (tx >> 3)) & 63;             // columns rotated by pixel>>5: the 32 lanes hit 32 different banks
+    tile[tx * 4 + 0][rc] = v[0]; tile[tx * 4 + 1][rc] = v[1]; tile[tx * 4 + 2][rc] = v[2]; tile[tx * 4 + 3][rc] = v[3];
+  }
+  __syncthreads();
+  const int cq = threadIdx.x & 15, py = threadIdx.x >> 4;   // 16 channel quads x 16 pixels
+#pragma unroll
+  for (int r = py; r < 128; r += 16) {
+    const long long p = p0 + r;
+    const int c = c0 + cq * 4;
+    if (p < P && c < Cw) {
+      const int ro = r >> 5;
+      f32x4 v = {tile[r][(cq * 4 + 0 + ro) & 63], tile[r][(cq * 4 + 1 + ro) & 63], tile[r][(cq * 4 + 2 + ro) & 63],
+                 tile[r][(cq * 4 + 3 + ro) & 63]};
+      *reinterpret_cast<f32x4*>(dst + ((long long)n * P + p) * cs + coff + c) = v;
+    }
+  }
+}
+
 // src [N][P][cs]+coff -> dst [N][C][P]
 __global__ void nhwc_to_nchw_kernel(const float* __restrict__ src, float* __restrict__ dst, int C, long long P,
                                     int cs, int coff, int accumulate) {
@@ -303,6 +337,12 @@ __global__ void synth_kernel(float* __restrict__ d, long long n, unsigned long l
 extern "C" int hpri_nchw_to_nhwc(const float* src, float* dst, int N, int C, long long P, int cs, int coff, int Cw,
                                  hipStream_t stream) {
   HPRI_REQUIRE(src && dst && N > 0 && C > 0 && P > 0 && Cw >= C && Cw + coff <= cs, "nchw_to_nhwc: bad arguments");
+  if (P % 4 == 0 && cs % 4 == 0 && coff % 4 == 0 && Cw % 4 == 0 && ((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0) {
+    dim3 grid4((unsigned)hpri_cdiv64(P, 128), (unsigned)hpri_cdiv(Cw, 64), (unsigned)N);
+    hipLaunchKernelGGL(nchw_to_nhwc_v4_kernel, grid4, dim3(256), 0, stream, src, dst, C, P, cs, coff, Cw);
+    HPRI_CHECK_LAUNCH();
+    return HPRI_OK;
+  }
   dim3 grid((unsigned)hpri_cdiv64(P, 64), (unsigned)hpri_cdiv(Cw, 32), (unsigned)N);
   hipLaunchKernelGGL(nchw_to_nhwc_kernel, grid, dim3(256), 0, stream, src, dst, C, P, cs, coff, Cw);
   HPRI_CHECK_LAUNCH();
