@@ -7,6 +7,6 @@ from .model_parts import DoubleConv, Down, OutConv, Up, set_precision  # noqa: F
 from .models import (CubeNET, SpectralUNET, UNet, initialize_model, set_parameter_requires_grad,  # noqa: F401
                      translate_load_dir)
 from .trainer import (BCEWithLogitsLoss, FusedAdam, FusedSGD, PRCurve, SegCounts, SegmentationModel,  # noqa: F401
-                      load_checkpoint, network_state_dict)
+                      average_precision, load_checkpoint, network_state_dict)
 
 __version__ = "0.1.0"

@@ -175,6 +175,30 @@ def best_dice_threshold(precision: torch.Tensor, recall: torch.Tensor, threshold
     return float(torch.round(t[i].to(torch.float), decimals=2)), float(p[i]), float(r[i])
 
 
+def average_precision(pred: torch.Tensor, target: torch.Tensor) -> float:
+    """``AveragePrecision(task='binary')`` of ``model_eval`` (PLTrainer.py:558-559, 650-651; torchmetrics 1.2.0 with
+    ``thresholds=None``): AP = sum_n (R_n - R_{n-1}) P_n over the distinct prediction values in descending order --
+    the same definition as ``sklearn.metrics.average_precision_score``.  Exact (no binning): one device sort and two
+    cumulative sums with torch's own kernels (plumbing, not the hot path); ties share one threshold."""
+    _require_cuda(pred, "prediction")
+    p = pred.detach().reshape(-1).to(torch.float32)
+    t = (target.reshape(-1).to(torch.int32) != 0)
+    order = torch.argsort(p, descending=True, stable=True)
+    ps, ts = p[order], t[order]
+    tp = torch.cumsum(ts.to(torch.float64), 0)
+    fp = torch.cumsum((~ts).to(torch.float64), 0)
+    last = torch.ones_like(ps, dtype=torch.bool)            # last element of every run of equal predictions
+    last[:-1] = ps[1:] != ps[:-1]
+    tp, fp = tp[last], fp[last]
+    npos = tp[-1]
+    if float(npos) == 0.0:
+        return float("nan")
+    precision = tp / (tp + fp)
+    recall = tp / npos
+    prev = torch.cat([torch.zeros(1, dtype=torch.float64, device=recall.device), recall[:-1]])
+    return float(((recall - prev) * precision).sum())
+
+
 # ---------------------------------------------------------------------------------------------------
 # optim.Adam / optim.SGD as one multi-tensor launch
 # ---------------------------------------------------------------------------------------------------

@@ -417,3 +417,10 @@ def optimizer_steps(kind: str, params, grads_per_step, **hyper):
             p.grad = None if g is None else g.detach().clone().float()
         opt.step()
     return [p.detach() for p in ps]
+
+
+def average_precision(probs: Tensor, target: Tensor) -> float:
+    """``AveragePrecision(task='binary')`` (PLTrainer.py:558-559): the step-wise sum sum_n (R_n - R_{n-1}) P_n that
+    torchmetrics shares with scikit-learn -- computed here by scikit-learn itself (installed; torchmetrics is not)."""
+    from sklearn.metrics import average_precision_score
+    return float(average_precision_score((target.flatten().to(torch.int32) != 0).numpy(), probs.detach().float().flatten().numpy()))

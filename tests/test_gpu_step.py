@@ -203,3 +203,15 @@ def test_validation_and_predict_steps():
     acc, dice, iou = O.seg_metrics(ref, m)
     assert round(met["val_dice"], 4) == round(dice, 4) and round(met["val_pos_iou"], 4) == round(iou, 4)
     assert abs(met["val_loss"] - float(O.bce_with_logits(ref, m))) < 1e-5
+
+
+def test_average_precision_matches_sklearn():
+    from hyperpri_amd.trainer import average_precision
+    n = 200000
+    p = (_u(61, (n,)) ** 2)
+    p[:1000] = torch.round(p[:1000] * 20) / 20          # plenty of ties
+    t = (_u(62, (n,)) < p).float()
+    got = average_precision(p.to(DEV), t.to(DEV))
+    want = O.average_precision(p, t)
+    assert abs(got - want) < 1e-9, (got, want)
+    assert average_precision(p.to(DEV), torch.zeros(n, device=DEV)) != average_precision(p.to(DEV), torch.zeros(n, device=DEV))  # nan
