@@ -159,3 +159,37 @@ def test_errors_the_callers_would_see():
         unet(torch.zeros(1, 4, 16, 16, device=DEV))            # channel mismatch
     with pytest.raises((RuntimeError, ValueError)):
         unet(torch.zeros(1, 3, 8, 8, device=DEV))              # 8x8: the fourth pool has nothing to pool (torch raises too)
+
+
+def test_frozen_parameters_get_no_gradient_and_the_rest_is_unchanged():
+    """feature_extraction / set_parameter_requires_grad (models.py:279-292) freezes parameters: frozen ones must end
+    with grad None, the others with exactly the gradient of the unfrozen run."""
+    net, sd, fwd, kw = _pair("unet")
+    x = _u(930, (2, 3, 24, 40)).to(DEV)
+    mask = (_u(931, (2, 1, 24, 40)) > 0.8).float().to(DEV)
+    crit = torch.nn.BCEWithLogitsLoss()
+
+    def reset():
+        for p in net.parameters():
+            p.grad = None
+        for m in net.modules():
+            if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+                m.reset_running_stats()
+    reset()
+    crit(net(x), mask).backward()
+    full = {k: p.grad.clone() for k, p in net.named_parameters()}
+    reset()
+    frozen = [k for k, _ in net.named_parameters() if k.startswith(("inc.", "down1.", "down2."))]
+    for k, p in net.named_parameters():
+        p.requires_grad_(k not in frozen)
+    crit(net(x), mask).backward()
+    for k, p in net.named_parameters():
+        if k in frozen:
+            assert p.grad is None, k
+        else:
+            assert torch.equal(p.grad, full[k]), k
+    # everything frozen + an input that needs no gradient: forward still works and builds no graph
+    for p in net.parameters():
+        p.requires_grad_(False)
+    out = net(x)
+    assert not out.requires_grad
