@@ -394,8 +394,10 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
                 _lib.call("hpri_col_reduce_plan", x.P, 1, cout, ctypes.byref(nblk), ctypes.byref(cpart))
                 ws = _ws(nblk.value * 2 * cpart.value + 2 * cout, dev)
                 _lib.call("hpri_col_sum", dyr.ptr, dyr.cs, dyr.coff, _p(db), acc_b, _p(ws), ws.numel(), x.P, cout, _stream())
-        dw, acc_w = tp.param_slot(weight)
-        if SIDE_STREAM and need_dx and _EVENT_LOG is None:
+        if not weight.requires_grad:          # frozen (feature_extraction, models.py:17-21): no weight gradient at all
+            pass
+        elif SIDE_STREAM and need_dx and _EVENT_LOG is None:
+            dw, acc_w = tp.param_slot(weight)
             main, side = torch.cuda.current_stream(dev), _side(dev)
             side.wait_stream(main)                      # dyr (and everything before it) is ready
             with torch.cuda.stream(side):
@@ -404,6 +406,7 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
                 t.record_stream(side)
             tp.used_side = True
         else:
+            dw, acc_w = tp.param_slot(weight)
             _wgrad(x, dyr, dw, acc_w, cin, cout, ks, bf16=lowp, split=split)
         if need_dx:
             gx, acc = tp.grad_slot(x)
@@ -553,10 +556,11 @@ def _upsample_into(tape: Tape, x1: Act, dst: Act, weight: Optional[torch.Tensor]
             _lib.call("hpri_col_reduce_plan", gu.P, 1, cup, ctypes.byref(nblk), ctypes.byref(cpart))
             ws = _ws(nblk.value * 2 * cpart.value + 2 * cup, dev)
             _lib.call("hpri_col_sum", gu.ptr, gu.cs, gu.coff, _p(db), acc_b, _p(ws), ws.numel(), gu.P, cup, _stream())
-        dw, acc_w = tp.param_slot(weight)
         bprec = precision or DEFAULT_PRECISION
-        _wgrad(x1, gu, dw, acc_w, cin, 4 * cup, 1, bmode=A_S2D, dst_mode=1, H2=H2, W2=W2, py0=py0, px0=px0, cup=cup,
-               bf16=bprec in ("bf16", "bf16x3"), split=int(bprec == "bf16x3"))
+        if weight.requires_grad:
+            dw, acc_w = tp.param_slot(weight)
+            _wgrad(x1, gu, dw, acc_w, cin, 4 * cup, 1, bmode=A_S2D, dst_mode=1, H2=H2, W2=W2, py0=py0, px0=px0, cup=cup,
+                   bf16=bprec in ("bf16", "bf16x3"), split=int(bprec == "bf16x3"))
         if need_dx1:
             gx, acc = tp.grad_slot(x1)
             if bprec in ("bf16", "bf16x3"):
