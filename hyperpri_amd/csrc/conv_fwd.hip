@@ -367,16 +367,23 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 // bits) and each k16-step issues three MFMAs, hi*hi + hi*lo + lo*hi, into the same fp32 accumulator -- ~4e-5 on the
 // logits instead of bf16's 2e-2, i.e. inside the reference's 1e-3 contract, at 3 bf16 MFMAs per product instead of
 // one 16x slower fp32 MFMA.  Stage = one tap (two planes) instead of one kernel row.
-template <int KS, int WM, int WN, int AMODE, int EPI, int SPLIT>
-__global__ __launch_bounds__(256, ((WM == 4 && !SPLIT) || (WM == 2 && SPLIT)) ? 3 : 2) void conv_fwd_bf16_kernel(ConvFwdArgs a) {
+// NTW = 32-channel tiles per wave: 2 (wave tile 64 px x 64 ch) or 1 (narrow: 64 px x 32 ch, workgroup 128 px x 64 ch,
+// 40.8 KB of LDS with one stage buffer and ~110 VGPRs: FOUR workgroups per CU)
+template <int KS, int WM, int WN, int AMODE, int EPI, int SPLIT, int NTW>
+__global__ __launch_bounds__(256, (SPLIT == 2) ? 2 : (NTW == 1) ? 4 : ((WM == 4 && !SPLIT) || (WM == 2 && SPLIT)) ? 3 : 2) void conv_fwd_bf16_kernel(ConvFwdArgs a) {
   constexpr int T = KS * KS, PAD = KS / 2;
   constexpr int TPIX = 64 * WM;
   constexpr int MAXHP = (KS == 1) ? TPIX : (WM == 2 ? 6 * 34 : 10 * 34);
-  constexpr int BN = 64 * WN;
+  constexpr int BN = 32 * NTW * WN;
   constexpr int CS = 40;                          // halves per staged pixel / per staged weight row (32 + 8 pad)
   constexpr int NLD_A = (MAXHP * 8 + 255) / 256;  // float4 global loads per thread per A chunk
   constexpr int TS = SPLIT ? 1 : KS;              // taps per stage
-  constexpr int NPL = SPLIT ? 2 : 1;              // operand planes (hi, lo)
+  constexpr int NPL = SPLIT + 1;                  // operand planes: hi | hi, lo | hi, mid, lo
+  // products issued per k16-step, smallest first (plane of A, plane of B); dropped terms are <= 2^-16 (two planes)
+  // resp. 2^-24 (three planes) relative
+  constexpr int NTERM = (SPLIT == 0) ? 1 : (SPLIT == 1) ? 3 : 6;
+  constexpr int TA[6] = {2, 0, 1, 1, 0, 0};       // the LAST NTERM entries are used: (hi,hi) | (lo,hi) (hi,lo) (hi,hi) |
+  constexpr int TB[6] = {0, 2, 1, 0, 1, 0};       // (lo,hi) (hi,lo) (mid,mid) (mid,hi) (hi,mid) (hi,hi)
   constexpr int SR = TS * NPL;                    // [BN][32] row blocks per B stage
   constexpr int NST = SPLIT ? T : KS;             // stages per 32-channel chunk
   constexpr int BS = 32;                          // halves per staged weight row: 64 bytes, unpadded, XOR-swizzled
@@ -384,7 +391,7 @@ __global__ __launch_bounds__(256, ((WM == 4 && !SPLIT) || (WM == 2 && SPLIT)) ? 
   // Stage buffers.  The 2x2 split kernel keeps ONE: 48.6 KB of LDS then lets three workgroups share a CU, and a third
   // workgroup hides more than prefetching the next stage inside the workgroup did (measured +5..16 %; a three-buffer
   // ring with two stages in flight measured 0 %).
-  constexpr int NBUF = (SPLIT && WM == 2) ? 1 : 2;
+  constexpr int NBUF = ((SPLIT && WM == 2) || NTW == 1) ? 1 : 2;
   __shared__ __attribute__((aligned(16))) __bf16 smem_h[NPL * MAXHP * CS + NBUF * SR * BN * BS];
   __bf16* a_lds = smem_h;
   __bf16* b_lds = smem_h + NPL * MAXHP * CS;
@@ -411,11 +418,11 @@ __global__ __launch_bounds__(256, ((WM == 4 && !SPLIT) || (WM == 2 && SPLIT)) ? 
   const int y0 = ty * TH, x0 = a.seg_xbeg[seg] + tx * TW;
   const int xlim = min(a.W, a.seg_xbeg[seg] + a.seg_ntx[seg] * TW);
 
-  f32x16 acc[2][2];
+  f32x16 acc[2][NTW];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NTW; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -494,18 +501,18 @@ __global__ __launch_bounds__(256, ((WM == 4 && !SPLIT) || (WM == 2 && SPLIT)) ? 
   _Pragma("unroll") for (int p = 0; p < NLD_A; ++p) {                                                \
     const int f = tid + p * 256;                                                                     \
     if ((f >> 3) < HP) {                                                                             \
-      const bf16x4 hi_ = __builtin_convertvector(areg[p], bf16x4);                                   \
-      *reinterpret_cast<bf16x4*>(a_lds + (f >> 3) * CS + (f & 7) * 4) = hi_;                         \
-      if (SPLIT) {                                                                                   \
-        const f32x4 rest_ = areg[p] - __builtin_convertvector(hi_, f32x4);                           \
-        *reinterpret_cast<bf16x4*>(a_lds + MAXHP * CS + (f >> 3) * CS + (f & 7) * 4) = __builtin_convertvector(rest_, bf16x4); \
+      f32x4 rest_ = areg[p];                                                                         \
+      _Pragma("unroll") for (int pl = 0; pl < NPL; ++pl) {                                           \
+        const bf16x4 h_ = __builtin_convertvector(rest_, bf16x4);                                    \
+        *reinterpret_cast<bf16x4*>(a_lds + pl * MAXHP * CS + (f >> 3) * CS + (f & 7) * 4) = h_;      \
+        if (pl + 1 < NPL) rest_ = rest_ - __builtin_convertvector(h_, f32x4);                        \
       }                                                                                              \
     }                                                                                                \
   }
 
   const int a_base = ((wm * 2 * RW + (li >> twl)) * HW + (li & (TW - 1))) * CS + lh * 8;
   const int a_mt = RW * HW * CS;
-  const int b_base = (wn * 64 + li) * BS;
+  const int b_base = (wn * (32 * NTW) + li) * BS;
   const int bsw0 = ((0 + lh) ^ ((li >> 1) & 3)) * 8, bsw1 = ((2 + lh) ^ ((li >> 1) & 3)) * 8;   // swizzled k16-step offsets
 
   if (NBUF > 1) { LOAD_STAGE(S0) }
@@ -534,15 +541,15 @@ __global__ __launch_bounds__(256, ((WM == 4 && !SPLIT) || (WM == 2 && SPLIT)) ? 
       for (int dx = 0; dx < KS; ++dx) {
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-          bf16x8 af[2], bf[2];
+          bf16x8 af[2], bf[NTW];
 #pragma unroll
           for (int mt = 0; mt < 2; ++mt) af[mt] = *reinterpret_cast<const bf16x8*>(ap + mt * a_mt + dx * CS + kk * 16);
 #pragma unroll
-          for (int nt = 0; nt < 2; ++nt) bf[nt] = *reinterpret_cast<const bf16x8*>(bp + (dx * BN + nt * 32) * BS + (kk ? bsw1 : bsw0));
+          for (int nt = 0; nt < NTW; ++nt) bf[nt] = *reinterpret_cast<const bf16x8*>(bp + (dx * BN + nt * 32) * BS + (kk ? bsw1 : bsw0));
 #pragma unroll
           for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
+            for (int nt = 0; nt < NTW; ++nt)
               acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mt], bf[nt], acc[mt][nt], 0, 0, 0);
         }
       }
@@ -551,25 +558,23 @@ __global__ __launch_bounds__(256, ((WM == 4 && !SPLIT) || (WM == 2 && SPLIT)) ? 
       const __bf16* ap = a_lds + a_base + (dy * HW + dx) * CS;
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
-        bf16x8 ah[2], al[2], bh[2], bl[2];
+        bf16x8 afr[NPL][2], bfr[NPL][NTW];
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-          ah[mt] = *reinterpret_cast<const bf16x8*>(ap + mt * a_mt + kk * 16);
-          al[mt] = *reinterpret_cast<const bf16x8*>(ap + MAXHP * CS + mt * a_mt + kk * 16);
-        }
+        for (int pl = 0; pl < NPL; ++pl) {
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-          bh[nt] = *reinterpret_cast<const bf16x8*>(bp + (nt * 32) * BS + (kk ? bsw1 : bsw0));
-          bl[nt] = *reinterpret_cast<const bf16x8*>(bp + (BN + nt * 32) * BS + (kk ? bsw1 : bsw0));
+          for (int mt = 0; mt < 2; ++mt)
+            afr[pl][mt] = *reinterpret_cast<const bf16x8*>(ap + pl * MAXHP * CS + mt * a_mt + kk * 16);
+#pragma unroll
+          for (int nt = 0; nt < NTW; ++nt)
+            bfr[pl][nt] = *reinterpret_cast<const bf16x8*>(bp + (pl * BN + nt * 32) * BS + (kk ? bsw1 : bsw0));
         }
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-          for (int nt = 0; nt < 2; ++nt) {
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
-          }
+          for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+            for (int t = 6 - NTERM; t < 6; ++t)
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[TA[t]][mt], bfr[TB[t]][nt], acc[mt][nt], 0, 0, 0);
       }
     }
   }
@@ -586,8 +591,8 @@ __global__ __launch_bounds__(256, ((WM == 4 && !SPLIT) || (WM == 2 && SPLIT)) ? 
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
-        const int n = nb * BN + wn * 64 + nt * 32 + li;
+      for (int nt = 0; nt < NTW; ++nt) {
+        const int n = nb * BN + wn * (32 * NTW) + nt * 32 + li;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -599,8 +604,8 @@ __global__ __launch_bounds__(256, ((WM == 4 && !SPLIT) || (WM == 2 && SPLIT)) ? 
     return;
   }
 #pragma unroll
-  for (int nt = 0; nt < 2; ++nt) {
-    const int n = nb * BN + wn * 64 + nt * 32 + li;
+  for (int nt = 0; nt < NTW; ++nt) {
+    const int n = nb * BN + wn * (32 * NTW) + nt * 32 + li;
     float b = 0.f;
     if (a.bias != nullptr && n < a.Cout) b = (EPI == HPRI_E_D2S) ? a.bias[n % a.Cup] : a.bias[n];
 #pragma unroll
@@ -612,8 +617,8 @@ __global__ __launch_bounds__(256, ((WM == 4 && !SPLIT) || (WM == 2 && SPLIT)) ? 
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      const int n = nb * BN + wn * 64 + nt * 32 + li;
+    for (int nt = 0; nt < NTW; ++nt) {
+      const int n = nb * BN + wn * (32 * NTW) + nt * 32 + li;
       if (EPI == HPRI_E_DIRECT) {
         if (n >= a.y_cw) continue;
 #pragma unroll
@@ -652,12 +657,12 @@ __global__ __launch_bounds__(256, ((WM == 4 && !SPLIT) || (WM == 2 && SPLIT)) ? 
     float* red = smem;                      // [4 waves][64 channels], reuses the A staging area
     const int vrows = min(TH, a.H - y0), vcols = min(TW, xlim - x0);
     const float cnt = (float)(vrows * vcols);
-    float mean[2];
+    float mean[NTW];
     __syncthreads();
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
+      for (int nt = 0; nt < NTW; ++nt) {
         float sacc = 0.f;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
@@ -677,13 +682,13 @@ __global__ __launch_bounds__(256, ((WM == 4 && !SPLIT) || (WM == 2 && SPLIT)) ? 
       }
       __syncthreads();
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
+      for (int nt = 0; nt < NTW; ++nt) {
         float t = 0.f;
 #pragma unroll
         for (int m = 0; m < WM; ++m) t += red[(m * WN + wn) * 64 + nt * 32 + li];
         if (pass == 0) mean[nt] = t / cnt;
         else if (wm == 0 && lh == 0) {
-          const int n = nb * BN + wn * 64 + nt * 32 + li;
+          const int n = nb * BN + wn * (32 * NTW) + nt * 32 + li;
           a.stats[(size_t)bx * a.Cout_pad + n] = make_float4(mean[nt], t, cnt, 0.f);
         }
       }
@@ -763,11 +768,14 @@ __global__ void splitk_finish_kernel(const float* __restrict__ ws, int ksplit, i
 
 // Tile-shape choice shared by the launcher and the sizing query.
 // Workgroup shape: 2x2 waves (128 px x 128 ch) when the output channels allow it, else 4x1 (256 px x 64 ch).
-// prec: 0 fp32, 1 bf16, 2 bf16x3.  The plain bf16 kernel always takes 4x1: its 51 KB of LDS and 168 VGPRs let THREE
+// prec: 0 fp32, 1 bf16, 2 bf16x3, 3 bf16x6.  The plain bf16 kernel always takes 4x1: its 51 KB of LDS and 168 VGPRs let THREE
 // workgroups share a CU, which beats the wider tile on every layer (measured +4..17 %); the waves of a workgroup leave
 // each barrier in phase, so only other workgroups can fill the matrix pipe while one is reading its fragments.
 static inline void conv_cfg(int Cout_pad, int* wm, int* wn, int prec = 0) {
-  if (Cout_pad % 128 == 0 && prec != 1) { *wm = 2; *wn = 2; } else { *wm = 4; *wn = 1; }
+  if (Cout_pad % 128 == 0 && prec != 1) { *wm = 2; *wn = 2; }
+  else if (prec == 3) { *wm = 2; *wn = 1; }      // bf16x6, 64-channel remainder: three 256-pixel planes do not fit in LDS;
+                                                 // the narrow 128 px x 64 ch workgroup (2x2 waves of 64 px x 32 ch) does
+  else { *wm = 4; *wn = 1; }
 }
 
 // Cut the image width into column bands of tile width 32 / 16 / 8 / 4 (host only).  Candidates: plain 32-wide
@@ -858,16 +866,16 @@ extern "C" int hpri_conv_fwd_plan(int N, int H, int W, int Cin_pad, int Cout_pad
   return conv_plan(N, H, W, Cin_pad, Cout_pad, KS, amode, epi, 0, ksplit, stat_tiles, ws_floats);
 }
 
-// the same query for hpri_conv_fwd_bf16 (split = 0: bf16, 1: bf16x3), whose workgroup shapes differ
+// the same query for hpri_conv_fwd_bf16 (split = 0: bf16, 1: bf16x3, 2: bf16x6), whose workgroup shapes differ
 extern "C" int hpri_conv_fwd_bf16_plan(int N, int H, int W, int Cin_pad, int Cout_pad, int KS, int amode, int epi,
                                        int split, int* ksplit, int* stat_tiles, size_t* ws_floats) {
-  return conv_plan(N, H, W, Cin_pad, Cout_pad, KS, amode, epi, split ? 2 : 1, ksplit, stat_tiles, ws_floats);
+  return conv_plan(N, H, W, Cin_pad, Cout_pad, KS, amode, epi, (split < 0 || split > 2) ? 1 : split + 1, ksplit, stat_tiles, ws_floats);
 }
 
-template <int KS, int WM, int WN, int AMODE, int EPI, int SPLIT>
+template <int KS, int WM, int WN, int AMODE, int EPI, int SPLIT, int NTW = 2>
 static int launch_conv_bf16(const ConvFwdArgs& a0, hipStream_t stream) {
   ConvFwdArgs a = a0;
-  constexpr int BN = 64 * WN;
+  constexpr int BN = 32 * NTW * WN;
   const ConvSegs sg = conv_segments(a.H, a.W, WM);
   a.nseg = sg.nseg; a.tiles_img = sg.tiles_img;
   for (int k = 0; k < HPRI_MAXSEG; ++k) { a.seg_twl[k] = sg.twl[k]; a.seg_xbeg[k] = sg.xbeg[k]; a.seg_ntx[k] = sg.ntx[k]; a.seg_first[k] = sg.first[k]; }
@@ -875,7 +883,7 @@ static int launch_conv_bf16(const ConvFwdArgs& a0, hipStream_t stream) {
   a.nbx = (NB >= conv_nbx_min()) ? NB : 0;
   dim3 grid((unsigned)tiles, (unsigned)NB, (unsigned)a.ksplit);
   if (a.nbx > 0) grid = dim3((unsigned)(hpri_cdiv(tiles, 8) * 8 * NB), 1u, (unsigned)a.ksplit);
-  hipLaunchKernelGGL((conv_fwd_bf16_kernel<KS, WM, WN, AMODE, EPI, SPLIT>), grid, dim3(256), 0, stream, a);
+  hipLaunchKernelGGL((conv_fwd_bf16_kernel<KS, WM, WN, AMODE, EPI, SPLIT, NTW>), grid, dim3(256), 0, stream, a);
   HPRI_CHECK_LAUNCH();
   return HPRI_OK;
 }
@@ -910,7 +918,8 @@ extern "C" int hpri_conv_fwd_bf16(const float* x, int x_cs, int x_coff, const vo
     if (epi == HPRI_E_D2S) HPRI_REQUIRE(Cout == 4 * Cup, "conv_fwd_bf16: D2S needs Cout == 4*Cup");
     HPRI_REQUIRE(!(amode == HPRI_A_S2D && epi == HPRI_E_D2S), "conv_fwd_bf16: S2D and D2S are exclusive");
   }
-  a.ksplit = conv_ksplit(N, H, W, Cin_pad, Cout_pad, KS, epi, amode, split ? 2 : 1);
+  HPRI_REQUIRE(split >= 0 && split <= 2, "conv_fwd_bf16: split must be 0 (bf16), 1 (bf16x3) or 2 (bf16x6)");
+  a.ksplit = conv_ksplit(N, H, W, Cin_pad, Cout_pad, KS, epi, amode, split + 1);
   a.ws = ws;
   if (a.ksplit > 1) {
     if (ws == nullptr || (size_t)a.ksplit * N * H * W * Cout_pad > ws_floats)
@@ -918,11 +927,12 @@ extern "C" int hpri_conv_fwd_bf16(const float* x, int x_cs, int x_coff, const vo
     a.stats = nullptr;
     a.accumulate = 0;
   }
-  int wm, wn; conv_cfg(Cout_pad, &wm, &wn, split ? 2 : 1);
+  int wm, wn; conv_cfg(Cout_pad, &wm, &wn, split + 1);
   int rc;
 #define HPRI_DISPATCH_B(KS_, AM_, EP_)                                                      \
-  rc = split ? ((wm == 2) ? launch_conv_bf16<KS_, 2, 2, AM_, EP_, 1>(a, stream) : launch_conv_bf16<KS_, 4, 1, AM_, EP_, 1>(a, stream)) \
-             : ((wm == 2) ? launch_conv_bf16<KS_, 2, 2, AM_, EP_, 0>(a, stream) : launch_conv_bf16<KS_, 4, 1, AM_, EP_, 0>(a, stream))
+  rc = (split == 2) ? ((wn == 2) ? launch_conv_bf16<KS_, 2, 2, AM_, EP_, 2>(a, stream) : launch_conv_bf16<KS_, 2, 2, AM_, EP_, 2, 1>(a, stream)) \
+     : (split == 1) ? ((wm == 2) ? launch_conv_bf16<KS_, 2, 2, AM_, EP_, 1>(a, stream) : launch_conv_bf16<KS_, 4, 1, AM_, EP_, 1>(a, stream)) \
+                    : ((wm == 2) ? launch_conv_bf16<KS_, 2, 2, AM_, EP_, 0>(a, stream) : launch_conv_bf16<KS_, 4, 1, AM_, EP_, 0>(a, stream))
   if (KS == 3) { HPRI_DISPATCH_B(3, HPRI_A_DIRECT, HPRI_E_DIRECT); }
   else if (amode == HPRI_A_S2D) { HPRI_DISPATCH_B(1, HPRI_A_S2D, HPRI_E_DIRECT); }
   else if (epi == HPRI_E_D2S) { HPRI_DISPATCH_B(1, HPRI_A_DIRECT, HPRI_E_D2S); }

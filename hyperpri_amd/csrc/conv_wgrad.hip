@@ -203,12 +203,15 @@ __device__ __forceinline__ bf16x8 tr_frag(const __bf16* p, int pitch4) {
 // strip without vertical halo): 50.7 KB of LDS and ~160 VGPRs, i.e. THREE workgroups per CU plus a register prefetch of
 // the next unit -- the 3x3 bf16 kernels were waiting for their global loads two thirds of the time.
 template <int KS, int CT, int NT, int BMODE, int SPLIT, int KR>
-__global__ __launch_bounds__(256, (KS == 3 && KR == 1) ? 3 : 2) void conv_wgrad_bf16_kernel(WgradArgs a) {
+__global__ __launch_bounds__(256, (KS == 3 && KR == 1 && SPLIT < 2) ? 3 : 2) void conv_wgrad_bf16_kernel(WgradArgs a) {
   constexpr int T = KR * KS, PAD = KS / 2, RS = KS / KR;   // T: taps of THIS workgroup; RS: kernel-row groups
   // one staged unit = SQ vertically adjacent 2x32 strips (SQ*64 pixels): the bf16 MFMAs retire so fast that the
   // staging + barrier cost must be amortised over more pixels than in the fp32 kernel
   constexpr int SQ = (KS == 3 && !SPLIT) ? 2 : 1;
-  constexpr int NPL = SPLIT ? 2 : 1;
+  constexpr int NPL = SPLIT + 1;                   // operand planes: hi | hi, lo | hi, mid, lo
+  constexpr int NTERM = (SPLIT == 0) ? 1 : (SPLIT == 1) ? 3 : 6;
+  constexpr int TA[6] = {2, 0, 1, 1, 0, 0};       // (dY plane, X plane) per MFMA, smallest products first; the LAST NTERM
+  constexpr int TB[6] = {0, 2, 1, 0, 1, 0};       // entries are used
   constexpr int SH = 2 * SQ, SW = 32, HH = SH + KR - 1, HW = SW + KS - 1, HP = HH * HW, NPIX = SH * SW;
   constexpr int BC = 64 * CT, BNW = 64 * NT;
   constexpr int PX = BC + 32, PY = BNW + 32;      // halves per staged pixel: data + 32 pad, i.e. a pitch of 48 / 80 dwords
@@ -275,8 +278,10 @@ _Pragma("unroll")                                                               
         if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W && c < a.x_cvalid)                            \
           v = *reinterpret_cast<const f32x4*>(a.x + ((size_t)(img * a.H + iy) * a.W + ix) * a.x_cs + a.x_coff + c);\
       }                                                                                              \
-      xr[0][p] = __builtin_convertvector(v, bf16x4);                                                 \
-      if (SPLIT) xr[NPL - 1][p] = __builtin_convertvector(v - __builtin_convertvector(xr[0][p], f32x4), bf16x4);\
+      _Pragma("unroll") for (int pl = 0; pl < NPL; ++pl) {                                           \
+        xr[pl][p] = __builtin_convertvector(v, bf16x4);                                              \
+        if (pl + 1 < NPL) v = v - __builtin_convertvector(xr[pl][p], f32x4);                         \
+      }                                                                                              \
     }                                                                                                \
 _Pragma("unroll")                                                                                    \
     for (int p = 0; p < NLD_Y; ++p) {                                                                \
@@ -294,8 +299,10 @@ _Pragma("unroll")                                                               
           v = *reinterpret_cast<const f32x4*>(a.dy + ((size_t)(img * a.H2 + yy) * a.W2 + xx) * a.dy_cs + a.dy_coff + co);\
         }                                                                                            \
       }                                                                                              \
-      yr[0][p] = __builtin_convertvector(v, bf16x4);                                                 \
-      if (SPLIT) yr[NPL - 1][p] = __builtin_convertvector(v - __builtin_convertvector(yr[0][p], f32x4), bf16x4);\
+      _Pragma("unroll") for (int pl = 0; pl < NPL; ++pl) {                                           \
+        yr[pl][p] = __builtin_convertvector(v, bf16x4);                                              \
+        if (pl + 1 < NPL) v = v - __builtin_convertvector(yr[pl][p], f32x4);                         \
+      }                                                                                              \
     }                                                                                                \
   }
   if (PREF && u_begin < u_end) LOAD_UNIT(u_begin)
@@ -307,16 +314,16 @@ _Pragma("unroll")                                                               
       const int f = tid + p * 256;
       const int pix = f / (BC / 4), c4 = f % (BC / 4);
       if (pix < HP) {
-        *reinterpret_cast<bf16x4*>(x_lds + pix * PX + c4 * 4) = xr[0][p];
-        if (SPLIT) *reinterpret_cast<bf16x4*>(x_lds + HP * PX + pix * PX + c4 * 4) = xr[NPL - 1][p];
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) *reinterpret_cast<bf16x4*>(x_lds + pl * HP * PX + pix * PX + c4 * 4) = xr[pl][p];
       }
     }
 #pragma unroll
     for (int p = 0; p < NLD_Y; ++p) {
       const int f = tid + p * 256;
       const int pix = f / (BNW / 4), n4 = f % (BNW / 4);
-      *reinterpret_cast<bf16x4*>(y_lds + pix * PY + n4 * 4) = yr[0][p];
-      if (SPLIT) *reinterpret_cast<bf16x4*>(y_lds + NPIX * PY + pix * PY + n4 * 4) = yr[NPL - 1][p];
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl) *reinterpret_cast<bf16x4*>(y_lds + pl * NPIX * PY + pix * PY + n4 * 4) = yr[pl][p];
     }
     __syncthreads();
     if (PREF && st + 1 < u_end) LOAD_UNIT(st + 1)
@@ -325,31 +332,26 @@ _Pragma("unroll")                                                               
 #pragma unroll
     for (int ks = 0; ks < NPIX / 16; ++ks) {
       const int py = ks >> 1, pxo = 16 * (ks & 1);
-      bf16x8 af[NT], afl[NT];
+      bf16x8 af[NPL][NT];
 #pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        af[j] = tr_frag(yb + (ks * 16) * PY + j * 32, 4 * PY);
-        if (SPLIT) afl[j] = tr_frag(yb + NPIX * PY + (ks * 16) * PY + j * 32, 4 * PY);
-      }
+      for (int pl = 0; pl < NPL; ++pl)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) af[pl][j] = tr_frag(yb + pl * NPIX * PY + (ks * 16) * PY + j * 32, 4 * PY);
 #pragma unroll
       for (int t = 0; t < T; ++t) {
         const int dy = t / KS, dx = t - dy * KS;
-        bf16x8 bfr[CT], bfl[CT];
+        bf16x8 bfr[NPL][CT];
 #pragma unroll
-        for (int i = 0; i < CT; ++i) {
-          bfr[i] = tr_frag(xb + ((py + dy) * HW + pxo + dx) * PX + i * 32, 4 * PX);
-          if (SPLIT) bfl[i] = tr_frag(xb + HP * PX + ((py + dy) * HW + pxo + dx) * PX + i * 32, 4 * PX);
-        }
+        for (int pl = 0; pl < NPL; ++pl)
+#pragma unroll
+          for (int i = 0; i < CT; ++i) bfr[pl][i] = tr_frag(xb + pl * HP * PX + ((py + dy) * HW + pxo + dx) * PX + i * 32, 4 * PX);
 #pragma unroll
         for (int i = 0; i < CT; ++i)
 #pragma unroll
-          for (int j = 0; j < NT; ++j) {
-            if (SPLIT) {
-              acc[t][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afl[j], bfr[i], acc[t][i][j], 0, 0, 0);
-              acc[t][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[j], bfl[i], acc[t][i][j], 0, 0, 0);
-            }
-            acc[t][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[j], bfr[i], acc[t][i][j], 0, 0, 0);
-          }
+          for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int q = 6 - NTERM; q < 6; ++q)
+              acc[t][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[TA[q]][j], bfr[TB[q]][i], acc[t][i][j], 0, 0, 0);
       }
     }
   }
@@ -500,6 +502,7 @@ extern "C" int hpri_conv_wgrad_bf16(const float* x, int x_cs, int x_coff, int x_
                                     int N, int H, int W, int Cin_pad, int Cout_pad, int KS, int bmode,
                                     int H2, int W2, int py0, int px0, int Cup, int split, hipStream_t stream) {
   HPRI_REQUIRE(x && dy && ws, "conv_wgrad_bf16: null pointer");
+  HPRI_REQUIRE(split >= 0 && split <= 2, "conv_wgrad_bf16: split must be 0 (bf16), 1 (bf16x3) or 2 (bf16x6)");
   HPRI_REQUIRE(KS == 1 || KS == 3, "conv_wgrad_bf16: kernel size must be 1 or 3");
   HPRI_REQUIRE(x_cs % 4 == 0 && x_coff % 4 == 0 && dy_cs % 4 == 0 && dy_coff % 4 == 0 && x_cvalid % 4 == 0 && dy_cvalid % 4 == 0,
                "conv_wgrad_bf16: channel strides/offsets/valid counts must be multiples of 4");
@@ -533,7 +536,11 @@ extern "C" int hpri_conv_wgrad_bf16(const float* x, int x_cs, int x_coff, int x_
     if (a.xcd_tiles > 0) { a.xcd_tiles *= 3; grid = dim3((unsigned)(splits * a.xcd_tiles), 1u, 1u); }
     else grid.z *= 3;
   }
-  if (split) {
+  if (split == 2) {
+    if (KS == 3) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<3, 1, 1, HPRI_A_DIRECT, 2, 1>), grid, dim3(256), 0, stream, a);
+    else if (bmode == HPRI_A_S2D) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<1, 2, 2, HPRI_A_S2D, 2, 1>), grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((conv_wgrad_bf16_kernel<1, 2, 2, HPRI_A_DIRECT, 2, 1>), grid, dim3(256), 0, stream, a);
+  } else if (split) {
     if (KS == 3) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<3, 1, 1, HPRI_A_DIRECT, 1, 1>), grid, dim3(256), 0, stream, a);
     else if (bmode == HPRI_A_S2D) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<1, 2, 2, HPRI_A_S2D, 1, 1>), grid, dim3(256), 0, stream, a);
     else hipLaunchKernelGGL((conv_wgrad_bf16_kernel<1, 2, 2, HPRI_A_DIRECT, 1, 1>), grid, dim3(256), 0, stream, a);

@@ -69,7 +69,8 @@ extern "C" int hpri_pack_weight_scaled(const float* w, float* wp, const float* c
 
 // ---- bf16 panels for conv_fwd_bf16.hip: [chunk][tap][Ncols_pad][32 k] (k contiguous per output column, the order the
 // MFMA B operand wants); same four modes as the fp32 pack; round-to-nearest-even.
-// split = 1 (mode "bf16x3"): two planes per tap, [chunk][tap][plane][Ncols_pad][32]: hi = bf16(w), lo = bf16(w - hi)
+// split = 1 (mode "bf16x3"): two planes per tap, [chunk][tap][plane][Ncols_pad][32]: hi = bf16(w), lo = bf16(w - hi);
+// split = 2 (mode "bf16x6"): three planes hi, mid, lo (24 mantissa bits: the fp32 value exactly)
 __global__ void pack_weight_bf16_kernel(const float* __restrict__ w, __bf16* __restrict__ wp, int mode, int K, int Ncols,
                                         int Ncols_pad, int T, int chunks, int src_d1, int Cup, int split) {
   const size_t total = (size_t)chunks * T * Ncols_pad * 32;
@@ -89,12 +90,16 @@ __global__ void pack_weight_bf16_kernel(const float* __restrict__ w, __bf16* __r
     }
     if (!split) {
       wp[idx] = (__bf16)v;
-    } else {
+    } else {               // split + 1 planes per tap: hi, (mid,) lo -- each the bf16 rounding of what the previous ones left
+      const int npl = split + 1;
       const size_t plane = (size_t)Ncols_pad * 32;
-      const size_t o = ((size_t)(chunk * T + t) * 2) * plane + (size_t)col * 32 + kk;
-      const __bf16 hi = (__bf16)v;
-      wp[o] = hi;
-      wp[o + plane] = (__bf16)(v - (float)hi);
+      const size_t o = ((size_t)(chunk * T + t) * npl) * plane + (size_t)col * 32 + kk;
+      float rest = v;
+      for (int pl = 0; pl < npl; ++pl) {
+        const __bf16 h = (__bf16)rest;
+        wp[o + pl * plane] = h;
+        rest -= (float)h;
+      }
     }
   }
 }
@@ -104,6 +109,7 @@ extern "C" int hpri_pack_weight_bf16(const float* w, void* wp, int mode, int K, 
   HPRI_REQUIRE(w && wp, "pack_weight_bf16: null pointer");
   HPRI_REQUIRE(mode >= 0 && mode <= 3 && K > 0 && Ncols > 0 && Ncols_pad >= Ncols && Ncols_pad % 64 == 0,
                "pack_weight_bf16: bad arguments");
+  HPRI_REQUIRE(split >= 0 && split <= 2, "pack_weight_bf16: split must be 0, 1 or 2");
   const int chunks = hpri_cdiv(K, 32);
   const size_t total = (size_t)chunks * T * Ncols_pad * 32;
   int blocks = (int)((total + 255) / 256);

@@ -26,8 +26,13 @@ E_DIRECT, E_D2S = 0, 1
 #   "bf16x3"         -- every contraction operand carried as bf16 hi + bf16 lo (16 mantissa bits), three bf16 MFMAs per
 #                       product (hi*hi + hi*lo + lo*hi), fp32 accumulate: ~4e-5 on the logits, i.e. INSIDE the 1e-3
 #                       contract, on the 16x faster pipe.
+#   "bf16x6"         -- three planes hi + mid + lo = 24 mantissa bits, i.e. every fp32 operand EXACTLY; six bf16 MFMAs per
+#                       product (the three cross terms below 2^-24 are dropped), fp32 accumulate: fp32-class accuracy
+#                       (what cuBLAS calls fp32 emulation) on the bf16 pipe.
 #                       Dice/IoU-level parity only (bf16 operands move logits by ~2e-2).
-PRECISIONS = ("fp32", "bf16", "bf16x3")
+PRECISIONS = ("fp32", "bf16", "bf16x3", "bf16x6")
+LOWP = ("bf16", "bf16x3", "bf16x6")
+_SPLIT = {"bf16": 0, "bf16x3": 1, "bf16x6": 2}
 DEFAULT_PRECISION = os.environ.get("HPRI_PRECISION", "fp32")
 
 
@@ -258,7 +263,7 @@ def _pack_bf16(w: torch.Tensor, mode: int, K: int, ncols: int, T: int, d1: int, 
                split: int = 0) -> Tuple[torch.Tensor, int]:
     ncols_pad = _rup(ncols, 64)
     chunks = (K + 31) // 32
-    wp = torch.empty(chunks * T * ncols_pad * 32 * (2 if split else 1), dtype=torch.bfloat16, device=w.device)
+    wp = torch.empty(chunks * T * ncols_pad * 32 * (split + 1), dtype=torch.bfloat16, device=w.device)
     _lib.call("hpri_pack_weight_bf16", _p(w), _p(wp), mode, K, ncols, ncols_pad, T, d1, cup, split, _stream())
     return wp, ncols_pad
 
@@ -272,7 +277,7 @@ def _conv_launch_bf16(x: Act, wp: torch.Tensor, bias: Optional[torch.Tensor], y:
     _lib.call("hpri_conv_fwd_bf16_plan", N, H, W, cin_pad, cout_pad, ks, amode, epi, split, ctypes.byref(ksplit),
               ctypes.byref(tiles), ctypes.byref(wsf))
     ws = _ws(wsf.value, x.buf.device) if wsf.value else None
-    tag = f"conv_fwd_{'bf16x3' if split else 'bf16'}<{ks},{'2x2' if (cout_pad % 128 == 0 and split) else '4x1'},{'s2d' if amode else 'direct'},{'d2s' if epi else 'direct'}>"
+    tag = f"conv_fwd_{('bf16', 'bf16x3', 'bf16x6')[split]}<{ks},{'2x2' if (cout_pad % 128 == 0 and split) else ('narrow' if split == 2 else '4x1')},{'s2d' if amode else 'direct'},{'d2s' if epi else 'direct'}>"
     if SHAPE_TAGS:
         tag += f" N{N} {H}x{W} K{cin_pad} N{cout}"
     with _timed(tag, 2.0 * N * H * W * (cin_true or cin_pad) * cout * ks * ks):
@@ -319,8 +324,8 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
     prec = precision or DEFAULT_PRECISION
     if prec not in PRECISIONS:
         raise RuntimeError(f"hyperpri_amd: unknown precision {prec!r}; choose from {PRECISIONS}")
-    lowp = prec in ("bf16", "bf16x3")
-    split = int(prec == "bf16x3")
+    lowp = prec in LOWP
+    split = _SPLIT.get(prec, 0)
     if lowp:
         wp, cout_pad = _pack_bf16(weight, 0, cin, cout, T, cin, split=split)
     else:
@@ -456,7 +461,7 @@ def _wgrad(x: Act, dy: Act, dw: torch.Tensor, accumulate: int, cin: int, cout: i
     _lib.call("hpri_wgrad_plan", N, H, W, cin_pad, cout_pad, ks, ctypes.byref(splits), ctypes.byref(cr), ctypes.byref(nr))
     ws = _ws(splits.value * ks * ks * cr.value * nr.value, x.buf.device)
     dy_cvalid = (4 * cup) if bmode == A_S2D else dy.cw
-    tag = f"conv_wgrad{('_bf16x3' if split else '_bf16') if bf16 else ''}<{ks},{'s2d' if bmode == A_S2D else 'direct'}>"
+    tag = f"conv_wgrad{('_bf16', '_bf16x3', '_bf16x6')[split] if bf16 else ''}<{ks},{'s2d' if bmode == A_S2D else 'direct'}>"
     if SHAPE_TAGS:
         tag += f" N{N} {H}x{W} C{cin_pad} N{cout}"
     if bf16:
@@ -518,8 +523,8 @@ def _upsample_into(tape: Tape, x1: Act, dst: Act, weight: Optional[torch.Tensor]
         if cin != x1.C or weight.shape[1] != cup:
             raise RuntimeError("hyperpri_amd: Up: ConvTranspose2d channel mismatch")
         uprec = precision or DEFAULT_PRECISION
-        bf16 = uprec in ("bf16", "bf16x3")
-        usplit = int(uprec == "bf16x3")
+        bf16 = uprec in LOWP
+        usplit = _SPLIT.get(uprec, 0)
         if bf16:
             wp, ncols_pad = _pack_bf16(weight, 2, cin, 4 * cup, 1, cup, cup, split=usplit)
             _conv_launch_bf16(x1, wp, bias, dst, None, x1.N, x1.H, x1.W, x1.cw, 4 * cup, ncols_pad, 4 * cup, 1,
@@ -560,14 +565,14 @@ def _upsample_into(tape: Tape, x1: Act, dst: Act, weight: Optional[torch.Tensor]
         if weight.requires_grad:
             dw, acc_w = tp.param_slot(weight)
             _wgrad(x1, gu, dw, acc_w, cin, 4 * cup, 1, bmode=A_S2D, dst_mode=1, H2=H2, W2=W2, py0=py0, px0=px0, cup=cup,
-                   bf16=bprec in ("bf16", "bf16x3"), split=int(bprec == "bf16x3"))
+                   bf16=bprec in LOWP, split=_SPLIT.get(bprec, 0))
         if need_dx1:
             gx, acc = tp.grad_slot(x1)
-            if bprec in ("bf16", "bf16x3"):
-                wpd, cols_pad = _pack_bf16(weight, 3, 4 * cup, cin, 1, cup, cup, split=int(bprec == "bf16x3"))
+            if bprec in LOWP:
+                wpd, cols_pad = _pack_bf16(weight, 3, 4 * cup, cin, 1, cup, cup, split=_SPLIT.get(bprec, 0))
                 _conv_launch_bf16(gu, wpd, None, gx, None, x1.N, x1.H, x1.W, 4 * cup, cin, cols_pad, gx.cw, 1,
                                   amode=A_S2D, accumulate=int(acc), H2=H2, W2=W2, py0=py0, px0=px0, cup=cup, cin_true=4 * cup,
-                                  split=int(bprec == "bf16x3"))
+                                  split=_SPLIT.get(bprec, 0))
             else:
                 wpd, cols_pad = _pack(weight, 3, 4 * cup, cin, 1, cup, cup)
                 _conv_launch(gu, wpd, None, gx, None, x1.N, x1.H, x1.W, 4 * cup, cin, cols_pad, gx.cw, 1,

@@ -229,3 +229,33 @@ def test_conv_bf16x3_mode_vs_exact(N, Cin, H, W, Cout, ks):
     yd.backward(r.to(DEV))
     assert float((xd.grad.cpu().double() - xc.grad).abs().max()) < 1e-4 * float(xc.grad.abs().max())
     assert float((wd.grad.cpu().double() - wc.grad).abs().max()) < 1e-4 * float(wc.grad.abs().max())
+
+
+@pytest.mark.parametrize("N,Cin,H,W,Cout,ks", [(2, 5, 9, 11, 7, 3), (1, 64, 20, 70, 128, 3), (2, 40, 13, 37, 64, 3),
+                                               (1, 24, 5, 33, 200, 1), (1, 512, 38, 60, 512, 3), (2, 238, 24, 40, 64, 3)])
+def test_conv_bf16x6_mode_is_as_exact_as_fp32(N, Cin, H, W, Cout, ks):
+    """precision="bf16x6": three bf16 planes = the fp32 operand exactly, six MFMAs per product.  Against the fp64
+    convolution it must be (almost) as close as the exact fp32 MFMA path is: both are measured and compared."""
+    from hyperpri_amd import engine as E
+    from hyperpri_amd.autograd import run
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(N * 1000 + Cin + H)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, ks, ks, generator=g) / (Cin * ks * ks) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    r = torch.randn(N, Cout, H, W, generator=g)
+    xc, wc = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yc = F.conv2d(xc.double(), wc.double(), b.double(), padding=ks // 2)
+    yc.backward(r.double())
+    err = {}
+    for prec in ("fp32", "bf16x6"):
+        xd, wd, bd = (t.to(DEV).requires_grad_(True) for t in (x, w, b))
+        yd = run(lambda tape, a, need: E.conv_bn_relu(tape, a[0], wd, bd, None, True, ks, need_dx=need[0], precision=prec),
+                 [xd], [wd, bd])
+        yd.backward(r.to(DEV))
+        err[prec] = (float((yd.detach().cpu().double() - yc.detach()).abs().max()) / float(yc.detach().abs().max()),
+                     float((xd.grad.cpu().double() - xc.grad).abs().max()) / float(xc.grad.abs().max()),
+                     float((wd.grad.cpu().double() - wc.grad).abs().max()) / float(wc.grad.abs().max()))
+    for e6, e32 in zip(err["bf16x6"], err["fp32"]):
+        assert e6 < 2e-6, err                      # ~fp32 rounding level (bf16x3 sits at 1e-5)
+        assert e6 <= 4.0 * e32 + 2e-7, err         # and never far from what the fp32 MFMA path itself achieves

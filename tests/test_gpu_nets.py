@@ -277,3 +277,66 @@ def test_full_size_cubenet64_bf16x3_vs_golden():
         g = float(grads[k].detach().double().norm())
         ref = z["grad_l2"][i]
         assert abs(g - ref) <= 1e-2 * ref + 1e-5, (k, g, ref)
+
+
+X6_CASES = [c for c in CASES if c[0] in ("net_unet3_tiny", "net_cubenet64_tiny", "net_cubenet128_tiny", "net_spectral_f50",
+                                          "net_cubenet128_300_small", "net_unet3_bilinear_tiny")]
+
+
+@pytest.mark.parametrize("name,xseed,xshape,mseed,thr", X6_CASES, ids=[c[0] for c in X6_CASES])
+def test_tiny_net_bf16x6_mode_is_fp32_class(name, xseed, xshape, mseed, thr):
+    """precision="bf16x6" carries every fp32 operand exactly (three bf16 planes) and drops only product terms below
+    2^-24: it must sit as close to the reference fixture as the exact fp32 path does (same 1e-3 / 1e-5 / 4-dp bars) AND
+    within a few fp32 ulps of the exact fp32 path itself -- logits within 2e-5, gradient norms within 5e-4 relative."""
+    import hyperpri_amd as H
+    z = _load(name)
+    net = _mk(name)
+    shapes = OrderedDict((k, tuple(v.shape)) for k, v in net.state_dict().items())
+    sd = O.synth_state_dict(shapes)
+    x = _u(xseed, xshape).to(DEV)
+    mask = (_u(mseed, (xshape[0], 1) + tuple(xshape[-2:])) > thr).float().to(DEV)
+    out = {}
+    for prec in ("fp32", "bf16x6"):
+        net.load_state_dict(sd)
+        net = H.set_precision(net.to(DEV), prec).train()
+        for p in net.parameters():
+            p.grad = None
+        logits = net(x)
+        loss = torch.nn.BCEWithLogitsLoss()(logits, mask)
+        loss.backward()
+        out[prec] = (logits.detach().cpu(), float(loss.detach()), [p.grad.detach().double().norm().item() for p in net.parameters()])
+    lg, loss6, g6 = out["bf16x6"]
+    assert np.abs(lg.numpy() - z["logits"]).max() < 1e-3
+    assert abs(loss6 - float(z["loss"])) < 1e-5
+    acc, dice, iou = O.seg_metrics(lg, mask.cpu())
+    assert round(dice, 4) == round(float(z["dice"]), 4) and round(iou, 4) == round(float(z["iou"]), 4)
+    lg32, loss32, g32 = out["fp32"]
+    assert float((lg - lg32).abs().max()) < 2e-5, float((lg - lg32).abs().max())
+    assert abs(loss6 - loss32) < 2e-6
+    for a, b in zip(g6, g32):
+        assert abs(a - b) <= 5e-4 * b + 1e-7, (a, b)      # tiny nets batch-normalise a handful of values: rounding noise is amplified
+
+
+def test_full_size_cubenet64_bf16x6_vs_golden_and_fp32_path():
+    """BASELINE config C2 at full size in mode bf16x6: the reference fixture's bars, and the distance to the exact path."""
+    import hyperpri_amd as H
+    z = _load("net_cubenet64_full")
+    net = H.CubeNET(238, 1, first_depth=64, bilinear=False)
+    shapes = OrderedDict((k, tuple(v.shape)) for k, v in net.state_dict().items())
+    sd = O.synth_state_dict(shapes)
+    x = _u(1234, (1, 1, 238, 608, 968)).to(DEV)
+    mask = (_u(4321, (1, 1, 608, 968)) > 0.9).float().to(DEV)
+    res = {}
+    for prec in ("fp32", "bf16x6"):
+        net.load_state_dict(sd)
+        net = H.set_precision(net.to(DEV), prec).train()
+        logits = net(x)
+        res[prec] = (logits.detach().cpu(), float(torch.nn.BCEWithLogitsLoss()(logits, mask).detach()))
+    lg, loss = res["bf16x6"]
+    stride = int(z["stride"])
+    assert np.abs(lg.numpy().reshape(-1)[::stride] - z["logits_sub"]).max() < 1e-3
+    assert abs(loss - float(z["loss"])) < 1e-5
+    acc, dice, iou = O.seg_metrics(lg, mask.cpu())
+    assert round(dice, 4) == round(float(z["dice"]), 4) and round(iou, 4) == round(float(z["iou"]), 4)
+    d = float((lg - res["fp32"][0]).abs().max())
+    assert d < 3e-5, d
