@@ -356,17 +356,21 @@ __global__ __launch_bounds__(256, (WM == 2) ? 3 : 2) void conv_fwd_kernel(ConvFw
 // epilogue, but operands are rounded to bf16 while they are staged into LDS and the contraction runs on
 // v_mfma_f32_32x32x16_bf16 (fp32 accumulate, fp32 activations in HBM).  Differences to the fp32 kernel:
 //   * A halo chunk in LDS: [pixel][32 ch bf16 + 8 pad] = 80-byte pitch (conflict-free ds_read_b128 of 8 k-values)
-//   * B panels pre-packed bf16 [tap][n][32 k] (k contiguous per output channel), 80-byte pitch in LDS
+//   * B panels pre-packed bf16 [tap][(plane)][n][32 k] (k contiguous per output channel), brought in by LDS-DMA into an
+//     unpadded, XOR-swizzled 64-byte-pitch layout
 //   * one barrier per KERNEL ROW (KS taps x 32 channels = 6 k16-steps x 4 tiles = 24 MFMAs per wave), because a
 //     bf16 MFMA retires 16x the flops of the fp32 one in half the cycles
-// Only the direct forms (3x3 / 1x1 forward and data gradient); ConvTranspose2d stays on the fp32 kernel.
+//   * workgroup shapes and buffer counts are chosen for residency (three workgroups per CU where LDS allows)
+// All forms of the fp32 kernel (3x3 / 1x1 forward and data gradient, ConvTranspose2d scatter / gather).
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 // SPLIT = 1 is precision mode "bf16x3": every operand is carried as hi = bf16(x) and lo = bf16(x - hi) (16 mantissa
 // bits) and each k16-step issues three MFMAs, hi*hi + hi*lo + lo*hi, into the same fp32 accumulator -- ~4e-5 on the
 // logits instead of bf16's 2e-2, i.e. inside the reference's 1e-3 contract, at 3 bf16 MFMAs per product instead of
-// one 16x slower fp32 MFMA.  Stage = one tap (two planes) instead of one kernel row.
+// one 16x slower fp32 MFMA.  SPLIT = 2 is "bf16x6": three planes hi, mid, lo = the fp32 operand exactly, six MFMAs
+// (all products down to 2^-16 relative; lo*mid, mid*lo, lo*lo < 2^-24 are dropped): fp32-class accuracy.
+// Stage = one tap (all planes) instead of one kernel row.
 // NTW = 32-channel tiles per wave: 2 (wave tile 64 px x 64 ch) or 1 (narrow: 64 px x 32 ch, workgroup 128 px x 64 ch,
 // 40.8 KB of LDS with one stage buffer and ~110 VGPRs: FOUR workgroups per CU)
 template <int KS, int WM, int WN, int AMODE, int EPI, int SPLIT, int NTW>
