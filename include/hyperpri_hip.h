@@ -78,9 +78,10 @@ int hpri_conv_fwd(const float* x, int x_cs, int x_coff, const float* wp, const f
 
 /* bf16-operand variants (precision mode "bf16", BASELINE.json config C5): operands rounded to bf16 while staged into
  * LDS, v_mfma_f32_32x32x16_bf16 with fp32 accumulate, fp32 activations in HBM.  Same modes, plan, workspace and
- * statistics contract as hpri_conv_fwd / hpri_pack_weight.  split = 1 (precision mode "bf16x3"): operands carried as
- * bf16 hi + bf16 lo (16 mantissa bits), three MFMAs per product (hi*hi + hi*lo + lo*hi); the packed weights then hold
- * two planes (twice the size). */
+ * statistics contract as hpri_conv_fwd / hpri_pack_weight (plan: hpri_conv_fwd_bf16_plan).  split = 1 (precision mode
+ * "bf16x3"): operands carried as bf16 hi + bf16 lo (16 mantissa bits), three MFMAs per product (hi*hi + hi*lo + lo*hi);
+ * split = 2 ("bf16x6"): hi + mid + lo = the fp32 operand exactly, six MFMAs per product (fp32-class accuracy); the
+ * packed weights hold split + 1 planes. */
 int hpri_conv_fwd_bf16_plan(int N, int H, int W, int Cin_pad, int Cout_pad, int KS, int amode, int epi, int split,
                             int* ksplit, int* stat_tiles, size_t* ws_floats);
 int hpri_pack_weight_bf16(const float* w, void* wp, int mode, int K, int Ncols, int Ncols_pad, int T, int src_d1,
