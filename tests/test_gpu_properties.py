@@ -249,3 +249,41 @@ def test_xcd_aware_grids_only_reorder_work():
         assert torch.equal(b, c)                                    # still run-to-run deterministic
         assert float((a - b).abs().max()) <= 1e-4 * float(a.abs().max()) + 1e-9
     assert lib.hpri_set_option(b"no_such_option", 1) == -1
+
+
+def test_spectral1650_full_width_properties():
+    """Config C3's network (SpectralUNET, 238 bands, F = 1650) at a quarter of its 608x700 patch: per-image BatchNorm means
+    an image's logits do not depend on what else is in the batch (models.py:132 loops over images) -- bit for bit --,
+    a train step is bit-wise reproducible, and the fp32-emulation mode stays within fp32 rounding of the exact path."""
+    import bench
+    import hyperpri_amd as HP
+    from hyperpri_amd import engine
+    net = HP.SpectralUNET(238, 1, 1650).to(DEV).train()
+    bench.synth_init_(net)
+    hh, ww = 304, 350
+    x = torch.empty((2, 238, hh, ww), device=DEV)
+    m = torch.empty((2, 1, hh, ww), device=DEV)
+    for i in range(2):
+        engine.synth_fill_(x[i], 1234 + i)
+        engine.synth_fill_(m[i], 4321 + i, mode=1, thr=0.9)
+    crit = torch.nn.BCEWithLogitsLoss()
+
+    def step(xx, mm):
+        for p in net.parameters():
+            p.grad = None
+        out = net(xx)
+        crit(out, mm).backward()
+        return out.detach().clone(), [p.grad.clone() for p in net.parameters()]
+    l2, g2 = step(x, m)
+    l2b, g2b = step(x, m)
+    assert torch.equal(l2, l2b) and all(torch.equal(a, b) for a, b in zip(g2, g2b))
+    l1, _ = step(x[:1], m[:1])
+    assert torch.equal(l1[0], l2[0])                      # per-image statistics: batch-independent in TRAIN mode
+    HP.set_precision(net, "bf16x6")
+    l6, g6 = step(x, m)
+    HP.set_precision(net, "fp32")
+    assert float((l6 - l2).abs().max()) < 3e-5
+    for a, b in zip(g6, g2):
+        # nine BatchNorm backward passes amplify rounding differences (the exact path itself sits 2e-3..5e-3 from the fp64
+        # oracle on the tiny SpectralUNET fixtures): relative L2, not element-wise
+        assert float((a - b).norm()) <= 5e-3 * float(b.norm()) + 1e-9
