@@ -286,4 +286,5 @@ def test_spectral1650_full_width_properties():
     for a, b in zip(g6, g2):
         # nine BatchNorm backward passes amplify rounding differences (the exact path itself sits 2e-3..5e-3 from the fp64
         # oracle on the tiny SpectralUNET fixtures): relative L2, not element-wise
-        assert float((a - b).norm()) <= 5e-3 * float(b.norm()) + 1e-9
+        if float(b.norm()) > 1e-6:       # Linear biases in front of BatchNorm: the true gradient is 0, both hold noise
+            assert float((a - b).norm()) <= 5e-3 * float(b.norm()), (float((a - b).norm()), float(b.norm()))
