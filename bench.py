@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """HSI cubes/sec, forward+backward, for the HyperPRI CubeNET-64 hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1: starts its own N ranks, see self_launch)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -47,18 +47,19 @@ def synth_init_(net):
 
 
 def pmc_traffic(tag):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/*_pmc_traffic.json,
-    produced by tools/measure.sh + tools/pmc_traffic.py with the gfx950 FETCH_SIZE correction); None if absent."""
+    """(HBM bytes per launch of the dominant kernel, source file) REPLAYED from the committed PMC passes
+    (profiles/*_pmc_traffic.json, produced by tools/measure.sh + tools/pmc_traffic.py with the gfx950 FETCH_SIZE
+    correction): hardware counters cannot be read from inside this process, so the figure is not measured in this run
+    and the JSON line says which file it came from.  (None, None) if absent."""
     import glob
-    import re
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
     if not files:
-        return None
-    m = re.match(r"(\w+)<(\d),(\dx\d|direct|s2d)", tag)
+        return None, None
     try:
         kern = json.load(open(files[-1]))["kernels"]
     except Exception:
-        return None
+        return None, None
+    src = os.path.relpath(files[-1], ROOT)
     if tag.startswith("conv_fwd<3,2x2"):
         key = "conv_fwd_kernel<3, 2, 2, 0, 0>"
     elif tag.startswith("conv_fwd<3,4x1"):
@@ -66,11 +67,11 @@ def pmc_traffic(tag):
     elif tag.startswith("conv_wgrad<3"):
         key = "conv_wgrad_kernel<3, 1, 1, 0>"
     else:
-        return None
+        return None, src
     for k, v in kern.items():
         if key in k:
-            return round(v["hbm_bytes_per_launch"])
-    return None
+            return round(v["hbm_bytes_per_launch"]), src
+    return None, src
 
 
 def host_cores():
@@ -125,6 +126,61 @@ def cpu_baseline():
                       f"{t:.2f} s/step"}
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(args, argv):
+    """``python bench.py --gpus N`` with no launcher around it: start N ranks with torch.distributed.run as a CHILD
+    process (this parent never touches the GPU, so nothing is exec'ed over an initialised device), relay rank 0's JSON
+    line and exit with the child's code.  Lightning does the same for ``strategy="ddp"`` (PLTrainer.py:434-442)."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__), *argv]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on this host driver (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=None, text=True, env=env)
+    line = None
+    for out in proc.stdout:
+        out = out.rstrip("\n")
+        if out.startswith("{") and '"metric"' in out:
+            line = out
+        elif out:
+            print(out, file=sys.stderr, flush=True)
+    rc = proc.wait()
+    if rc != 0:
+        raise SystemExit(f"bench.py: a rank failed (torch.distributed.run exit code {rc})" if rc > 0 else rc)
+    if line is None:
+        raise SystemExit("bench.py: the ranks finished without printing a result line")
+    print(line, flush=True)
+
+
+def dry_launch_rank():
+    """Launcher rehearsal on CPU (tests/test_bench_launcher.py): gloo ranks, the contract's barrier + max-over-ranks
+    timing around a trivial all-reduce, one JSON line from rank 0.  No GPU work, no claims."""
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    if os.environ.get("HPRI_DRY_LAUNCH_FAIL_RANK") == str(rank):     # tests: a rank that dies before the rendezvous
+        raise SystemExit(3)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.barrier()
+    t0 = time.perf_counter()
+    t = torch.ones(4) * (rank + 1)
+    dist.all_reduce(t)
+    dist.barrier()
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"metric": "launcher rehearsal (no GPU work)", "value": None, "n_gpus": world,
+                          "allreduce_sum": float(t[0]), "seconds": float(dt)}), flush=True)
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -137,13 +193,19 @@ def main():
                          "'bf16_mode', never as 'value'); 0 = skip")
     ap.add_argument("--force-sync", action="store_true",
                     help="rehearsal: run the RCCL GradSync path (process group, hooks, all-reduce) even with one rank")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="launcher rehearsal: the ranks run a gloo all-reduce on the CPU instead of the GPU workload")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args, sys.argv[1:])       # before anything touches the GPU
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.dry_launch:
+        return dry_launch_rank()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_pg = world > 1 or args.force_sync
@@ -194,6 +256,13 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     loss_val = float(loss.detach())
+    grad_sync = None
+    if sync is not None:
+        ov = sync.overlap_ms()           # last timed step: per bucket, all-reduce issue -> finish() return (stream time)
+        grad_sync = {"backend": "nccl (RCCL)", "grad_mb": round(sum(b.flat.numel() for b in sync.buckets) * 4 / 2 ** 20, 1),
+                     "gradients_written_in_place": True, "overlap": ov,
+                     "note": "buckets are issued from inside the backward tape as their last gradient lands; "
+                             "issue_to_finish_ms[0] is the window in which communication ran beside the rest of backward"}
 
     # ---- optimizer step: excluded from the metric, reported beside it ----
     optimizer_step = None
@@ -274,10 +343,12 @@ def main():
         summ = engine.event_log_summary()
         engine.enable_event_log(False)
         dom = max(summ.items(), key=lambda kv: kv[1]["total_ms"])
-        traffic = pmc_traffic(dom[0])
+        traffic, traffic_src = pmc_traffic(dom[0])
         roofline = {"bound": "mfma", "kernel": dom[0], "achieved": round(dom[1]["tflops"], 2),
                     "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(dom[1]["tflops"] / PEAK_F32_MFMA_TFLOPS, 4),
-                    "traffic": traffic, "avg_launch_ms": round(dom[1]["avg_ms"], 4), "launches_per_step": dom[1]["launches"] // 2,
+                    "traffic": traffic, "traffic_source": (f"replayed from {traffic_src} (rocprofv3 --pmc passes of this "
+                                                           "workload, committed; not measured in this run)") if traffic_src else None,
+                    "avg_launch_ms": round(dom[1]["avg_ms"], 4), "launches_per_step": dom[1]["launches"] // 2,
                     "algorithmic_gflop_per_launch": round(dom[1]["flops_per_launch"] / 1e9, 3),
                     "all_mfma_kernels": {k: {"avg_ms": round(v["avg_ms"], 4), "tflops": round(v["tflops"], 2),
                                              "launches_per_step": v["launches"] // 2,
@@ -300,6 +371,8 @@ def main():
                                    "BCEWithLogits, fwd+bwd" + (" + RCCL grad all-reduce" if world > 1 else ""),
                        "global_batch": world * BATCH, "parallelism": f"dp{world}"},
             "loss": round(loss_val, 6),
+            "rccl_ranks": world if use_pg else 0,
+            "grad_sync": grad_sync,
             "model_tflops": round(value * GFLOP_PER_CUBE / 1e3 / world, 2),
             "roofline": roofline, "cpu_baseline": cpu, "optimizer_step": optimizer_step, "bf16x6_mode": bf16x6_mode, "bf16x3_mode": bf16x3_mode, "bf16_mode": bf16_mode,
         }

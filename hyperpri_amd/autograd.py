@@ -31,15 +31,17 @@ def _as4d(t: torch.Tensor) -> torch.Tensor:
 
 class _HipFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, program: Callable, n_in: int, params: Sequence[torch.Tensor], *tensors: torch.Tensor):
+    def forward(ctx, program: Callable, n_in: int, params: Sequence[torch.Tensor], grad_on: bool, *tensors: torch.Tensor):
         with torch.cuda.device(tensors[0].device):      # launches and current_stream() follow the data's device
-            return _HipFn._forward(ctx, program, n_in, params, *tensors)
+            return _HipFn._forward(ctx, program, n_in, params, grad_on, *tensors)
 
     @staticmethod
-    def _forward(ctx, program: Callable, n_in: int, params: Sequence[torch.Tensor], *tensors: torch.Tensor):
+    def _forward(ctx, program: Callable, n_in: int, params: Sequence[torch.Tensor], grad_on: bool, *tensors: torch.Tensor):
         inputs = tensors[:n_in]
-        need = list(ctx.needs_input_grad[3:])
-        record = any(need)
+        need = list(ctx.needs_input_grad[4:])
+        # needs_input_grad is True for trainable parameters even under torch.no_grad() / inference_mode(), and
+        # is_grad_enabled() is always False inside Function.forward: the caller's grad mode is passed in by run()
+        record = grad_on and any(need)
         tape = Tape(record)
         acts: List[Act] = []
         for t in inputs:
@@ -76,7 +78,7 @@ class _HipFn(torch.autograd.Function):
         tape.backward()
         if tape.used_side:
             join_side(gout.device)          # weight gradients issued on the side stream
-        need = ctx.needs_input_grad[3:]
+        need = ctx.needs_input_grad[4:]
         res = []
         for i, a in enumerate(ctx.acts):
             g = tape.grads.get(id(a)) if need[i] else None
@@ -87,11 +89,14 @@ class _HipFn(torch.autograd.Function):
             else:
                 res.append(g.to_nchw().reshape(ctx.in_shapes[i]))
         for j, p in enumerate(ctx.params):
-            res.append(tape.param_grads.get(id(p)) if need[ctx.n_in + j] else None)
+            # gradients the engine wrote into a GradSync bucket are handed over by GradSync.finish(), not by autograd
+            sunk = id(p) in tape.sunk
+            res.append(tape.param_grads.get(id(p)) if (need[ctx.n_in + j] and not sunk) else None)
+        tape.sunk.clear()
         tape.grads.clear()
         tape.param_grads.clear()
         ctx.acts = ctx.params = ctx.out_act = ctx.holder = None
-        return (None, None, None, *res)
+        return (None, None, None, None, *res)
 
 
 def run(program: Callable, inputs: Sequence[torch.Tensor], params: Sequence[torch.Tensor]) -> torch.Tensor:
@@ -106,4 +111,4 @@ def run(program: Callable, inputs: Sequence[torch.Tensor], params: Sequence[torc
             raise RuntimeError("hyperpri_amd: parameters must be contiguous")
     for t in inputs:
         _require_cuda(t, "input tensor")
-    return _HipFn.apply(program, len(inputs), tuple(params), *inputs, *params)
+    return _HipFn.apply(program, len(inputs), tuple(params), torch.is_grad_enabled(), *inputs, *params)

@@ -72,7 +72,8 @@ extern "C" int hpri_pack_weight_scaled(const float* w, float* wp, const float* c
 // split = 1 (mode "bf16x3"): two planes per tap, [chunk][tap][plane][Ncols_pad][32]: hi = bf16(w), lo = bf16(w - hi);
 // split = 2 (mode "bf16x6"): three planes hi, mid, lo (24 mantissa bits: the fp32 value exactly)
 __global__ void pack_weight_bf16_kernel(const float* __restrict__ w, __bf16* __restrict__ wp, int mode, int K, int Ncols,
-                                        int Ncols_pad, int T, int chunks, int src_d1, int Cup, int split) {
+                                        int Ncols_pad, int T, int chunks, int src_d1, int Cup, int split,
+                                        const float* __restrict__ colscale) {
   const size_t total = (size_t)chunks * T * Ncols_pad * 32;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
     const int kk = (int)(idx & 31);
@@ -87,6 +88,7 @@ __global__ void pack_weight_bf16_kernel(const float* __restrict__ w, __bf16* __r
       else if (mode == 1) v = w[((size_t)k * src_d1 + col) * T + (T - 1 - t)];
       else if (mode == 2) { const int tap = col / Cup, co = col - tap * Cup; v = w[((size_t)k * Cup + co) * 4 + tap]; }
       else { const int tap = k / Cup, co = k - tap * Cup; v = w[((size_t)col * Cup + co) * 4 + tap]; }
+      if (colscale != nullptr) v *= colscale[col];     // eval-mode BN folded into the conv (scaled in fp32, then split)
     }
     if (!split) {
       wp[idx] = (__bf16)v;
@@ -115,7 +117,24 @@ extern "C" int hpri_pack_weight_bf16(const float* w, void* wp, int mode, int K, 
   int blocks = (int)((total + 255) / 256);
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(pack_weight_bf16_kernel, dim3(blocks), dim3(256), 0, stream, w, reinterpret_cast<__bf16*>(wp), mode, K,
-                     Ncols, Ncols_pad, T, chunks, src_d1, Cup, split);
+                     Ncols, Ncols_pad, T, chunks, src_d1, Cup, split, (const float*)nullptr);
+  HPRI_CHECK_LAUNCH();
+  return HPRI_OK;
+}
+
+// Forward pack (mode 0) in the bf16 plane layouts with a per-output-channel scale: eval-mode BN folded into the conv
+// for the bf16 / bf16x3 / bf16x6 predict path (PLTrainer.py:530-532).
+extern "C" int hpri_pack_weight_bf16_scaled(const float* w, void* wp, const float* colscale, int K, int Ncols, int Ncols_pad,
+                                            int T, int src_d1, int split, hipStream_t stream) {
+  HPRI_REQUIRE(w && wp && colscale, "pack_weight_bf16_scaled: null pointer");
+  HPRI_REQUIRE(K > 0 && Ncols > 0 && Ncols_pad >= Ncols && Ncols_pad % 64 == 0, "pack_weight_bf16_scaled: bad arguments");
+  HPRI_REQUIRE(split >= 0 && split <= 2, "pack_weight_bf16_scaled: split must be 0, 1 or 2");
+  const int chunks = hpri_cdiv(K, 32);
+  const size_t total = (size_t)chunks * T * Ncols_pad * 32;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(pack_weight_bf16_kernel, dim3(blocks), dim3(256), 0, stream, w, reinterpret_cast<__bf16*>(wp), 0, K,
+                     Ncols, Ncols_pad, T, chunks, src_d1, 0, split, colscale);
   HPRI_CHECK_LAUNCH();
   return HPRI_OK;
 }

@@ -3,23 +3,33 @@
 The reference trains with Lightning ``strategy="ddp"`` (PLTrainer.py:434-442): one process per GPU,
 per-rank batch 2, un-synced BatchNorm, gradients averaged by an all-reduce.  The modules here are
 ordinary ``nn.Module``s, so stock ``DistributedDataParallel`` works unchanged; ``GradSync`` is the
-MI355X-shaped equivalent used by bench.py: parameters are grouped into a few large flat buckets in
-reverse registration order (= the order backward produces them), and as soon as the last gradient of
-a bucket lands its all-reduce is issued asynchronously on RCCL's stream (backend "nccl" is RCCL on
-ROCm; xGMI is point-to-point, so few large messages beat many small ones).  ``finish()`` waits,
-averages and hands the reduced values back as ``param.grad``.
-Works with any backend (``gloo`` on CPU for tests).
+MI355X-shaped equivalent used by bench.py:
+
+* parameters are grouped into a few large flat buckets in reverse registration order (= the order
+  backward produces them; xGMI is point-to-point, so few large messages beat many small ones);
+* the buckets ARE the gradient storage: ``GradSync`` registers itself as the engine's gradient sink, so the
+  weight-gradient kernels write straight into their slice of a bucket (no per-tensor copy), and the tape tells
+  the sink the moment a parameter's gradient is final -- also when the whole network runs as ONE autograd node;
+* as soon as the last gradient of a bucket has landed its all-reduce is issued asynchronously on RCCL's
+  stream (backend "nccl" is RCCL on ROCm), overlapping the rest of backward; ``finish()`` waits, averages
+  and installs the bucket views as ``param.grad``.
+
+Gradients that reach a parameter through plain autograd (a foreign module, a CPU test) arrive through a
+post-accumulate-grad hook and are copied into the bucket instead.  Works with any backend (``gloo`` on CPU).
 """
 from __future__ import annotations
 
-from typing import List, Optional
+import contextlib
+from typing import Dict, List, Optional, Tuple
 
 import torch
 import torch.distributed as dist
 
+from . import engine
+
 
 class _Bucket:
-    __slots__ = ("params", "offsets", "flat", "pending", "work")
+    __slots__ = ("params", "offsets", "flat", "pending", "work", "landed", "t_issue")
 
     def __init__(self, params: List[torch.nn.Parameter]):
         self.params = params
@@ -27,10 +37,16 @@ class _Bucket:
         n = 0
         for p in params:
             self.offsets.append(n)
-            n += p.numel()
+            n += (p.numel() + 3) // 4 * 4          # 16-byte aligned slices: the HIP kernels store float4
         self.flat = torch.zeros(n, dtype=params[0].dtype, device=params[0].device)
         self.pending = len(params)
         self.work = None
+        self.landed: set = set()
+        self.t_issue = None
+
+    def view(self, i: int) -> torch.Tensor:
+        p = self.params[i]
+        return self.flat[self.offsets[i]:self.offsets[i] + p.numel()].view_as(p)
 
 
 class GradSync:
@@ -52,7 +68,7 @@ class GradSync:
                 cur, size = [], 0
         if cur:
             self.buckets.append(_Bucket(cur))
-        self._where = {}
+        self._where: Dict[int, Tuple[_Bucket, int]] = {}
         self._hooks = []
         for b in self.buckets:
             for i, p in enumerate(b.params):
@@ -60,6 +76,11 @@ class GradSync:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
         self.module = module
         self.broadcast_buffers = broadcast_buffers
+        self._accumulating = False      # inside no_sync(): gradients add up locally, no collective
+        self._micro = 0                 # backward passes since the last finish()
+        self._direct: set = set()       # ids of parameters whose gradient the engine wrote into the bucket this step
+        self._events = None             # (per-bucket issue events, end-of-finish event) of the last step
+        engine.set_grad_sink(self)
 
     # torch DDP broadcasts BN buffers from rank 0 every forward (broadcast_buffers=True default);
     # call this before eval/checkpoint to mimic it
@@ -68,34 +89,115 @@ class GradSync:
             for b in self.module.buffers():
                 dist.broadcast(b, 0, group=self.group)
 
-    def _on_grad(self, p: torch.Tensor) -> None:
+    @contextlib.contextmanager
+    def no_sync(self):
+        """Gradient accumulation: backward passes inside this context add into the buckets without communicating;
+        the first backward after it (followed by ``finish()``) reduces the sum -- torch DDP's ``no_sync`` semantics."""
+        old = self._accumulating
+        self._accumulating = True
+        try:
+            yield
+        finally:
+            self._accumulating = old
+
+    # ---- engine gradient sink -------------------------------------------------------------------------------------
+    def slot(self, p: torch.Tensor):
+        """Storage for p's gradient inside its bucket and whether the kernel must add to what is there."""
+        w = self._where.get(id(p))
+        if w is None:
+            return None
+        b, i = w
+        self._guard(b, i)
+        self._direct.add(id(p))
+        return b.view(i), (self._micro > 0)
+
+    def ready(self, p: torch.Tensor) -> None:
         b, i = self._where[id(p)]
-        n = p.numel()
-        b.flat[b.offsets[i]:b.offsets[i] + n].copy_(p.grad.reshape(-1))
+        self._landed(b, i)
+
+    # ---- plain autograd path ----------------------------------------------------------------------------------------
+    def _on_grad(self, p: torch.Tensor) -> None:
+        if id(p) in self._direct:
+            return
+        b, i = self._where[id(p)]
+        self._guard(b, i)
+        v = b.view(i)
+        if p.grad.data_ptr() != v.data_ptr():     # (p.grad may BE the view: installed by the previous finish())
+            v.copy_(p.grad)                       # with micro-batches autograd has already summed them into p.grad
+        self._landed(b, i)
+
+    def _guard(self, b: _Bucket, i: int) -> None:
+        if b.work is not None or i in b.landed:
+            raise RuntimeError(
+                "hyperpri_amd.GradSync: a second backward reached a bucket whose all-reduce is already issued. "
+                "Call finish() after every backward, or wrap all but the last micro-batch in `with sync.no_sync():`.")
+
+    def _landed(self, b: _Bucket, i: int) -> None:
+        b.landed.add(i)
         b.pending -= 1
-        if b.pending == 0 and self.collective:
-            b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        if b.pending == 0 and self.collective and not self._accumulating:
+            self._issue(b)
+
+    def _issue(self, b: _Bucket) -> None:
+        if b.flat.is_cuda:
+            b.t_issue = torch.cuda.Event(enable_timing=True)
+            b.t_issue.record()
+        b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def end_micro_batch(self) -> None:
+        """Close an accumulation micro-batch (called by the user after each backward inside ``no_sync``)."""
+        for b in self.buckets:
+            b.pending = len(b.params)
+            b.landed.clear()
+        self._direct.clear()
+        self._micro += 1
 
     def finish(self) -> None:
         """Wait for the outstanding all-reduces and install the averaged gradients."""
+        if self._accumulating:
+            self.end_micro_batch()
+            return
         for b in self.buckets:
             if b.pending != 0:
-                # parameters that got no gradient this step contribute zeros
-                for i, p in enumerate(b.params):
-                    if p.grad is None:
-                        b.flat[b.offsets[i]:b.offsets[i] + p.numel()].zero_()
+                # parameters that got no gradient this step contribute zeros (unless earlier micro-batches did)
+                if self._micro == 0:
+                    for i, p in enumerate(b.params):
+                        if i not in b.landed:
+                            b.view(i).zero_()
                 if self.collective and b.work is None:
-                    b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                    self._issue(b)
             if b.work is not None:
                 b.work.wait()
                 b.work = None
             if self.world > 1:
                 b.flat.div_(self.world)
             for i, p in enumerate(b.params):
-                p.grad = b.flat[b.offsets[i]:b.offsets[i] + p.numel()].view_as(p)
+                p.grad = b.view(i)
             b.pending = len(b.params)
+            b.landed.clear()
+        firsts = [b.t_issue for b in self.buckets if b.t_issue is not None]
+        if firsts:
+            t_end = torch.cuda.Event(enable_timing=True)
+            t_end.record()
+            self._events = (firsts, t_end)
+        for b in self.buckets:
+            b.t_issue = None
+        self._direct.clear()
+        self._micro = 0
+
+    def overlap_ms(self) -> Optional[dict]:
+        """After a device sync: per-bucket time from the issue of its all-reduce to the return of ``finish()``
+        (stream time on the compute stream; the first entry is the window in which communication ran beside backward)."""
+        ev = self._events
+        if not ev:
+            return None
+        firsts, t_end = ev
+        return {"buckets": len(self.buckets), "bucket_mb": [round(b.flat.numel() * 4 / 2 ** 20, 1) for b in self.buckets],
+                "issue_to_finish_ms": [round(e.elapsed_time(t_end), 3) for e in firsts]}
 
     def remove(self) -> None:
         for h in self._hooks:
             h.remove()
         self._hooks.clear()
+        if engine._GRAD_SINK is self:
+            engine.set_grad_sink(None)

@@ -133,6 +133,7 @@ class Tape:
         self.param_grads: Dict[int, torch.Tensor] = {}
         self.keep: List[object] = []
         self.used_side = False
+        self.sunk: Dict[int, torch.Tensor] = {}     # parameters whose gradient was written into the grad sink's storage
 
     def grad_slot(self, a: Act) -> Tuple[Act, bool]:
         """(gradient view for ``a``, accumulate?) -- allocates a fresh buffer the first time."""
@@ -156,13 +157,29 @@ class Tape:
         g = self.param_grads.get(id(p))
         if g is not None:
             return g, 1
+        acc = 0
+        sink = _GRAD_SINK
+        if sink is not None:
+            got = sink.slot(p)             # (view of a flat all-reduce bucket, accumulate?) or None
+            if got is not None:
+                g, acc = got
+                self.param_grads[id(p)] = g
+                self.sunk[id(p)] = p
+                return g, int(acc)
         g = torch.empty(p.shape, dtype=torch.float32, device=p.device)
         self.param_grads[id(p)] = g
         return g, 0
 
     def backward(self) -> None:
+        sink = _GRAD_SINK
+        seen = 0
         for node in reversed(self.nodes):
             node(self)
+            if sink is not None and len(self.sunk) > seen:
+                # every parameter belongs to exactly one op, so its gradient is final once that op's node has run
+                for p in list(self.sunk.values())[seen:]:
+                    sink.ready(p)
+                seen = len(self.sunk)
         self.nodes.clear()
         self.keep.clear()
 
@@ -251,21 +268,82 @@ def _ws(nfloats: int, device) -> torch.Tensor:
     return torch.empty(max(int(nfloats), 4), dtype=torch.float32, device=device)
 
 
+# ---- gradient sink (ddp.GradSync): parameter gradients are written straight into flat all-reduce buckets -------------
+# sink.slot(p) -> (tensor shaped like p inside a bucket, accumulate?) or None;  sink.ready(p) is called from the tape as
+# soon as p's gradient is final, so the bucket's RCCL all-reduce overlaps the rest of backward.
+_GRAD_SINK = None
+
+
+def set_grad_sink(sink) -> None:
+    global _GRAD_SINK
+    _GRAD_SINK = sink
+
+
+# ---- packed-weight cache ------------------------------------------------------------------------------------------------
+# The MFMA panel layouts are derived copies of the nn.Parameters.  They are rebuilt only when a parameter
+# changes: the key holds the tensor's version counter (bumped by every in-place torch op: optimizer steps, copy_,
+# load_state_dict), its data pointer, and _PARAM_EPOCH, which our own raw-pointer writers (FusedAdam / FusedSGD,
+# synth_fill_) bump because they bypass the version counter.
+_PARAM_EPOCH = 0
+_BN_EPOCH = 0               # bumped whenever a training-mode forward updates running statistics (raw-pointer writes)
+_PACK_CACHE: Dict[int, Dict[tuple, tuple]] = {}
+PACK_CACHE = True
+PACK_LAUNCHES = 0           # pack kernels launched (tests / profiles)
+
+
+def bump_param_epoch() -> None:
+    """Tell the engine that parameter memory was modified behind torch's back (raw-pointer kernels)."""
+    global _PARAM_EPOCH
+    _PARAM_EPOCH += 1
+
+
+def _cached_pack(w: torch.Tensor, key: tuple, build, extra=None):
+    """``extra``: further state the packed copy depends on (BN statistics of a folded conv); a mismatch rebuilds."""
+    if not PACK_CACHE:
+        return build()
+    ent = _PACK_CACHE.get(id(w))
+    try:
+        ver = w._version
+    except RuntimeError:        # inference tensors carry no version counter: never cache them
+        return build()
+    stamp = (w.data_ptr(), ver, _PARAM_EPOCH)
+    if ent is None or ent["stamp"] != stamp:
+        if ent is None:
+            import weakref
+            wid = id(w)
+            weakref.finalize(w, _PACK_CACHE.pop, wid, None)
+        ent = _PACK_CACHE[id(w)] = {"stamp": stamp, "packs": {}}
+    got = ent["packs"].get(key)
+    if got is None or got[0] != extra:
+        got = ent["packs"][key] = (extra, build())
+    return got[1]
+
+
 def _pack(w: torch.Tensor, mode: int, K: int, ncols: int, T: int, cup: int, d1: int) -> Tuple[torch.Tensor, int]:
     ncols_pad = _rup(ncols, 64)
-    n = _lib.load().hpri_packed_weight_floats(K, ncols_pad, T)
-    wp = torch.empty(n, dtype=torch.float32, device=w.device)
-    _lib.call("hpri_pack_weight", _p(w), _p(wp), mode, K, ncols, ncols_pad, T, cup, 0, d1, _stream())
-    return wp, ncols_pad
+
+    def build():
+        global PACK_LAUNCHES
+        n = _lib.load().hpri_packed_weight_floats(K, ncols_pad, T)
+        wp = torch.empty(n, dtype=torch.float32, device=w.device)
+        _lib.call("hpri_pack_weight", _p(w), _p(wp), mode, K, ncols, ncols_pad, T, cup, 0, d1, _stream())
+        PACK_LAUNCHES += 1
+        return wp
+    return _cached_pack(w, ("f32", mode, K, ncols, T, cup, d1), build), ncols_pad
 
 
 def _pack_bf16(w: torch.Tensor, mode: int, K: int, ncols: int, T: int, d1: int, cup: int = 0,
                split: int = 0) -> Tuple[torch.Tensor, int]:
     ncols_pad = _rup(ncols, 64)
-    chunks = (K + 31) // 32
-    wp = torch.empty(chunks * T * ncols_pad * 32 * (split + 1), dtype=torch.bfloat16, device=w.device)
-    _lib.call("hpri_pack_weight_bf16", _p(w), _p(wp), mode, K, ncols, ncols_pad, T, d1, cup, split, _stream())
-    return wp, ncols_pad
+
+    def build():
+        global PACK_LAUNCHES
+        chunks = (K + 31) // 32
+        wp = torch.empty(chunks * T * ncols_pad * 32 * (split + 1), dtype=torch.bfloat16, device=w.device)
+        _lib.call("hpri_pack_weight_bf16", _p(w), _p(wp), mode, K, ncols, ncols_pad, T, d1, cup, split, _stream())
+        PACK_LAUNCHES += 1
+        return wp
+    return _cached_pack(w, ("bf16", mode, K, ncols, T, d1, cup, split), build), ncols_pad
 
 
 def _conv_launch_bf16(x: Act, wp: torch.Tensor, bias: Optional[torch.Tensor], y: Act, stats: Optional[torch.Tensor],
@@ -319,11 +397,11 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
     if cin != x.C:
         raise RuntimeError(f"hyperpri_amd: conv expects {cin} input channels, got {x.C}")
     cin_pad = x.cw
-    if bn is not None and not train and not tape.record and (precision or DEFAULT_PRECISION) == "fp32" and FOLD_EVAL_BN:
-        return _conv_folded_eval(x, weight, bias, bn, ks, cin, cout, relu)
     prec = precision or DEFAULT_PRECISION
     if prec not in PRECISIONS:
         raise RuntimeError(f"hyperpri_amd: unknown precision {prec!r}; choose from {PRECISIONS}")
+    if bn is not None and not train and not tape.record and FOLD_EVAL_BN:
+        return _conv_folded_eval(x, weight, bias, bn, ks, cin, cout, relu, prec)
     lowp = prec in LOWP
     split = _SPLIT.get(prec, 0)
     if lowp:
@@ -361,6 +439,8 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
         st = torch.empty(5 * G * cout, dtype=torch.float32, device=dev)   # mean, invstd, var_unbiased, scale, shift
         mean, invstd, varu, scale, shift = (st[i * G * cout:(i + 1) * G * cout] for i in range(5))
         if use_batch:
+            global _BN_EPOCH
+            _BN_EPOCH += 1
             _lib.call("hpri_bn_finalize", _p(stats), tiles // G, G, cout_pad, cout, _p(bn.weight), _p(bn.bias),
                       bn.eps, bn.momentum, _p(mean), _p(invstd), _p(varu), _p(scale), _p(shift),
                       _p(bn.running_mean), _p(bn.running_var), _p(bn.num_batches_tracked), _stream())
@@ -429,24 +509,53 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
 
 
 FOLD_EVAL_BN = True   # inference only (no tape): conv + eval-mode BN + ReLU as ONE kernel with BN folded into w and b
+FOLD_LAUNCHES = 0     # folded conv+BN+ReLU stages executed (tests assert that the predict path really takes them)
 
 
 def _conv_folded_eval(x: Act, weight: torch.Tensor, bias: Optional[torch.Tensor], bn: BNRef, ks: int, cin: int, cout: int,
-                      relu: bool) -> Act:
+                      relu: bool, prec: str = "fp32") -> Act:
     """Eval-mode Conv -> BatchNorm -> ReLU (running statistics) without the normalise pass: w' = w*gamma/sqrt(var+eps),
     b' = (b-mean)*gamma/sqrt(var+eps)+beta, ReLU in the conv epilogue.  Used when nothing is recorded for backward
     (torch.no_grad / inference_mode: PLTrainer.py:530,626)."""
+    global FOLD_LAUNCHES
+    FOLD_LAUNCHES += 1
     dev = x.buf.device
     T = ks * ks
-    fold = torch.empty(2 * cout, dtype=torch.float32, device=dev)
-    scale, fbias = fold[:cout], fold[cout:]
-    _lib.call("hpri_bn_fold", _p(bn.running_mean), _p(bn.running_var), _p(bn.weight), _p(bn.bias), _p(bias), bn.eps, cout,
-              _p(scale), _p(fbias), _stream())
     cout_pad = _rup(cout, 64)
-    wp = torch.empty(_lib.load().hpri_packed_weight_floats(cin, cout_pad, T), dtype=torch.float32, device=dev)
-    _lib.call("hpri_pack_weight_scaled", _p(weight), _p(wp), _p(scale), cin, cout, cout_pad, T, cin, _stream())
+    lowp = prec in LOWP
+    split = _SPLIT.get(prec, 0)
+
+    def build():
+        global PACK_LAUNCHES
+        PACK_LAUNCHES += 1
+        fold = torch.empty(2 * cout, dtype=torch.float32, device=dev)
+        _lib.call("hpri_bn_fold", _p(bn.running_mean), _p(bn.running_var), _p(bn.weight), _p(bn.bias), _p(bias), bn.eps, cout,
+                  _p(fold[:cout]), _p(fold[cout:]), _stream())
+        if lowp:   # bf16 / bf16x3 / bf16x6 predict path: the same fold, weights scaled in fp32 and then rounded / split
+            wp = torch.empty(((cin + 31) // 32) * T * cout_pad * 32 * (split + 1), dtype=torch.bfloat16, device=dev)
+            _lib.call("hpri_pack_weight_bf16_scaled", _p(weight), _p(wp), _p(fold[:cout]), cin, cout, cout_pad, T, cin, split,
+                      _stream())
+        else:
+            wp = torch.empty(_lib.load().hpri_packed_weight_floats(cin, cout_pad, T), dtype=torch.float32, device=dev)
+            _lib.call("hpri_pack_weight_scaled", _p(weight), _p(wp), _p(fold[:cout]), cin, cout, cout_pad, T, cin, _stream())
+        return wp, fold
+
+    def ver(t):
+        try:
+            return (t.data_ptr(), t._version)
+        except RuntimeError:
+            return (t.data_ptr(), -1)
+    bn_state = (_BN_EPOCH, ver(bn.running_mean), ver(bn.running_var), ver(bn.weight), ver(bn.bias),
+                None if bias is None else ver(bias))
+    wp, fold = _cached_pack(weight, ("fold", prec, ks), build, extra=bn_state)
+    fbias = fold[cout:]
     y = Act.new(x.N, x.H, x.W, cout, dev)
-    _conv_launch(x, wp, fbias, y, None, x.N, x.H, x.W, x.cw, cout, cout_pad, y.cw, ks, accumulate=2 if relu else 0, cin_true=cin)
+    if lowp:
+        _conv_launch_bf16(x, wp, fbias, y, None, x.N, x.H, x.W, x.cw, cout, cout_pad, y.cw, ks, accumulate=2 if relu else 0,
+                          cin_true=cin, split=split)
+    else:
+        _conv_launch(x, wp, fbias, y, None, x.N, x.H, x.W, x.cw, cout, cout_pad, y.cw, ks, accumulate=2 if relu else 0,
+                     cin_true=cin)
     return y
 
 
@@ -716,4 +825,5 @@ def synth_fill_(t: torch.Tensor, seed: int, mode: int = 0, thr: float = 0.0, sca
     if not t.is_contiguous():
         raise RuntimeError("synth_fill_: tensor must be contiguous")
     _lib.call("hpri_synth_fill", _p(t), t.numel(), seed % (1 << 64), mode, thr, scale, _stream())
+    bump_param_epoch()          # t may be parameter storage
     return t

@@ -69,8 +69,13 @@ class CubeStager:
         self._next = 0
 
     def host_slot(self, slot: Optional[int] = None) -> np.ndarray:
-        """The pinned (N,H,W,B) staging array of the slot the next ``submit()`` will send -- fill it in place."""
-        return self._host[self._next if slot is None else slot].numpy()
+        """The pinned (N,H,W,B) staging array of the slot the next ``submit()`` will send -- fill it in place.
+        Blocks until that slot's previous host-to-device copy has finished reading it (every other wait of the stager is
+        GPU-side, so without this a host loop that never synchronises could overwrite a slot whose DMA is still queued)."""
+        k = self._next if slot is None else slot
+        if self._ready[k] is not None:
+            self._ready[k].synchronize()
+        return self._host[k].numpy()
 
     def submit(self) -> torch.Tensor:
         """Send the current slot; returns the device view.  The caller's current stream waits for the transfer; the
@@ -103,12 +108,23 @@ class CubeStager:
         if self.unsqueeze:
             x = x.unsqueeze(1)                                   # (N,1,C,H,W) as dataset.py:269-270
         x._hpri_zero_padded = True
+        x._hpri_slot = k
         return x
 
-    def release(self, slot_tensor: Optional[torch.Tensor] = None) -> None:
-        """Mark the most recently submitted slot as consumed up to this point of the current stream (call it after
-        the step that used it has been enqueued, e.g. after ``loss.backward()``)."""
-        k = (self._next - 1) % self.slots
+    def release(self, slot_tensor=None) -> None:
+        """Mark a slot as consumed up to this point of the current stream (call it after the step that used it has been
+        enqueued, e.g. after ``loss.backward()``).  ``slot_tensor`` is the tensor ``submit()`` returned (or its slot
+        index); without it the most recently submitted slot is meant."""
+        if slot_tensor is None:
+            k = (self._next - 1) % self.slots
+        elif isinstance(slot_tensor, int):
+            k = slot_tensor
+        else:
+            k = getattr(slot_tensor, "_hpri_slot", None)
+            if k is None:
+                raise ValueError("CubeStager.release: not a tensor returned by submit()")
+        if not 0 <= k < self.slots:
+            raise ValueError(f"CubeStager.release: slot {k} out of range")
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(self.device))
         self._consumed[k] = ev

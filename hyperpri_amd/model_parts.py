@@ -23,6 +23,15 @@ def _double_conv_ops(tape, x, seq, train, need_dx=True, precision=None):
     return E.conv_bn_relu(tape, h, seq[3].weight, seq[3].bias, E.BNRef(seq[4]), train, 3, precision=precision)
 
 
+def has_hooks(module):
+    """True when any sub-module carries forward hooks: the networks then call their children one by one (each its own
+    autograd node, hooks fire as in the reference) instead of running as one fused tape."""
+    for m in module.modules():
+        if m is not module and (m._forward_hooks or m._forward_pre_hooks or m._backward_hooks or m._backward_pre_hooks):
+            return True
+    return False
+
+
 def set_precision(module, precision):
     """Select the contraction arithmetic ("fp32" exact, default | "bf16" MFMA) for ``module`` and all its children.
     Not part of the reference API; the default keeps the reference's fp32 semantics."""
@@ -58,9 +67,11 @@ class Down(nn.Module):
         super().__init__()
         self.maxpool_conv = nn.Sequential(nn.MaxPool2d(2), DoubleConv(in_channels, out_channels))
 
+    def _ops(self, tape, x):
+        return self.maxpool_conv[1]._ops(tape, E.maxpool2(tape, x))
+
     def forward(self, x):
-        dc = self.maxpool_conv[1]
-        return run(lambda tape, a, need: dc._ops(tape, E.maxpool2(tape, a[0])), [x], list(self.parameters()))
+        return run(lambda tape, a, need: self._ops(tape, a[0]), [x], list(self.parameters()))
 
 
 class Up(nn.Module):
@@ -82,15 +93,15 @@ class Up(nn.Module):
             self.up = nn.ConvTranspose2d(in_channels, in_channels // 2, kernel_size=2, stride=2)
             self.conv = DoubleConv(in_channels // 2 if use_attention else in_channels, out_channels)
 
-    def forward(self, x1, x2):
+    def _ops(self, tape, x1, x2, need_dx1=True):
         w = None if self.bilinear else self.up.weight
         b = None if self.bilinear else self.up.bias
         join = E.up_attention if self.use_attention else E.up_concat
+        return self.conv._ops(tape, join(tape, x1, x2, w, b, need_dx1=need_dx1,
+                                         precision=getattr(self, "hpri_precision", None)))
 
-        def prog(tape, a, need):
-            return self.conv._ops(tape, join(tape, a[0], a[1], w, b, need_dx1=need[0],
-                                              precision=getattr(self, "hpri_precision", None)))
-        return run(prog, [x1, x2], list(self.parameters()))
+    def forward(self, x1, x2):
+        return run(lambda tape, a, need: self._ops(tape, a[0], a[1], need[0]), [x1, x2], list(self.parameters()))
 
 
 class OutConv(nn.Module):
@@ -100,6 +111,8 @@ class OutConv(nn.Module):
         super(OutConv, self).__init__()
         self.conv = nn.Conv2d(in_channels, out_channels, kernel_size=1)
 
+    def _ops(self, tape, x, need_dx=True):
+        return E.out_conv(tape, x, self.conv.weight, self.conv.bias, need_dx)
+
     def forward(self, x):
-        return run(lambda tape, a, need: E.out_conv(tape, a[0], self.conv.weight, self.conv.bias, need[0]),
-                   [x], list(self.parameters()))
+        return run(lambda tape, a, need: self._ops(tape, a[0], need[0]), [x], list(self.parameters()))

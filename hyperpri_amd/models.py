@@ -12,7 +12,7 @@ import torch.nn.functional as F
 from . import engine as E
 from .autograd import run
 from .model_parts import *  # noqa: F401,F403  (the reference's callers star-import everything)
-from .model_parts import DoubleConv, Down, OutConv, Up
+from .model_parts import DoubleConv, Down, OutConv, Up, has_hooks
 
 
 def set_parameter_requires_grad(model, feature_extraction):
@@ -40,17 +40,37 @@ class UNet(nn.Module):
         self.up4 = Up(w[1], w[0] * factor, bilinear, use_attention=use_attention)
         self.outc = OutConv(w[0], n_classes)
 
+    # One autograd node for the whole network (default): the skip tensors x1..x4 feed two consumers each, and inside
+    # one tape their two gradient contributions are summed by the HIP kernels (accumulating epilogues) instead of by
+    # autograd's ATen add.  ``fused_tape = False`` (or forward hooks on a child) calls the children one by one, each its
+    # own node -- what a foreign composition of these modules gets anyway.
+    fused_tape = True
+
     def forward(self, x):
-        x1 = self.inc(x)
-        x2 = self.down1(x1)
-        x3 = self.down2(x2)
-        x4 = self.down3(x3)
-        x5 = self.down4(x4)
-        y = self.up1(x5, x4)
-        y = self.up2(y, x3)
-        y = self.up3(y, x2)
-        y = self.up4(y, x1)
-        logits = self.outc(y)
+        if self.fused_tape and not has_hooks(self):
+            def prog(tape, a, need):
+                x1 = self.inc._ops(tape, a[0], need[0])
+                x2 = self.down1._ops(tape, x1)
+                x3 = self.down2._ops(tape, x2)
+                x4 = self.down3._ops(tape, x3)
+                x5 = self.down4._ops(tape, x4)
+                y = self.up1._ops(tape, x5, x4)
+                y = self.up2._ops(tape, y, x3)
+                y = self.up3._ops(tape, y, x2)
+                y = self.up4._ops(tape, y, x1)
+                return self.outc._ops(tape, y)
+            logits = run(prog, [x], list(self.parameters()))
+        else:
+            x1 = self.inc(x)
+            x2 = self.down1(x1)
+            x3 = self.down2(x2)
+            x4 = self.down3(x3)
+            x5 = self.down4(x4)
+            y = self.up1(x5, x4)
+            y = self.up2(y, x3)
+            y = self.up3(y, x2)
+            y = self.up4(y, x1)
+            logits = self.outc(y)
         if self.analyze:
             return (logits, logits, torch.sigmoid(logits))
         return logits
@@ -140,38 +160,59 @@ class CubeNET(torch.nn.Module):
             self.upconv4 = DoubleConv(64 + first_depth, 64)
         self.outc = OutConv(64, self.n_classes)
 
+    def _stem_ops(self, tape, x, need_dx):
+        prec = getattr(self, "hpri_precision", None)
+        h = E.conv_bn_relu(tape, x, self.first_conv.weight, self.first_conv.bias, E.BNRef(self.inc[1]),
+                           self.training, 3, need_dx=need_dx, precision=prec)
+        return E.conv_bn_relu(tape, h, self.inc2[0].weight, self.inc2[0].bias, E.BNRef(self.inc2[1]),
+                              self.training, 3, precision=prec)
+
     def _stem(self, x):
-        def prog(tape, a, need):
-            prec = getattr(self, "hpri_precision", None)
-            h = E.conv_bn_relu(tape, a[0], self.first_conv.weight, self.first_conv.bias, E.BNRef(self.inc[1]),
-                               self.training, 3, need_dx=need[0], precision=prec)
-            return E.conv_bn_relu(tape, h, self.inc2[0].weight, self.inc2[0].bias, E.BNRef(self.inc2[1]),
-                                  self.training, 3, precision=prec)
         params = list(self.inc.parameters()) + list(self.inc2.parameters())
-        return run(prog, [x], params)
+        return run(lambda tape, a, need: self._stem_ops(tape, a[0], need[0]), [x], params)
+
+    def _up4_ops(self, tape, y, x1, need_dx1=True):
+        """Last decoder stage: ``up4`` (first_depth 64) or the inline upsample4 -> pad -> cat -> upconv4 (models.py:229-240)."""
+        if self.first_depth == 64:
+            return self.up4._ops(tape, y, x1, need_dx1)
+        w4 = None if self.bilinear else self.upsample4.weight
+        b4 = None if self.bilinear else self.upsample4.bias
+        cat = E.up_concat(tape, y, x1, w4, b4, need_dx1=need_dx1, precision=getattr(self, "hpri_precision", None))
+        return self.upconv4._ops(tape, cat)
+
+    fused_tape = True       # see UNet.fused_tape
 
     def forward(self, x):
         if x.dim() != 5 or x.shape[2] != self.depth:
             raise ValueError(f"CubeNET expects (N,1,{self.depth},R,C), got {tuple(x.shape)}")
-        x1 = self._stem(x)
-        x2 = self.down1(x1)
-        x3 = self.down2(x2)
-        x4 = self.down3(x3)
-        x5 = self.down4(x4)
-        y = self.up1(x5, x4)
-        y = self.up2(y, x3)
-        y = self.up3(y, x2)
-        if self.first_depth == 64:
-            y = self.up4(y, x1)
-        else:
-            w4 = None if self.bilinear else self.upsample4.weight
-            b4 = None if self.bilinear else self.upsample4.bias
-
+        if self.fused_tape and not has_hooks(self):
             def prog(tape, a, need):
-                cat = E.up_concat(tape, a[0], a[1], w4, b4, need_dx1=need[0], precision=getattr(self, "hpri_precision", None))
-                return self.upconv4._ops(tape, cat)
-            y = run(prog, [y, x1], list(self.upsample4.parameters()) + list(self.upconv4.parameters()))
-        logits = self.outc(y)
+                x1 = self._stem_ops(tape, a[0], need[0])
+                x2 = self.down1._ops(tape, x1)
+                x3 = self.down2._ops(tape, x2)
+                x4 = self.down3._ops(tape, x3)
+                x5 = self.down4._ops(tape, x4)
+                y = self.up1._ops(tape, x5, x4)
+                y = self.up2._ops(tape, y, x3)
+                y = self.up3._ops(tape, y, x2)
+                y = self._up4_ops(tape, y, x1)
+                return self.outc._ops(tape, y)
+            logits = run(prog, [x], list(self.parameters()))
+        else:
+            x1 = self._stem(x)
+            x2 = self.down1(x1)
+            x3 = self.down2(x2)
+            x4 = self.down3(x3)
+            x5 = self.down4(x4)
+            y = self.up1(x5, x4)
+            y = self.up2(y, x3)
+            y = self.up3(y, x2)
+            if self.first_depth == 64:
+                y = self.up4(y, x1)
+            else:
+                params4 = list(self.upsample4.parameters()) + list(self.upconv4.parameters())
+                y = run(lambda tape, a, need: self._up4_ops(tape, a[0], a[1], need[0]), [y, x1], params4)
+            logits = self.outc(y)
         if self.analyze:
             return (logits, logits, torch.sigmoid(logits))
         return logits

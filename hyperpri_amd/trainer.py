@@ -22,7 +22,7 @@ import torch
 from torch import nn
 
 from . import _lib
-from .engine import _p, _require_cuda, _stream
+from .engine import _p, _require_cuda, _stream, bump_param_epoch
 
 
 def _flat(t: torch.Tensor, what: str) -> torch.Tensor:
@@ -100,6 +100,40 @@ class SegCounts:
     def compute(self) -> Dict[str, float]:
         tp, fp, fn, tn = (float(v) for v in self.counts.tolist())     # the one host synchronisation
         return metrics_from_counts(tp, fp, fn, tn)
+
+
+class _StepCounts:
+    """One (TP, FP, FN, TN) row per step, kept on the device ([capacity, 4] int64, no host sync until ``rows()``)."""
+
+    def __init__(self, threshold: float, device, capacity: int = 256):
+        self.threshold = float(threshold)
+        self.buf = torch.zeros((capacity, 4), dtype=torch.int64, device=device)
+        self.weights: List[int] = []
+        self.n = 0
+
+    def reset(self) -> None:
+        self.buf.zero_()
+        self.weights.clear()
+        self.n = 0
+
+    def update(self, pred: torch.Tensor, mask: torch.Tensor) -> None:
+        _require_cuda(pred, "prediction")
+        with torch.cuda.device(pred.device):
+            if self.n == self.buf.shape[0]:
+                grown = torch.zeros((2 * self.n, 4), dtype=torch.int64, device=self.buf.device)
+                grown[:self.n].copy_(self.buf)
+                self.buf = grown
+            x = _flat(pred.detach(), "prediction")
+            y = _flat(mask if mask.dtype == torch.float32 else mask.to(torch.float32), "mask")
+            if x.numel() != y.numel():
+                raise ValueError("prediction and mask differ in size")
+            row = self.buf[self.n]
+            _lib.call("hpri_seg_counts", _p(x), _p(y), x.numel(), self.threshold, 1, _p(row), _stream())
+            self.weights.append(int(pred.shape[0]))
+            self.n += 1
+
+    def rows(self) -> Tuple[List[List[float]], List[int]]:
+        return [[float(v) for v in r] for r in self.buf[:self.n].tolist()], list(self.weights)
 
 
 def metrics_from_counts(tp: float, fp: float, fn: float, tn: float) -> Dict[str, float]:
@@ -248,6 +282,7 @@ class FusedAdam(torch.optim.Optimizer):
                               _ptr_array([self.state[p]["exp_avg_sq"] for p in plist]), n, len(plist),
                               float(group["lr"]), float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]),
                               int(step), _p(grad_scale), _stream())
+        bump_param_epoch()      # parameters were written through raw pointers: packed-weight caches are stale
         return loss
 
 
@@ -289,6 +324,7 @@ class FusedSGD(torch.optim.Optimizer):
                     bufs = _ptr_array([self.state[p]["momentum_buffer"] for p in plist]) if mom != 0.0 else None
                     _lib.call("hpri_sgd_step", _ptr_array(plist), _ptr_array([p.grad for p in plist]), bufs, n, len(plist),
                               float(group["lr"]), mom, float(group["weight_decay"]), first, _p(grad_scale), _stream())
+        bump_param_epoch()
         return loss
 
 
@@ -308,7 +344,7 @@ class SegmentationModel(nn.Module):
         self.p_optimizer, self.p_learn_rate, self.p_decay, self.p_momentum = optimizer, lr, weight_decay, momentum
         self.threshold = threshold
         self.predict_labels: List[torch.Tensor] = []
-        self._counts: Dict[str, SegCounts] = {}
+        self._counts: Dict[str, "_StepCounts"] = {}
         self._loss: Dict[str, List[torch.Tensor]] = {}
 
     # -- PLTrainer.py:166-183
@@ -332,7 +368,7 @@ class SegmentationModel(nn.Module):
         loss = self.f_criterion(pred, batch["mask"])
         c = self._counts.get(stage)
         if c is None or c.threshold != threshold:
-            c = self._counts[stage] = SegCounts(threshold, pred.device)
+            c = self._counts[stage] = _StepCounts(threshold, pred.device)
         c.update(pred, batch["mask"])
         self._loss.setdefault(stage, []).append(loss.detach())
         return pred, loss
@@ -351,15 +387,23 @@ class SegmentationModel(nn.Module):
         return self._forward(batch["image"]).cpu()
 
     def epoch_metrics(self, stage: str, reset: bool = True) -> Dict[str, float]:
-        """{'<stage>_loss', '<stage>_acc', '<stage>_dice', '<stage>_pos_iou'} over the steps since the last reset.
-        acc/dice/IoU are computed from the epoch's summed counts (the reference averages per-step values; with
-        equal-size batches the two differ only where a step has no positive pixel)."""
+        """{'<stage>_loss', '<stage>_acc', '<stage>_dice', '<stage>_pos_iou'} over the steps since the last reset, as
+        the reference logs them: every step computes its own Accuracy / Dice / +IoU and ``self.log(..., on_epoch=True)``
+        averages the per-step VALUES weighted by batch size (PLTrainer.py:88-96, 113-118) -- a mean of ratios, which is
+        what ``ModelCheckpoint(monitor='val_dice')`` (PLTrainer.py:352) ranks checkpoints by.  The ratio of the epoch's
+        summed counts (what one would report for the whole split) is returned beside it under ``<stage>_*_pooled``."""
         out: Dict[str, float] = {}
         if stage in self._loss and self._loss[stage]:
             out[f"{stage}_loss"] = float(torch.stack(self._loss[stage]).mean())
-        if stage in self._counts:
-            m = self._counts[stage].compute()
-            out.update({f"{stage}_acc": m["acc"], f"{stage}_dice": m["dice"], f"{stage}_pos_iou": m["pos_iou"]})
+        if stage in self._counts and self._counts[stage].n:
+            steps, weights = self._counts[stage].rows()      # the one host synchronisation
+            wsum = float(sum(weights))
+            per = [metrics_from_counts(*r) for r in steps]
+            for k in ("acc", "dice", "pos_iou"):
+                out[f"{stage}_{k}"] = sum(w * m[k] for w, m in zip(weights, per)) / wsum
+            pooled = metrics_from_counts(*[sum(r[j] for r in steps) for j in range(4)])
+            out.update({f"{stage}_acc_pooled": pooled["acc"], f"{stage}_dice_pooled": pooled["dice"],
+                        f"{stage}_pos_iou_pooled": pooled["pos_iou"]})
         if reset:
             self._loss.pop(stage, None)
             if stage in self._counts:

@@ -63,6 +63,9 @@ int hpri_bn_fold(const float* running_mean, const float* running_var, const floa
                  const float* conv_bias, float eps, int C, float* scale, float* fbias, hipStream_t stream);
 int hpri_pack_weight_scaled(const float* w, float* wp, const float* colscale, int K, int Ncols, int Ncols_pad, int T,
                             int src_d1, hipStream_t stream);
+/* the same fold for the bf16 / bf16x3 / bf16x6 modes (scale applied in fp32, then rounded / split into planes) */
+int hpri_pack_weight_bf16_scaled(const float* w, void* wp, const float* colscale, int K, int Ncols, int Ncols_pad, int T,
+                                 int src_d1, int split, hipStream_t stream);
 
 /* ---- implicit-GEMM convolution, fp32 MFMA (conv_fwd.hip) ----------------------------------------
  * Replaces F.conv2d / F.conv3d / F.linear / F.conv_transpose2d forward and their data gradients

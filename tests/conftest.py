@@ -17,3 +17,27 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+# Parity margins observed by the GPU tests (max error / tolerance per check), written to gpurun_out/parity_margins.json
+# at the end of the session so the numbers behind "green" can be read and quoted.
+MARGINS = {}
+
+
+def record_margin(key, value, tol):
+    cur = MARGINS.get(key)
+    if cur is None or value > cur["value"]:
+        MARGINS[key] = {"value": float(value), "tol": float(tol)}
+
+
+def pytest_sessionfinish(session, exitstatus):
+    if not MARGINS:
+        return
+    import json
+    out = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "parity_margins.json"), "w") as f:
+            json.dump(MARGINS, f, indent=1, sort_keys=True)
+    except OSError:
+        pass

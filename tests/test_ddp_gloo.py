@@ -63,3 +63,52 @@ def test_gradsync_single_process_is_identity():
     sync.finish()
     for a, b in zip(g, [p.grad for p in net.parameters()]):
         assert torch.equal(a, b)
+
+
+def _worker_accum(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from hyperpri_amd.ddp import GradSync
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(7, 33), torch.nn.ReLU(), torch.nn.Linear(33, 1))
+    sync = GradSync(net, bucket_mb=0.0001)
+    xs = []
+    for k in range(3):
+        torch.manual_seed(200 + 10 * k + rank)
+        xs.append(torch.randn(4, 7))
+    local = [torch.zeros_like(p) for p in net.parameters()]
+    for x in xs:
+        for a, g in zip(local, torch.autograd.grad(net(x).sum(), list(net.parameters()))):
+            a += g
+    # two backward passes per step without no_sync(): must raise, not mix reduced and local gradients
+    net(xs[0]).sum().backward()
+    raised = False
+    try:
+        net(xs[1]).sum().backward()
+    except RuntimeError as e:
+        raised = "second backward" in str(e)
+    sync.finish()
+    # three micro-batches: two under no_sync, the last one communicates the sum
+    for p in net.parameters():
+        p.grad = None
+    with sync.no_sync():
+        for x in xs[:2]:
+            net(x).sum().backward()
+            sync.finish()
+    net(xs[2]).sum().backward()
+    sync.finish()
+    out[rank] = (raised, [p.grad.clone() for p in net.parameters()], local)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradsync_world2_micro_batches_and_guard():
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker_accum, args=(world, _free_port(), out), nprocs=world, join=True)
+    (r0, g0, l0), (r1, g1, l1) = out[0], out[1]
+    assert r0 and r1
+    for a0, a1, x0, x1 in zip(g0, g1, l0, l1):
+        assert torch.equal(a0, a1)
+        torch.testing.assert_close(a0, (x0 + x1) / 2, rtol=1e-5, atol=1e-6)

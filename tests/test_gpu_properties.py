@@ -112,17 +112,41 @@ def test_gradsync_single_rank_matches_plain_gradients():
     _, plain = _step(net, x, m)
     net.load_state_dict(sd)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    sync = None
     try:
         sync = GradSync(net, bucket_mb=8.0, force=True)
         for p in net.parameters():
             p.grad = None
         torch.nn.BCEWithLogitsLoss()(net(x), m).backward()
+        # the whole network is one autograd node: the engine wrote every gradient straight into its bucket slice and
+        # the buckets' all-reduces were issued from inside the tape, before backward() returned
+        assert all(p.grad is None for p in net.parameters())
         sync.finish()
         torch.cuda.synchronize()
         for p, g in zip(net.parameters(), plain):
             assert torch.equal(p.grad, g)
-        sync.remove()
+        ov = sync.overlap_ms()
+        assert ov is not None and len(ov["issue_to_finish_ms"]) == len(sync.buckets)
+        # a second backward without finish() must not silently mix reduced and local gradients
+        torch.nn.BCEWithLogitsLoss()(net(x), m).backward()
+        with pytest.raises(RuntimeError, match="second backward"):
+            torch.nn.BCEWithLogitsLoss()(net(x), m).backward()
+        sync.finish()
+        # gradient accumulation: two micro-batches under no_sync + one outside == sum of three local gradients
+        for p in net.parameters():
+            p.grad = None
+        with sync.no_sync():
+            for _ in range(2):
+                torch.nn.BCEWithLogitsLoss()(net(x), m).backward()
+                sync.finish()
+        torch.nn.BCEWithLogitsLoss()(net(x), m).backward()
+        sync.finish()
+        torch.cuda.synchronize()
+        for p, g in zip(net.parameters(), plain):
+            assert float((p.grad - 3 * g).abs().max()) <= 2e-6 * float(g.abs().max()) * 3 + 1e-9
     finally:
+        if sync is not None:
+            sync.remove()
         dist.destroy_process_group()
 
 
@@ -190,11 +214,17 @@ def test_eval_bn_folding_matches_unfused_eval():
     net.eval()
     try:
         engine.FOLD_EVAL_BN = False
+        n0 = engine.FOLD_LAUNCHES
         with torch.no_grad():
             ref = net(x)
+        assert engine.FOLD_LAUNCHES == n0                 # unfused: conv, then the normalise+ReLU pass
         engine.FOLD_EVAL_BN = True
         with torch.no_grad():
             fold = net(x)
+        assert engine.FOLD_LAUNCHES == n0 + 18            # every conv->BN->ReLU stage of CubeNET-64 took the folded kernel
+        with torch.inference_mode():                      # Lightning's predict path (PLTrainer.py:530): trainable params
+            fold2 = net(x)
+        assert engine.FOLD_LAUNCHES == n0 + 36 and torch.equal(fold, fold2)
     finally:
         engine.FOLD_EVAL_BN = True
     assert (ref - fold).abs().max() < 2e-5
