@@ -770,6 +770,18 @@ __global__ void splitk_finish_kernel(const float* __restrict__ ws, int ksplit, i
   }
 }
 
+// Launch of the split-K epilogue (shared by the fp32, bf16 and bf16-plane convolution launchers).
+extern "C" int hpri_splitk_finish(const float* ws, int ksplit, int Cout_pad, const float* bias, float* y, int y_cs, int y_coff,
+                                  float* stats, int N, int HW, int Cout, int y_cw, int accumulate, int relu, hipStream_t stream) {
+  const int c4 = y_cw >> 2;
+  int cq = 1; while (cq < c4 && cq < 64) cq <<= 1;
+  dim3 grid((unsigned)hpri_cdiv(HW, SK_PIX), (unsigned)hpri_cdiv(hpri_cdiv(y_cw, 4), cq), (unsigned)N);
+  hipLaunchKernelGGL(splitk_finish_kernel, grid, dim3(256), 0, stream, ws, ksplit, Cout_pad, bias, y, y_cs, y_coff,
+                     reinterpret_cast<float4*>(stats), HW, (long long)N * HW, Cout, y_cw, cq, accumulate, relu);
+  HPRI_CHECK_LAUNCH();
+  return HPRI_OK;
+}
+
 // Tile-shape choice shared by the launcher and the sizing query.
 // Workgroup shape: 2x2 waves (128 px x 128 ch) when the output channels allow it, else 4x1 (256 px x 64 ch).
 // prec: 0 fp32, 1 bf16, 2 bf16x3, 3 bf16x6.  The plain bf16 kernel always takes 4x1: its 51 KB of LDS and 168 VGPRs let THREE
@@ -943,13 +955,7 @@ extern "C" int hpri_conv_fwd_bf16(const float* x, int x_cs, int x_coff, const vo
   else { HPRI_DISPATCH_B(1, HPRI_A_DIRECT, HPRI_E_DIRECT); }
 #undef HPRI_DISPATCH_B
   if (rc != HPRI_OK || a.ksplit == 1) return rc;
-  const int c4 = a.y_cw >> 2;
-  int cq = 1; while (cq < c4 && cq < 64) cq <<= 1;
-  dim3 grid((unsigned)hpri_cdiv(H * W, SK_PIX), (unsigned)hpri_cdiv(hpri_cdiv(a.y_cw, 4), cq), (unsigned)N);
-  hipLaunchKernelGGL(splitk_finish_kernel, grid, dim3(256), 0, stream, ws, a.ksplit, Cout_pad, bias, y, y_cs, y_coff,
-                     reinterpret_cast<float4*>(stats), H * W, (long long)N * H * W, Cout, a.y_cw, cq, accumulate & 1, a.relu);
-  HPRI_CHECK_LAUNCH();
-  return HPRI_OK;
+  return hpri_splitk_finish(ws, a.ksplit, Cout_pad, bias, y, y_cs, y_coff, stats, N, H * W, Cout, a.y_cw, accumulate & 1, a.relu, stream);
 }
 
 extern "C" int hpri_conv_fwd(const float* x, int x_cs, int x_coff, const float* wp, const float* bias,
@@ -1002,11 +1008,5 @@ extern "C" int hpri_conv_fwd(const float* x, int x_cs, int x_coff, const float* 
   else { HPRI_DISPATCH(1, HPRI_A_DIRECT, HPRI_E_DIRECT); }
 #undef HPRI_DISPATCH
   if (rc != HPRI_OK || a.ksplit == 1) return rc;
-  const int c4 = a.y_cw >> 2;
-  int cq = 1; while (cq < c4 && cq < 64) cq <<= 1;
-  dim3 grid((unsigned)hpri_cdiv(H * W, SK_PIX), (unsigned)hpri_cdiv(hpri_cdiv(a.y_cw, 4), cq), (unsigned)N);
-  hipLaunchKernelGGL(splitk_finish_kernel, grid, dim3(256), 0, stream, ws, a.ksplit, Cout_pad, bias, y, y_cs, y_coff,
-                     reinterpret_cast<float4*>(stats), H * W, (long long)N * H * W, Cout, a.y_cw, cq, accumulate & 1, a.relu);
-  HPRI_CHECK_LAUNCH();
-  return HPRI_OK;
+  return hpri_splitk_finish(ws, a.ksplit, Cout_pad, bias, y, y_cs, y_coff, stats, N, H * W, Cout, a.y_cw, accumulate & 1, a.relu, stream);
 }

@@ -62,10 +62,11 @@ class Act:
 
     Invariant: channels [C, cw) (cw = C rounded up to 8) exist inside the stride and hold zeros, so
     consumers may run their K loop over ``cw`` channels."""
-    __slots__ = ("buf", "N", "H", "W", "C", "cs", "coff")
+    __slots__ = ("buf", "N", "H", "W", "C", "cs", "coff", "pl")
 
     def __init__(self, buf: torch.Tensor, N: int, H: int, W: int, C: int, cs: int, coff: int = 0):
         self.buf, self.N, self.H, self.W, self.C, self.cs, self.coff = buf, N, H, W, C, cs, coff
+        self.pl: Optional["Planes"] = None      # bf16 plane copy of this activation (bf16 precision modes), see planes_of
 
     @property
     def cw(self) -> int:
@@ -120,6 +121,50 @@ class Act:
         out = torch.empty((self.N, self.C, self.H, self.W), dtype=torch.float32, device=self.buf.device)
         _lib.call("hpri_nhwc_to_nchw", self.ptr, _p(out), self.N, self.C, self.H * self.W, self.cs, self.coff, 0, _stream())
         return out
+
+
+class Planes:
+    """bf16 NHWC planes of an activation: plane p (0 = bf16(x), 1 = bf16(x - hi), ...) starts ``plane`` elements after
+    the previous one, ``cs`` elements per pixel (a multiple of 32), channels [C, cs) are zero.  In the bf16 precision
+    modes the 3x3 convolutions bring their operands into LDS by DMA straight from these planes (csrc/conv_bf16v2.hip)."""
+    __slots__ = ("buf", "plane", "cs", "coff", "npl")
+
+    def __init__(self, buf: torch.Tensor, plane: int, cs: int, coff: int, npl: int):
+        self.buf, self.plane, self.cs, self.coff, self.npl = buf, plane, cs, coff, npl
+
+
+PLANE_CONV = os.environ.get("HPRI_PLANE_CONV", "1") != "0"   # bf16 mode: 3x3 convs on bf16 planes (0: round-1 kernel)
+PLANE_CONVERSIONS = 0        # generic fp32 -> planes passes launched (fused producers do not count)
+
+
+def planes_of(x: Act, npl: int = 1) -> Planes:
+    """The bf16 planes of ``x``; produced by the generic conversion pass unless the kernel that produced ``x`` has
+    already written them."""
+    global PLANE_CONVERSIONS
+    if x.pl is not None and x.pl.npl >= npl:
+        return x.pl
+    cs16 = _rup(x.C, 32)
+    buf = torch.empty(npl * x.P * cs16, dtype=torch.bfloat16, device=x.buf.device)
+    _lib.call("hpri_to_planes", x.ptr, x.cs, x.coff, _p(buf), x.P * cs16, cs16, 0, x.P, x.C, cs16, npl, _stream())
+    PLANE_CONVERSIONS += 1
+    x.pl = Planes(buf, x.P * cs16, cs16, 0, npl)
+    return x.pl
+
+
+def _conv_launch_v2(x: Act, wp: torch.Tensor, bias: Optional[torch.Tensor], y: Act, stats: Optional[torch.Tensor],
+                    cin: int, cout: int, cout_pad: int, y_cw: int, accumulate: int = 0) -> None:
+    """3x3 convolution on bf16 planes (forward, or data gradient with the mode-1 pack)."""
+    pl = planes_of(x, 1)
+    cin_pad = _rup(cin, 32)
+    ksplit = ctypes.c_int(); tiles = ctypes.c_int(); wsf = ctypes.c_size_t()
+    _lib.call("hpri_conv_bf16v2_plan", x.N, x.H, x.W, cin_pad, cout_pad, ctypes.byref(ksplit), ctypes.byref(tiles), ctypes.byref(wsf))
+    ws = _ws(wsf.value, x.buf.device) if wsf.value else None
+    tag = f"conv_planes_bf16<3,{'4x2' if cout_pad % 128 == 0 else '8x1'}>"
+    if SHAPE_TAGS:
+        tag += f" N{x.N} {x.H}x{x.W} K{cin_pad} N{cout}"
+    with _timed(tag, 2.0 * x.N * x.H * x.W * cin * cout * 9):
+        _lib.call("hpri_conv_bf16v2", _p(pl.buf), pl.plane, pl.cs, pl.coff, _p(wp), _p(bias), y.ptr, y.cs, y.coff, _p(stats),
+                  x.N, x.H, x.W, cin_pad, cout, cout_pad, y_cw, accumulate, 0, _p(ws), wsf.value, _stream())
 
 
 class Tape:
@@ -404,6 +449,7 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
         return _conv_folded_eval(x, weight, bias, bn, ks, cin, cout, relu, prec)
     lowp = prec in LOWP
     split = _SPLIT.get(prec, 0)
+    v2 = PLANE_CONV and prec == "bf16" and ks == 3        # operands by LDS-DMA from bf16 planes (conv_bf16v2.hip)
     if lowp:
         wp, cout_pad = _pack_bf16(weight, 0, cin, cout, T, cin, split=split)
     else:
@@ -418,7 +464,10 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
     tiles = 0
     if use_batch:
         ksp = ctypes.c_int(); tl = ctypes.c_int(); wsf = ctypes.c_size_t()
-        if lowp:
+        if v2:
+            _lib.call("hpri_conv_bf16v2_plan", x.N, x.H, x.W, _rup(cin, 32), cout_pad, ctypes.byref(ksp), ctypes.byref(tl),
+                      ctypes.byref(wsf))
+        elif lowp:
             _lib.call("hpri_conv_fwd_bf16_plan", x.N, x.H, x.W, cin_pad, cout_pad, ks, A_DIRECT, E_DIRECT, split,
                       ctypes.byref(ksp), ctypes.byref(tl), ctypes.byref(wsf))
         else:
@@ -426,7 +475,9 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
                       ctypes.byref(tl), ctypes.byref(wsf))
         tiles = tl.value
         stats = torch.empty(tiles * cout_pad * 4, dtype=torch.float32, device=dev)
-    if lowp:
+    if v2:
+        _conv_launch_v2(x, wp, bias, yr, stats, cin, cout, cout_pad, yr.cw)
+    elif lowp:
         _conv_launch_bf16(x, wp, bias, yr, stats, x.N, x.H, x.W, cin_pad, cout, cout_pad, yr.cw, ks, cin_true=cin, split=split)
     else:
         _conv_launch(x, wp, bias, yr, stats, x.N, x.H, x.W, cin_pad, cout, cout_pad, yr.cw, ks, cin_true=cin)
@@ -495,7 +546,10 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
             _wgrad(x, dyr, dw, acc_w, cin, cout, ks, bf16=lowp, split=split)
         if need_dx:
             gx, acc = tp.grad_slot(x)
-            if lowp:
+            if v2:
+                wpd, cin_cols_pad = _pack_bf16(weight, 1, cout, cin, T, cin, split=0)
+                _conv_launch_v2(dyr, wpd, None, gx, None, cout, cin, cin_cols_pad, gx.cw, accumulate=int(acc))
+            elif lowp:
                 wpd, cin_cols_pad = _pack_bf16(weight, 1, cout, cin, T, cin, split=split)
                 _conv_launch_bf16(dyr, wpd, None, gx, None, x.N, x.H, x.W, dyr.cw, cin, cin_cols_pad, gx.cw, ks,
                                   accumulate=int(acc), cin_true=cout, split=split)
@@ -550,7 +604,9 @@ def _conv_folded_eval(x: Act, weight: torch.Tensor, bias: Optional[torch.Tensor]
     wp, fold = _cached_pack(weight, ("fold", prec, ks), build, extra=bn_state)
     fbias = fold[cout:]
     y = Act.new(x.N, x.H, x.W, cout, dev)
-    if lowp:
+    if lowp and PLANE_CONV and prec == "bf16" and ks == 3:
+        _conv_launch_v2(x, wp, fbias, y, None, cin, cout, cout_pad, y.cw, accumulate=2 if relu else 0)
+    elif lowp:
         _conv_launch_bf16(x, wp, fbias, y, None, x.N, x.H, x.W, x.cw, cout, cout_pad, y.cw, ks, accumulate=2 if relu else 0,
                           cin_true=cin, split=split)
     else:

@@ -94,6 +94,21 @@ int hpri_conv_fwd_bf16(const float* x, int x_cs, int x_coff, const void* wp, con
                        int KS, int amode, int epi, int accumulate, int H2, int W2, int py0, int px0, int Cup, int split,
                        float* ws, size_t ws_floats, hipStream_t stream);
 
+/* bf16 activation PLANES (conv_bf16v2.hip): in the bf16 modes the producer of an activation writes it as bf16 NHWC
+ * planes (plane 0 = bf16(x), plane 1 = bf16(x - hi), ...; `plane_stride` elements apart, `cs16` elements per pixel,
+ * channels [C, cw16) zero), so the 3x3 convolution (model_parts.py:22,25; models.py:169,177; forward, or data gradient
+ * with the mode-1 pack) brings BOTH operands into LDS by LDS-DMA.  hpri_to_planes is the generic producer (fp32 NHWC
+ * view -> planes); plan / workspace / statistics contract as hpri_conv_fwd (split-K finish: hpri_splitk_finish). */
+int hpri_to_planes(const float* x, int cs, int coff, void* planes, long long plane_stride, int cs16, int coff16,
+                   long long P, int C, int cw16, int npl, hipStream_t stream);
+int hpri_conv_bf16v2_plan(int N, int H, int W, int Cin_pad, int Cout_pad, int* ksplit, int* stat_tiles,
+                          size_t* ws_floats);
+int hpri_conv_bf16v2(const void* xp, long long x_plane, int x_cs, int x_coff, const void* wp, const float* bias, float* y,
+                     int y_cs, int y_coff, float* stats, int N, int H, int W, int Cin_pad, int Cout, int Cout_pad, int y_cw,
+                     int accumulate, int split, float* ws, size_t ws_floats, hipStream_t stream);
+int hpri_splitk_finish(const float* ws, int ksplit, int Cout_pad, const float* bias, float* y, int y_cs, int y_coff,
+                       float* stats, int N, int HW, int Cout, int y_cw, int accumulate, int relu, hipStream_t stream);
+
 /* ---- weight gradients, fp32 MFMA, deterministic split-K (conv_wgrad.hip) --------------------------
  * Replaces the wgrad half of autograd for the same layers.  dst_mode 0 writes OIHW / (out,in),
  * dst_mode 1 writes ConvTranspose2d's (Cin,Cout,2,2).  Workspace: splits*KS*KS*Cr*Nr floats. */

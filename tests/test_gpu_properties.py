@@ -165,7 +165,9 @@ def test_inference_mode_and_no_grad_match_eval_forward():
         a = net(x)
     with torch.inference_mode():
         b = net(x)
-    assert torch.equal(a, ref) and torch.equal(b, ref)
+    # no_grad / inference_mode take the predict path (eval-mode BN folded into the conv); the grad-enabled eval forward
+    # keeps conv -> normalise+ReLU for its tape: same function, different rounding
+    assert torch.equal(a, b) and float((a - ref).abs().max()) < 2e-5
     assert not a.requires_grad and a.is_contiguous() and a.shape == (2, 1, 64, 96)
 
 

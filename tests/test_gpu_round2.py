@@ -127,6 +127,8 @@ def test_epoch_metrics_average_per_step_values():
     import hyperpri_amd as H
     from hyperpri_amd.trainer import SegmentationModel, metrics_from_counts
     net, x, _ = _net("unet")
+    with torch.no_grad():
+        net.outc.conv.bias.fill_(0.45)          # generator weights alone predict no positive pixel at threshold 0.5
     model = SegmentationModel(net).to(DEV).eval()
     masks = [(_u(4321, (2, 1, 36, 50)) > 0.9).float(), (_u(4399, (2, 1, 36, 50)) > 0.3).float()]   # very different positives
     per, tot = [], np.zeros(4)
