@@ -31,12 +31,13 @@ def _as4d(t: torch.Tensor) -> torch.Tensor:
 
 class _HipFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, program: Callable, n_in: int, params: Sequence[torch.Tensor], grad_on: bool, *tensors: torch.Tensor):
+    def forward(ctx, program: Callable, n_in: int, params: Sequence[torch.Tensor], grad_on, *tensors: torch.Tensor):
         with torch.cuda.device(tensors[0].device):      # launches and current_stream() follow the data's device
             return _HipFn._forward(ctx, program, n_in, params, grad_on, *tensors)
 
     @staticmethod
-    def _forward(ctx, program: Callable, n_in: int, params: Sequence[torch.Tensor], grad_on: bool, *tensors: torch.Tensor):
+    def _forward(ctx, program: Callable, n_in: int, params: Sequence[torch.Tensor], grad_on, *tensors: torch.Tensor):
+        grad_on, input_planes = grad_on          # (caller's grad mode, bf16 planes wanted for the inputs)
         inputs = tensors[:n_in]
         need = list(ctx.needs_input_grad[4:])
         # needs_input_grad is True for trainable parameters even under torch.no_grad() / inference_mode(), and
@@ -46,7 +47,7 @@ class _HipFn(torch.autograd.Function):
         acts: List[Act] = []
         for t in inputs:
             _require_cuda(t, "input tensor")
-            acts.append(Act.from_tensor(_as4d(t)))
+            acts.append(Act.from_tensor(_as4d(t), input_planes))
         out = program(tape, acts, need[:n_in])
         if isinstance(out, Act):
             res = out.to_tensor()
@@ -99,9 +100,10 @@ class _HipFn(torch.autograd.Function):
         return (None, None, None, None, *res)
 
 
-def run(program: Callable, inputs: Sequence[torch.Tensor], params: Sequence[torch.Tensor]) -> torch.Tensor:
+def run(program: Callable, inputs: Sequence[torch.Tensor], params: Sequence[torch.Tensor], input_planes: int = 0) -> torch.Tensor:
     """Run ``program`` as one autograd node.  ``params`` are the nn.Parameters the program reads (the
-    program closes over the owning module; they are listed here so autograd routes their gradients)."""
+    program closes over the owning module; they are listed here so autograd routes their gradients).
+    ``input_planes`` > 0: the layout pass of an NCHW input also writes that many bf16 planes (bf16 plane mode)."""
     dev = inputs[0].device
     for p in params:
         _require_cuda(p, "module parameter")
@@ -111,4 +113,4 @@ def run(program: Callable, inputs: Sequence[torch.Tensor], params: Sequence[torc
             raise RuntimeError("hyperpri_amd: parameters must be contiguous")
     for t in inputs:
         _require_cuda(t, "input tensor")
-    return _HipFn.apply(program, len(inputs), tuple(params), torch.is_grad_enabled(), *inputs, *params)
+    return _HipFn.apply(program, len(inputs), tuple(params), (torch.is_grad_enabled(), int(input_planes)), *inputs, *params)

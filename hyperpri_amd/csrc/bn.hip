@@ -116,11 +116,12 @@ __global__ void bn_fold_kernel(const float* __restrict__ rm, const float* __rest
 __global__ void bn_apply_relu_kernel(const float* __restrict__ x, int x_cs, int x_coff, float* __restrict__ y,
                                      int y_cs, int y_coff, const float* __restrict__ scale,
                                      const float* __restrict__ shift, int pix_per_group, int C, int Cw, int CQ,
-                                     int relu) {
+                                     int relu, PlaneOut pl) {
   const int rows = 256 / CQ;
   const int cq = threadIdx.x % CQ, pr = threadIdx.x / CQ;
   const int c = (blockIdx.y * CQ + cq) * 4;
-  if (c >= Cw) return;
+  const bool in_f = c < Cw, in_p = pl.p != nullptr && c < pl.cw;
+  if (!in_f && !in_p) return;
   const int g = blockIdx.z;
   float sc[4], sh[4];
 #pragma unroll
@@ -135,11 +136,14 @@ __global__ void bn_apply_relu_kernel(const float* __restrict__ x, int x_cs, int 
   const size_t base = (size_t)g * pix_per_group;
   for (int q = q0 + pr; q < q1; q += rows) {
     const size_t p = base + q;
-    const float4 v = *reinterpret_cast<const float4*>(x + p * x_cs + x_coff + c);
-    float4 o;
-    o.x = v.x * sc[0] + sh[0]; o.y = v.y * sc[1] + sh[1]; o.z = v.z * sc[2] + sh[2]; o.w = v.w * sc[3] + sh[3];
-    if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
-    *reinterpret_cast<float4*>(y + p * y_cs + y_coff + c) = o;
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (in_f) {
+      const float4 v = *reinterpret_cast<const float4*>(x + p * x_cs + x_coff + c);
+      o.x = v.x * sc[0] + sh[0]; o.y = v.y * sc[1] + sh[1]; o.z = v.z * sc[2] + sh[2]; o.w = v.w * sc[3] + sh[3];
+      if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+      *reinterpret_cast<float4*>(y + p * y_cs + y_coff + c) = o;
+    }
+    if (in_p) plane_store4(pl, p, c, o.x, o.y, o.z, o.w);
   }
 }
 
@@ -258,13 +262,19 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, int dy_cs, int
                                     const float* __restrict__ mean, const float* __restrict__ invstd,
                                     const float* __restrict__ scale, const float* __restrict__ shift,
                                     const float* __restrict__ sums, int pix_per_group, int C, int Cw, int CQ,
-                                    int relu, int use_batch_stats, float* __restrict__ dxpart, int Cpart) {
+                                    int relu, int use_batch_stats, float* __restrict__ dxpart, int Cpart, PlaneOut pl) {
   __shared__ float4 red[256];
   const int rows = 256 / CQ;
   const int cq = threadIdx.x % CQ, pr = threadIdx.x / CQ;
   const int c = (blockIdx.y * CQ + cq) * 4;
   const int g = blockIdx.z;
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool in_p = pl.p != nullptr && c < pl.cw;
+  if (c >= Cw && in_p) {           // plane pad channels beyond the fp32 width: zeros
+    const int per = (pix_per_group + gridDim.x - 1) / gridDim.x;
+    const int q0 = blockIdx.x * per, q1 = min(pix_per_group, q0 + per);
+    for (int q = q0 + pr; q < q1; q += rows) plane_store4(pl, (size_t)g * pix_per_group + q, c, 0.f, 0.f, 0.f, 0.f);
+  }
   if (c < Cw) {
     const float inv_np = 1.f / (float)pix_per_group;
     float sc[4], sh[4], mu[4], is[4], k1[4], k2[4];
@@ -297,6 +307,7 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, int dy_cs, int
         acc[j] += o[j];
       }
       *reinterpret_cast<float4*>(dx + p * dx_cs + dx_coff + c) = make_float4(o[0], o[1], o[2], o[3]);
+      if (in_p) plane_store4(pl, p, c, o[0], o[1], o[2], o[3]);
     }
   }
   if (dxpart != nullptr) {
@@ -313,6 +324,17 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, int dy_cs, int
 }
 
 // ------------------------------------------- C ABI ---------------------------------------------
+extern "C" int hpri_bn_apply_relu_pl(const float* x, int x_cs, int x_coff, float* y, int y_cs, int y_coff,
+                                     const float* scale, const float* shift, long long P, long long pix_per_group,
+                                     int C, int Cw, int relu, void* planes, long long plane_stride, int pl_cs, int pl_coff,
+                                     int pl_cw, int npl, hipStream_t stream);
+extern "C" int hpri_bn_relu_bwd_pl(const float* dy, int dy_cs, int dy_coff, const float* x, int x_cs, int x_coff,
+                                   float* dx, int dx_cs, int dx_coff, const float* mean, const float* invstd,
+                                   const float* scale, const float* shift, float* dgamma, float* dbeta,
+                                   int accumulate_param_grads, float* dbias, int accumulate_dbias, float* workspace,
+                                   size_t ws_floats, long long P, long long pix_per_group, int C, int Cw, int relu,
+                                   int use_batch_stats, void* planes, long long plane_stride, int pl_cs, int pl_coff,
+                                   int pl_cw, int npl, hipStream_t stream);
 static inline int pick_cq(int c4) { int q = 1; while (q < c4 && q < 64) q <<= 1; return q; }
 static inline int ew_blocks(long long total) {
   long long b = (total + 255) / 256;
@@ -365,19 +387,30 @@ extern "C" int hpri_bn_fold(const float* running_mean, const float* running_var,
 extern "C" int hpri_bn_apply_relu(const float* x, int x_cs, int x_coff, float* y, int y_cs, int y_coff,
                                   const float* scale, const float* shift, long long P, long long pix_per_group,
                                   int C, int Cw, int relu, hipStream_t stream) {
+  return hpri_bn_apply_relu_pl(x, x_cs, x_coff, y, y_cs, y_coff, scale, shift, P, pix_per_group, C, Cw, relu, nullptr, 0, 0, 0, 0,
+                               0, stream);
+}
+
+// the same pass, also writing the result as bf16 planes (planes == nullptr: fp32 only); see PlaneOut
+extern "C" int hpri_bn_apply_relu_pl(const float* x, int x_cs, int x_coff, float* y, int y_cs, int y_coff,
+                                     const float* scale, const float* shift, long long P, long long pix_per_group,
+                                     int C, int Cw, int relu, void* planes, long long plane_stride, int pl_cs, int pl_coff,
+                                     int pl_cw, int npl, hipStream_t stream) {
   HPRI_REQUIRE(x && y && scale && shift, "bn_apply_relu: null pointer");
+  PlaneOut po;
+  { const int rc_ = hpri_plane_out(&po, planes, plane_stride, pl_cs, pl_coff, pl_cw, npl, C); if (rc_ != HPRI_OK) return rc_; }
   HPRI_REQUIRE(Cw % 4 == 0 && Cw >= C && x_cs % 4 == 0 && y_cs % 4 == 0 && x_coff % 4 == 0 && y_coff % 4 == 0 &&
                    Cw + x_coff <= x_cs && Cw + y_coff <= y_cs,
                "bn_apply_relu: channel layout must be float4-aligned and fit the strides");
   HPRI_REQUIRE(P > 0 && pix_per_group > 0 && P % pix_per_group == 0, "bn_apply_relu: bad pixel counts");
   const int G = (int)(P / pix_per_group);
-  const int c4 = Cw >> 2, cq = pick_cq(c4), rows = 256 / cq, ycols = hpri_cdiv(c4, cq);
+  const int c4 = (Cw > po.cw ? Cw : po.cw) >> 2, cq = pick_cq(c4), rows = 256 / cq, ycols = hpri_cdiv(c4, cq);
   long long nbx = 4096 / ((long long)ycols * G);
   const long long maxb = (pix_per_group + rows * 4 - 1) / (rows * 4);
   if (nbx > maxb) nbx = maxb;
   if (nbx < 1) nbx = 1;
   hipLaunchKernelGGL(bn_apply_relu_kernel, dim3((unsigned)nbx, ycols, G), dim3(256), 0, stream, x, x_cs, x_coff, y, y_cs,
-                     y_coff, scale, shift, (int)pix_per_group, C, Cw, cq, relu);
+                     y_coff, scale, shift, (int)pix_per_group, C, Cw, cq, relu, po);
   HPRI_CHECK_LAUNCH();
   return HPRI_OK;
 }
@@ -402,7 +435,22 @@ extern "C" int hpri_bn_relu_bwd(const float* dy, int dy_cs, int dy_coff, const f
                                 int accumulate_param_grads, float* dbias, int accumulate_dbias, float* workspace,
                                 size_t ws_floats, long long P, long long pix_per_group, int C, int Cw, int relu,
                                 int use_batch_stats, hipStream_t stream) {
+  return hpri_bn_relu_bwd_pl(dy, dy_cs, dy_coff, x, x_cs, x_coff, dx, dx_cs, dx_coff, mean, invstd, scale, shift, dgamma, dbeta,
+                             accumulate_param_grads, dbias, accumulate_dbias, workspace, ws_floats, P, pix_per_group, C, Cw, relu,
+                             use_batch_stats, nullptr, 0, 0, 0, 0, 0, stream);
+}
+
+// the same, with dx also written as bf16 planes for the data-gradient / weight-gradient kernels of the bf16 modes
+extern "C" int hpri_bn_relu_bwd_pl(const float* dy, int dy_cs, int dy_coff, const float* x, int x_cs, int x_coff,
+                                   float* dx, int dx_cs, int dx_coff, const float* mean, const float* invstd,
+                                   const float* scale, const float* shift, float* dgamma, float* dbeta,
+                                   int accumulate_param_grads, float* dbias, int accumulate_dbias, float* workspace,
+                                   size_t ws_floats, long long P, long long pix_per_group, int C, int Cw, int relu,
+                                   int use_batch_stats, void* planes, long long plane_stride, int pl_cs, int pl_coff,
+                                   int pl_cw, int npl, hipStream_t stream) {
   HPRI_REQUIRE(dy && x && dx && mean && invstd && scale && shift && workspace, "bn_relu_bwd: null pointer");
+  PlaneOut po;
+  { const int rc_ = hpri_plane_out(&po, planes, plane_stride, pl_cs, pl_coff, pl_cw, npl, C); if (rc_ != HPRI_OK) return rc_; }
   HPRI_REQUIRE(Cw % 4 == 0 && Cw >= C && dy_cs % 4 == 0 && x_cs % 4 == 0 && dx_cs % 4 == 0 && dy_coff % 4 == 0 &&
                    x_coff % 4 == 0 && dx_coff % 4 == 0, "bn_relu_bwd: channel layout must be float4-aligned");
   HPRI_REQUIRE(P > 0 && pix_per_group > 0 && P % pix_per_group == 0 && pix_per_group < (1ll << 31), "bn_relu_bwd: bad pixel counts");
@@ -430,10 +478,10 @@ extern "C" int hpri_bn_relu_bwd(const float* dy, int dy_cs, int dy_coff, const f
   }
   // the apply kernel uses the same (pixel blocks x channel columns x groups) grid as the reduce, so its dx column
   // partials have the reduce's layout; Cw may add one more channel column than C (zero pads)
-  const int ycols_w = hpri_cdiv(Cw >> 2, cq);
+  const int ycols_w = hpri_cdiv((Cw > po.cw ? Cw : po.cw) >> 2, cq);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nblk, ycols_w, G), dim3(256), 0, stream, dy, dy_cs, dy_coff, x, x_cs,
                      x_coff, dx, dx_cs, dx_coff, mean, invstd, scale, shift, sums, (int)pix_per_group, C, Cw, cq, relu,
-                     use_batch_stats, dbias != nullptr ? dxpart : nullptr, Cpart);
+                     use_batch_stats, dbias != nullptr ? dxpart : nullptr, Cpart, po);
   HPRI_CHECK_LAUNCH();
   if (dbias != nullptr) {
     hipLaunchKernelGGL(col_finalize_kernel, dim3(hpri_cdiv(C, 32), G), dim3(1024), 0, stream, dxpart, nblk, Cpart, C, dxsums,

@@ -32,3 +32,30 @@ static inline int64_t hpri_cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b
 // A-operand / epilogue addressing modes of the implicit-GEMM kernels.
 enum { HPRI_A_DIRECT = 0, HPRI_A_S2D = 1 };   // S2D: gather 2x2 stride-2 patches (convT dgrad / wgrad)
 enum { HPRI_E_DIRECT = 0, HPRI_E_D2S = 1 };   // D2S: scatter 2x2 stride-2 patches (convT forward)
+
+// Optional second output of the element-wise producers: the same values as bf16 NHWC planes (hi | hi,lo | hi,mid,lo:
+// plane k = bf16 of what the previous planes left), which the bf16-mode convolutions stage by LDS-DMA
+// (conv_bf16v2.hip).  Channels [C, cw) of the planes are zero-filled by the producer.
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+struct PlaneOut { __bf16* p; long long plane; int cs, coff, cw, npl; };
+
+#ifdef __HIPCC__
+__device__ __forceinline__ void plane_store4(const PlaneOut& pl, size_t pix, int c, float o0, float o1, float o2, float o3) {
+  float v[4] = {o0, o1, o2, o3};
+  for (int k = 0; k < pl.npl; ++k) {
+    bf16x4_t h;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const __bf16 t = (__bf16)v[j]; h[j] = t; v[j] -= (float)t; }
+    *reinterpret_cast<bf16x4_t*>(pl.p + (size_t)k * pl.plane + pix * pl.cs + pl.coff + c) = h;
+  }
+}
+#endif
+
+// host: fill a PlaneOut from C-ABI arguments (planes == nullptr: no plane output)
+static inline int hpri_plane_out(PlaneOut* po, void* planes, long long plane_stride, int pl_cs, int pl_coff, int pl_cw, int npl, int C) {
+  po->p = reinterpret_cast<__bf16*>(planes); po->plane = plane_stride; po->cs = pl_cs; po->coff = pl_coff; po->cw = pl_cw; po->npl = npl;
+  if (planes == nullptr) { po->cw = 0; po->npl = 0; return HPRI_OK; }
+  HPRI_REQUIRE(npl >= 1 && npl <= 3 && pl_cw >= C && pl_cw % 4 == 0 && pl_coff % 4 == 0 && pl_cs % 4 == 0 && pl_coff + pl_cw <= pl_cs &&
+                   plane_stride % 4 == 0 && ((uintptr_t)planes & 7) == 0, "bad plane geometry");
+  return HPRI_OK;
+}

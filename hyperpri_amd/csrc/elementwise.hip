@@ -39,7 +39,7 @@ __global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, float* __rest
 // the 560 MB cubes are: a 64 channel x 128 pixel tile, float4 reads along the pixels (512-byte runs per channel row),
 // float4 writes along the channels (256-byte runs per pixel).
 __global__ __launch_bounds__(256) void nchw_to_nhwc_v4_kernel(const float* __restrict__ src, float* __restrict__ dst, int C,
-                                                              long long P, int cs, int coff, int Cw) {
+                                                              long long P, int cs, int coff, int Cw, PlaneOut pl) {
   __shared__ float tile[128][65];                    // [pixel][channel], pitch 65: conflict-free scalar transposition
   const int n = blockIdx.z;
   const long long p0 = (long long)blockIdx.x * 128;
@@ -60,11 +60,12 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_v4_kernel(const float* __res
   for (int r = py; r < 128; r += 16) {
     const long long p = p0 + r;
     const int c = c0 + cq * 4;
-    if (p < P && c < Cw) {
+    if (p < P && (c < Cw || c < pl.cw)) {
       const int ro = r >> 5;
       f32x4 v = {tile[r][(cq * 4 + 0 + ro) & 63], tile[r][(cq * 4 + 1 + ro) & 63], tile[r][(cq * 4 + 2 + ro) & 63],
-                 tile[r][(cq * 4 + 3 + ro) & 63]};
-      *reinterpret_cast<f32x4*>(dst + ((long long)n * P + p) * cs + coff + c) = v;
+                 tile[r][(cq * 4 + 3 + ro) & 63]};           // channels >= C were staged as zeros
+      if (c < Cw) *reinterpret_cast<f32x4*>(dst + ((long long)n * P + p) * cs + coff + c) = v;
+      if (c < pl.cw) plane_store4(pl, (size_t)((long long)n * P + p), c, v[0], v[1], v[2], v[3]);
     }
   }
 }
@@ -96,7 +97,8 @@ __global__ void nhwc_to_nchw_kernel(const float* __restrict__ src, float* __rest
 
 // ---------------------------------- MaxPool2d(2) ------------------------------------------------
 __global__ void maxpool2_fwd_kernel(const float* __restrict__ x, int x_cs, int x_coff, float* __restrict__ y, int y_cs,
-                                    int y_coff, int N, int H, int W, int OH, int OW, int C4) {
+                                    int y_coff, int N, int H, int W, int OH, int OW, int C4v, int C4, PlaneOut pl) {
+  // C4v = channel quads with fp32 data, C4 >= C4v = quads covered (the extra ones only zero-fill plane pad channels)
   const long long total = (long long)N * OH * OW * C4;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const int c = (int)(i % C4) * 4;
@@ -104,6 +106,8 @@ __global__ void maxpool2_fwd_kernel(const float* __restrict__ x, int x_cs, int x
     const int ox = (int)(r % OW); r /= OW;
     const int oy = (int)(r % OH);
     const int n = (int)(r / OH);
+    const size_t opix = (size_t)(((long long)n * OH + oy) * OW + ox);
+    if (c >= C4v * 4) { plane_store4(pl, opix, c, 0.f, 0.f, 0.f, 0.f); continue; }
     const float* b = x + (((long long)n * H + 2 * oy) * W + 2 * ox) * x_cs + x_coff + c;
     const float4 v00 = *reinterpret_cast<const float4*>(b);
     const float4 v01 = *reinterpret_cast<const float4*>(b + x_cs);
@@ -114,7 +118,8 @@ __global__ void maxpool2_fwd_kernel(const float* __restrict__ x, int x_cs, int x
     m.y = fmaxf(fmaxf(v00.y, v01.y), fmaxf(v10.y, v11.y));
     m.z = fmaxf(fmaxf(v00.z, v01.z), fmaxf(v10.z, v11.z));
     m.w = fmaxf(fmaxf(v00.w, v01.w), fmaxf(v10.w, v11.w));
-    *reinterpret_cast<float4*>(y + (((long long)n * OH + oy) * OW + ox) * y_cs + y_coff + c) = m;
+    *reinterpret_cast<float4*>(y + opix * y_cs + y_coff + c) = m;
+    if (pl.p != nullptr) plane_store4(pl, opix, c, m.x, m.y, m.z, m.w);
   }
 }
 
@@ -334,15 +339,32 @@ __global__ void synth_kernel(float* __restrict__ d, long long n, unsigned long l
 }
 
 // ------------------------------------------- C ABI ---------------------------------------------
+extern "C" int hpri_nchw_to_nhwc_pl(const float* src, float* dst, int N, int C, long long P, int cs, int coff, int Cw,
+                                    void* planes, long long plane_stride, int pl_cs, int pl_coff, int pl_cw, int npl,
+                                    hipStream_t stream);
+extern "C" int hpri_maxpool2_fwd_pl(const float* x, int x_cs, int x_coff, float* y, int y_cs, int y_coff, int N, int H,
+                                    int W, int C, void* planes, long long plane_stride, int pl_cs, int pl_coff, int pl_cw,
+                                    int npl, hipStream_t stream);
 extern "C" int hpri_nchw_to_nhwc(const float* src, float* dst, int N, int C, long long P, int cs, int coff, int Cw,
                                  hipStream_t stream) {
+  return hpri_nchw_to_nhwc_pl(src, dst, N, C, P, cs, coff, Cw, nullptr, 0, 0, 0, 0, 0, stream);
+}
+
+// the same, also writing bf16 planes (16-byte aligned problems only: P % 4 == 0 etc.; returns HPRI_ERR_UNSUPPORTED otherwise
+// when planes are requested, so the caller can fall back to hpri_to_planes)
+extern "C" int hpri_nchw_to_nhwc_pl(const float* src, float* dst, int N, int C, long long P, int cs, int coff, int Cw,
+                                    void* planes, long long plane_stride, int pl_cs, int pl_coff, int pl_cw, int npl,
+                                    hipStream_t stream) {
   HPRI_REQUIRE(src && dst && N > 0 && C > 0 && P > 0 && Cw >= C && Cw + coff <= cs, "nchw_to_nhwc: bad arguments");
+  PlaneOut po;
+  { const int rc_ = hpri_plane_out(&po, planes, plane_stride, pl_cs, pl_coff, pl_cw, npl, C); if (rc_ != HPRI_OK) return rc_; }
   if (P % 4 == 0 && cs % 4 == 0 && coff % 4 == 0 && Cw % 4 == 0 && ((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0) {
-    dim3 grid4((unsigned)hpri_cdiv64(P, 128), (unsigned)hpri_cdiv(Cw, 64), (unsigned)N);
-    hipLaunchKernelGGL(nchw_to_nhwc_v4_kernel, grid4, dim3(256), 0, stream, src, dst, C, P, cs, coff, Cw);
+    dim3 grid4((unsigned)hpri_cdiv64(P, 128), (unsigned)hpri_cdiv(Cw > po.cw ? Cw : po.cw, 64), (unsigned)N);
+    hipLaunchKernelGGL(nchw_to_nhwc_v4_kernel, grid4, dim3(256), 0, stream, src, dst, C, P, cs, coff, Cw, po);
     HPRI_CHECK_LAUNCH();
     return HPRI_OK;
   }
+  if (planes != nullptr) return hpri_set_error(HPRI_ERR_UNSUPPORTED, "nchw_to_nhwc_pl: plane output needs the 16-byte aligned form");
   dim3 grid((unsigned)hpri_cdiv64(P, 64), (unsigned)hpri_cdiv(Cw, 32), (unsigned)N);
   hipLaunchKernelGGL(nchw_to_nhwc_kernel, grid, dim3(256), 0, stream, src, dst, C, P, cs, coff, Cw);
   HPRI_CHECK_LAUNCH();
@@ -362,11 +384,21 @@ extern "C" int hpri_nhwc_to_nchw(const float* src, float* dst, int N, int C, lon
 
 extern "C" int hpri_maxpool2_fwd(const float* x, int x_cs, int x_coff, float* y, int y_cs, int y_coff, int N, int H,
                                  int W, int C, hipStream_t stream) {
+  return hpri_maxpool2_fwd_pl(x, x_cs, x_coff, y, y_cs, y_coff, N, H, W, C, nullptr, 0, 0, 0, 0, 0, stream);
+}
+
+// MaxPool2d(2), also writing the pooled map as bf16 planes (planes == nullptr: fp32 only)
+extern "C" int hpri_maxpool2_fwd_pl(const float* x, int x_cs, int x_coff, float* y, int y_cs, int y_coff, int N, int H,
+                                    int W, int C, void* planes, long long plane_stride, int pl_cs, int pl_coff, int pl_cw,
+                                    int npl, hipStream_t stream) {
   HPRI_REQUIRE(x && y && N > 0 && H >= 2 && W >= 2 && C > 0 && C % 4 == 0, "maxpool2_fwd: bad arguments");
   HPRI_REQ_V4(x_cs, x_coff); HPRI_REQ_V4(y_cs, y_coff);
+  PlaneOut po;
+  { const int rc_ = hpri_plane_out(&po, planes, plane_stride, pl_cs, pl_coff, pl_cw, npl, C); if (rc_ != HPRI_OK) return rc_; }
   const int OH = H / 2, OW = W / 2;
-  hipLaunchKernelGGL(maxpool2_fwd_kernel, dim3(ew_blocks((long long)N * OH * OW * (C / 4))), dim3(256), 0, stream, x, x_cs,
-                     x_coff, y, y_cs, y_coff, N, H, W, OH, OW, C / 4);
+  const int c4 = (C > po.cw ? C : po.cw) / 4;
+  hipLaunchKernelGGL(maxpool2_fwd_kernel, dim3(ew_blocks((long long)N * OH * OW * c4)), dim3(256), 0, stream, x, x_cs,
+                     x_coff, y, y_cs, y_coff, N, H, W, OH, OW, C / 4, c4, po);
   HPRI_CHECK_LAUNCH();
   return HPRI_OK;
 }

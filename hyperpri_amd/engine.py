@@ -96,9 +96,10 @@ class Act:
                                 (self.H * self.W * self.cs, 1, self.W * self.cs, self.cs), self.coff)
 
     @staticmethod
-    def from_tensor(t: torch.Tensor) -> "Act":
+    def from_tensor(t: torch.Tensor, npl: int = 0) -> "Act":
         """(N,C,H,W) tensor -> Act.  Zero-copy when t is channels-last with a stride that already
-        provides the zero pad; otherwise one nchw->nhwc HIP transpose (dataset.py:267-271 hands NCHW)."""
+        provides the zero pad; otherwise one nchw->nhwc HIP transpose (dataset.py:267-271 hands NCHW), which for
+        ``npl`` > 0 also writes the bf16 planes the bf16-mode first convolution stages by DMA."""
         _require_cuda(t, "input tensor")
         N, C, H, W = t.shape
         st = t.stride()
@@ -114,7 +115,11 @@ class Act:
         if not t.is_contiguous():
             t = t.contiguous()   # rare: arbitrary strides from the caller
         a = Act.new(N, H, W, C, t.device)
-        _lib.call("hpri_nchw_to_nhwc", _p(t), a.ptr, N, C, H * W, a.cs, 0, a.cw, _stream())
+        if npl > 0 and PLANE_PRODUCERS and (H * W) % 4 == 0 and t.data_ptr() % 16 == 0:
+            pl = new_planes(a, npl)
+            _lib.call("hpri_nchw_to_nhwc_pl", _p(t), a.ptr, N, C, H * W, a.cs, 0, a.cw, *_pl_args(pl), _stream())
+        else:
+            _lib.call("hpri_nchw_to_nhwc", _p(t), a.ptr, N, C, H * W, a.cs, 0, a.cw, _stream())
         return a
 
     def to_nchw(self) -> torch.Tensor:
@@ -134,7 +139,29 @@ class Planes:
 
 
 PLANE_CONV = os.environ.get("HPRI_PLANE_CONV", "1") != "0"   # bf16 mode: 3x3 convs on bf16 planes (0: round-1 kernel)
+PLANE_PRODUCERS = True       # producers (BN-apply, BN-backward, ...) write the planes themselves; False: generic pass only
 PLANE_CONVERSIONS = 0        # generic fp32 -> planes passes launched (fused producers do not count)
+
+
+def new_planes(x: Act, npl: int = 1) -> Planes:
+    """Uninitialised plane storage for ``x`` (the producing kernel fills it, pad channels included)."""
+    cs16 = _rup(x.C, 32)
+    buf = torch.empty(npl * x.P * cs16, dtype=torch.bfloat16, device=x.buf.device)
+    x.pl = Planes(buf, x.P * cs16, cs16, 0, npl)
+    return x.pl
+
+
+def _pl_args(pl: Optional[Planes]):
+    """(planes, plane_stride, cs, coff, cw, npl) arguments of the *_pl entry points; all zero = fp32 only."""
+    if pl is None:
+        return ctypes.c_void_p(0), 0, 0, 0, 0, 0
+    return _p(pl.buf), pl.plane, pl.cs, pl.coff, pl.cs - pl.coff, pl.npl
+
+
+def input_planes_for(module) -> int:
+    """Planes the input layout pass should write for a network whose first layer is a 3x3 convolution."""
+    prec = getattr(module, "hpri_precision", None) or DEFAULT_PRECISION
+    return 1 if (PLANE_CONV and PLANE_PRODUCERS and prec == "bf16") else 0
 
 
 def planes_of(x: Act, npl: int = 1) -> Planes:
@@ -500,8 +527,11 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
                       bn.eps, cout, _p(mean), _p(invstd), _p(scale), _p(shift), _stream())
         y = Act.new(x.N, x.H, x.W, cout, dev)
         ppg = (x.P // G)
-        _lib.call("hpri_bn_apply_relu", yr.ptr, yr.cs, yr.coff, y.ptr, y.cs, y.coff, _p(scale), _p(shift),
-                  x.P, ppg, cout, y.cw, int(relu), _stream())
+        # bf16 plane mode: the normalise pass also writes y as bf16 planes -- what the next 3x3 convolution (and the
+        # weight gradient) stage by DMA -- so no conversion pass has to read y again
+        ypl = new_planes(y, 1) if (v2 and PLANE_PRODUCERS) else None
+        _lib.call("hpri_bn_apply_relu_pl", yr.ptr, yr.cs, yr.coff, y.ptr, y.cs, y.coff, _p(scale), _p(shift),
+                  x.P, ppg, cout, y.cw, int(relu), *_pl_args(ypl), _stream())
     if not tape.record:
         return y
 
@@ -519,9 +549,10 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
             dbet, _ = tp.param_slot(bn.bias)
             db, acc_b = (tp.param_slot(bias) if bias is not None else (None, 0))
             mean, invstd, varu, scale, shift = (st[i * G * cout:(i + 1) * G * cout] for i in range(5))
-            _lib.call("hpri_bn_relu_bwd", g.ptr, g.cs, g.coff, yr.ptr, yr.cs, yr.coff, dyr.ptr, dyr.cs, dyr.coff,
+            dpl = new_planes(dyr, 1) if (v2 and need_dx and PLANE_PRODUCERS) else None     # read by the data gradient
+            _lib.call("hpri_bn_relu_bwd_pl", g.ptr, g.cs, g.coff, yr.ptr, yr.cs, yr.coff, dyr.ptr, dyr.cs, dyr.coff,
                       _p(mean), _p(invstd), _p(scale), _p(shift), _p(dgam), _p(dbet), acc_g, _p(db), acc_b,
-                      _p(ws), ws.numel(), x.P, x.P // G, cout, dyr.cw, int(relu), int(use_batch), _stream())
+                      _p(ws), ws.numel(), x.P, x.P // G, cout, dyr.cw, int(relu), int(use_batch), *_pl_args(dpl), _stream())
         else:
             dyr = g
             if bias is not None:
@@ -651,7 +682,9 @@ def maxpool2(tape: Tape, x: Act) -> Act:
     if x.H < 2 or x.W < 2:
         raise RuntimeError("hyperpri_amd: MaxPool2d(2) needs H, W >= 2")
     y = Act.new(x.N, x.H // 2, x.W // 2, x.C, x.buf.device)
-    _lib.call("hpri_maxpool2_fwd", x.ptr, x.cs, x.coff, y.ptr, y.cs, y.coff, x.N, x.H, x.W, x.cw, _stream())
+    # plane mode (the input carries bf16 planes): the pooled map is written as planes too, for the next 3x3 convolution
+    ypl = new_planes(y, x.pl.npl) if (x.pl is not None and PLANE_PRODUCERS) else None
+    _lib.call("hpri_maxpool2_fwd_pl", x.ptr, x.cs, x.coff, y.ptr, y.cs, y.coff, x.N, x.H, x.W, x.cw, *_pl_args(ypl), _stream())
     if tape.record:
         def bwd(tp: Tape) -> None:
             g = tp.grads.pop(id(y), None)

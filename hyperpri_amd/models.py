@@ -59,7 +59,7 @@ class UNet(nn.Module):
                 y = self.up3._ops(tape, y, x2)
                 y = self.up4._ops(tape, y, x1)
                 return self.outc._ops(tape, y)
-            logits = run(prog, [x], list(self.parameters()))
+            logits = run(prog, [x], list(self.parameters()), input_planes=E.input_planes_for(self))
         else:
             x1 = self.inc(x)
             x2 = self.down1(x1)
@@ -197,7 +197,7 @@ class CubeNET(torch.nn.Module):
                 y = self.up3._ops(tape, y, x2)
                 y = self._up4_ops(tape, y, x1)
                 return self.outc._ops(tape, y)
-            logits = run(prog, [x], list(self.parameters()))
+            logits = run(prog, [x], list(self.parameters()), input_planes=E.input_planes_for(self))
         else:
             x1 = self._stem(x)
             x2 = self.down1(x1)

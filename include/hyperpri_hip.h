@@ -142,6 +142,22 @@ int hpri_bn_relu_bwd(const float* dy, int dy_cs, int dy_coff, const float* x, in
                      int C, int Cw, int relu, int use_batch_stats, hipStream_t stream);
 int hpri_col_sum(const float* src, int cs, int coff, float* out, int accumulate, float* workspace, size_t ws_floats,
                  long long P, int C, hipStream_t stream);
+/* the same two passes, also writing their output as bf16 planes (hpri_to_planes layout; channels [C, pl_cw) zero) for
+ * the bf16-mode convolutions: the producer writes the planes, so no conversion pass reads the fp32 tensor again */
+int hpri_nchw_to_nhwc_pl(const float* src, float* dst, int N, int C, long long P, int cs, int coff, int Cw, void* planes,
+                         long long plane_stride, int pl_cs, int pl_coff, int pl_cw, int npl, hipStream_t stream);
+int hpri_maxpool2_fwd_pl(const float* x, int x_cs, int x_coff, float* y, int y_cs, int y_coff, int N, int H, int W, int C,
+                         void* planes, long long plane_stride, int pl_cs, int pl_coff, int pl_cw, int npl,
+                         hipStream_t stream);
+int hpri_bn_apply_relu_pl(const float* x, int x_cs, int x_coff, float* y, int y_cs, int y_coff, const float* scale,
+                          const float* shift, long long P, long long pix_per_group, int C, int Cw, int relu, void* planes,
+                          long long plane_stride, int pl_cs, int pl_coff, int pl_cw, int npl, hipStream_t stream);
+int hpri_bn_relu_bwd_pl(const float* dy, int dy_cs, int dy_coff, const float* x, int x_cs, int x_coff, float* dx,
+                        int dx_cs, int dx_coff, const float* mean, const float* invstd, const float* scale,
+                        const float* shift, float* dgamma, float* dbeta, int accumulate_param_grads, float* dbias,
+                        int accumulate_dbias, float* workspace, size_t ws_floats, long long P, long long pix_per_group,
+                        int C, int Cw, int relu, int use_batch_stats, void* planes, long long plane_stride, int pl_cs,
+                        int pl_coff, int pl_cw, int npl, hipStream_t stream);
 
 /* ---- bandwidth-bound ops (elementwise.hip) ---------------------------------------------------------
  * layout change at the module boundary (dataset.py:267-271 hands NC(D)HW), nn.MaxPool2d(2)
