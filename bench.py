@@ -354,6 +354,21 @@ def main():
                                              "launches_per_step": v["launches"] // 2,
                                              "ms_per_step": round(v["total_ms"] / 2, 3)} for k, v in sorted(summ.items())}}
 
+    # ---- north_star's named kernel: the 238->64 encoder conv (models.py:169) against the bf16 MFMA roofline ----
+    first_conv = None
+    if rank == 0 and not args.no_roofline:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import first_conv as FC
+        torch.cuda.empty_cache()
+        r = FC.measure(reps=10)
+        first_conv = {"layer": "CubeNET-64 first_conv 238->64, 3x3, batch 2, forward (bias + BN partial statistics in the epilogue)",
+                      "mode": "bf16 operand planes resident in HBM, both operands by LDS-DMA, v_mfma_f32_32x32x16_bf16, f32 accumulate "
+                              "and f32 output (precision mode 'bf16'; the layout pass that writes the planes is a separate kernel)",
+                      "ms": r["bf16_planes"]["ms"], "TF": r["bf16_planes"]["tflops"], "frac_of_2.5PF": r["bf16_planes"]["frac_of_2.5PF"],
+                      "hbm_bytes_algorithmic": int(r["bf16_planes"]["algorithmic_hbm_mb"] * 1e6),
+                      "hbm_bytes_measured": "profiles/r02_first_conv_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/first_conv.py)",
+                      "fp32_kernel_same_layer": r["fp32"]}
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline()
@@ -374,7 +389,7 @@ def main():
             "rccl_ranks": world if use_pg else 0,
             "grad_sync": grad_sync,
             "model_tflops": round(value * GFLOP_PER_CUBE / 1e3 / world, 2),
-            "roofline": roofline, "cpu_baseline": cpu, "optimizer_step": optimizer_step, "bf16x6_mode": bf16x6_mode, "bf16x3_mode": bf16x3_mode, "bf16_mode": bf16_mode,
+            "roofline": roofline, "roofline_238to64": first_conv, "cpu_baseline": cpu, "optimizer_step": optimizer_step, "bf16x6_mode": bf16x6_mode, "bf16x3_mode": bf16x3_mode, "bf16_mode": bf16_mode,
         }
         print(json.dumps(out), flush=True)
     if use_pg:

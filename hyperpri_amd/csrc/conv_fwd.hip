@@ -439,7 +439,8 @@ __global__ __launch_bounds__(256, (SPLIT == 2) ? 2 : (NTW == 1) ? 4 : ((WM == 4 
   // ---- B stages: SR row blocks (taps x planes) of BN rows x 64 bytes, contiguous per row block in the packed tensor.
   // LDS-DMA (global_load_lds_dwordx4): no VGPR staging, no ds_write.  A wave instruction fills 1 KB = 16 rows; lane l
   // lands on 16-byte slot l&3 of row l>>2.  Rows are unpadded (64-byte pitch), so the four 16-byte segments of a row are
-  // XOR-swizzled with (row>>1)&3 to keep the ds_read_b128 of 16 consecutive rows conflict-free; the DMA cannot permute,
+  // XOR-swizzled with (row>>2)&3 to keep the ds_read_b128 of 32 consecutive rows conflict-free (ds_read_b128 is served
+  // in the lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, ...: (row>>1)&3 left them 2-way conflicted); the DMA cannot permute,
   // but every lane chooses WHICH global segment it fetches, which is the same thing.
   const __bf16* wpk = reinterpret_cast<const __bf16*>(a.wp);
   int goff[NLD_B];
@@ -447,7 +448,7 @@ __global__ __launch_bounds__(256, (SPLIT == 2) ? 2 : (NTW == 1) ? 4 : ((WM == 4 
   for (int p = 0; p < NLD_B; ++p) {
     const int R = (p * 4 + wave) * 16 + (lane >> 2);          // row within the stage
     const int rb = R / BN, n = R % BN;
-    const int ls = (lane & 3) ^ ((n >> 1) & 3);               // logical segment stored at physical slot lane&3
+    const int ls = (lane & 3) ^ ((n >> 2) & 3);               // logical segment stored at physical slot lane&3
     goff[p] = (rb * a.Cout_pad + nb * BN + n) * 32 + ls * 8;  // halves, relative to the stage's first row block
   }
 #define LOAD_STAGE(s_)                                                                               \
@@ -517,7 +518,7 @@ __global__ __launch_bounds__(256, (SPLIT == 2) ? 2 : (NTW == 1) ? 4 : ((WM == 4 
   const int a_base = ((wm * 2 * RW + (li >> twl)) * HW + (li & (TW - 1))) * CS + lh * 8;
   const int a_mt = RW * HW * CS;
   const int b_base = (wn * (32 * NTW) + li) * BS;
-  const int bsw0 = ((0 + lh) ^ ((li >> 1) & 3)) * 8, bsw1 = ((2 + lh) ^ ((li >> 1) & 3)) * 8;   // swizzled k16-step offsets
+  const int bsw0 = ((0 + lh) ^ ((li >> 2) & 3)) * 8, bsw1 = ((2 + lh) ^ ((li >> 2) & 3)) * 8;   // swizzled k16-step offsets
 
   if (NBUF > 1) { LOAD_STAGE(S0) }
   LOAD_A(chunk0 * 32)

@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""The north_star's named kernel on its own: CubeNET-64's 238->64 3x3 encoder convolution (models.py:169) on a batch of
+two 238x608x968 cubes, forward, in the bf16 plane mode (bf16 NHWC input planes already resident, fp32 output + BatchNorm
+partial statistics), and for comparison the exact fp32 kernel.  Prints one JSON object; run it under
+``rocprofv3 --kernel-trace --stats`` / ``--pmc FETCH_SIZE`` / ``--pmc WRITE_SIZE`` for profiles/r02_first_conv.*.
+
+Algorithmic work per launch (batch 2): 2 x 161.36 GFLOP; algorithmic HBM bytes: bf16 input planes 2 x 301.3 MB
+(256 padded channels) + fp32 output 2 x 150.7 MB + weights 0.3 MB = 904.3 MB."""
+import ctypes
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+from hyperpri_amd import _lib  # noqa: E402
+
+N, H, W, CIN, COUT = 2, 608, 968, 238, 64
+FLOPS = 2.0 * N * H * W * CIN * COUT * 9
+PEAK_BF16 = 2500.0      # TFLOP/s, MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+
+
+def measure(reps=20, modes=("bf16_planes", "fp32")):
+    lib = _lib.load()
+    dev = torch.device("cuda", 0)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    cs, cs16, cout_pad = 240, 256, 64
+    x = torch.zeros(N * H * W, cs, device=dev)
+    x[:, :CIN] = torch.rand(N * H * W, CIN, device=dev) - 0.5
+    w = (torch.rand(COUT * CIN * 9, device=dev) - 0.5) * 0.1
+    b = torch.rand(COUT, device=dev)
+    y = torch.empty(N * H * W * COUT, device=dev)
+    out = {"shape": {"N": N, "H": H, "W": W, "Cin": CIN, "Cout": COUT, "ks": 3}, "gflop_per_launch": FLOPS / 1e9}
+    for mode in modes:
+        k, tl, wsf = ctypes.c_int(), ctypes.c_int(), ctypes.c_size_t()
+        if mode == "bf16_planes":
+            planes = torch.empty(N * H * W * cs16, dtype=torch.bfloat16, device=dev)
+            assert lib.hpri_to_planes(P(x), cs, 0, P(planes), 0, cs16, 0, N * H * W, CIN, cs16, 1, st) == 0
+            wp = torch.empty((cs16 // 32) * 9 * cout_pad * 32, dtype=torch.bfloat16, device=dev)
+            assert lib.hpri_pack_weight_bf16(P(w), P(wp), 0, CIN, COUT, cout_pad, 9, CIN, 0, 0, st) == 0
+            lib.hpri_conv_bf16v2_plan(N, H, W, cs16, cout_pad, ctypes.byref(k), ctypes.byref(tl), ctypes.byref(wsf))
+            stats = torch.empty(tl.value * cout_pad * 4, device=dev)
+            ws = torch.empty(max(wsf.value, 4), device=dev)
+            call = lambda: lib.hpri_conv_bf16v2(P(planes), 0, cs16, 0, P(wp), P(b), P(y), COUT, 0, P(stats), N, H, W, cs16, COUT,
+                                                cout_pad, COUT, 0, 0, P(ws), ws.numel(), st)
+            alg_bytes = N * H * W * (cs16 * 2 + COUT * 4) + wp.numel() * 2
+        else:
+            wp = torch.empty(lib.hpri_packed_weight_floats(CIN, cout_pad, 9), device=dev)
+            assert lib.hpri_pack_weight(P(w), P(wp), 0, CIN, COUT, cout_pad, 9, 0, 0, CIN, st) == 0
+            lib.hpri_conv_fwd_plan(N, H, W, cs, cout_pad, 3, 0, 0, ctypes.byref(k), ctypes.byref(tl), ctypes.byref(wsf))
+            stats = torch.empty(tl.value * cout_pad * 4, device=dev)
+            ws = torch.empty(max(wsf.value, 4), device=dev)
+            call = lambda: lib.hpri_conv_fwd(P(x), cs, 0, P(wp), P(b), P(y), COUT, 0, P(stats), N, H, W, cs, COUT, cout_pad, COUT, 3,
+                                             0, 0, 0, 0, 0, 0, 0, 0, P(ws), ws.numel(), st)
+            alg_bytes = N * H * W * (cs * 4 + COUT * 4) + wp.numel() * 4
+        for _ in range(3):
+            assert call() == 0, lib.hpri_last_error()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            call()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        tf = FLOPS / ms / 1e9
+        out[mode] = {"ms": round(ms, 4), "tflops": round(tf, 1), "algorithmic_hbm_mb": round(alg_bytes / 1e6, 1),
+                     "algorithmic_tb_s": round(alg_bytes / ms / 1e9, 2)}
+        if mode == "bf16_planes":
+            out[mode]["frac_of_2.5PF"] = round(tf / PEAK_BF16, 4)
+        else:
+            out[mode]["frac_of_157.3TF"] = round(tf / 157.3, 4)
+    return out
+
+
+if __name__ == "__main__":
+    reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+    modes = tuple(sys.argv[2].split(",")) if len(sys.argv) > 2 else ("bf16_planes", "fp32")
+    print(json.dumps(measure(reps, modes)))
