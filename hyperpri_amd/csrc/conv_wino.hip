@@ -1,0 +1,362 @@
+// Winograd F(2x2, 3x3) convolution in exact fp32 on the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32): forward and data
+// gradient of the 3x3 / pad-1 / stride-1 convolutions of DoubleConv (reference model_parts.py:22,25; models.py:169,177).
+//
+// The direct implicit GEMM spends 36 multiplies per 2x2 outputs and channel pair; Winograd's minimal filtering spends 16:
+//     V = B^T d B   (4x4 input tile d, per input channel)         B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
+//     U = G g G^T   (3x3 filter g, per channel pair; packed once) G   = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]
+//     M[xi] = sum_cin V[xi] * U[xi]   for the 16 frequencies xi   (16 GEMMs: [tiles x Cin] x [Cin x Cout])
+//     Y = A^T M A   (2x2 outputs)                                 A^T = [1 1 1 0; 0 1 -1 -1]
+// i.e. 2.25x fewer MFMAs in the same arithmetic type (cuDNN runs the reference's fp32 convolutions the same way);
+// results differ from the direct sum by fp32 rounding of the transforms only (measured: profiles/r02_precision_error.json).
+//
+//   workgroup  512 threads = 8 waves, one per CU (two waves per SIMD); output tile 16x16 pixels = 64 Winograd tiles x 64
+//              output channels.  Wave w owns frequencies (a, 2b) and (a, 2b+1) with a = w>>1, b = w&1 for all 64 tiles:
+//              2 frequencies x 2 tile groups x 2 channel groups of 32x32 accumulators = 128 VGPRs.
+//   A (input)  18x18 halo x 32 channels per chunk, fp32, 128-byte pixel rows in a 20-wide grid, filled by LDS-DMA
+//              (quads XOR-swizzled with (pixel>>1)&7: the stride-2 tile reads are 2-way conflicted at worst), double
+//              buffered; pixels outside the image come from a page of zeros.  The input transform happens in registers on
+//              the way to the MFMA: 6 ds_read_b128 + 5 packed adds per tile group and 8-channel stage.
+//   B (U)      per 8-channel stage each wave DMA-loads the 2 x [8 k][64 n] panels of ITS frequencies into a private LDS
+//              area (double buffered): no workgroup barrier is needed for the weights at all.
+//   sync       one barrier per 32-channel chunk (128 MFMAs per wave); vmcnt(0) per stage (the DMA has had a whole stage)
+//   epilogue   the 16 frequency planes meet in LDS ([xi][32 tiles][32 ch], four passes), each thread applies A^T . A
+//              to two (tile, channel) pairs per pass, adds the bias, stores 2x2 pixels (128-byte runs per pixel) and
+//              keeps its 32 outputs for the two-pass BatchNorm partial statistics of the tile.
+#include "common.h"
+
+__device__ __attribute__((aligned(64))) float hpri_wino_zero[16];
+
+struct WinoArgs {
+  const float* x; int x_cs, x_coff;
+  const float* up;              // packed U: [Cin_pad/8][16][8][Cout_pad]
+  const float* bias;
+  float* y; int y_cs, y_coff;
+  float4* stats;                // [N*tiles_img][Cout_pad] (mean, M2, count, 0) or nullptr
+  int N, H, W, Cin_pad, Cout, Cout_pad, y_cw, accumulate, relu;
+  int tiles_x, tiles_y;
+};
+
+#define WINO_HW 20               // halo grid width (18 used)
+#define WINO_SLOTS (18 * WINO_HW)
+#define WINO_A_BYTES (WINO_SLOTS * 128)
+#define WINO_B_WAVE 4096         // bytes per wave per stage: 2 frequencies x [8][64] fp32
+#define WINO_B_BYTES (8 * WINO_B_WAVE)
+
+__global__ __launch_bounds__(512, 2) void conv_wino_kernel(WinoArgs a) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * WINO_A_BYTES + 2 * WINO_B_BYTES];
+  unsigned char* a_lds = smem;
+  unsigned char* b_lds = smem + 2 * WINO_A_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int fa = wave >> 1, fb = wave & 1;          // frequency row a, column pair b: xi = (fa, 2 fb + e), e = 0, 1
+  const int tiles_img = a.tiles_x * a.tiles_y;
+  const int nbc = a.Cout_pad >> 6;                  // channel blocks of one pixel tile are adjacent in launch order: the
+  const int bx = blockIdx.x / nbc, nb = blockIdx.x - bx * nbc;   // input halo is fetched from HBM once and re-read from L2
+  const int img = bx / tiles_img, tin = bx - img * tiles_img;
+  const int ty0 = tin / a.tiles_x, tx0 = tin - ty0 * a.tiles_x;
+  const int Y0 = ty0 * 16, X0 = tx0 * 16;
+
+  // B^T row fa: two input rows r1, r2 with signs; columns needed for b pair fb: c0..c0+2 (R0,R1,R2 or R1,R2,R3)
+  //   a=0: d0 - d2 | a=1: d1 + d2 | a=2: d2 - d1 | a=3: d1 - d3
+  const int r1 = (fa == 0) ? 0 : 1, r2 = (fa == 3) ? 3 : 2;
+  const float s1 = (fa == 2) ? -1.f : 1.f, s2 = (fa == 1 || fa == 2) ? 1.f : -1.f;
+  const int c0 = fb;                                // fb = 0: columns 0,1,2 -> V[.][0] = R0 - R2, V[.][1] = R1 + R2
+                                                    // fb = 1: columns 1,2,3 -> V[.][2] = R2 - R1, V[.][3] = R1 - R3
+  // ---- A halo DMA: instruction i covers slots [8i, 8i+8); lane -> slot 8i + (lane>>3), physical quad lane&7 ----
+  const float* ximg = a.x + (size_t)img * a.H * a.W * a.x_cs + a.x_coff;
+  constexpr int NIA = (WINO_SLOTS / 8 + 7) / 8;     // per wave (the last round is partial)
+  int aoff[NIA];
+#pragma unroll
+  for (int q = 0; q < NIA; ++q) {
+    const int slot = (q * 8 + wave) * 8 + (lane >> 3);
+    int off = -1;
+    if (slot < WINO_SLOTS) {
+      const int hy = slot / WINO_HW, hx = slot - hy * WINO_HW;
+      const int iy = Y0 + hy - 1, ix = X0 + hx - 1;
+      if (hx < 18 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
+        off = (iy * a.W + ix) * a.x_cs + ((((lane & 7) ^ ((slot >> 1) & 7))) << 2);
+    }
+    aoff[q] = off;
+  }
+  const int lq = (lane & 7);                        // physical quad this lane fills; logical quad = lq ^ swz(slot)
+  const float* zpage = hpri_wino_zero + (lane & 3) * 4;
+#define LOAD_A(chunk_)                                                                                                \
+  {                                                                                                                   \
+    unsigned char* la_ = a_lds + ((chunk_) & 1) * WINO_A_BYTES;                                                       \
+    _Pragma("unroll") for (int q = 0; q < NIA; ++q) {                                                                 \
+      const int inst_ = q * 8 + wave;                                                                                 \
+      if (inst_ * 8 < WINO_SLOTS) {                                                                                   \
+        const int slot_ = inst_ * 8 + (lane >> 3);                                                                    \
+        const int lquad_ = lq ^ ((slot_ >> 1) & 7);                                                                   \
+        const bool ok_ = aoff[q] >= 0 && ((chunk_) * 32 + lquad_ * 4) < a.Cin_pad;                                    \
+        const float* src_ = ok_ ? (ximg + (size_t)(unsigned)aoff[q] + (chunk_) * 32) : zpage;                         \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_,                         \
+                                         (__attribute__((address_space(3))) void*)(la_ + inst_ * 1024), 16, 0, 0);    \
+      }                                                                                                               \
+    }                                                                                                                 \
+  }
+  // ---- B DMA: stage s (8 channels): this wave's frequencies e = 0,1, halves h = 0,1 of the 8 k rows ----
+  int goff[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int e = p >> 1, h = p & 1;
+    const int xi = fa * 4 + 2 * fb + e;
+    goff[p] = ((xi * 8 + 4 * h + (lane >> 4)) * a.Cout_pad) + nb * 64 + (lane & 15) * 4;
+  }
+  unsigned char* bw = b_lds + wave * WINO_B_WAVE;
+#define LOAD_B(s_)                                                                                                    \
+  {                                                                                                                   \
+    const float* pb_ = a.up + (size_t)(s_) * 16 * 8 * a.Cout_pad;                                                     \
+    unsigned char* lb_ = bw + ((s_) & 1) * WINO_B_BYTES;                                                              \
+    _Pragma("unroll") for (int p = 0; p < 4; ++p)                                                                     \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pb_ + goff[p]),              \
+                                         (__attribute__((address_space(3))) void*)(lb_ + p * 1024), 16, 0, 0);        \
+  }
+
+  // lane's tile in tile group mt: (ty, tx) = (mt*4 + (li>>3), li&7); halo slot of its input pixel (r, c):
+  //   hp = (2 ty + r) * 20 + 2 tx + c
+  int hpb[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) hpb[mt] = (2 * (mt * 4 + (li >> 3))) * WINO_HW + 2 * (li & 7);
+
+  f32x16 acc[2][2][2];                              // [frequency e][tile group mt][channel group nt]
+#pragma unroll
+  for (int e = 0; e < 2; ++e)
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[e][mt][nt][r] = 0.f;
+
+  const int nstages = a.Cin_pad >> 3;
+  const int nchunks = (a.Cin_pad + 31) >> 5;
+  LOAD_A(0)
+  LOAD_B(0)
+  for (int chunk = 0; chunk < nchunks; ++chunk) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                   // chunk's halo is visible; everyone has left the previous chunk
+    if (chunk + 1 < nchunks) { LOAD_A(chunk + 1) }
+    const unsigned char* ab = a_lds + (chunk & 1) * WINO_A_BYTES;
+    const int sg = min(4, nstages - chunk * 4);
+    for (int g = 0; g < sg; ++g) {
+      const int s = chunk * 4 + g;
+      if (s + 1 < nstages) { LOAD_B(s + 1) }
+      const float* bp = reinterpret_cast<const float*>(bw + (s & 1) * WINO_B_BYTES);
+      // weights of the stage: bfr[e][nt][j] = U[xi_e][k = 4 lh + j][n = nt*32 + li]
+      float bfr[2][2][4];
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) bfr[e][nt][j] = bp[(e * 8 + lh * 4 + j) * 64 + nt * 32 + li];
+      const int quad = 2 * g + lh;                  // this lane half's channel quad inside the chunk
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        // row combination R[c] = s1 d[r1][c] + s2 d[r2][c] for the three columns this wave needs
+        f32x4 R[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const int h1 = hpb[mt] + r1 * WINO_HW + c0 + c, h2 = hpb[mt] + r2 * WINO_HW + c0 + c;
+          const f32x4 d1 = *reinterpret_cast<const f32x4*>(ab + h1 * 128 + ((quad ^ ((h1 >> 1) & 7)) << 4));
+          const f32x4 d2 = *reinterpret_cast<const f32x4*>(ab + h2 * 128 + ((quad ^ ((h2 >> 1) & 7)) << 4));
+          R[c] = s1 * d1 + s2 * d2;
+        }
+        // fb = 0: V0 = R[0] - R[2], V1 = R[1] + R[2]   |   fb = 1 (R = R1,R2,R3): V2 = R[1] - R[0], V3 = R[0] - R[2]
+        const f32x4 v0 = fb ? (R[1] - R[0]) : (R[0] - R[2]);
+        const f32x4 v1 = fb ? (R[0] - R[2]) : (R[1] + R[2]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) {
+            acc[0][mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(v0[j], bfr[0][nt][j], acc[0][mt][nt], 0, 0, 0);
+            acc[1][mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(v1[j], bfr[1][nt][j], acc[1][mt][nt], 0, 0, 0);
+          }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next stage's panels (and the next halo) have had a whole stage
+    }
+  }
+#undef LOAD_A
+#undef LOAD_B
+  __syncthreads();
+
+  // ------------------------------- epilogue -------------------------------
+  // acc[e][mt][nt][r]: tile t = (r&3) + 8*(r>>2) + 4*lh of group mt, channel nt*32 + li, frequency (fa, 2 fb + e)
+  float* ex = reinterpret_cast<float*>(smem);       // [16 xi][32 tiles][32 ch]
+  const int oc = tid & 31, otq = tid >> 5;          // output phase: channel lane, tile pair index
+  float outv[2][2][2][4];                           // [mt][nt][pair][pixel]
+  const int vrows = min(16, a.H - Y0), vcols = min(16, a.W - X0);
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int xi = fa * 4 + 2 * fb + e;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int t = (r & 3) + 8 * (r >> 2) + 4 * lh;
+          ex[(xi * 32 + t) * 32 + li] = acc[e][mt][nt][r];
+        }
+      }
+      __syncthreads();
+      const int n = nb * 64 + nt * 32 + oc;
+      const float bias = (a.bias != nullptr && n < a.Cout) ? a.bias[n] : 0.f;
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const int t = otq * 2 + p;
+        float m[16];
+#pragma unroll
+        for (int xi = 0; xi < 16; ++xi) m[xi] = ex[(xi * 32 + t) * 32 + oc];
+        // Y = A^T M A with A^T = [1 1 1 0; 0 1 -1 -1]
+        const float u0 = m[0] + m[4] + m[8], u1 = m[1] + m[5] + m[9], u2 = m[2] + m[6] + m[10], u3 = m[3] + m[7] + m[11];
+        const float w0 = m[4] - m[8] - m[12], w1 = m[5] - m[9] - m[13], w2 = m[6] - m[10] - m[14], w3 = m[7] - m[11] - m[15];
+        float o[4] = {u0 + u1 + u2, u1 - u2 - u3, w0 + w1 + w2, w1 - w2 - w3};
+        const int py = 2 * (mt * 4 + (t >> 3)), px = 2 * (t & 7);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          float v = o[k] + bias;
+          if (a.relu) v = fmaxf(v, 0.f);
+          if (n >= a.Cout) v = 0.f;
+          const int yy = py + (k >> 1), xx = px + (k & 1);
+          const bool ok = yy < vrows && xx < vcols;
+          if (ok && n < a.y_cw) {
+            float* dst = a.y + ((size_t)(img * a.H + Y0 + yy) * a.W + X0 + xx) * a.y_cs + a.y_coff + n;
+            if (a.accumulate) v += *dst;
+            *dst = v;
+          }
+          outv[mt][nt][p][k] = ok ? v : 0.f;
+          if (a.accumulate) outv[mt][nt][p][k] = 0.f;     // statistics are never requested together with accumulate
+        }
+      }
+      __syncthreads();
+    }
+
+  if (a.stats != nullptr) {
+    // two-pass per-tile statistics over the valid pixels: thread (oc, otq) holds 16 pixels of channels oc and 32+oc
+    float* red = reinterpret_cast<float*>(smem);    // [16 otq][64 ch]
+    const float cnt = (float)(vrows * vcols);
+    float mean[2];
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        float sacc = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int p = 0; p < 2; ++p) {
+            const int t = otq * 2 + p;
+            const int py = 2 * (mt * 4 + (t >> 3)), px = 2 * (t & 7);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const bool ok = (py + (k >> 1)) < vrows && (px + (k & 1)) < vcols;
+              const float v = outv[mt][nt][p][k];
+              if (pass == 0) sacc += v;
+              else if (ok) { const float d = v - mean[nt]; sacc += d * d; }
+            }
+          }
+        red[otq * 64 + nt * 32 + oc] = sacc;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        float tsum = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) tsum += red[q * 64 + nt * 32 + oc];
+        if (pass == 0) mean[nt] = tsum / cnt;
+        else if (otq == 0) a.stats[(size_t)bx * a.Cout_pad + nb * 64 + nt * 32 + oc] = make_float4(mean[nt], tsum, cnt, 0.f);
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// ---- filter transform: U = G g G^T, packed [Cin_pad/8][16][8][Ncols_pad] ------------------------------------------------
+// mode 0: forward       g(k = c, col = n)[t] = W[n][c][t]            (W: [Cout][Cin][3][3], src_d1 = Cin)
+// mode 1: data gradient g(k = n, col = c)[t] = W[n][c][8 - t]        (K = Cout, columns = Cin)
+__global__ void wino_pack_kernel(const float* __restrict__ w, float* __restrict__ up, int mode, int K, int Ncols, int Ncols_pad,
+                                 int stages, int src_d1, const float* __restrict__ colscale) {
+  const size_t total = (size_t)stages * 8 * Ncols_pad;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int col = (int)(idx % Ncols_pad);
+    const int kk = (int)((idx / Ncols_pad) % 8);
+    const int st = (int)(idx / ((size_t)Ncols_pad * 8));
+    const int k = st * 8 + kk;
+    float g[3][3];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      float v = 0.f;
+      if (k < K && col < Ncols) {
+        v = (mode == 0) ? w[((size_t)col * src_d1 + k) * 9 + t] : w[((size_t)k * src_d1 + col) * 9 + (8 - t)];
+        if (colscale != nullptr) v *= colscale[col];
+      }
+      g[t / 3][t % 3] = v;
+    }
+    // Gg: 4x3
+    float gg[4][3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      gg[0][q] = g[0][q];
+      gg[1][q] = 0.5f * (g[0][q] + g[1][q] + g[2][q]);
+      gg[2][q] = 0.5f * (g[0][q] - g[1][q] + g[2][q]);
+      gg[3][q] = g[2][q];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float u0 = gg[i][0], u1 = 0.5f * (gg[i][0] + gg[i][1] + gg[i][2]), u2 = 0.5f * (gg[i][0] - gg[i][1] + gg[i][2]),
+                  u3 = gg[i][2];
+      const float u[4] = {u0, u1, u2, u3};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) up[(((size_t)st * 16 + i * 4 + j) * 8 + kk) * Ncols_pad + col] = u[j];
+    }
+  }
+}
+
+extern "C" size_t hpri_wino_packed_floats(int K, int Ncols_pad) { return (size_t)hpri_cdiv(K, 8) * 16 * 8 * Ncols_pad; }
+
+extern "C" int hpri_wino_pack(const float* w, float* up, const float* colscale, int mode, int K, int Ncols, int Ncols_pad,
+                              int src_d1, hipStream_t stream) {
+  HPRI_REQUIRE(w && up, "wino_pack: null pointer");
+  HPRI_REQUIRE((mode == 0 || mode == 1) && K > 0 && Ncols > 0 && Ncols_pad >= Ncols && Ncols_pad % 64 == 0, "wino_pack: bad arguments");
+  const int stages = hpri_cdiv(K, 8);
+  const size_t total = (size_t)stages * 8 * Ncols_pad;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(wino_pack_kernel, dim3(blocks), dim3(256), 0, stream, w, up, mode, K, Ncols, Ncols_pad, stages, src_d1, colscale);
+  HPRI_CHECK_LAUNCH();
+  return HPRI_OK;
+}
+
+extern "C" int hpri_conv_wino_plan(int N, int H, int W, int* stat_tiles) {
+  *stat_tiles = N * hpri_cdiv(H, 16) * hpri_cdiv(W, 16);
+  return HPRI_OK;
+}
+
+// 3x3 / pad 1 / stride 1 convolution, Winograd F(2x2,3x3), fp32.  x: fp32 NHWC view with channels [Cin, Cin_pad) zero
+// (Cin_pad a multiple of 8); up from hpri_wino_pack; accumulate bit 0: y += result, bit 1: ReLU epilogue.
+extern "C" int hpri_conv_wino(const float* x, int x_cs, int x_coff, const float* up, const float* bias, float* y, int y_cs,
+                              int y_coff, float* stats, int N, int H, int W, int Cin_pad, int Cout, int Cout_pad, int y_cw,
+                              int accumulate, hipStream_t stream) {
+  HPRI_REQUIRE(x && up && y, "conv_wino: null pointer");
+  HPRI_REQUIRE(N > 0 && H > 0 && W > 0, "conv_wino: empty image");
+  HPRI_REQUIRE(Cin_pad > 0 && Cin_pad % 8 == 0, "conv_wino: Cin_pad must be a positive multiple of 8");
+  HPRI_REQUIRE(Cout_pad % 64 == 0 && Cout <= Cout_pad && Cout > 0, "conv_wino: Cout_pad must be a multiple of 64 >= Cout");
+  HPRI_REQUIRE(x_cs % 4 == 0 && x_coff % 4 == 0 && x_coff + Cin_pad <= x_cs, "conv_wino: input channel stride/offset");
+  HPRI_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)up & 15) == 0, "conv_wino: pointers must be 16-byte aligned");
+  HPRI_REQUIRE((long long)H * W * x_cs < (1ll << 31), "conv_wino: one image of the input view exceeds 2^31 elements");
+  HPRI_REQUIRE(!((accumulate & 1) && stats != nullptr), "conv_wino: statistics are not available together with accumulate");
+  WinoArgs a;
+  a.x = x; a.x_cs = x_cs; a.x_coff = x_coff; a.up = up; a.bias = bias; a.y = y; a.y_cs = y_cs; a.y_coff = y_coff;
+  a.stats = reinterpret_cast<float4*>(stats);
+  a.N = N; a.H = H; a.W = W; a.Cin_pad = Cin_pad; a.Cout = Cout; a.Cout_pad = Cout_pad;
+  a.y_cw = y_cw < Cout ? Cout : y_cw; a.accumulate = accumulate & 1; a.relu = (accumulate >> 1) & 1;
+  HPRI_REQUIRE(a.y_cw + y_coff <= y_cs, "conv_wino: output channels exceed the channel stride");
+  a.tiles_x = hpri_cdiv(W, 16); a.tiles_y = hpri_cdiv(H, 16);
+  dim3 grid((unsigned)(N * a.tiles_x * a.tiles_y * (Cout_pad / 64)), 1u, 1u);
+  hipLaunchKernelGGL(conv_wino_kernel, grid, dim3(512), 0, stream, a);
+  HPRI_CHECK_LAUNCH();
+  return HPRI_OK;
+}

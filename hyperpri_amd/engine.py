@@ -138,6 +138,38 @@ class Planes:
         self.buf, self.plane, self.cs, self.coff, self.npl = buf, plane, cs, coff, npl
 
 
+# fp32 mode: 3x3 convolutions (forward and data gradient) by Winograd F(2x2,3x3) on the fp32 MFMA (csrc/conv_wino.hip):
+# 2.25x fewer multiplies in the same arithmetic type; 0 = direct implicit GEMM everywhere
+WINOGRAD = os.environ.get("HPRI_WINOGRAD", "1") != "0"
+WINO_MIN_BLOCKS = 256        # workgroups (16x16-pixel tiles x 64-channel blocks) below which the direct split-K kernel is used
+
+
+def _wino_ok(x: "Act", ncols: int) -> bool:
+    return WINOGRAD and x.N * ((x.H + 15) // 16) * ((x.W + 15) // 16) * (_rup(ncols, 64) // 64) >= WINO_MIN_BLOCKS
+
+
+def _pack_wino(w: torch.Tensor, mode: int, K: int, ncols: int, d1: int) -> Tuple[torch.Tensor, int]:
+    ncols_pad = _rup(ncols, 64)
+
+    def build():
+        global PACK_LAUNCHES
+        up = torch.empty(_lib.load().hpri_wino_packed_floats(K, ncols_pad), dtype=torch.float32, device=w.device)
+        _lib.call("hpri_wino_pack", _p(w), _p(up), ctypes.c_void_p(0), mode, K, ncols, ncols_pad, d1, _stream())
+        PACK_LAUNCHES += 1
+        return up
+    return _cached_pack(w, ("wino", mode, K, ncols, d1), build), ncols_pad
+
+
+def _conv_launch_wino(x: Act, up: torch.Tensor, bias: Optional[torch.Tensor], y: Act, stats: Optional[torch.Tensor],
+                      cin: int, cout: int, cout_pad: int, y_cw: int, accumulate: int = 0) -> None:
+    tag = "conv_winograd_f32<3,F(2x2)>"
+    if SHAPE_TAGS:
+        tag += f" N{x.N} {x.H}x{x.W} K{x.cw} N{cout}"
+    with _timed(tag, 2.0 * x.N * x.H * x.W * cin * cout * 9):     # flops of the DIRECT sum it replaces ("effective")
+        _lib.call("hpri_conv_wino", x.ptr, x.cs, x.coff, _p(up), _p(bias), y.ptr, y.cs, y.coff, _p(stats), x.N, x.H, x.W, x.cw,
+                  cout, cout_pad, y_cw, accumulate, _stream())
+
+
 PLANE_CONV = os.environ.get("HPRI_PLANE_CONV", "1") != "0"   # bf16 mode: 3x3 convs on bf16 planes (0: round-1 kernel)
 PLANE_PRODUCERS = True       # producers (BN-apply, BN-backward, ...) write the planes themselves; False: generic pass only
 PLANE_CONVERSIONS = 0        # generic fp32 -> planes passes launched (fused producers do not count)
@@ -477,7 +509,11 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
     lowp = prec in LOWP
     split = _SPLIT.get(prec, 0)
     v2 = PLANE_CONV and prec == "bf16" and ks == 3        # operands by LDS-DMA from bf16 planes (conv_bf16v2.hip)
-    if lowp:
+    wino = prec == "fp32" and ks == 3 and groups == 1 and _wino_ok(x, cout)
+    wino_d = prec == "fp32" and ks == 3 and groups == 1 and _wino_ok(x, cin)     # the data gradient has Cin columns
+    if wino:
+        wp, cout_pad = _pack_wino(weight, 0, cin, cout, cin)
+    elif lowp:
         wp, cout_pad = _pack_bf16(weight, 0, cin, cout, T, cin, split=split)
     else:
         wp, cout_pad = _pack(weight, 0, cin, cout, T, 0, cin)
@@ -491,7 +527,9 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
     tiles = 0
     if use_batch:
         ksp = ctypes.c_int(); tl = ctypes.c_int(); wsf = ctypes.c_size_t()
-        if v2:
+        if wino:
+            _lib.call("hpri_conv_wino_plan", x.N, x.H, x.W, ctypes.byref(tl))
+        elif v2:
             _lib.call("hpri_conv_bf16v2_plan", x.N, x.H, x.W, _rup(cin, 32), cout_pad, ctypes.byref(ksp), ctypes.byref(tl),
                       ctypes.byref(wsf))
         elif lowp:
@@ -502,7 +540,9 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
                       ctypes.byref(tl), ctypes.byref(wsf))
         tiles = tl.value
         stats = torch.empty(tiles * cout_pad * 4, dtype=torch.float32, device=dev)
-    if v2:
+    if wino:
+        _conv_launch_wino(x, wp, bias, yr, stats, cin, cout, cout_pad, yr.cw)
+    elif v2:
         _conv_launch_v2(x, wp, bias, yr, stats, cin, cout, cout_pad, yr.cw)
     elif lowp:
         _conv_launch_bf16(x, wp, bias, yr, stats, x.N, x.H, x.W, cin_pad, cout, cout_pad, yr.cw, ks, cin_true=cin, split=split)
@@ -577,7 +617,10 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
             _wgrad(x, dyr, dw, acc_w, cin, cout, ks, bf16=lowp, split=split)
         if need_dx:
             gx, acc = tp.grad_slot(x)
-            if v2:
+            if wino_d:
+                upd, cin_cols_pad = _pack_wino(weight, 1, cout, cin, cin)
+                _conv_launch_wino(dyr, upd, None, gx, None, cout, cin, cin_cols_pad, gx.cw, accumulate=int(acc))
+            elif v2:
                 wpd, cin_cols_pad = _pack_bf16(weight, 1, cout, cin, T, cin, split=0)
                 _conv_launch_v2(dyr, wpd, None, gx, None, cout, cin, cin_cols_pad, gx.cw, accumulate=int(acc))
             elif lowp:
@@ -609,6 +652,7 @@ def _conv_folded_eval(x: Act, weight: torch.Tensor, bias: Optional[torch.Tensor]
     cout_pad = _rup(cout, 64)
     lowp = prec in LOWP
     split = _SPLIT.get(prec, 0)
+    wino = prec == "fp32" and ks == 3 and _wino_ok(x, cout)
 
     def build():
         global PACK_LAUNCHES
@@ -616,7 +660,10 @@ def _conv_folded_eval(x: Act, weight: torch.Tensor, bias: Optional[torch.Tensor]
         fold = torch.empty(2 * cout, dtype=torch.float32, device=dev)
         _lib.call("hpri_bn_fold", _p(bn.running_mean), _p(bn.running_var), _p(bn.weight), _p(bn.bias), _p(bias), bn.eps, cout,
                   _p(fold[:cout]), _p(fold[cout:]), _stream())
-        if lowp:   # bf16 / bf16x3 / bf16x6 predict path: the same fold, weights scaled in fp32 and then rounded / split
+        if wino:   # Winograd layout: the filter transform is linear, so the column scale goes in front of it
+            wp = torch.empty(_lib.load().hpri_wino_packed_floats(cin, cout_pad), dtype=torch.float32, device=dev)
+            _lib.call("hpri_wino_pack", _p(weight), _p(wp), _p(fold[:cout]), 0, cin, cout, cout_pad, cin, _stream())
+        elif lowp:   # bf16 / bf16x3 / bf16x6 predict path: the same fold, weights scaled in fp32 and then rounded / split
             wp = torch.empty(((cin + 31) // 32) * T * cout_pad * 32 * (split + 1), dtype=torch.bfloat16, device=dev)
             _lib.call("hpri_pack_weight_bf16_scaled", _p(weight), _p(wp), _p(fold[:cout]), cin, cout, cout_pad, T, cin, split,
                       _stream())
@@ -632,10 +679,12 @@ def _conv_folded_eval(x: Act, weight: torch.Tensor, bias: Optional[torch.Tensor]
             return (t.data_ptr(), -1)
     bn_state = (_BN_EPOCH, ver(bn.running_mean), ver(bn.running_var), ver(bn.weight), ver(bn.bias),
                 None if bias is None else ver(bias))
-    wp, fold = _cached_pack(weight, ("fold", prec, ks), build, extra=bn_state)
+    wp, fold = _cached_pack(weight, ("fold", prec, ks, wino), build, extra=bn_state)
     fbias = fold[cout:]
     y = Act.new(x.N, x.H, x.W, cout, dev)
-    if lowp and PLANE_CONV and prec == "bf16" and ks == 3:
+    if wino:
+        _conv_launch_wino(x, wp, fbias, y, None, cin, cout, cout_pad, y.cw, accumulate=2 if relu else 0)
+    elif lowp and PLANE_CONV and prec == "bf16" and ks == 3:
         _conv_launch_v2(x, wp, fbias, y, None, cin, cout, cout_pad, y.cw, accumulate=2 if relu else 0)
     elif lowp:
         _conv_launch_bf16(x, wp, fbias, y, None, x.N, x.H, x.W, x.cw, cout, cout_pad, y.cw, ks, accumulate=2 if relu else 0,

@@ -79,6 +79,19 @@ int hpri_conv_fwd(const float* x, int x_cs, int x_coff, const float* wp, const f
                   int KS, int amode, int epi, int accumulate, int H2, int W2, int py0, int px0, int Cup, float* ws,
                   size_t ws_floats, hipStream_t stream);
 
+/* ---- Winograd F(2x2,3x3), exact fp32 MFMA (conv_wino.hip) ---------------------------------------------------------
+ * 3x3 / pad 1 / stride 1 convolutions (model_parts.py:22,25; models.py:169,177), forward and data gradient, with 16 instead
+ * of 36 multiplies per 2x2 outputs.  hpri_wino_pack transforms the filters (U = G g G^T; mode 0 forward, mode 1 data
+ * gradient, optional per-column scale for the eval-mode BN fold) into [K/8][16][8][Ncols_pad]; hpri_conv_wino_plan gives
+ * the number of BatchNorm partial records (one per 16x16-pixel tile); `accumulate` bit 0: y += result, bit 1: ReLU. */
+size_t hpri_wino_packed_floats(int K, int Ncols_pad);
+int hpri_wino_pack(const float* w, float* up, const float* colscale, int mode, int K, int Ncols, int Ncols_pad, int src_d1,
+                   hipStream_t stream);
+int hpri_conv_wino_plan(int N, int H, int W, int* stat_tiles);
+int hpri_conv_wino(const float* x, int x_cs, int x_coff, const float* up, const float* bias, float* y, int y_cs, int y_coff,
+                   float* stats, int N, int H, int W, int Cin_pad, int Cout, int Cout_pad, int y_cw, int accumulate,
+                   hipStream_t stream);
+
 /* bf16-operand variants (precision mode "bf16", BASELINE.json config C5): operands rounded to bf16 while staged into
  * LDS, v_mfma_f32_32x32x16_bf16 with fp32 accumulate, fp32 activations in HBM.  Same modes, plan, workspace and
  * statistics contract as hpri_conv_fwd / hpri_pack_weight (plan: hpri_conv_fwd_bf16_plan).  split = 1 (precision mode
