@@ -34,7 +34,22 @@ struct WinoArgs {
   float4* stats;                // [N*tiles_img][Cout_pad] (mean, M2, count, 0) or nullptr
   int N, H, W, Cin_pad, Cout, Cout_pad, y_cw, accumulate, relu;
   int tiles_x, tiles_y;
+  unsigned long long* stamps;   // diagnostic builds (-DHPRI_STAMPS) only
 };
+
+#ifdef HPRI_STAMPS
+#define STAMP(i_)                                                                                          \
+  {                                                                                                        \
+    unsigned long long t_;                                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                                     \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                            \
+    __builtin_amdgcn_sched_barrier(0);                                                                     \
+    if (a.stamps != nullptr && (threadIdx.x & 255) == 0)                                                   \
+      a.stamps[((size_t)blockIdx.x * 2 + (threadIdx.x >> 8)) * 8 + (i_)] = t_;                              \
+  }
+#else
+#define STAMP(i_)
+#endif
 
 #define WINO_HW 20               // halo grid width (18 used)
 #define WINO_SLOTS (18 * WINO_HW)
@@ -132,17 +147,48 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(WinoArgs a) {
 
   const int nstages = a.Cin_pad >> 3;
   const int nchunks = (a.Cin_pad + 31) >> 5;
+  STAMP(0)
   LOAD_A(0)
   LOAD_B(0)
+  // The two waves of a SIMD run the same program; to keep them from issuing their DMA pieces (each costs the issuing wave
+  // 60-150 cycles without an MFMA) at the same moment, waves 0-3 issue the next stage's loads at the start of a stage and
+  // waves 4-7 in its middle, between the two tile groups: one wave's issue stall is covered by its partner's MFMAs.
+  // Issue order inside a stage is weights first, then (first stage of a chunk) the next chunk's halo, so the counted wait
+  // at the end of that stage retires the weights and leaves the halo in flight for up to four stages.
+  const bool late = wave >= 4;
+#define WAIT_VM(n_) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n_) : "memory")
+#define ISSUE_LOADS()                                                   \
+  {                                                                     \
+    if (s + 1 < nstages) { LOAD_B(s + 1) }                              \
+    if (g == 0 && chunk + 1 < nchunks) { LOAD_A(chunk + 1) }            \
+  }
+#define TILE_GROUP(mt)                                                                                                 \
+  {                                                                                                                    \
+    /* row combination R[c] = s1 d[r1][c] + s2 d[r2][c] for the three columns this wave needs */                       \
+    f32x4 R[3];                                                                                                        \
+    _Pragma("unroll") for (int c = 0; c < 3; ++c) {                                                                    \
+      const int h1 = hpb[mt] + r1 * WINO_HW + c0 + c, h2 = hpb[mt] + r2 * WINO_HW + c0 + c;                            \
+      const f32x4 d1 = *reinterpret_cast<const f32x4*>(ab + h1 * 128 + ((quad ^ ((h1 >> 1) & 7)) << 4));               \
+      const f32x4 d2 = *reinterpret_cast<const f32x4*>(ab + h2 * 128 + ((quad ^ ((h2 >> 1) & 7)) << 4));               \
+      R[c] = s1 * d1 + s2 * d2;                                                                                        \
+    }                                                                                                                  \
+    /* fb = 0: V0 = R0 - R2, V1 = R1 + R2   |   fb = 1 (R = R1,R2,R3): V2 = R2 - R1, V3 = R1 - R3 */                   \
+    const f32x4 v0 = fb ? (R[1] - R[0]) : (R[0] - R[2]);                                                               \
+    const f32x4 v1 = fb ? (R[0] - R[2]) : (R[1] + R[2]);                                                               \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                      \
+        _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) {                                                             \
+          acc[0][mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(v0[j], bfr[0][nt][j], acc[0][mt][nt], 0, 0, 0);        \
+          acc[1][mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(v1[j], bfr[1][nt][j], acc[1][mt][nt], 0, 0, 0);        \
+        }                                                                                                              \
+  }
   for (int chunk = 0; chunk < nchunks; ++chunk) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                   // chunk's halo is visible; everyone has left the previous chunk
-    if (chunk + 1 < nchunks) { LOAD_A(chunk + 1) }
     const unsigned char* ab = a_lds + (chunk & 1) * WINO_A_BYTES;
     const int sg = min(4, nstages - chunk * 4);
     for (int g = 0; g < sg; ++g) {
       const int s = chunk * 4 + g;
-      if (s + 1 < nstages) { LOAD_B(s + 1) }
+      if (!late) ISSUE_LOADS()
       const float* bp = reinterpret_cast<const float*>(bw + (s & 1) * WINO_B_BYTES);
       // weights of the stage: bfr[e][nt][j] = U[xi_e][k = 4 lh + j][n = nt*32 + li]
       float bfr[2][2][4];
@@ -153,125 +199,117 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(WinoArgs a) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) bfr[e][nt][j] = bp[(e * 8 + lh * 4 + j) * 64 + nt * 32 + li];
       const int quad = 2 * g + lh;                  // this lane half's channel quad inside the chunk
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt) {
-        // row combination R[c] = s1 d[r1][c] + s2 d[r2][c] for the three columns this wave needs
-        f32x4 R[3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          const int h1 = hpb[mt] + r1 * WINO_HW + c0 + c, h2 = hpb[mt] + r2 * WINO_HW + c0 + c;
-          const f32x4 d1 = *reinterpret_cast<const f32x4*>(ab + h1 * 128 + ((quad ^ ((h1 >> 1) & 7)) << 4));
-          const f32x4 d2 = *reinterpret_cast<const f32x4*>(ab + h2 * 128 + ((quad ^ ((h2 >> 1) & 7)) << 4));
-          R[c] = s1 * d1 + s2 * d2;
-        }
-        // fb = 0: V0 = R[0] - R[2], V1 = R[1] + R[2]   |   fb = 1 (R = R1,R2,R3): V2 = R[1] - R[0], V3 = R[0] - R[2]
-        const f32x4 v0 = fb ? (R[1] - R[0]) : (R[0] - R[2]);
-        const f32x4 v1 = fb ? (R[0] - R[2]) : (R[1] + R[2]);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int nt = 0; nt < 2; ++nt) {
-            acc[0][mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(v0[j], bfr[0][nt][j], acc[0][mt][nt], 0, 0, 0);
-            acc[1][mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(v1[j], bfr[1][nt][j], acc[1][mt][nt], 0, 0, 0);
-          }
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next stage's panels (and the next halo) have had a whole stage
+      TILE_GROUP(0)
+      __builtin_amdgcn_sched_barrier(0);
+      if (late) ISSUE_LOADS()
+      __builtin_amdgcn_sched_barrier(0);
+      TILE_GROUP(1)
+      // the next stage's weights must have landed; a halo issued in this stage (after them) may stay in flight
+      if (g == 0 && chunk + 1 < nchunks && s + 1 < nstages) { if (wave < 5) WAIT_VM(6); else WAIT_VM(5); }
+      else WAIT_VM(0);
     }
   }
+#undef TILE_GROUP
+#undef ISSUE_LOADS
+#undef WAIT_VM
 #undef LOAD_A
 #undef LOAD_B
+  STAMP(1)
   __syncthreads();
 
   // ------------------------------- epilogue -------------------------------
-  // acc[e][mt][nt][r]: tile t = (r&3) + 8*(r>>2) + 4*lh of group mt, channel nt*32 + li, frequency (fa, 2 fb + e)
-  float* ex = reinterpret_cast<float*>(smem);       // [16 xi][32 tiles][32 ch]
-  const int oc = tid & 31, otq = tid >> 5;          // output phase: channel lane, tile pair index
-  float outv[2][2][2][4];                           // [mt][nt][pair][pixel]
+  // acc[e][mt][nt][r]: tile t = (r&3) + 8*(r>>2) + 4*lh of group mt, channel nt*32 + li, frequency (fa, 2 fb + e).
+  // Two passes (tile groups): the 16 frequency planes of 32 tiles x 64 channels meet in LDS (128 KB), then every thread
+  // owns one (tile, channel quad): 16 float4 reads, A^T . A, bias, and 2x2 pixels stored as float4.
+  float* ex = reinterpret_cast<float*>(smem);       // [16 xi][32 tiles][64 ch]
+  static_assert(16 * 32 * 64 * 4 <= 2 * WINO_A_BYTES + 2 * WINO_B_BYTES, "exchange buffer must fit the staging LDS");
+  const int ot = tid >> 4, oq = tid & 15;           // output phase: tile of the group, channel quad
+  const int n0 = nb * 64 + oq * 4;
+  f32x4 outv[2][4];                                 // [mt][pixel] x 4 channels
   const int vrows = min(16, a.H - Y0), vcols = min(16, a.W - X0);
+  f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+  if (a.bias != nullptr) {
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
+    for (int c = 0; c < 4; ++c) if (n0 + c < a.Cout) bias4[c] = a.bias[n0 + c];
+  }
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
+  for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        const int xi = fa * 4 + 2 * fb + e;
+    for (int e = 0; e < 2; ++e) {
+      const int xi = fa * 4 + 2 * fb + e;
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int t = (r & 3) + 8 * (r >> 2) + 4 * lh;
-          ex[(xi * 32 + t) * 32 + li] = acc[e][mt][nt][r];
+          ex[(xi * 32 + t) * 64 + nt * 32 + li] = acc[e][mt][nt][r];
         }
-      }
-      __syncthreads();
-      const int n = nb * 64 + nt * 32 + oc;
-      const float bias = (a.bias != nullptr && n < a.Cout) ? a.bias[n] : 0.f;
-#pragma unroll
-      for (int p = 0; p < 2; ++p) {
-        const int t = otq * 2 + p;
-        float m[16];
-#pragma unroll
-        for (int xi = 0; xi < 16; ++xi) m[xi] = ex[(xi * 32 + t) * 32 + oc];
-        // Y = A^T M A with A^T = [1 1 1 0; 0 1 -1 -1]
-        const float u0 = m[0] + m[4] + m[8], u1 = m[1] + m[5] + m[9], u2 = m[2] + m[6] + m[10], u3 = m[3] + m[7] + m[11];
-        const float w0 = m[4] - m[8] - m[12], w1 = m[5] - m[9] - m[13], w2 = m[6] - m[10] - m[14], w3 = m[7] - m[11] - m[15];
-        float o[4] = {u0 + u1 + u2, u1 - u2 - u3, w0 + w1 + w2, w1 - w2 - w3};
-        const int py = 2 * (mt * 4 + (t >> 3)), px = 2 * (t & 7);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          float v = o[k] + bias;
-          if (a.relu) v = fmaxf(v, 0.f);
-          if (n >= a.Cout) v = 0.f;
-          const int yy = py + (k >> 1), xx = px + (k & 1);
-          const bool ok = yy < vrows && xx < vcols;
-          if (ok && n < a.y_cw) {
-            float* dst = a.y + ((size_t)(img * a.H + Y0 + yy) * a.W + X0 + xx) * a.y_cs + a.y_coff + n;
-            if (a.accumulate) v += *dst;
-            *dst = v;
-          }
-          outv[mt][nt][p][k] = ok ? v : 0.f;
-          if (a.accumulate) outv[mt][nt][p][k] = 0.f;     // statistics are never requested together with accumulate
-        }
-      }
-      __syncthreads();
     }
+    __syncthreads();
+    f32x4 m[16];
+#pragma unroll
+    for (int xi = 0; xi < 16; ++xi) m[xi] = *reinterpret_cast<const f32x4*>(ex + (xi * 32 + ot) * 64 + oq * 4);
+    // Y = A^T M A with A^T = [1 1 1 0; 0 1 -1 -1]
+    const f32x4 u0 = m[0] + m[4] + m[8], u1 = m[1] + m[5] + m[9], u2 = m[2] + m[6] + m[10], u3 = m[3] + m[7] + m[11];
+    const f32x4 w0 = m[4] - m[8] - m[12], w1 = m[5] - m[9] - m[13], w2 = m[6] - m[10] - m[14], w3 = m[7] - m[11] - m[15];
+    f32x4 o[4] = {u0 + u1 + u2, u1 - u2 - u3, w0 + w1 + w2, w1 - w2 - w3};
+    const int py = 2 * (mt * 4 + (ot >> 3)), px = 2 * (ot & 7);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      f32x4 v = o[k] + bias4;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        if (a.relu) v[c] = fmaxf(v[c], 0.f);
+        if (n0 + c >= a.Cout) v[c] = 0.f;
+      }
+      const int yy = py + (k >> 1), xx = px + (k & 1);
+      const bool ok = yy < vrows && xx < vcols;
+      if (ok && n0 < a.y_cw) {
+        float* dst = a.y + ((size_t)(img * a.H + Y0 + yy) * a.W + X0 + xx) * a.y_cs + a.y_coff + n0;
+        if (a.accumulate) v += *reinterpret_cast<const f32x4*>(dst);
+        *reinterpret_cast<f32x4*>(dst) = v;
+      }
+      const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+      outv[mt][k] = ok ? v : zero4;
+    }
+    __syncthreads();
+  }
 
+  STAMP(2)
   if (a.stats != nullptr) {
-    // two-pass per-tile statistics over the valid pixels: thread (oc, otq) holds 16 pixels of channels oc and 32+oc
-    float* red = reinterpret_cast<float*>(smem);    // [16 otq][64 ch]
+    // two-pass per-tile statistics over the valid pixels: thread (ot, oq) holds 8 pixels of channels 4 oq .. 4 oq + 3
+    float* red = reinterpret_cast<float*>(smem);    // [32 ot][64 ch]
     const float cnt = (float)(vrows * vcols);
-    float mean[2];
+    f32x4 mean4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
+      f32x4 sacc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
-        float sacc = 0.f;
+      for (int mt = 0; mt < 2; ++mt) {
+        const int py = 2 * (mt * 4 + (ot >> 3)), px = 2 * (ot & 7);
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-          for (int p = 0; p < 2; ++p) {
-            const int t = otq * 2 + p;
-            const int py = 2 * (mt * 4 + (t >> 3)), px = 2 * (t & 7);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-              const bool ok = (py + (k >> 1)) < vrows && (px + (k & 1)) < vcols;
-              const float v = outv[mt][nt][p][k];
-              if (pass == 0) sacc += v;
-              else if (ok) { const float d = v - mean[nt]; sacc += d * d; }
-            }
-          }
-        red[otq * 64 + nt * 32 + oc] = sacc;
+        for (int k = 0; k < 4; ++k) {
+          const bool ok = (py + (k >> 1)) < vrows && (px + (k & 1)) < vcols;
+          if (pass == 0) sacc += outv[mt][k];
+          else if (ok) { const f32x4 d = outv[mt][k] - mean4; sacc += d * d; }
+        }
+      }
+      *reinterpret_cast<f32x4*>(red + ot * 64 + oq * 4) = sacc;
+      __syncthreads();
+      // channel c = tid (64 threads): sum over the 32 tiles
+      if (tid < 64) {
+        float tsum = 0.f;
+#pragma unroll 8
+        for (int q = 0; q < 32; ++q) tsum += red[q * 64 + tid];
+        if (pass == 0) red[32 * 64 + tid] = tsum / cnt;
+        else a.stats[(size_t)bx * a.Cout_pad + nb * 64 + tid] = make_float4(red[32 * 64 + tid], tsum, cnt, 0.f);
       }
       __syncthreads();
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
-        float tsum = 0.f;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) tsum += red[q * 64 + nt * 32 + oc];
-        if (pass == 0) mean[nt] = tsum / cnt;
-        else if (otq == 0) a.stats[(size_t)bx * a.Cout_pad + nb * 64 + nt * 32 + oc] = make_float4(mean[nt], tsum, cnt, 0.f);
-      }
+      if (pass == 0) mean4 = *reinterpret_cast<const f32x4*>(red + 32 * 64 + oq * 4);
       __syncthreads();
     }
   }
+  STAMP(3)
 }
 
 // ---- filter transform: U = G g G^T, packed [Cin_pad/8][16][8][Ncols_pad] ------------------------------------------------
@@ -330,6 +368,9 @@ extern "C" int hpri_wino_pack(const float* w, float* up, const float* colscale, 
   return HPRI_OK;
 }
 
+static unsigned long long* hpri_wino_stamps = nullptr;   // diagnostic builds: set through hpri_wino_set_stamps
+extern "C" int hpri_wino_set_stamps(unsigned long long* p) { hpri_wino_stamps = p; return HPRI_OK; }
+
 extern "C" int hpri_conv_wino_plan(int N, int H, int W, int* stat_tiles) {
   *stat_tiles = N * hpri_cdiv(H, 16) * hpri_cdiv(W, 16);
   return HPRI_OK;
@@ -354,9 +395,243 @@ extern "C" int hpri_conv_wino(const float* x, int x_cs, int x_coff, const float*
   a.N = N; a.H = H; a.W = W; a.Cin_pad = Cin_pad; a.Cout = Cout; a.Cout_pad = Cout_pad;
   a.y_cw = y_cw < Cout ? Cout : y_cw; a.accumulate = accumulate & 1; a.relu = (accumulate >> 1) & 1;
   HPRI_REQUIRE(a.y_cw + y_coff <= y_cs, "conv_wino: output channels exceed the channel stride");
+  HPRI_REQUIRE(y_cs % 4 == 0 && y_coff % 4 == 0 && a.y_cw % 4 == 0 && ((uintptr_t)y & 15) == 0,
+               "conv_wino: the output view must be float4-aligned (stride, offset and written width multiples of 4)");
   a.tiles_x = hpri_cdiv(W, 16); a.tiles_y = hpri_cdiv(H, 16);
+  a.stamps = hpri_wino_stamps;
   dim3 grid((unsigned)(N * a.tiles_x * a.tiles_y * (Cout_pad / 64)), 1u, 1u);
   hipLaunchKernelGGL(conv_wino_kernel, grid, dim3(512), 0, stream, a);
+  HPRI_CHECK_LAUNCH();
+  return HPRI_OK;
+}
+
+// =====================================================================================================================
+// Winograd weight gradient.  With M = U (.) V and Y = A^T M A, the gradient of the transformed filter is
+//     dU[xi][cin][cout] = sum over tiles  V[xi][tile][cin] * dM[xi][tile][cout],   dM = A dY A^T   (A = [1 0; 1 1; 1 -1; 0 -1])
+// and dg = G^T dU G: again 16 instead of 36 multiplies per 2x2 output pixels and channel pair.  Sixteen GEMMs whose
+// reduction runs over the TILES: MFMA rows = cin, columns = cout, k = tile; both operands are transformed in registers.
+//
+//   workgroup  8 waves, wave (a, b) owns frequencies (a, 2b), (a, 2b+1) of one 64 (cin) x 64 (cout) block:
+//              2 x 2 x 2 accumulator tiles = 128 VGPRs; it walks a contiguous run of strips ("split-K" over the tiles) and
+//              writes ONE partial slab ws[split][xi][cin][cout]; hpri_wino_wgrad_reduce sums the slabs in a fixed order
+//              (deterministic) and applies G^T . G on the way into the OIHW gradient.
+//   stage      one strip of 16 tiles (2 output rows x 32 columns): input halo 4 x 34 pixels x 64 cin and dY 2 x 32 pixels
+//              x 64 cout, both [pixel][channel] by LDS-DMA (lanes index the channel: every ds_read_b32 is 32 consecutive
+//              dwords), double buffered; 64 MFMAs per wave, one barrier.
+struct WinoWgradArgs {
+  const float* x; int x_cs, x_coff, x_cvalid;
+  const float* dy; int dy_cs, dy_coff, dy_cvalid;
+  float* ws;                    // [splits][16][Cr][Nr]
+  int N, H, W, Cr, Nr, cblk;
+  int strips_x, strips_y, total, per_split;
+};
+
+#define WG_XROW 36               // staged halo pixels per row (34 used)
+#define WG_X_BYTES (4 * WG_XROW * 256)
+#define WG_Y_BYTES (2 * 32 * 256)
+#define WG_STAGE_BYTES (WG_X_BYTES + WG_Y_BYTES)
+
+__global__ __launch_bounds__(512, 2) void conv_wino_wgrad_kernel(WinoWgradArgs a) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * WG_STAGE_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int fa = wave >> 1, fb = wave & 1;
+  const int split = blockIdx.x, cb = blockIdx.y % a.cblk, nbk = blockIdx.y / a.cblk;
+  const int c_blk = cb * 64, n_blk = nbk * 64;
+  const int u0 = split * a.per_split, u1 = min(a.total, u0 + a.per_split);
+
+  // input-transform roles (as the forward kernel): rows r1, r2 with signs, columns c0 .. c0+2
+  const int r1 = (fa == 0) ? 0 : 1, r2 = (fa == 3) ? 3 : 2;
+  const float s1 = (fa == 2) ? -1.f : 1.f, s2 = (fa == 1 || fa == 2) ? 1.f : -1.f;
+  const int c0 = fb;
+  // dM = A dY A^T: row part T[q] = ta0 dY[0][q] + ta1 dY[1][q] with (ta0, ta1) = (1,0) (1,1) (1,-1) (0,-1) for a = 0..3
+  const float ta0 = (fa == 3) ? 0.f : 1.f, ta1 = (fa == 0) ? 0.f : (fa == 1 ? 1.f : -1.f);
+
+  f32x16 acc[2][2][2];                              // [frequency e][cin tile ct][cout tile nt]
+#pragma unroll
+  for (int e = 0; e < 2; ++e)
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[e][ct][nt][r] = 0.f;
+
+  const float* zpage = hpri_wino_zero + (lane & 3) * 4;
+  // DMA pieces of a stage: x rows 4 x 9 pieces (4 pixels x 256 B each), dy 2 x 8 pieces; piece p of this wave = p*8 + wave
+  constexpr int NPX = 4 * (WG_XROW / 4), NPY = 2 * 8, NPW = (NPX + NPY + 7) / 8;
+#define LOAD_UNIT(u_, buf_)                                                                                            \
+  {                                                                                                                    \
+    int q_ = (u_);                                                                                                     \
+    const int sx_ = q_ % a.strips_x; q_ /= a.strips_x;                                                                 \
+    const int sy_ = q_ % a.strips_y; const int img_ = q_ / a.strips_y;                                                 \
+    const int y0_ = sy_ * 2, x0_ = sx_ * 32;                                                                           \
+    unsigned char* lb_ = smem + (buf_) * WG_STAGE_BYTES;                                                               \
+    _Pragma("unroll") for (int p = 0; p < NPW; ++p) {                                                                  \
+      const int piece_ = p * 8 + wave;                                                                                 \
+      if (piece_ < NPX + NPY) {                                                                                        \
+        const float* src_ = zpage;                                                                                     \
+        if (piece_ < NPX) {                                                                                            \
+          const int row_ = piece_ / (WG_XROW / 4), px_ = (piece_ % (WG_XROW / 4)) * 4 + (lane >> 4);                   \
+          const int iy_ = y0_ + row_ - 1, ix_ = x0_ + px_ - 1, c_ = c_blk + (lane & 15) * 4;                           \
+          if (px_ < 34 && iy_ >= 0 && iy_ < a.H && ix_ >= 0 && ix_ < a.W && c_ < a.x_cvalid)                           \
+            src_ = a.x + ((size_t)(img_ * a.H + iy_) * a.W + ix_) * a.x_cs + a.x_coff + c_;                            \
+        } else {                                                                                                       \
+          const int pp_ = piece_ - NPX;                                                                                \
+          const int row_ = pp_ >> 3, px_ = (pp_ & 7) * 4 + (lane >> 4);                                                \
+          const int iy_ = y0_ + row_, ix_ = x0_ + px_, n_ = n_blk + (lane & 15) * 4;                                   \
+          if (iy_ < a.H && ix_ < a.W && n_ < a.dy_cvalid)                                                              \
+            src_ = a.dy + ((size_t)(img_ * a.H + iy_) * a.W + ix_) * a.dy_cs + a.dy_coff + n_;                         \
+        }                                                                                                              \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_,                          \
+                                         (__attribute__((address_space(3))) void*)(lb_ + piece_ * 1024), 16, 0, 0);    \
+      }                                                                                                                \
+    }                                                                                                                  \
+  }
+
+  if (u0 < u1) LOAD_UNIT(u0, 0)
+  for (int u = u0; u < u1; ++u) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                   // this unit has landed for everyone; the other buffer is free
+    if (u + 1 < u1) LOAD_UNIT(u + 1, (u + 1 - u0) & 1)
+    const float* xs = reinterpret_cast<const float*>(smem + ((u - u0) & 1) * WG_STAGE_BYTES);
+    const float* ys = xs + WG_X_BYTES / 4;
+#pragma unroll 2
+    for (int kk = 0; kk < 8; ++kk) {                // MFMA k-step: tiles 2 kk + lh of the strip
+      const int tile = 2 * kk + lh;
+      float va[2][2], vb[2][2];                     // [frequency e][cin tile | cout tile]
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        float R[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const float d1 = xs[(r1 * WG_XROW + 2 * tile + c0 + c) * 64 + ct * 32 + li];
+          const float d2 = xs[(r2 * WG_XROW + 2 * tile + c0 + c) * 64 + ct * 32 + li];
+          R[c] = s1 * d1 + s2 * d2;
+        }
+        va[0][ct] = fb ? (R[1] - R[0]) : (R[0] - R[2]);
+        va[1][ct] = fb ? (R[0] - R[2]) : (R[1] + R[2]);
+      }
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const float y00 = ys[(0 * 32 + 2 * tile + 0) * 64 + nt * 32 + li], y01 = ys[(0 * 32 + 2 * tile + 1) * 64 + nt * 32 + li];
+        const float y10 = ys[(1 * 32 + 2 * tile + 0) * 64 + nt * 32 + li], y11 = ys[(1 * 32 + 2 * tile + 1) * 64 + nt * 32 + li];
+        const float t0 = ta0 * y00 + ta1 * y10, t1 = ta0 * y01 + ta1 * y11;
+        // column part for b = 2 fb + e:  b=0: t0 | b=1: t0 + t1 | b=2: t0 - t1 | b=3: -t1
+        vb[0][nt] = fb ? (t0 - t1) : t0;
+        vb[1][nt] = fb ? (-t1) : (t0 + t1);
+      }
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt)
+            acc[e][ct][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[e][ct], vb[e][nt], acc[e][ct][nt], 0, 0, 0);
+    }
+  }
+#undef LOAD_UNIT
+  // slab: ws[split][xi][c][n]; accumulator rows = cin (register index), columns = cout (lane)
+  float* slab = a.ws + (size_t)split * 16 * a.Cr * a.Nr;
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int xi = fa * 4 + 2 * fb + e;
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const int n = n_blk + nt * 32 + li;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int c = c_blk + ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          slab[((size_t)xi * a.Cr + c) * a.Nr + n] = acc[e][ct][nt][r];
+        }
+      }
+  }
+}
+
+// dW[n][c][3][3] (+)= G^T (sum over splits of dU[.][c][n]) G, fixed summation order.  One thread per (c, n).
+__global__ void wino_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int splits, int Cr, int Nr,
+                                         int Cin, int Cout, int accumulate) {
+  const int n = blockIdx.x * 64 + (threadIdx.x & 63), c = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (n >= Cout || c >= Cin) return;
+  float u[16];
+#pragma unroll
+  for (int xi = 0; xi < 16; ++xi) u[xi] = 0.f;
+  const size_t slab = (size_t)16 * Cr * Nr;
+  for (int k = 0; k < splits; ++k) {
+    const float* p = ws + (size_t)k * slab + (size_t)c * Nr + n;
+#pragma unroll
+    for (int xi = 0; xi < 16; ++xi) u[xi] += p[(size_t)xi * Cr * Nr];
+  }
+  // t = G^T u (3x4 . 4x4), G^T = [1 .5 .5 0; 0 .5 -.5 0; 0 .5 .5 1]
+  float t[3][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    t[0][j] = u[0 * 4 + j] + 0.5f * (u[1 * 4 + j] + u[2 * 4 + j]);
+    t[1][j] = 0.5f * (u[1 * 4 + j] - u[2 * 4 + j]);
+    t[2][j] = 0.5f * (u[1 * 4 + j] + u[2 * 4 + j]) + u[3 * 4 + j];
+  }
+  float* o = dw + ((size_t)n * Cin + c) * 9;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const float g0 = t[i][0] + 0.5f * (t[i][1] + t[i][2]), g1 = 0.5f * (t[i][1] - t[i][2]), g2 = 0.5f * (t[i][1] + t[i][2]) + t[i][3];
+    o[i * 3 + 0] = accumulate ? o[i * 3 + 0] + g0 : g0;
+    o[i * 3 + 1] = accumulate ? o[i * 3 + 1] + g1 : g1;
+    o[i * 3 + 2] = accumulate ? o[i * 3 + 2] + g2 : g2;
+  }
+}
+
+extern "C" int hpri_wino_wgrad_plan(int N, int H, int W, int Cin_pad, int Cout_pad, int* splits, int* Cr, int* Nr) {
+  const int cblk = hpri_cdiv(Cin_pad, 64), nblk = hpri_cdiv(Cout_pad, 64);
+  const int total = N * hpri_cdiv(H, 2) * hpri_cdiv(W, 32);
+  *Cr = cblk * 64; *Nr = nblk * 64;
+  const int tiles = cblk * nblk;
+  // one workgroup per CU: splits such that tiles * splits is close to a multiple of 256, with >= 8 strips per split
+  int best = 1; double best_eff = 0.0;
+  for (int k = 1; k <= 512; ++k) {
+    if (k > 1 && total / k < 8) break;
+    const double per_cu = (double)tiles * k / 256.0;
+    double eff = per_cu / (double)((long long)(per_cu + 0.999999));
+    if (per_cu < 1.0) eff = per_cu;
+    if (eff > best_eff + 1e-9) { best_eff = eff; best = k; }
+  }
+  *splits = best;
+  return HPRI_OK;
+}
+
+// Weight gradient of a 3x3 / pad 1 convolution by Winograd: slabs in ws (splits*16*Cr*Nr floats, hpri_wino_wgrad_plan),
+// then hpri_wino_wgrad_reduce into dW (OIHW).
+extern "C" int hpri_conv_wino_wgrad(const float* x, int x_cs, int x_coff, int x_cvalid, const float* dy, int dy_cs, int dy_coff,
+                                    int dy_cvalid, float* ws, size_t ws_floats, int N, int H, int W, int Cin_pad, int Cout_pad,
+                                    hipStream_t stream) {
+  HPRI_REQUIRE(x && dy && ws, "conv_wino_wgrad: null pointer");
+  HPRI_REQUIRE(N > 0 && H > 0 && W > 0 && Cin_pad > 0 && Cout_pad > 0, "conv_wino_wgrad: bad sizes");
+  HPRI_REQUIRE(x_cs % 4 == 0 && x_coff % 4 == 0 && dy_cs % 4 == 0 && dy_coff % 4 == 0 && x_cvalid % 4 == 0 && dy_cvalid % 4 == 0,
+               "conv_wino_wgrad: channel strides / offsets / valid counts must be multiples of 4");
+  HPRI_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)dy & 15) == 0, "conv_wino_wgrad: pointers must be 16-byte aligned");
+  WinoWgradArgs a;
+  a.x = x; a.x_cs = x_cs; a.x_coff = x_coff; a.x_cvalid = x_cvalid; a.dy = dy; a.dy_cs = dy_cs; a.dy_coff = dy_coff; a.dy_cvalid = dy_cvalid;
+  a.ws = ws; a.N = N; a.H = H; a.W = W;
+  int splits;
+  hpri_wino_wgrad_plan(N, H, W, Cin_pad, Cout_pad, &splits, &a.Cr, &a.Nr);
+  if ((size_t)splits * 16 * a.Cr * a.Nr > ws_floats) return hpri_set_error(HPRI_ERR_WORKSPACE, "conv_wino_wgrad: workspace too small");
+  a.cblk = a.Cr / 64;
+  a.strips_x = hpri_cdiv(W, 32); a.strips_y = hpri_cdiv(H, 2); a.total = N * a.strips_x * a.strips_y;
+  a.per_split = hpri_cdiv(a.total, splits);
+  dim3 grid((unsigned)splits, (unsigned)(a.cblk * (a.Nr / 64)), 1u);
+  hipLaunchKernelGGL(conv_wino_wgrad_kernel, grid, dim3(512), 0, stream, a);
+  HPRI_CHECK_LAUNCH();
+  return HPRI_OK;
+}
+
+extern "C" int hpri_wino_wgrad_reduce(const float* ws, float* dw, int N, int H, int W, int Cin, int Cin_pad, int Cout, int Cout_pad,
+                                      int accumulate, hipStream_t stream) {
+  HPRI_REQUIRE(ws && dw && Cin > 0 && Cout > 0, "wino_wgrad_reduce: bad arguments");
+  int splits, Cr, Nr;
+  hpri_wino_wgrad_plan(N, H, W, Cin_pad, Cout_pad, &splits, &Cr, &Nr);
+  dim3 grid((unsigned)hpri_cdiv(Cout, 64), (unsigned)hpri_cdiv(Cin, 4));
+  hipLaunchKernelGGL(wino_wgrad_reduce_kernel, grid, dim3(256), 0, stream, ws, dw, splits, Cr, Nr, Cin, Cout, accumulate);
   HPRI_CHECK_LAUNCH();
   return HPRI_OK;
 }

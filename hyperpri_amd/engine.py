@@ -141,6 +141,7 @@ class Planes:
 # fp32 mode: 3x3 convolutions (forward and data gradient) by Winograd F(2x2,3x3) on the fp32 MFMA (csrc/conv_wino.hip):
 # 2.25x fewer multiplies in the same arithmetic type; 0 = direct implicit GEMM everywhere
 WINOGRAD = os.environ.get("HPRI_WINOGRAD", "1") != "0"
+WINO_WGRAD = os.environ.get("HPRI_WINO_WGRAD", "1") != "0"     # ... and the weight gradients
 WINO_MIN_BLOCKS = 256        # workgroups (16x16-pixel tiles x 64-channel blocks) below which the direct split-K kernel is used
 
 
@@ -709,6 +710,19 @@ def _wgrad(x: Act, dy: Act, dw: torch.Tensor, accumulate: int, cin: int, cout: i
     tag = f"conv_wgrad{('_bf16', '_bf16x3', '_bf16x6')[split] if bf16 else ''}<{ks},{'s2d' if bmode == A_S2D else 'direct'}>"
     if SHAPE_TAGS:
         tag += f" N{N} {H}x{W} C{cin_pad} N{cout}"
+    if (not bf16) and ks == 3 and bmode == A_DIRECT and dst_mode == 0 and WINOGRAD and WINO_WGRAD and N * H * W >= 4096:
+        # Winograd weight gradient (conv_wino.hip): 16 instead of 36 multiplies per 2x2 pixels and channel pair
+        sp = ctypes.c_int(); wcr = ctypes.c_int(); wnr = ctypes.c_int()
+        _lib.call("hpri_wino_wgrad_plan", N, H, W, cin_pad, cout_pad, ctypes.byref(sp), ctypes.byref(wcr), ctypes.byref(wnr))
+        wws = _ws(sp.value * 16 * wcr.value * wnr.value, x.buf.device)
+        wtag = "conv_wgrad_winograd_f32<3>"
+        if SHAPE_TAGS:
+            wtag += f" N{N} {H}x{W} C{cin_pad} N{cout}"
+        with _timed(wtag, 2.0 * N * H * W * cin * cout * 9):
+            _lib.call("hpri_conv_wino_wgrad", x.ptr, x.cs, x.coff, cin_pad, dy.ptr, dy.cs, dy.coff, dy.cw, _p(wws), wws.numel(),
+                      N, H, W, cin_pad, cout_pad, _stream())
+        _lib.call("hpri_wino_wgrad_reduce", _p(wws), _p(dw), N, H, W, cin, cin_pad, cout, cout_pad, accumulate, _stream())
+        return
     if bf16:
         with _timed(tag, 2.0 * N * H * W * cin * cout * ks * ks):
             _lib.call("hpri_conv_wgrad_bf16", x.ptr, x.cs, x.coff, cin_pad, dy.ptr, dy.cs, dy.coff, dy_cvalid, _p(ws), ws.numel(),

@@ -92,6 +92,16 @@ int hpri_conv_wino(const float* x, int x_cs, int x_coff, const float* up, const 
                    float* stats, int N, int H, int W, int Cin_pad, int Cout, int Cout_pad, int y_cw, int accumulate,
                    hipStream_t stream);
 
+/* Winograd weight gradient (dU = sum over tiles of V * (A dY A^T), dg = G^T dU G): slabs ws[split][16][Cr][Nr] from
+ * hpri_conv_wino_wgrad (sizes: hpri_wino_wgrad_plan), fixed-order sum + inverse filter transform into OIHW by
+ * hpri_wino_wgrad_reduce. */
+int hpri_wino_wgrad_plan(int N, int H, int W, int Cin_pad, int Cout_pad, int* splits, int* Cr, int* Nr);
+int hpri_conv_wino_wgrad(const float* x, int x_cs, int x_coff, int x_cvalid, const float* dy, int dy_cs, int dy_coff,
+                         int dy_cvalid, float* ws, size_t ws_floats, int N, int H, int W, int Cin_pad, int Cout_pad,
+                         hipStream_t stream);
+int hpri_wino_wgrad_reduce(const float* ws, float* dw, int N, int H, int W, int Cin, int Cin_pad, int Cout, int Cout_pad,
+                           int accumulate, hipStream_t stream);
+
 /* bf16-operand variants (precision mode "bf16", BASELINE.json config C5): operands rounded to bf16 while staged into
  * LDS, v_mfma_f32_32x32x16_bf16 with fp32 accumulate, fp32 activations in HBM.  Same modes, plan, workspace and
  * statistics contract as hpri_conv_fwd / hpri_pack_weight (plan: hpri_conv_fwd_bf16_plan).  split = 1 (precision mode

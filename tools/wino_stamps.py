@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Cycle shares of a conv_wino workgroup (diagnostic build, tools/build_stamps.sh): main loop | output transform + stores |
+statistics, median over workgroups."""
+import ctypes, json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+SHAPES = [(2, 608, 968, 238, 64), (2, 608, 968, 64, 64), (2, 304, 484, 128, 128), (2, 152, 242, 256, 256)]
+def rup(x, m): return (x + m - 1) // m * m
+lib = ctypes.CDLL(os.path.join(ROOT, "hyperpri_amd", "lib", "libv2stamps.so"))
+lib.hpri_last_error.restype = ctypes.c_char_p
+lib.hpri_wino_packed_floats.restype = ctypes.c_size_t
+dev = torch.device("cuda", 0)
+st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+P = lambda t: ctypes.c_void_p(t.data_ptr())
+for (N, H, W, Cin, Cout) in SHAPES:
+    cs, cout_pad = rup(Cin, 8), rup(Cout, 64)
+    x = torch.zeros(N * H * W, cs, device=dev); x[:, :Cin] = torch.randn(N * H * W, Cin, device=dev)
+    w = torch.randn(Cout, Cin, 3, 3, device=dev) * 0.1
+    b = torch.randn(Cout, device=dev)
+    up = torch.empty(lib.hpri_wino_packed_floats(Cin, cout_pad), device=dev)
+    assert lib.hpri_wino_pack(P(w), P(up), ctypes.c_void_p(0), 0, Cin, Cout, cout_pad, Cin, st) == 0
+    tl = ctypes.c_int(); lib.hpri_conv_wino_plan(N, H, W, ctypes.byref(tl))
+    stats = torch.zeros(tl.value * cout_pad * 4, device=dev)
+    y = torch.zeros(N * H * W * Cout, device=dev)
+    nwg = tl.value * (cout_pad // 64)
+    stamps = torch.zeros(nwg * 2 * 8, dtype=torch.int64, device=dev)
+    lib.hpri_wino_set_stamps(P(stamps))
+    for _ in range(3):
+        rc = lib.hpri_conv_wino(P(x), cs, 0, P(up), P(b), P(y), Cout, 0, P(stats), N, H, W, cs, Cout, cout_pad, Cout, 0, st)
+        assert rc == 0, lib.hpri_last_error()
+    torch.cuda.synchronize()
+    t = stamps.view(-1, 2, 8).cpu().double()
+    names = ["main loop", "transform+store", "statistics"]
+    print(f"N{N} {H}x{W} {Cin}->{Cout}: {nwg} workgroups, {Cin // 8 if Cin % 8 == 0 else cs // 8} stages")
+    for g in (0, 1):
+        d = [t[:, g, i + 1] - t[:, g, i] for i in range(3)]
+        tot = t[:, g, 3] - t[:, g, 0]
+        print(f"   waves {4*g}-{4*g+3}: total {tot.median():8.0f} | " + " | ".join(f"{n} {v.median():7.0f} ({100 * v.median() / tot.median():4.1f} %)" for n, v in zip(names, d)) + f" | per stage {d[0].median() / (cs // 8):6.0f}")
