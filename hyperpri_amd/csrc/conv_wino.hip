@@ -155,60 +155,87 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(WinoArgs a) {
   // waves 4-7 in its middle, between the two tile groups: one wave's issue stall is covered by its partner's MFMAs.
   // Issue order inside a stage is weights first, then (first stage of a chunk) the next chunk's halo, so the counted wait
   // at the end of that stage retires the weights and leaves the halo in flight for up to four stages.
+  //
+  // Vector-ALU diet (the VALU shares the SIMD's issue port with the MFMAs; tools/wino_stamps.py ablations):
+  //   * halo addresses: h*128 + ((quad ^ swz(h)) << 4) == (h*128 + (swz(h) << 4)) ^ (quad << 4): twelve per-lane constants,
+  //     one XOR + one ADD (buffer select) per read
+  //   * transform: with sigma = s1*s2, P[c] = d1[c] + sigma d2[c] (one FMA), V'0 / V'1 = one add/sub each, and the common sign
+  //     s1 (-1 only for frequency row 2) is applied once to the accumulators in the epilogue
+  //   * the column-pair variant (fb) is a compile-time parameter of the loop body: no per-element selects
+  //   * the 16 weight values of the NEXT stage are read right after the wait that retires their DMA, behind the last MFMAs
   const bool late = wave >= 4;
+  const float sigma = s1 * s2;
+  int pre[2][6];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const int h1 = hpb[mt] + r1 * WINO_HW + c0 + c, h2 = hpb[mt] + r2 * WINO_HW + c0 + c;
+      pre[mt][2 * c + 0] = h1 * 128 + (((h1 >> 1) & 7) << 4);
+      pre[mt][2 * c + 1] = h2 * 128 + (((h2 >> 1) & 7) << 4);
+    }
 #define WAIT_VM(n_) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n_) : "memory")
+#if defined(WINO_DIAG) && (WINO_DIAG & 4)
+#define ISSUE_LOADS() {}
+#else
 #define ISSUE_LOADS()                                                   \
   {                                                                     \
     if (s + 1 < nstages) { LOAD_B(s + 1) }                              \
     if (g == 0 && chunk + 1 < nchunks) { LOAD_A(chunk + 1) }            \
   }
-#define TILE_GROUP(mt)                                                                                                 \
+#endif
+#define READ_BFR(s_)                                                                                                   \
   {                                                                                                                    \
-    /* row combination R[c] = s1 d[r1][c] + s2 d[r2][c] for the three columns this wave needs */                       \
-    f32x4 R[3];                                                                                                        \
+    const float* bp_ = reinterpret_cast<const float*>(bw + ((s_) & 1) * WINO_B_BYTES);                                 \
+    _Pragma("unroll") for (int e = 0; e < 2; ++e)                                                                      \
+        _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                                               \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) bfr[e][nt][j] = bp_[(e * 8 + lh * 4 + j) * 64 + nt * 32 + li]; \
+  }
+#define TILE_GROUP(mt, FB_)                                                                                            \
+  {                                                                                                                    \
+    f32x4 P[3];                                                                                                        \
     _Pragma("unroll") for (int c = 0; c < 3; ++c) {                                                                    \
-      const int h1 = hpb[mt] + r1 * WINO_HW + c0 + c, h2 = hpb[mt] + r2 * WINO_HW + c0 + c;                            \
-      const f32x4 d1 = *reinterpret_cast<const f32x4*>(ab + h1 * 128 + ((quad ^ ((h1 >> 1) & 7)) << 4));               \
-      const f32x4 d2 = *reinterpret_cast<const f32x4*>(ab + h2 * 128 + ((quad ^ ((h2 >> 1) & 7)) << 4));               \
-      R[c] = s1 * d1 + s2 * d2;                                                                                        \
+      const f32x4 d1 = *reinterpret_cast<const f32x4*>(smem + ((pre[mt][2 * c + 0] ^ q16) + aboff));                   \
+      const f32x4 d2 = *reinterpret_cast<const f32x4*>(smem + ((pre[mt][2 * c + 1] ^ q16) + aboff));                   \
+      P[c] = d1 + sigma * d2;                                                                                          \
     }                                                                                                                  \
-    /* fb = 0: V0 = R0 - R2, V1 = R1 + R2   |   fb = 1 (R = R1,R2,R3): V2 = R2 - R1, V3 = R1 - R3 */                   \
-    const f32x4 v0 = fb ? (R[1] - R[0]) : (R[0] - R[2]);                                                               \
-    const f32x4 v1 = fb ? (R[0] - R[2]) : (R[1] + R[2]);                                                               \
+    /* FB_ = 0: V0 = P0 - P2, V1 = P1 + P2   |   FB_ = 1 (P = columns 1,2,3): V2 = P2 - P1, V3 = P1 - P3 */            \
+    const f32x4 v0 = FB_ ? (P[1] - P[0]) : (P[0] - P[2]);                                                              \
+    const f32x4 v1 = FB_ ? (P[0] - P[2]) : (P[1] + P[2]);                                                              \
     _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                      \
         _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) {                                                             \
           acc[0][mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(v0[j], bfr[0][nt][j], acc[0][mt][nt], 0, 0, 0);        \
           acc[1][mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(v1[j], bfr[1][nt][j], acc[1][mt][nt], 0, 0, 0);        \
         }                                                                                                              \
   }
-  for (int chunk = 0; chunk < nchunks; ++chunk) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                   // chunk's halo is visible; everyone has left the previous chunk
-    const unsigned char* ab = a_lds + (chunk & 1) * WINO_A_BYTES;
-    const int sg = min(4, nstages - chunk * 4);
-    for (int g = 0; g < sg; ++g) {
-      const int s = chunk * 4 + g;
-      if (!late) ISSUE_LOADS()
-      const float* bp = reinterpret_cast<const float*>(bw + (s & 1) * WINO_B_BYTES);
-      // weights of the stage: bfr[e][nt][j] = U[xi_e][k = 4 lh + j][n = nt*32 + li]
-      float bfr[2][2][4];
-#pragma unroll
-      for (int e = 0; e < 2; ++e)
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) bfr[e][nt][j] = bp[(e * 8 + lh * 4 + j) * 64 + nt * 32 + li];
-      const int quad = 2 * g + lh;                  // this lane half's channel quad inside the chunk
-      TILE_GROUP(0)
-      __builtin_amdgcn_sched_barrier(0);
-      if (late) ISSUE_LOADS()
-      __builtin_amdgcn_sched_barrier(0);
-      TILE_GROUP(1)
-      // the next stage's weights must have landed; a halo issued in this stage (after them) may stay in flight
-      if (g == 0 && chunk + 1 < nchunks && s + 1 < nstages) { if (wave < 5) WAIT_VM(6); else WAIT_VM(5); }
-      else WAIT_VM(0);
-    }
+#define MAIN_LOOP(FB_)                                                                                                 \
+  for (int chunk = 0; chunk < nchunks; ++chunk) {                                                                      \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                   \
+    __builtin_amdgcn_s_barrier();          /* chunk's halo is visible; everyone has left the previous chunk */         \
+    const int aboff = (chunk & 1) * WINO_A_BYTES;                                                                      \
+    const int sg = min(4, nstages - chunk * 4);                                                                        \
+    if (chunk == 0) { READ_BFR(0) }                                                                                    \
+    for (int g = 0; g < sg; ++g) {                                                                                     \
+      const int s = chunk * 4 + g;                                                                                     \
+      if (!late) ISSUE_LOADS()                                                                                         \
+      const int q16 = (2 * g + lh) << 4;    /* this lane half's channel quad inside the chunk, as a byte offset */      \
+      TILE_GROUP(0, FB_)                                                                                               \
+      __builtin_amdgcn_sched_barrier(0);                                                                               \
+      if (late) ISSUE_LOADS()                                                                                          \
+      __builtin_amdgcn_sched_barrier(0);                                                                               \
+      TILE_GROUP(1, FB_)                                                                                               \
+      /* the next stage's weights must have landed; a halo issued in this stage (after them) may stay in flight */     \
+      if (g == 0 && chunk + 1 < nchunks && s + 1 < nstages) { if (wave < 5) WAIT_VM(6); else WAIT_VM(5); }             \
+      else WAIT_VM(0);                                                                                                 \
+      __builtin_amdgcn_sched_barrier(0);                                                                               \
+      if (s + 1 < nstages) { READ_BFR(s + 1) }                                                                         \
+      __builtin_amdgcn_sched_barrier(0);                                                                               \
+    }                                                                                                                  \
   }
+  float bfr[2][2][4];                               // weights of the stage: bfr[e][nt][j] = U[xi_e][k = 4 lh + j][n = nt*32 + li]
+  if (fb) { MAIN_LOOP(1) } else { MAIN_LOOP(0) }
+#undef MAIN_LOOP
+#undef READ_BFR
 #undef TILE_GROUP
 #undef ISSUE_LOADS
 #undef WAIT_VM
@@ -242,7 +269,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(WinoArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int t = (r & 3) + 8 * (r >> 2) + 4 * lh;
-          ex[(xi * 32 + t) * 64 + nt * 32 + li] = acc[e][mt][nt][r];
+          ex[(xi * 32 + t) * 64 + nt * 32 + li] = s1 * acc[e][mt][nt][r];     // s1: the transform sign left out of the loop
         }
     }
     __syncthreads();
@@ -446,6 +473,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_wgrad_kernel(WinoWgradArgs a
   const int c0 = fb;
   // dM = A dY A^T: row part T[q] = ta0 dY[0][q] + ta1 dY[1][q] with (ta0, ta1) = (1,0) (1,1) (1,-1) (0,-1) for a = 0..3
   const float ta0 = (fa == 3) ? 0.f : 1.f, ta1 = (fa == 0) ? 0.f : (fa == 1 ? 1.f : -1.f);
+  const float sigma = s1 * s2;
 
   f32x16 acc[2][2][2];                              // [frequency e][cin tile ct][cout tile nt]
 #pragma unroll
@@ -489,47 +517,47 @@ __global__ __launch_bounds__(512, 2) void conv_wino_wgrad_kernel(WinoWgradArgs a
     }                                                                                                                  \
   }
 
-  if (u0 < u1) LOAD_UNIT(u0, 0)
-  for (int u = u0; u < u1; ++u) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                   // this unit has landed for everyone; the other buffer is free
-    if (u + 1 < u1) LOAD_UNIT(u + 1, (u + 1 - u0) & 1)
-    const float* xs = reinterpret_cast<const float*>(smem + ((u - u0) & 1) * WG_STAGE_BYTES);
-    const float* ys = xs + WG_X_BYTES / 4;
-#pragma unroll 2
-    for (int kk = 0; kk < 8; ++kk) {                // MFMA k-step: tiles 2 kk + lh of the strip
-      const int tile = 2 * kk + lh;
-      float va[2][2], vb[2][2];                     // [frequency e][cin tile | cout tile]
-#pragma unroll
-      for (int ct = 0; ct < 2; ++ct) {
-        float R[3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          const float d1 = xs[(r1 * WG_XROW + 2 * tile + c0 + c) * 64 + ct * 32 + li];
-          const float d2 = xs[(r2 * WG_XROW + 2 * tile + c0 + c) * 64 + ct * 32 + li];
-          R[c] = s1 * d1 + s2 * d2;
-        }
-        va[0][ct] = fb ? (R[1] - R[0]) : (R[0] - R[2]);
-        va[1][ct] = fb ? (R[0] - R[2]) : (R[1] + R[2]);
-      }
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
-        const float y00 = ys[(0 * 32 + 2 * tile + 0) * 64 + nt * 32 + li], y01 = ys[(0 * 32 + 2 * tile + 1) * 64 + nt * 32 + li];
-        const float y10 = ys[(1 * 32 + 2 * tile + 0) * 64 + nt * 32 + li], y11 = ys[(1 * 32 + 2 * tile + 1) * 64 + nt * 32 + li];
-        const float t0 = ta0 * y00 + ta1 * y10, t1 = ta0 * y01 + ta1 * y11;
-        // column part for b = 2 fb + e:  b=0: t0 | b=1: t0 + t1 | b=2: t0 - t1 | b=3: -t1
-        vb[0][nt] = fb ? (t0 - t1) : t0;
-        vb[1][nt] = fb ? (-t1) : (t0 + t1);
-      }
-#pragma unroll
-      for (int e = 0; e < 2; ++e)
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-          for (int nt = 0; nt < 2; ++nt)
-            acc[e][ct][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[e][ct], vb[e][nt], acc[e][ct][nt], 0, 0, 0);
+#define K_LOOP(FB_)                                                                                                    \
+    _Pragma("unroll 2") for (int kk = 0; kk < 8; ++kk) {      /* MFMA k-step: tiles 2 kk + lh of the strip */            \
+      const int tile = 2 * kk + lh;                                                                                    \
+      float va[2][2], vb[2][2];                     /* [frequency e][cin tile | cout tile] */                          \
+      _Pragma("unroll") for (int ct = 0; ct < 2; ++ct) {                                                               \
+        float P[3];                                                                                                    \
+        _Pragma("unroll") for (int c = 0; c < 3; ++c) {                                                                \
+          const float d1 = xs[(r1 * WG_XROW + 2 * tile + c0 + c) * 64 + ct * 32 + li];                                 \
+          const float d2 = xs[(r2 * WG_XROW + 2 * tile + c0 + c) * 64 + ct * 32 + li];                                 \
+          P[c] = d1 + sigma * d2;                                                                                      \
+        }                                                                                                              \
+        va[0][ct] = FB_ ? (P[1] - P[0]) : (P[0] - P[2]);                                                               \
+        va[1][ct] = FB_ ? (P[0] - P[2]) : (P[1] + P[2]);                                                               \
+      }                                                                                                                \
+      _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) {                                                               \
+        const float y00 = ys[(0 * 32 + 2 * tile + 0) * 64 + nt * 32 + li], y01 = ys[(0 * 32 + 2 * tile + 1) * 64 + nt * 32 + li]; \
+        const float y10 = ys[(1 * 32 + 2 * tile + 0) * 64 + nt * 32 + li], y11 = ys[(1 * 32 + 2 * tile + 1) * 64 + nt * 32 + li]; \
+        const float t0 = ta0 * y00 + ta1 * y10, t1 = ta0 * y01 + ta1 * y11;                                            \
+        /* column part for b = 2 fb + e:  b=0: t0 | b=1: t0 + t1 | b=2: t0 - t1 | b=3: -t1 */                          \
+        vb[0][nt] = FB_ ? (t0 - t1) : t0;                                                                              \
+        vb[1][nt] = FB_ ? (-t1) : (t0 + t1);                                                                           \
+      }                                                                                                                \
+      _Pragma("unroll") for (int e = 0; e < 2; ++e)                                                                    \
+          _Pragma("unroll") for (int ct = 0; ct < 2; ++ct)                                                             \
+              _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                                         \
+                  acc[e][ct][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[e][ct], vb[e][nt], acc[e][ct][nt], 0, 0, 0); \
     }
+  // the column-pair variant is chosen once per wave, outside the unit loop (two copies of the loop, no selects inside)
+#define UNIT_LOOP(FB_)                                                                                                 \
+  for (int u = u0; u < u1; ++u) {                                                                                      \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                   \
+    __builtin_amdgcn_s_barrier();          /* this unit has landed for everyone; the other buffer is free */           \
+    if (u + 1 < u1) LOAD_UNIT(u + 1, (u + 1 - u0) & 1)                                                                 \
+    const float* xs = reinterpret_cast<const float*>(smem + ((u - u0) & 1) * WG_STAGE_BYTES);                          \
+    const float* ys = xs + WG_X_BYTES / 4;                                                                             \
+    K_LOOP(FB_)                                                                                                        \
   }
+  if (u0 < u1) LOAD_UNIT(u0, 0)
+  if (fb) { UNIT_LOOP(1) } else { UNIT_LOOP(0) }
+#undef UNIT_LOOP
+#undef K_LOOP
 #undef LOAD_UNIT
   // slab: ws[split][xi][c][n]; accumulator rows = cin (register index), columns = cout (lane)
   float* slab = a.ws + (size_t)split * 16 * a.Cr * a.Nr;
@@ -544,7 +572,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_wgrad_kernel(WinoWgradArgs a
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int c = c_blk + ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          slab[((size_t)xi * a.Cr + c) * a.Nr + n] = acc[e][ct][nt][r];
+          slab[((size_t)xi * a.Cr + c) * a.Nr + n] = s1 * acc[e][ct][nt][r];    // s1: the transform sign left out of the loop
         }
       }
   }

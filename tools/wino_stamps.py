@@ -5,9 +5,11 @@ import ctypes, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
-SHAPES = [(2, 608, 968, 238, 64), (2, 608, 968, 64, 64), (2, 304, 484, 128, 128), (2, 152, 242, 256, 256)]
+SHAPES = [(2, 608, 968, 238, 64), (2, 304, 484, 128, 128)]
 def rup(x, m): return (x + m - 1) // m * m
-lib = ctypes.CDLL(os.path.join(ROOT, "hyperpri_amd", "lib", "libv2stamps.so"))
+LIBNAME = os.environ.get("WINO_LIB", "libv2stamps.so")
+print("library", LIBNAME)
+lib = ctypes.CDLL(os.path.join(ROOT, "hyperpri_amd", "lib", LIBNAME))
 lib.hpri_last_error.restype = ctypes.c_char_p
 lib.hpri_wino_packed_floats.restype = ctypes.c_size_t
 dev = torch.device("cuda", 0)
