@@ -166,7 +166,8 @@ def _conv_launch_wino(x: Act, up: torch.Tensor, bias: Optional[torch.Tensor], y:
     tag = "conv_winograd_f32<3,F(2x2)>"
     if SHAPE_TAGS:
         tag += f" N{x.N} {x.H}x{x.W} K{x.cw} N{cout}"
-    with _timed(tag, 2.0 * x.N * x.H * x.W * cin * cout * 9):     # flops of the DIRECT sum it replaces ("effective")
+    wtiles = x.N * ((x.H + 1) // 2) * ((x.W + 1) // 2)
+    with _timed(tag, 2.0 * x.N * x.H * x.W * cin * cout * 9, executed=2.0 * wtiles * 16 * cin * cout):
         _lib.call("hpri_conv_wino", x.ptr, x.cs, x.coff, _p(up), _p(bias), y.ptr, y.cs, y.coff, _p(stats), x.N, x.H, x.W, x.cw,
                   cout, cout_pad, y_cw, accumulate, _stream())
 
@@ -317,10 +318,14 @@ def enable_event_log(on: bool = True):
 
 
 class _timed:
-    __slots__ = ("tag", "flops", "e0")
+    """``flops``: algorithmic flops of the DIRECT contraction the launch stands for (2*M*N*K, true channel counts);
+    ``executed``: multiply-add flops the kernel actually issues on the matrix pipe (differs for Winograd: 16 instead of
+    36 multiplies per 2x2 outputs and channel pair); defaults to ``flops``."""
+    __slots__ = ("tag", "flops", "executed", "e0")
 
-    def __init__(self, tag: str, flops: float):
+    def __init__(self, tag: str, flops: float, executed: Optional[float] = None):
         self.tag, self.flops, self.e0 = tag, flops, None
+        self.executed = flops if executed is None else executed
 
     def __enter__(self):
         if _EVENT_LOG is not None:
@@ -331,7 +336,7 @@ class _timed:
         if self.e0 is not None:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record()
-            _EVENT_LOG.setdefault(self.tag, []).append((self.e0, e1, self.flops))
+            _EVENT_LOG.setdefault(self.tag, []).append((self.e0, e1, self.flops, self.executed))
         return False
 
 
@@ -339,11 +344,13 @@ def event_log_summary():
     """{tag: {"launches", "total_ms", "avg_ms", "flops_per_launch", "tflops"}} (call after a device sync)."""
     out = {}
     for tag, evs in (_EVENT_LOG or {}).items():
-        ms = [a.elapsed_time(b) for a, b, _ in evs]
-        fl = sum(f for _, _, f in evs)
+        ms = [a.elapsed_time(b) for a, b, _, _ in evs]
+        fl = sum(f for _, _, f, _ in evs)
+        ex = sum(x for _, _, _, x in evs)
         tot = sum(ms)
         out[tag] = {"launches": len(evs), "total_ms": tot, "avg_ms": tot / len(evs), "flops_per_launch": fl / len(evs),
-                    "tflops": fl / (tot * 1e-3) / 1e12 if tot > 0 else 0.0}
+                    "tflops": fl / (tot * 1e-3) / 1e12 if tot > 0 else 0.0,
+                    "executed_flops_per_launch": ex / len(evs), "executed_tflops": ex / (tot * 1e-3) / 1e12 if tot > 0 else 0.0}
     return out
 
 
@@ -718,7 +725,7 @@ def _wgrad(x: Act, dy: Act, dw: torch.Tensor, accumulate: int, cin: int, cout: i
         wtag = "conv_wgrad_winograd_f32<3>"
         if SHAPE_TAGS:
             wtag += f" N{N} {H}x{W} C{cin_pad} N{cout}"
-        with _timed(wtag, 2.0 * N * H * W * cin * cout * 9):
+        with _timed(wtag, 2.0 * N * H * W * cin * cout * 9, executed=2.0 * N * ((H + 1) // 2) * ((W + 1) // 2) * 16 * cin * cout):
             _lib.call("hpri_conv_wino_wgrad", x.ptr, x.cs, x.coff, cin_pad, dy.ptr, dy.cs, dy.coff, dy.cw, _p(wws), wws.numel(),
                       N, H, W, cin_pad, cout_pad, _stream())
         _lib.call("hpri_wino_wgrad_reduce", _p(wws), _p(dw), N, H, W, cin, cin_pad, cout, cout_pad, accumulate, _stream())

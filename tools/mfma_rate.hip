@@ -1,0 +1,156 @@
+// Issue rate of the two MFMA instructions the convolution kernels are built on, measured with s_memtime inside the
+// kernel: cycles per MFMA per SIMD as a function of how much of the chip is busy (power management, not the
+// instruction's documented pass count, sets the practical ceiling).   hipcc --offload-arch=gfx950 -O3 mfma_rate.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#include <algorithm>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// NV independent vector-ALU instructions after every MFMA (VK = 0: v_fma_f32, 1: v_pk_fma_f32, 2: v_xor_b32): does the
+// vector ALU run in the MFMA's shadow, or does it take issue cycles away from the matrix pipe?
+template <int KIND, int NV, int VK>
+__global__ __launch_bounds__(512) void mix_kernel(unsigned long long* out, int iters, float seed) {
+  f32x16 acc[4];
+  for (int i = 0; i < 4; ++i)
+    for (int r = 0; r < 16; ++r) acc[i][r] = seed * (float)(threadIdx.x + i + r);
+  float a = seed + threadIdx.x, b = seed - threadIdx.x;
+  bf16x8 a8, b8;
+  for (int i = 0; i < 8; ++i) { a8[i] = (__bf16)(a + i); b8[i] = (__bf16)(b - i); }
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  f2 x[8];
+  int xi[8];
+  for (int i = 0; i < 8; ++i) { x[i] = f2{seed + i, seed - i}; xi[i] = threadIdx.x + i; }
+  const f2 m = {seed, seed}, c = {seed * 0.5f, seed};
+  unsigned long long t0, t1;
+  __syncthreads();
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (KIND == 0) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+        else acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, b8, acc[i], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+          const int r = (i * NV + v) & 7;
+          if (VK == 0) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(x[r].x) : "v"(m.x), "v"(c.x));
+          else if (VK == 1) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(x[r]) : "v"(m), "v"(c));
+          else asm volatile("v_xor_b32 %0, %1, %0" : "+v"(xi[r]) : "v"(xi[(r + 1) & 7]));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+  }
+  asm volatile("s_nop 0" ::: "memory");
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
+  float s = 0.f;
+  for (int i = 0; i < 4; ++i)
+    for (int r = 0; r < 16; ++r) s += acc[i][r];
+  for (int i = 0; i < 8; ++i) s += x[i].x + x[i].y + (float)xi[i];
+  if (s == 12345.678f) out[0] = 1;
+  if ((threadIdx.x & 63) == 0) out[1 + blockIdx.x * 8 + (threadIdx.x >> 6)] = t1 - t0;
+}
+
+template <int KIND, int NV, int VK>
+void run_mix(const char* name, const char* vname, int blocks, int threads, int iters, double ideal) {
+  unsigned long long* d;
+  hipMalloc(&d, (1 + (size_t)blocks * 8) * 8);
+  hipMemset(d, 0, (1 + (size_t)blocks * 8) * 8);
+  for (int w = 0; w < 2; ++w) mix_kernel<KIND, NV, VK><<<blocks, threads>>>(d, iters, 0.f);
+  hipDeviceSynchronize();
+  const int waves = threads / 64;
+  std::vector<unsigned long long> h(1 + (size_t)blocks * 8);
+  hipMemcpy(h.data(), d, h.size() * 8, hipMemcpyDeviceToHost);
+  std::vector<double> v;
+  for (int b = 0; b < blocks; ++b) for (int w = 0; w < waves; ++w) v.push_back((double)h[1 + b * 8 + w]);
+  std::sort(v.begin(), v.end());
+  const double per_simd = (double)iters * 16 * (waves / 4.0);
+  printf("{\"mfma\": \"%s\", \"valu\": \"%s\", \"valu_per_mfma\": %d, \"workgroups\": %d, \"waves_per_simd\": %.1f, "
+         "\"ticks_per_mfma\": %.2f, \"documented\": %.0f}\n", name, vname, NV, blocks, waves / 4.0, v[v.size() / 2] / per_simd, ideal);
+  hipFree(d);
+}
+
+template <int KIND>
+__global__ __launch_bounds__(512) void rate_kernel(unsigned long long* out, int iters, float seed) {
+  f32x16 acc[4];
+  for (int i = 0; i < 4; ++i)
+    for (int r = 0; r < 16; ++r) acc[i][r] = seed * (float)(threadIdx.x + i + r);
+  float a = seed + threadIdx.x, b = seed - threadIdx.x;
+  bf16x8 a8, b8;
+  for (int i = 0; i < 8; ++i) { a8[i] = (__bf16)(a + i); b8[i] = (__bf16)(b - i); }
+  unsigned long long t0, t1;
+  __syncthreads();
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (KIND == 0) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+        else acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, b8, acc[i], 0, 0, 0);
+      }
+  }
+  asm volatile("s_nop 0" ::: "memory");
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
+  float s = 0.f;
+  for (int i = 0; i < 4; ++i)
+    for (int r = 0; r < 16; ++r) s += acc[i][r];
+  if (s == 12345.678f) out[0] = 1;                       // keep the accumulators alive
+  if ((threadIdx.x & 63) == 0) out[1 + blockIdx.x * 8 + (threadIdx.x >> 6)] = t1 - t0;
+}
+
+template <int KIND>
+void run(const char* name, int blocks, int threads, int iters, double ideal) {
+  unsigned long long* d;
+  hipMalloc(&d, (1 + (size_t)blocks * 8) * 8);
+  hipMemset(d, 0, (1 + (size_t)blocks * 8) * 8);
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int w = 0; w < 3; ++w) rate_kernel<KIND><<<blocks, threads>>>(d, iters, 0.f);   // warm, and load the chip
+  hipEventRecord(e0);
+  rate_kernel<KIND><<<blocks, threads>>>(d, iters, 0.f);
+  hipEventRecord(e1);
+  hipDeviceSynchronize();
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  const int waves = threads / 64;
+  std::vector<unsigned long long> h(1 + (size_t)blocks * 8);
+  hipMemcpy(h.data(), d, h.size() * 8, hipMemcpyDeviceToHost);
+  std::vector<double> v;
+  for (int b = 0; b < blocks; ++b) for (int w = 0; w < waves; ++w) v.push_back((double)h[1 + b * 8 + w]);
+  std::sort(v.begin(), v.end());
+  const double med = v[v.size() / 2];
+  const double per_simd = (double)iters * 16 * (waves / 4.0);       // MFMAs one SIMD issues (waves/4 waves on it)
+  printf("{\"mfma\": \"%s\", \"workgroups\": %d, \"waves_per_simd\": %.1f, \"ticks_per_mfma\": %.2f, \"documented\": %.0f, "
+         "\"kernel_ms\": %.3f, \"ghz_if_ticks_are_clocks\": %.3f}\n", name, blocks, waves / 4.0, med / per_simd, ideal, ms,
+         med / (ms * 1e6));
+  hipFree(d);
+}
+
+int main() {
+  const int iters = 20000;
+  for (int blocks : {8, 64, 256}) {
+    for (int threads : {256, 512}) {
+      run<0>("f32_32x32x2", blocks, threads, iters, 64);
+      run<1>("bf16_32x32x16", blocks, threads, iters * 2, 32);
+    }
+  }
+  const int it2 = 4000;
+#define MIX(K_, N_, V_, kn_, vn_, ideal_)                                  \
+  run_mix<K_, N_, V_>(kn_, vn_, 256, 256, it2, ideal_);                     \
+  run_mix<K_, N_, V_>(kn_, vn_, 256, 512, it2, ideal_);
+  MIX(0, 2, 0, "f32_32x32x2", "v_fma_f32", 64)
+  MIX(0, 4, 0, "f32_32x32x2", "v_fma_f32", 64)
+  MIX(0, 8, 0, "f32_32x32x2", "v_fma_f32", 64)
+  MIX(0, 2, 1, "f32_32x32x2", "v_pk_fma_f32", 64)
+  MIX(0, 4, 1, "f32_32x32x2", "v_pk_fma_f32", 64)
+  MIX(0, 4, 2, "f32_32x32x2", "v_xor_b32", 64)
+  MIX(0, 8, 2, "f32_32x32x2", "v_xor_b32", 64)
+  MIX(1, 2, 0, "bf16_32x32x16", "v_fma_f32", 32)
+  MIX(1, 4, 0, "bf16_32x32x16", "v_fma_f32", 32)
+  MIX(1, 2, 1, "bf16_32x32x16", "v_pk_fma_f32", 32)
+  MIX(1, 4, 2, "bf16_32x32x16", "v_xor_b32", 32)
+  return 0;
+}

@@ -28,13 +28,20 @@ for (N, H, W, Cin, Cout) in SHAPES:
     nwg = tl.value * (cout_pad // 64)
     stamps = torch.zeros(nwg * 2 * 8, dtype=torch.int64, device=dev)
     lib.hpri_wino_set_stamps(P(stamps))
-    for _ in range(3):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for it in range(3):
+        if it == 2:
+            e0.record()
         rc = lib.hpri_conv_wino(P(x), cs, 0, P(up), P(b), P(y), Cout, 0, P(stats), N, H, W, cs, Cout, cout_pad, Cout, 0, st)
         assert rc == 0, lib.hpri_last_error()
+    e1.record()
     torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1)
     t = stamps.view(-1, 2, 8).cpu().double()
     names = ["main loop", "transform+store", "statistics"]
     print(f"N{N} {H}x{W} {Cin}->{Cout}: {nwg} workgroups, {Cin // 8 if Cin % 8 == 0 else cs // 8} stages")
+    span = float(t[:, :, 3].max() - t[:, :, 0].min())
+    print(f"   launch {ms:.3f} ms; first stamp -> last stamp {span:.0f} ticks = {span / ms / 1e6:.3f} GHz if s_memtime counts shader clocks")
     for g in (0, 1):
         d = [t[:, g, i + 1] - t[:, g, i] for i in range(3)]
         tot = t[:, g, 3] - t[:, g, 0]
