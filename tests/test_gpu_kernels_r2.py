@@ -1,0 +1,197 @@
+"""Round-2 kernels called directly through the C ABI (include/hyperpri_hip.h) against a plain torch reference of the
+same op in fp64 on the CPU: the fp32 Winograd F(2x2,3x3) forward / data-gradient / weight-gradient kernels
+(conv_wino.hip: Conv2d(k=3, padding=1) of model_parts.py:23,26 and its autograd) and the bf16-plane convolution
+(conv_bf16v2.hip, precision mode "bf16").  Odd and ragged geometries, accumulate / ReLU epilogues, BatchNorm partial
+statistics, channel-slice views.  Needs a real MI355X: ``-m gpu``."""
+import ctypes
+
+import pytest
+import torch
+
+from conftest import record_margin
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def rup(x, m):
+    return (x + m - 1) // m * m
+
+
+def P(t):
+    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from hyperpri_amd import _lib
+    return _lib.load()
+
+
+def _st():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chan_stats(stats, tiles, cout_pad, cout):
+    """Per-tile (mean, M2, count) records -> per-channel mean and biased variance (Chan merge in fp64)."""
+    s = stats.view(tiles, cout_pad, 4).double().cpu()
+    n = s[:, :, 2]
+    mean = (s[:, :, 0] * n).sum(0) / n.sum(0)
+    m2 = (s[:, :, 1] + n * (s[:, :, 0] - mean) ** 2).sum(0)
+    return mean[:cout], (m2 / n.sum(0))[:cout], n.sum(0)[:cout]
+
+
+GEOM = [(1, 17, 23, 5, 7), (2, 36, 50, 64, 64), (1, 76, 121, 128, 192), (2, 38, 60, 40, 64), (1, 16, 16, 8, 64),
+        (1, 1, 1, 8, 8), (1, 2, 3, 3, 1), (1, 33, 31, 238, 64)]
+
+
+@pytest.mark.parametrize("shape", GEOM)
+@pytest.mark.parametrize("mode", [0, 1])
+def test_winograd_forward_and_data_gradient_vs_fp64(lib, shape, mode):
+    """mode 0: y = conv2d(x, W) + b.  mode 1: the data-gradient form -- the same kernel on the transposed, 180-degree
+    rotated weight (pack mode 1), as engine.py uses it for dX."""
+    N, H, W, Cin, Cout = shape
+    torch.manual_seed(11 + mode)
+    cs, cout_pad, ycs = rup(Cin, 8), rup(Cout, 64), rup(Cout, 8)
+    x = torch.zeros(N * H * W, cs, device=DEV)
+    x[:, :Cin] = torch.randn(N * H * W, Cin, device=DEV)
+    if mode == 0:
+        w = torch.randn(Cout, Cin, 3, 3, device=DEV) * 0.1
+        d1 = Cin
+        wt = w.double().cpu()
+    else:
+        w = torch.randn(Cin, Cout, 3, 3, device=DEV) * 0.1
+        d1 = Cout
+        wt = w.double().cpu().permute(1, 0, 2, 3).flip(2, 3)
+    b = torch.randn(Cout, device=DEV)
+    up = torch.empty(lib.hpri_wino_packed_floats(Cin, cout_pad), device=DEV)
+    assert lib.hpri_wino_pack(P(w), P(up), P(None), mode, Cin, Cout, cout_pad, d1, _st()) == 0
+    xt = x[:, :Cin].reshape(N, H, W, Cin).permute(0, 3, 1, 2).double().cpu()
+    ref = torch.nn.functional.conv2d(xt, wt, b.double().cpu(), padding=1).permute(0, 2, 3, 1).reshape(-1, Cout)
+    tl = ctypes.c_int()
+    lib.hpri_conv_wino_plan(N, H, W, ctypes.byref(tl))
+    for acc, want in ((0, ref), (2, ref.clamp(min=0)), (1, ref + 0.25)):
+        y = torch.full((N * H * W, ycs), 0.25, device=DEV)
+        stats = torch.zeros(tl.value * cout_pad * 4, device=DEV) if acc != 1 else None
+        rc = lib.hpri_conv_wino(P(x), cs, 0, P(up), P(b), P(y), ycs, 0, P(stats), N, H, W, cs, Cout, cout_pad, ycs, acc, _st())
+        assert rc == 0, lib.hpri_last_error()
+        torch.cuda.synchronize()
+        got = y[:, :Cout].double().cpu()
+        scale = max(1.0, float(want.abs().max()))
+        err = float((got - want).abs().max())
+        record_margin(f"wino/fwd{mode}/acc{acc}/{N}x{H}x{W}x{Cin}x{Cout}", err, 5e-5 * scale)
+        assert err < 5e-5 * scale, (shape, mode, acc, err)
+        if Cout < ycs:
+            assert float(y[:, Cout:].abs().max()) in (0.0, 0.25)       # pad channels: zero-filled or untouched, never garbage
+        if stats is not None:
+            mean, var, cnt = _chan_stats(stats, tl.value, cout_pad, Cout)
+            assert torch.all(cnt == N * H * W)
+            assert float((mean - want.mean(0)).abs().max()) < 1e-4 * scale
+            assert float((var - want.var(0, unbiased=False)).abs().max()) < 1e-4 * scale * scale
+
+
+def test_winograd_forward_channel_slice_views(lib):
+    """Input and output are channel slices of wider buffers (the skip-concat layout, model_parts.py:87): the kernel
+    must read only [coff, coff+Cin) and write only [coff, coff+Cout)."""
+    N, H, W, Cin, Cout = 1, 20, 28, 16, 64
+    torch.manual_seed(5)
+    xcs, xoff, ycs, yoff = 40, 8, 136, 64
+    xb = torch.randn(N * H * W, xcs, device=DEV)
+    w = torch.randn(Cout, Cin, 3, 3, device=DEV) * 0.1
+    cout_pad = rup(Cout, 64)
+    up = torch.empty(lib.hpri_wino_packed_floats(Cin, cout_pad), device=DEV)
+    assert lib.hpri_wino_pack(P(w), P(up), P(None), 0, Cin, Cout, cout_pad, Cin, _st()) == 0
+    yb = torch.full((N * H * W, ycs), 7.0, device=DEV)
+    rc = lib.hpri_conv_wino(P(xb), xcs, xoff, P(up), P(None), P(yb), ycs, yoff, P(None), N, H, W, Cin, Cout, cout_pad, Cout, 0, _st())
+    assert rc == 0, lib.hpri_last_error()
+    torch.cuda.synchronize()
+    xt = xb[:, xoff:xoff + Cin].reshape(N, H, W, Cin).permute(0, 3, 1, 2).double().cpu()
+    ref = torch.nn.functional.conv2d(xt, w.double().cpu(), None, padding=1).permute(0, 2, 3, 1).reshape(-1, Cout)
+    assert float((yb[:, yoff:yoff + Cout].double().cpu() - ref).abs().max()) < 5e-5 * float(ref.abs().max())
+    assert torch.all(yb[:, :yoff] == 7.0) and torch.all(yb[:, yoff + Cout:] == 7.0)
+
+
+def test_winograd_rejects_unaligned_output(lib):
+    """The output transform stores float4 channel vectors: a channel stride that is not a multiple of 4 is an error
+    return (HPRI_REQUIRE), not a silent scatter over the neighbouring pixels."""
+    N, H, W, Cin, Cout = 1, 8, 8, 8, 7
+    x = torch.zeros(N * H * W, 8, device=DEV)
+    up = torch.zeros(lib.hpri_wino_packed_floats(Cin, 64), device=DEV)
+    y = torch.zeros(N * H * W * 8, device=DEV)
+    rc = lib.hpri_conv_wino(P(x), 8, 0, P(up), P(None), P(y), 7, 0, P(None), N, H, W, 8, Cout, 64, 7, 0, _st())
+    assert rc != 0
+    assert b"y_cs" in lib.hpri_last_error() or b"align" in lib.hpri_last_error().lower()
+
+
+@pytest.mark.parametrize("shape", GEOM + [(2, 76, 121, 64, 128), (2, 152, 242, 16, 64)])
+def test_winograd_weight_gradient_vs_fp64(lib, shape):
+    """dW = sum over tiles of V (x) (A dY A^T) in the Winograd domain, then G^T dU G -- against conv2d_weight in
+    fp64; a second call with accumulate=1 must add onto the first (the fused tape's gradient sink)."""
+    N, H, W, Cin, Cout = shape
+    torch.manual_seed(23)
+    cs, cso, cout_pad = rup(Cin, 8), rup(Cout, 8), rup(Cout, 64)
+    x = torch.zeros(N * H * W, cs, device=DEV)
+    x[:, :Cin] = torch.randn(N * H * W, Cin, device=DEV)
+    dy = torch.zeros(N * H * W, cso, device=DEV)
+    dy[:, :Cout] = torch.randn(N * H * W, Cout, device=DEV)
+    xt = x[:, :Cin].reshape(N, H, W, Cin).permute(0, 3, 1, 2).double().cpu()
+    dt = dy[:, :Cout].reshape(N, H, W, Cout).permute(0, 3, 1, 2).double().cpu()
+    ref = torch.nn.grad.conv2d_weight(xt, (Cout, Cin, 3, 3), dt, padding=1)
+    sp, cr, nr = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    lib.hpri_wino_wgrad_plan(N, H, W, cs, cout_pad, ctypes.byref(sp), ctypes.byref(cr), ctypes.byref(nr))
+    ws = torch.empty(sp.value * 16 * cr.value * nr.value, device=DEV)
+    dw = torch.full((Cout, Cin, 3, 3), 0.5, device=DEV)
+    for acc in (0, 1):
+        rc = lib.hpri_conv_wino_wgrad(P(x), cs, 0, cs, P(dy), cso, 0, cso, P(ws), ws.numel(), N, H, W, cs, cout_pad, _st())
+        assert rc == 0, lib.hpri_last_error()
+        assert lib.hpri_wino_wgrad_reduce(P(ws), P(dw), N, H, W, Cin, cs, Cout, cout_pad, acc, _st()) == 0
+    torch.cuda.synchronize()
+    sc = max(1.0, float(ref.abs().max()))
+    err = float((dw.double().cpu() - 2 * ref).abs().max())
+    record_margin(f"wino/wgrad/{N}x{H}x{W}x{Cin}x{Cout}", err, 4e-5 * sc)
+    assert err < 4e-5 * sc, (shape, err)
+    # too small a workspace is an error return, not an overrun
+    rc = lib.hpri_conv_wino_wgrad(P(x), cs, 0, cs, P(dy), cso, 0, cso, P(ws), max(ws.numel() // 2, 1) - 1, N, H, W, cs, cout_pad, _st())
+    assert rc != 0
+
+
+@pytest.mark.parametrize("shape", [(2, 36, 50, 64, 64), (1, 76, 121, 128, 192), (1, 17, 23, 40, 64), (1, 33, 31, 238, 64),
+                                   (2, 38, 60, 256, 128)])
+def test_bf16_plane_conv_vs_fp64_of_rounded_operands(lib, shape):
+    """conv_bf16v2: operands are bf16 planes in HBM (written by hpri_to_planes), products accumulate in fp32.  The
+    reference is conv2d in fp64 of the SAME bf16-rounded operands, so the only difference is fp32 summation order."""
+    N, H, W, Cin, Cout = shape
+    torch.manual_seed(31)
+    cs, cs16, cout_pad = rup(Cin, 8), rup(Cin, 32), rup(Cout, 64)
+    x = torch.zeros(N * H * W, cs, device=DEV)
+    x[:, :Cin] = torch.randn(N * H * W, Cin, device=DEV)
+    w = torch.randn(Cout, Cin, 3, 3, device=DEV) * 0.05
+    b = torch.randn(Cout, device=DEV)
+    planes = torch.empty(N * H * W * cs16, dtype=torch.bfloat16, device=DEV)
+    assert lib.hpri_to_planes(P(x), cs, 0, P(planes), 0, cs16, 0, N * H * W, Cin, cs16, 1, _st()) == 0
+    wpb = torch.empty(((Cin + 31) // 32) * 9 * cout_pad * 32, dtype=torch.bfloat16, device=DEV)
+    assert lib.hpri_pack_weight_bf16(P(w), P(wpb), 0, Cin, Cout, cout_pad, 9, Cin, 0, 0, _st()) == 0
+    k, tl, wsf = ctypes.c_int(), ctypes.c_int(), ctypes.c_size_t()
+    lib.hpri_conv_bf16v2_plan(N, H, W, cs16, cout_pad, ctypes.byref(k), ctypes.byref(tl), ctypes.byref(wsf))
+    ws = torch.empty(max(wsf.value, 4), device=DEV)
+    stats = torch.zeros(tl.value * cout_pad * 4, device=DEV)
+    y = torch.zeros(N * H * W, Cout, device=DEV)
+    rc = lib.hpri_conv_bf16v2(P(planes), 0, cs16, 0, P(wpb), P(b), P(y), Cout, 0, P(stats), N, H, W, cs16, Cout, cout_pad, Cout, 0, 0,
+                              P(ws), ws.numel(), _st())
+    assert rc == 0, lib.hpri_last_error()
+    torch.cuda.synchronize()
+    # the plane pass rounds to nearest-even bf16 and zero-fills the channel pad
+    pl = planes.view(N * H * W, cs16)
+    assert torch.equal(pl[:, :Cin], x[:, :Cin].to(torch.bfloat16))
+    assert float(pl[:, Cin:].float().abs().max()) == 0.0 if cs16 > Cin else True
+    xr = x[:, :Cin].to(torch.bfloat16).double().cpu().reshape(N, H, W, Cin).permute(0, 3, 1, 2)
+    wr = w.to(torch.bfloat16).double().cpu()
+    ref = torch.nn.functional.conv2d(xr, wr, b.double().cpu(), padding=1).permute(0, 2, 3, 1).reshape(-1, Cout)
+    sc = max(1.0, float(ref.abs().max()))
+    err = float((y.double().cpu() - ref).abs().max())
+    record_margin(f"bf16v2/{N}x{H}x{W}x{Cin}x{Cout}", err, 2e-5 * sc)
+    assert err < 2e-5 * sc, (shape, err)
+    mean, var, cnt = _chan_stats(stats, tl.value, cout_pad, Cout)
+    assert torch.all(cnt == N * H * W)
+    assert float((mean - ref.mean(0)).abs().max()) < 1e-4 * sc
+    assert float((var - ref.var(0, unbiased=False)).abs().max()) < 1e-4 * sc * sc
