@@ -566,3 +566,18 @@ extern "C" int hpri_wgrad_reduce(const float* ws, float* dw, int N, int H, int W
   HPRI_CHECK_LAUNCH();
   return HPRI_OK;
 }
+
+// The same fixed-order reduction for callers that planned their own pixel splits (hpri_conv_wgrad_bf16v2): slabs
+// ws[splits][KS*KS][Nr][Cr].
+extern "C" int hpri_wgrad_reduce_ex(const float* ws, float* dw, int splits, int Cr, int Nr, int Cin, int Cout, int KS, int dst_mode,
+                                    int Cup, int accumulate, hipStream_t stream) {
+  HPRI_REQUIRE(ws && dw && Cin > 0 && Cout > 0 && splits > 0, "wgrad_reduce_ex: bad arguments");
+  HPRI_REQUIRE(KS == 1 || KS == 3, "wgrad_reduce_ex: kernel size must be 1 or 3");
+  HPRI_REQUIRE(Cin <= Cr && Cout <= Nr, "wgrad_reduce_ex: slab smaller than the gradient");
+  if (dst_mode == 1) HPRI_REQUIRE(Cup > 0 && Cout == 4 * Cup, "wgrad_reduce_ex: convT layout needs Cout == 4*Cup");
+  dim3 grid((unsigned)hpri_cdiv(Cin, 32), (unsigned)Cout);
+  if (KS == 3) hipLaunchKernelGGL((wgrad_reduce_kernel<9>), grid, dim3(1024), 0, stream, ws, dw, splits, Cr, Nr, Cin, Cout, dst_mode, Cup, accumulate);
+  else hipLaunchKernelGGL((wgrad_reduce_kernel<1>), grid, dim3(1024), 0, stream, ws, dw, splits, Cr, Nr, Cin, Cout, dst_mode, Cup, accumulate);
+  HPRI_CHECK_LAUNCH();
+  return HPRI_OK;
+}

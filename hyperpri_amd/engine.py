@@ -173,6 +173,7 @@ def _conv_launch_wino(x: Act, up: torch.Tensor, bias: Optional[torch.Tensor], y:
 
 
 PLANE_CONV = os.environ.get("HPRI_PLANE_CONV", "1") != "0"   # bf16 mode: 3x3 convs on bf16 planes (0: round-1 kernel)
+PLANE_WGRAD = os.environ.get("HPRI_PLANE_WGRAD", "1") != "0"  # ... and their weight gradients (0: round-1 kernel)
 PLANE_PRODUCERS = True       # producers (BN-apply, BN-backward, ...) write the planes themselves; False: generic pass only
 PLANE_CONVERSIONS = 0        # generic fp32 -> planes passes launched (fused producers do not count)
 
@@ -597,7 +598,8 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
             dbet, _ = tp.param_slot(bn.bias)
             db, acc_b = (tp.param_slot(bias) if bias is not None else (None, 0))
             mean, invstd, varu, scale, shift = (st[i * G * cout:(i + 1) * G * cout] for i in range(5))
-            dpl = new_planes(dyr, 1) if (v2 and need_dx and PLANE_PRODUCERS) else None     # read by the data gradient
+            # read by the data gradient and by the weight gradient
+            dpl = new_planes(dyr, 1) if (v2 and (need_dx or (PLANE_WGRAD and weight.requires_grad)) and PLANE_PRODUCERS) else None
             _lib.call("hpri_bn_relu_bwd_pl", g.ptr, g.cs, g.coff, yr.ptr, yr.cs, yr.coff, dyr.ptr, dyr.cs, dyr.coff,
                       _p(mean), _p(invstd), _p(scale), _p(shift), _p(dgam), _p(dbet), acc_g, _p(db), acc_b,
                       _p(ws), ws.numel(), x.P, x.P // G, cout, dyr.cw, int(relu), int(use_batch), *_pl_args(dpl), _stream())
@@ -729,6 +731,20 @@ def _wgrad(x: Act, dy: Act, dw: torch.Tensor, accumulate: int, cin: int, cout: i
             _lib.call("hpri_conv_wino_wgrad", x.ptr, x.cs, x.coff, cin_pad, dy.ptr, dy.cs, dy.coff, dy.cw, _p(wws), wws.numel(),
                       N, H, W, cin_pad, cout_pad, _stream())
         _lib.call("hpri_wino_wgrad_reduce", _p(wws), _p(dw), N, H, W, cin, cin_pad, cout, cout_pad, accumulate, _stream())
+        return
+    if bf16 and split == 0 and ks == 3 and bmode == A_DIRECT and dst_mode == 0 and PLANE_CONV and PLANE_WGRAD:
+        # bf16 planes of both operands (written by their producers) -> LDS by DMA (conv_wgrad_bf16v2.hip)
+        xpl, dpl = planes_of(x, 1), planes_of(dy, 1)
+        sp = ctypes.c_int(); pcr = ctypes.c_int(); pnr = ctypes.c_int()
+        _lib.call("hpri_wgrad_bf16v2_plan", N, H, W, xpl.cs, cout_pad, ctypes.byref(sp), ctypes.byref(pcr), ctypes.byref(pnr))
+        pws = _ws(sp.value * 9 * pcr.value * pnr.value, x.buf.device)
+        ptag = "conv_wgrad_planes_bf16<3>"
+        if SHAPE_TAGS:
+            ptag += f" N{N} {H}x{W} C{xpl.cs} N{cout}"
+        with _timed(ptag, 2.0 * N * H * W * cin * cout * 9):
+            _lib.call("hpri_conv_wgrad_bf16v2", _p(xpl.buf), xpl.cs, xpl.coff, xpl.cs - xpl.coff, _p(dpl.buf), dpl.cs, dpl.coff,
+                      dpl.cs - dpl.coff, _p(pws), pws.numel(), N, H, W, xpl.cs, cout_pad, _stream())
+        _lib.call("hpri_wgrad_reduce_ex", _p(pws), _p(dw), sp.value, pcr.value, pnr.value, cin, cout, 3, 0, 0, accumulate, _stream())
         return
     if bf16:
         with _timed(tag, 2.0 * N * H * W * cin * cout * ks * ks):

@@ -144,6 +144,17 @@ int hpri_conv_wgrad_bf16(const float* x, int x_cs, int x_coff, int x_cvalid, con
                          int KS, int bmode, int H2, int W2, int py0, int px0, int Cup, int split, hipStream_t stream);
 int hpri_wgrad_reduce(const float* ws, float* dw, int N, int H, int W, int Cin, int Cin_pad, int Cout, int Cout_pad,
                       int KS, int dst_mode, int Cup, int accumulate, hipStream_t stream);
+/* The same fixed-order reduction for slabs whose pixel splits the caller planned itself (hpri_wgrad_bf16v2_plan). */
+int hpri_wgrad_reduce_ex(const float* ws, float* dw, int splits, int Cr, int Nr, int Cin, int Cout, int KS, int dst_mode,
+                         int Cup, int accumulate, hipStream_t stream);
+/* Weight gradient of the 3x3 / pad 1 convolutions from bf16 PLANES (conv_wgrad_bf16v2.hip; precision mode "bf16"; the
+ * autograd of model_parts.py:22,25 and models.py:169,177): plane 0 of the conv input and of the output gradient (NHWC,
+ * strides / offsets / valid widths multiples of 8 elements), both by LDS-DMA; slabs ws[splits][9][Nr][Cr] (sizes from
+ * the plan), finished by hpri_wgrad_reduce_ex(ws, dw, splits, Cr, Nr, Cin, Cout, 3, 0, 0, accumulate). */
+int hpri_wgrad_bf16v2_plan(int N, int H, int W, int Cin_pad, int Cout_pad, int* splits, int* Cr, int* Nr);
+int hpri_conv_wgrad_bf16v2(const void* x_planes, int x_cs, int x_coff, int x_cvalid, const void* dy_planes, int dy_cs,
+                           int dy_coff, int dy_cvalid, float* ws, size_t ws_floats, int N, int H, int W, int Cin_pad,
+                           int Cout_pad, hipStream_t stream);
 
 /* ---- BatchNorm (+ReLU) (bn.hip): nn.BatchNorm2d/3d/1d + nn.ReLU, model_parts.py:23-27; models.py:113-114,
  * 172-173,178-179.  G groups = independent statistic sets (G = N for SpectralUNET's per-image loop,

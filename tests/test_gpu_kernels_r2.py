@@ -195,3 +195,42 @@ def test_bf16_plane_conv_vs_fp64_of_rounded_operands(lib, shape):
     assert torch.all(cnt == N * H * W)
     assert float((mean - ref.mean(0)).abs().max()) < 1e-4 * sc
     assert float((var - ref.var(0, unbiased=False)).abs().max()) < 1e-4 * sc * sc
+
+
+@pytest.mark.parametrize("shape", [(1, 17, 23, 5, 7), (2, 36, 50, 64, 64), (1, 76, 121, 128, 192), (2, 38, 60, 40, 64), (1, 4, 32, 64, 64),
+                                   (1, 3, 3, 8, 8), (1, 33, 31, 238, 64), (1, 1, 1, 3, 1)])
+def test_bf16_plane_weight_gradient_vs_fp64_of_rounded_operands(lib, shape):
+    """conv_wgrad_bf16v2: X and dY planes by LDS-DMA, transposed LDS reads, fp32 accumulate, deterministic split-K.
+    Reference: conv2d_weight in fp64 of the same bf16-rounded operands; accumulate=1 adds onto the first result."""
+    N, H, W, Cin, Cout = shape
+    torch.manual_seed(41)
+    cs, cso, cs16, cso16 = rup(Cin, 8), rup(Cout, 8), rup(Cin, 32), rup(Cout, 32)
+    x = torch.zeros(N * H * W, cs, device=DEV)
+    x[:, :Cin] = torch.randn(N * H * W, Cin, device=DEV)
+    dy = torch.zeros(N * H * W, cso, device=DEV)
+    dy[:, :Cout] = torch.randn(N * H * W, Cout, device=DEV)
+    xp = torch.empty(N * H * W * cs16, dtype=torch.bfloat16, device=DEV)
+    dp = torch.empty(N * H * W * cso16, dtype=torch.bfloat16, device=DEV)
+    assert lib.hpri_to_planes(P(x), cs, 0, P(xp), 0, cs16, 0, N * H * W, Cin, cs16, 1, _st()) == 0
+    assert lib.hpri_to_planes(P(dy), cso, 0, P(dp), 0, cso16, 0, N * H * W, Cout, cso16, 1, _st()) == 0
+    sp, cr, nr = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    lib.hpri_wgrad_bf16v2_plan(N, H, W, cs16, rup(Cout, 64), ctypes.byref(sp), ctypes.byref(cr), ctypes.byref(nr))
+    ws = torch.empty(sp.value * 9 * cr.value * nr.value, device=DEV)
+    dw = torch.full((Cout, Cin, 3, 3), 0.5, device=DEV)
+    for acc in (0, 1):
+        rc = lib.hpri_conv_wgrad_bf16v2(P(xp), cs16, 0, cs16, P(dp), cso16, 0, cso16, P(ws), ws.numel(), N, H, W, cs16, rup(Cout, 64), _st())
+        assert rc == 0, lib.hpri_last_error()
+        rc = lib.hpri_wgrad_reduce_ex(P(ws), P(dw), sp.value, cr.value, nr.value, Cin, Cout, 3, 0, 0, acc, _st())
+        assert rc == 0, lib.hpri_last_error()
+    torch.cuda.synchronize()
+    xr = x[:, :Cin].to(torch.bfloat16).double().cpu().reshape(N, H, W, Cin).permute(0, 3, 1, 2)
+    dr = dy[:, :Cout].to(torch.bfloat16).double().cpu().reshape(N, H, W, Cout).permute(0, 3, 1, 2)
+    ref = torch.nn.grad.conv2d_weight(xr, (Cout, Cin, 3, 3), dr, padding=1)
+    sc = max(1.0, float(ref.abs().max()))
+    err = float((dw.double().cpu() - 2 * ref).abs().max())
+    record_margin(f"wgrad_bf16v2/{N}x{H}x{W}x{Cin}x{Cout}", err, 4e-6 * sc)
+    assert err < 4e-6 * sc, (shape, err)
+    # a workspace that is too small is an error return
+    assert lib.hpri_conv_wgrad_bf16v2(P(xp), cs16, 0, cs16, P(dp), cso16, 0, cso16, P(ws), ws.numel() - 1, N, H, W, cs16, rup(Cout, 64), _st()) != 0
+    # misaligned channel stride is an error return
+    assert lib.hpri_conv_wgrad_bf16v2(P(xp), cs16 + 4, 0, cs16, P(dp), cso16, 0, cso16, P(ws), ws.numel(), N, H, W, cs16, rup(Cout, 64), _st()) != 0

@@ -73,14 +73,19 @@ void run_mix(const char* name, const char* vname, int blocks, int threads, int i
   hipFree(d);
 }
 
+__device__ __forceinline__ float rnd(unsigned x) {      // hash -> uniform in (-1, 1) * 2^-6
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  return ((float)(x & 0xffffff) / 8388608.f - 1.f) * 0.015625f;
+}
 template <int KIND>
 __global__ __launch_bounds__(512) void rate_kernel(unsigned long long* out, int iters, float seed) {
   f32x16 acc[4];
+  const unsigned g = (blockIdx.x * 512 + threadIdx.x) * 64u + (unsigned)seed;
   for (int i = 0; i < 4; ++i)
-    for (int r = 0; r < 16; ++r) acc[i][r] = seed * (float)(threadIdx.x + i + r);
-  float a = seed + threadIdx.x, b = seed - threadIdx.x;
+    for (int r = 0; r < 16; ++r) acc[i][r] = seed == 0.f ? 0.f : rnd(g + i * 16 + r);
+  float a = seed == 0.f ? 0.f : rnd(g + 101), b = seed == 0.f ? 0.f : rnd(g + 102);
   bf16x8 a8, b8;
-  for (int i = 0; i < 8; ++i) { a8[i] = (__bf16)(a + i); b8[i] = (__bf16)(b - i); }
+  for (int i = 0; i < 8; ++i) { a8[i] = (__bf16)(seed == 0.f ? 0.f : rnd(g + 200 + i)); b8[i] = (__bf16)(seed == 0.f ? 0.f : rnd(g + 300 + i)); }
   unsigned long long t0, t1;
   __syncthreads();
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
@@ -103,15 +108,15 @@ __global__ __launch_bounds__(512) void rate_kernel(unsigned long long* out, int 
 }
 
 template <int KIND>
-void run(const char* name, int blocks, int threads, int iters, double ideal) {
+void run(const char* name, int blocks, int threads, int iters, double ideal, float seed = 0.f) {
   unsigned long long* d;
   hipMalloc(&d, (1 + (size_t)blocks * 8) * 8);
   hipMemset(d, 0, (1 + (size_t)blocks * 8) * 8);
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
-  for (int w = 0; w < 3; ++w) rate_kernel<KIND><<<blocks, threads>>>(d, iters, 0.f);   // warm, and load the chip
+  for (int w = 0; w < 6; ++w) rate_kernel<KIND><<<blocks, threads>>>(d, iters, seed);   // warm, and load the chip
   hipEventRecord(e0);
-  rate_kernel<KIND><<<blocks, threads>>>(d, iters, 0.f);
+  rate_kernel<KIND><<<blocks, threads>>>(d, iters, seed);
   hipEventRecord(e1);
   hipDeviceSynchronize();
   float ms; hipEventElapsedTime(&ms, e0, e1);
@@ -123,9 +128,10 @@ void run(const char* name, int blocks, int threads, int iters, double ideal) {
   std::sort(v.begin(), v.end());
   const double med = v[v.size() / 2];
   const double per_simd = (double)iters * 16 * (waves / 4.0);       // MFMAs one SIMD issues (waves/4 waves on it)
-  printf("{\"mfma\": \"%s\", \"workgroups\": %d, \"waves_per_simd\": %.1f, \"ticks_per_mfma\": %.2f, \"documented\": %.0f, "
-         "\"kernel_ms\": %.3f, \"ghz_if_ticks_are_clocks\": %.3f}\n", name, blocks, waves / 4.0, med / per_simd, ideal, ms,
-         med / (ms * 1e6));
+  const double flops = (KIND == 0 ? 4096.0 : 32768.0) * iters * 16.0 * waves * blocks;
+  printf("{\"mfma\": \"%s\", \"data\": \"%s\", \"workgroups\": %d, \"waves_per_simd\": %.1f, \"ticks_per_mfma\": %.2f, \"documented\": %.0f, "
+         "\"kernel_ms\": %.3f, \"ghz_if_ticks_are_clocks\": %.3f, \"tflops\": %.1f}\n", name, seed == 0.f ? "zeros" : "random", blocks,
+         waves / 4.0, med / per_simd, ideal, ms, med / (ms * 1e6), flops / (ms * 1e9));
   hipFree(d);
 }
 
@@ -136,6 +142,11 @@ int main() {
       run<0>("f32_32x32x2", blocks, threads, iters, 64);
       run<1>("bf16_32x32x16", blocks, threads, iters * 2, 32);
     }
+  }
+  for (int rep = 0; rep < 2; ++rep) {              // sustained: ~100 ms of back-to-back launches each
+    run<0>("f32_32x32x2", 256, 512, 60000, 64, 7.f);
+    run<1>("bf16_32x32x16", 256, 512, 120000, 32, 7.f);
+    run<1>("bf16_32x32x16", 256, 256, 120000, 32, 7.f);
   }
   const int it2 = 4000;
 #define MIX(K_, N_, V_, kn_, vn_, ideal_)                                  \
