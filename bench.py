@@ -52,7 +52,7 @@ def pmc_traffic(tag):
     correction): hardware counters cannot be read from inside this process, so the figure is not measured in this run
     and the JSON line says which file it came from.  (None, None) if absent."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic.json")))   # the fp32 bench passes only
     if not files:
         return None, None
     try:
