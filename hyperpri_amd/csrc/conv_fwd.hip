@@ -237,118 +237,9 @@ __global__ __launch_bounds__(256, (WM == 2) ? 3 : 2) void conv_fwd_kernel(ConvFw
 #undef LOAD_PANEL
 #undef STORE_PANEL
 
-  // ------------------------------- epilogue -------------------------------
-  // acc[mt][nt][r]: M-tile pixel m = (r&3) + 8*(r>>2) + 4*lh -> row m >> twl, column m & (TW-1);
-  //                 channel = nb*BN + wn*64 + nt*32 + li
-  if (a.ksplit > 1) {   // raw partial sums; bias, store and BN statistics happen in splitk_finish_kernel
-    float* wsz = a.ws + (size_t)blockIdx.z * ((size_t)a.N * a.H * a.W) * a.Cout_pad;
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
-        const int n = nb * BN + wn * 64 + nt * 32 + li;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;
-          const int iy = y0 + (wm * 2 + mt) * RW + (m >> twl), ix = x0 + (m & (TW - 1));
-          if (iy < a.H && ix < xlim) wsz[((size_t)(img * a.H + iy) * a.W + ix) * a.Cout_pad + n] = acc[mt][nt][r];
-        }
-      }
-    }
-    return;
-  }
-#pragma unroll
-  for (int nt = 0; nt < 2; ++nt) {
-    const int n = nb * BN + wn * 64 + nt * 32 + li;
-    float b = 0.f;
-    if (a.bias != nullptr && n < a.Cout) b = (EPI == HPRI_E_D2S) ? a.bias[n % a.Cup] : a.bias[n];
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { acc[mt][nt][r] += b; if (a.relu) acc[mt][nt][r] = fmaxf(acc[mt][nt][r], 0.f); }
-  }
-
-#pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      const int n = nb * BN + wn * 64 + nt * 32 + li;
-      if (EPI == HPRI_E_DIRECT) {
-        if (n >= a.y_cw) continue;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;
-          const int iy = y0 + (wm * 2 + mt) * RW + (m >> twl), ix = x0 + (m & (TW - 1));
-          if (iy < a.H && ix < xlim) {
-            float* p = a.y + ((size_t)(img * a.H + iy) * a.W + ix) * a.y_cs + a.y_coff + n;
-            float v = (n < a.Cout) ? acc[mt][nt][r] : 0.f;
-            if (a.accumulate) v += *p;
-            *p = v;
-          }
-        }
-      } else {  // D2S: n = tap*Cup + co -> hi-res pixel (2*iy + t_y + py0, 2*ix + t_x + px0), channel co
-        if (n >= a.Cout) continue;
-        const int tap = n / a.Cup, co = n - tap * a.Cup;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;
-          const int iy = y0 + (wm * 2 + mt) * RW + (m >> twl), ix = x0 + (m & (TW - 1));
-          if (iy < a.H && ix < xlim) {
-            float* p = a.y + ((size_t)(img * a.H2 + 2 * iy + (tap >> 1) + a.py0) * a.W2 + 2 * ix + (tap & 1) + a.px0) * a.y_cs +
-                       a.y_coff + co;
-            float v = acc[mt][nt][r];
-            if (a.accumulate) v += *p;
-            *p = v;
-          }
-        }
-      }
-    }
-  }
-
-  if (a.stats != nullptr) {
-    // per-tile, per-channel (mean, M2, count) over the tile's valid pixels; two passes over the
-    // accumulators (sum, then squared deviations from the tile mean) -- no E[x^2]-E[x]^2 cancellation.
-    float* red = smem;                      // [4 waves][64 channels], reuses the A staging area
-    const int vrows = min(TH, a.H - y0), vcols = min(TW, xlim - x0);
-    const float cnt = (float)(vrows * vcols);
-    float mean[2];
-    __syncthreads();
-#pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
-        float sacc = 0.f;
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;
-            const int iy = y0 + (wm * 2 + mt) * RW + (m >> twl), ix = x0 + (m & (TW - 1));
-            if (iy < a.H && ix < xlim) {
-              const float v = acc[mt][nt][r];
-              if (pass == 0) sacc += v;
-              else { const float d = v - mean[nt]; sacc += d * d; }
-            }
-          }
-        }
-        sacc += __shfl_xor(sacc, 32);
-        if (lh == 0) red[wave * 64 + nt * 32 + li] = sacc;
-      }
-      __syncthreads();
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
-        float t = 0.f;
-#pragma unroll
-        for (int m = 0; m < WM; ++m) t += red[(m * WN + wn) * 64 + nt * 32 + li];
-        if (pass == 0) mean[nt] = t / cnt;
-        else if (wm == 0 && lh == 0) {
-          const int n = nb * BN + wn * 64 + nt * 32 + li;
-          a.stats[(size_t)bx * a.Cout_pad + n] = make_float4(mean[nt], t, cnt, 0.f);
-        }
-      }
-      __syncthreads();
-    }
-  }
+#define HPRI_EPI_NTW 2
+#include "conv_fwd_epilogue.inc"
+#undef HPRI_EPI_NTW
 }
 
 // -------------------------------------------------------------------------------------------------------------
@@ -588,118 +479,9 @@ __global__ __launch_bounds__(256, (SPLIT == 2) ? 2 : (NTW == 1) ? 4 : ((WM == 4 
 #undef LOAD_A
 #undef STORE_A
 
-  // ------------------------------- epilogue -------------------------------
-  // acc[mt][nt][r]: M-tile pixel m = (r&3) + 8*(r>>2) + 4*lh -> row m >> twl, column m & (TW-1);
-  //                 channel = nb*BN + wn*64 + nt*32 + li
-  if (a.ksplit > 1) {   // raw partial sums; bias, store and BN statistics happen in splitk_finish_kernel
-    float* wsz = a.ws + (size_t)blockIdx.z * ((size_t)a.N * a.H * a.W) * a.Cout_pad;
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-#pragma unroll
-      for (int nt = 0; nt < NTW; ++nt) {
-        const int n = nb * BN + wn * (32 * NTW) + nt * 32 + li;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;
-          const int iy = y0 + (wm * 2 + mt) * RW + (m >> twl), ix = x0 + (m & (TW - 1));
-          if (iy < a.H && ix < xlim) wsz[((size_t)(img * a.H + iy) * a.W + ix) * a.Cout_pad + n] = acc[mt][nt][r];
-        }
-      }
-    }
-    return;
-  }
-#pragma unroll
-  for (int nt = 0; nt < NTW; ++nt) {
-    const int n = nb * BN + wn * (32 * NTW) + nt * 32 + li;
-    float b = 0.f;
-    if (a.bias != nullptr && n < a.Cout) b = (EPI == HPRI_E_D2S) ? a.bias[n % a.Cup] : a.bias[n];
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { acc[mt][nt][r] += b; if (a.relu) acc[mt][nt][r] = fmaxf(acc[mt][nt][r], 0.f); }
-  }
-
-#pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
-#pragma unroll
-    for (int nt = 0; nt < NTW; ++nt) {
-      const int n = nb * BN + wn * (32 * NTW) + nt * 32 + li;
-      if (EPI == HPRI_E_DIRECT) {
-        if (n >= a.y_cw) continue;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;
-          const int iy = y0 + (wm * 2 + mt) * RW + (m >> twl), ix = x0 + (m & (TW - 1));
-          if (iy < a.H && ix < xlim) {
-            float* p = a.y + ((size_t)(img * a.H + iy) * a.W + ix) * a.y_cs + a.y_coff + n;
-            float v = (n < a.Cout) ? acc[mt][nt][r] : 0.f;
-            if (a.accumulate) v += *p;
-            *p = v;
-          }
-        }
-      } else {  // D2S: n = tap*Cup + co -> hi-res pixel (2*iy + t_y + py0, 2*ix + t_x + px0), channel co
-        if (n >= a.Cout) continue;
-        const int tap = n / a.Cup, co = n - tap * a.Cup;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;
-          const int iy = y0 + (wm * 2 + mt) * RW + (m >> twl), ix = x0 + (m & (TW - 1));
-          if (iy < a.H && ix < xlim) {
-            float* p = a.y + ((size_t)(img * a.H2 + 2 * iy + (tap >> 1) + a.py0) * a.W2 + 2 * ix + (tap & 1) + a.px0) * a.y_cs +
-                       a.y_coff + co;
-            float v = acc[mt][nt][r];
-            if (a.accumulate) v += *p;
-            *p = v;
-          }
-        }
-      }
-    }
-  }
-
-  if (a.stats != nullptr) {
-    // per-tile, per-channel (mean, M2, count) over the tile's valid pixels; two passes over the
-    // accumulators (sum, then squared deviations from the tile mean) -- no E[x^2]-E[x]^2 cancellation.
-    float* red = smem;                      // [4 waves][64 channels], reuses the A staging area
-    const int vrows = min(TH, a.H - y0), vcols = min(TW, xlim - x0);
-    const float cnt = (float)(vrows * vcols);
-    float mean[NTW];
-    __syncthreads();
-#pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-#pragma unroll
-      for (int nt = 0; nt < NTW; ++nt) {
-        float sacc = 0.f;
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;
-            const int iy = y0 + (wm * 2 + mt) * RW + (m >> twl), ix = x0 + (m & (TW - 1));
-            if (iy < a.H && ix < xlim) {
-              const float v = acc[mt][nt][r];
-              if (pass == 0) sacc += v;
-              else { const float d = v - mean[nt]; sacc += d * d; }
-            }
-          }
-        }
-        sacc += __shfl_xor(sacc, 32);
-        if (lh == 0) red[wave * 64 + nt * 32 + li] = sacc;
-      }
-      __syncthreads();
-#pragma unroll
-      for (int nt = 0; nt < NTW; ++nt) {
-        float t = 0.f;
-#pragma unroll
-        for (int m = 0; m < WM; ++m) t += red[(m * WN + wn) * 64 + nt * 32 + li];
-        if (pass == 0) mean[nt] = t / cnt;
-        else if (wm == 0 && lh == 0) {
-          const int n = nb * BN + wn * (32 * NTW) + nt * 32 + li;
-          a.stats[(size_t)bx * a.Cout_pad + n] = make_float4(mean[nt], t, cnt, 0.f);
-        }
-      }
-      __syncthreads();
-    }
-  }
+#define HPRI_EPI_NTW NTW
+#include "conv_fwd_epilogue.inc"
+#undef HPRI_EPI_NTW
 }
 
 // Split-K epilogue: y = sum_z ws[z] + bias (fixed order), NHWC store (optionally accumulating), and per-block BN
