@@ -272,7 +272,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(WinoArgs a) {
           ex[(xi * 32 + t) * 64 + nt * 32 + li] = s1 * acc[e][mt][nt][r];     // s1: the transform sign left out of the loop
         }
     }
+    if (mt == 0) { STAMP(4) }
     __syncthreads();
+    if (mt == 0) { STAMP(5) }
     f32x4 m[16];
 #pragma unroll
     for (int xi = 0; xi < 16; ++xi) m[xi] = *reinterpret_cast<const f32x4*>(ex + (xi * 32 + ot) * 64 + oq * 4);
@@ -299,7 +301,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(WinoArgs a) {
       const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
       outv[mt][k] = ok ? v : zero4;
     }
+    if (mt == 0) { STAMP(6) }
     __syncthreads();
+    if (mt == 0) { STAMP(7) }
   }
 
   STAMP(2)

@@ -1,0 +1,407 @@
+// 3x3 / pad 1 / stride 1 convolution, Winograd F(2x2,3x3) in fp32 on v_mfma_f32_32x32x2_f32 -- second form of the fused
+// kernel of conv_wino.hip (reference model_parts.py:22,25; models.py:169,177; forward, and data gradient with the mode-1 pack).
+//
+// What changed against conv_wino.hip, and why (on this chip every vector / LDS instruction of an fp32-MFMA loop
+// is paid in matrix-pipe time, and a 157 KB workgroup leaves its CU idle through its whole output transform):
+//   workgroup  256 threads = 4 waves, 16 x 8 output pixels (32 tiles) x 64 channels x 16 frequencies, 78 KB of LDS:
+//              TWO workgroups per CU, so one workgroup's output transform runs under the other one's MFMAs and a barrier
+//              stalls four waves, not eight
+//   wave a     owns frequency ROW a: all four column frequencies b, both channel groups: 4 x 2 accumulator tiles (128 VGPRs).
+//              input transform: P[c] = d[r1][c] + sigma d[r2][c] (4 FMAs), V = (P0-P2, P1+P2, P2-P1, P1-P3): 32 vector
+//              instructions per 32 MFMAs (was 40), 8 halo reads (was 12)
+//   weights    U packed with k innermost ([Cin/8][16 freq][Cout_pad][8]): a lane's four k values are one ds_read_b128
+//              (8 per stage instead of 16 dword reads); the panel of a wave is private and SINGLE-buffered: its 32 values are
+//              read into registers at the start of a stage, then the next stage's DMA overwrites the panel under the MFMAs
+//   epilogue   M A (column transform) is applied in registers before the LDS exchange: 8 instead of 16 planes go through
+//              LDS (the ds_write_b32 rate, 64 B/clk/CU, is what the exchange costs)
+//   DMA        both operands by buffer_load ... lds: 32-bit per-lane offsets against an SGPR descriptor (no 64-bit address
+//              arithmetic per piece), out-of-image halo pixels zero-filled by the descriptor's range check
+// Halo layout, swizzle, statistics and argument contract as conv_wino.hip.
+#include "common.h"
+
+struct Wino4Args {
+  const float* x; int x_cs, x_coff;
+  const float* up;              // packed U, k innermost: [Cin_pad/8][16][Cout_pad][8]
+  const float* bias;
+  float* y; int y_cs, y_coff;
+  float4* stats;                // [N*tiles_img][Cout_pad] (mean, M2, count, 0) or nullptr
+  int N, H, W, Cin_pad, Cout, Cout_pad, y_cw, accumulate, relu;
+  int tiles_x, tiles_y;
+  unsigned long long* stamps;   // diagnostic builds (-DHPRI_STAMPS) only
+};
+
+#ifdef HPRI_STAMPS
+#define STAMP(i_)                                                                                          \
+  {                                                                                                        \
+    unsigned long long t_;                                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                                     \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                            \
+    __builtin_amdgcn_sched_barrier(0);                                                                     \
+    if (a.stamps != nullptr && (threadIdx.x & 127) == 0)                                                   \
+      a.stamps[((size_t)blockIdx.x * 2 + (threadIdx.x >> 7)) * 8 + (i_)] = t_;                              \
+  }
+#else
+#define STAMP(i_)
+#endif
+
+#define W4_HW 18                           // halo grid: 10 rows x 18 columns of 128-byte pixel slots (32 channels)
+#define W4_SLOTS (10 * W4_HW)
+#define W4_AI 23                           // halo DMA instructions (8 slots each; the last one half used)
+#define W4_A_BYTES (W4_AI * 1024)
+#define W4_B_WAVE 8192                     // bytes per wave per stage: 4 frequencies x [64 n][8 k] fp32
+
+__global__ __launch_bounds__(256, 2) void conv_wino4_kernel(Wino4Args a) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * W4_A_BYTES + 4 * W4_B_WAVE];
+  unsigned char* b_lds = smem + 2 * W4_A_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int fa = wave;                              // frequency row
+  const int tiles_img = a.tiles_x * a.tiles_y;
+  const int nbc = a.Cout_pad >> 6;                  // channel blocks of one pixel tile are adjacent in launch order
+  const int bx = blockIdx.x / nbc, nb = blockIdx.x - bx * nbc;
+  const int img = bx / tiles_img, tin = bx - img * tiles_img;
+  const int ty0 = tin / a.tiles_x, tx0 = tin - ty0 * a.tiles_x;
+  const int Y0 = ty0 * 8, X0 = tx0 * 16;
+
+  // B^T row fa: two input rows r1, r2:  a=0: d0 - d2 | a=1: d1 + d2 | a=2: d2 - d1 | a=3: d1 - d3   (= s1 (d[r1] + sigma d[r2]))
+  const int r1 = (fa == 0) ? 0 : 1, r2 = (fa == 3) ? 3 : 2;
+  const float s1 = (fa == 2) ? -1.f : 1.f, s2 = (fa == 1 || fa == 2) ? 1.f : -1.f;
+  const float sigma = s1 * s2;
+
+  // ---- halo DMA (buffer_load ... lds): instruction i covers slots [8i, 8i+8); lane -> slot 8i + (lane>>3), physical quad
+  //      lane&7.  The per-lane byte offset goes in as the 32-bit voffset of a buffer descriptor over this image; pixels outside
+  //      the image get an offset beyond the descriptor's range: the hardware range check writes ZEROS into their LDS slots
+  //      (tools/lds_dma_oob.hip), so there is no zero page, no select and no 64-bit address arithmetic per piece ----
+  const float* ximg = a.x + (size_t)img * a.H * a.W * a.x_cs + a.x_coff;
+  const __amdgpu_buffer_rsrc_t rs_a =
+      __builtin_amdgcn_make_buffer_rsrc((void*)ximg, 0, (int)(((long long)a.H * a.W * a.x_cs - a.x_coff) * 4), 0x00020000);
+  constexpr int NIA = (W4_AI + 3) / 4;              // per wave (the last round is partial)
+  constexpr unsigned OOB = 0xFFFFFFF0u;
+  unsigned aoff[NIA];
+#pragma unroll
+  for (int q = 0; q < NIA; ++q) {
+    const int slot = (q * 4 + wave) * 8 + (lane >> 3);
+    unsigned off = OOB;
+    if (slot < W4_SLOTS) {
+      const int hy = slot / W4_HW, hx = slot - hy * W4_HW;
+      const int iy = Y0 + hy - 1, ix = X0 + hx - 1;
+      if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
+        off = (unsigned)((iy * a.W + ix) * a.x_cs + ((((lane & 7) ^ ((slot >> 1) & 7))) << 2)) * 4u;
+    }
+    aoff[q] = off;
+  }
+  const int lq = (lane & 7);
+#define LOAD_A(chunk_)                                                                                                \
+  {                                                                                                                   \
+    unsigned char* la_ = smem + ((chunk_) & 1) * W4_A_BYTES;                                                          \
+    const bool tail_ = ((chunk_) * 32 + 32) > a.Cin_pad;      /* last chunk of a channel count that is not a multiple of 32 */ \
+    _Pragma("unroll") for (int q = 0; q < NIA; ++q) {                                                                 \
+      const int inst_ = q * 4 + wave;                                                                                 \
+      if (inst_ < W4_AI) {                                                                                            \
+        unsigned vo_ = aoff[q];                                                                                       \
+        if (tail_) {                                                                                                  \
+          const int slot_ = inst_ * 8 + (lane >> 3);                                                                  \
+          const int lquad_ = lq ^ ((slot_ >> 1) & 7);                                                                 \
+          if (((chunk_) * 32 + lquad_ * 4) >= a.Cin_pad) vo_ = OOB;                                                   \
+        }                                                                                                             \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (__attribute__((address_space(3))) void*)(la_ + inst_ * 1024), 16, vo_, \
+                                                 (chunk_) * 128, 0, 0);                                               \
+      }                                                                                                               \
+    }                                                                                                                 \
+  }
+  // ---- weight DMA: stage s, piece p = 2 b + (n half): lane -> row n = 32 (p&1) + (lane>>1), physical 16-byte half lane&1,
+  //      which holds logical half (lane&1) ^ ((n>>3)&1) (conflict-free ds_read_b128 of a lane's four k values) ----
+  const unsigned goff0 = (unsigned)(((fa * 4) * a.Cout_pad + nb * 64 + (lane >> 1)) * 8 + 4 * ((lane & 1) ^ ((lane >> 4) & 1))) * 4u;
+  const int gstep_b = a.Cout_pad * 8 * 4;           // bytes between column frequencies
+  const __amdgpu_buffer_rsrc_t rs_b =
+      __builtin_amdgcn_make_buffer_rsrc((void*)a.up, 0, (int)((long long)(a.Cin_pad >> 3) * 16 * 8 * a.Cout_pad * 4), 0x00020000);
+  unsigned char* bw = b_lds + wave * W4_B_WAVE;
+#define LOAD_B(s_)                                                                                                    \
+  {                                                                                                                   \
+    const int sb_ = (s_) * 16 * gstep_b;                                                                              \
+    B_PIECE(0) B_PIECE(1) B_PIECE(2) B_PIECE(3) B_PIECE(4) B_PIECE(5) B_PIECE(6) B_PIECE(7)                           \
+  }
+// NB the instruction's immediate offset is added to the LDS address as well as to the memory address: everything goes through soffset
+#define B_PIECE(p_)                                                                                                   \
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (__attribute__((address_space(3))) void*)(bw + (p_) * 1024), 16, goff0, \
+                                           sb_ + ((p_) >> 1) * gstep_b + ((p_) & 1) * 1024, 0, 0);
+
+  // lane's tile: (ty, tx) = (li>>3, li&7); halo slot of its input pixel (r, c): (2 ty + r) * 18 + 2 tx + c
+  const int hpb = (2 * (li >> 3)) * W4_HW + 2 * (li & 7);
+  int pre[8];                                       // XOR-form halo addresses: [2 c + (row r1 | r2)]
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int h1 = hpb + r1 * W4_HW + c, h2 = hpb + r2 * W4_HW + c;
+    pre[2 * c + 0] = h1 * 128 + (((h1 >> 1) & 7) << 4);
+    pre[2 * c + 1] = h2 * 128 + (((h2 >> 1) & 7) << 4);
+  }
+  const int boff = li * 32 + ((lh ^ ((li >> 3) & 1)) << 4);
+
+  f32x16 acc[4][2];                                 // [column frequency b][channel group nt]
+#pragma unroll
+  for (int b = 0; b < 4; ++b)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[b][nt][r] = 0.f;
+
+  const int nstages = a.Cin_pad >> 3;
+  const int nchunks = (a.Cin_pad + 31) >> 5;
+#ifndef WINO4_NO_STAGGER
+  // Two workgroups share a CU, and all workgroups of a launch take the same time: without help both run their output
+  // transform (no MFMAs) at the same moment, for the whole launch.  The SECOND occupants of the first round (the dispatcher
+  // hands workgroups 0-255 to 256 different CUs, 256-511 to the same CUs again) sleep once for a little more than an epilogue
+  // (exchange + output transform + statistics: ~16.4 k cycles when shared); from then on each CU's two slots stay that far
+  // apart and one's epilogue runs under the other's main loop (tools/wino4_stamps.py: 97-99 % of the epilogue time covered).
+  if ((blockIdx.x >> 8) == 1) {
+    const long long wait = 20000;
+    const long long t0 = (long long)__builtin_amdgcn_s_memtime();
+    while ((long long)__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(32);
+  }
+#endif
+  STAMP(0)
+#ifdef HPRI_STAMPS
+  if (a.stamps != nullptr && (threadIdx.x & 127) == 0) {       // where this workgroup runs: HW_ID (CU, SE, ...) and XCC_ID
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    a.stamps[((size_t)blockIdx.x * 2 + (threadIdx.x >> 7)) * 8 + 6] = ((unsigned long long)xcc << 32) | hw;
+  }
+#endif
+  LOAD_A(0)
+  LOAD_B(0)
+#define WAIT_VM(n_) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n_) : "memory")
+  f32x4 bfr[4][2];                                  // weights of the stage: bfr[b][nt][j] = U[(fa, b)][k = 4 lh + j][n = nt*32 + li]
+  for (int chunk = 0; chunk < nchunks; ++chunk) {
+    const int aboff = (chunk & 1) * W4_A_BYTES;
+    const int sg = min(4, nstages - chunk * 4);
+    for (int g = 0; g < sg; ++g) {
+      const int s = chunk * 4 + g;
+      // the weights of this stage were issued one stage ago, BEFORE that stage's halo pieces (if any): in-order completion
+      if (g == 1 && chunk + 1 < nchunks) { if (wave < 3) WAIT_VM(6); else WAIT_VM(5); }
+      else WAIT_VM(0);
+      if (g == 0) __builtin_amdgcn_s_barrier();     // the chunk's halo is visible to all four waves; all have left the previous chunk
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) bfr[b][nt] = *reinterpret_cast<const f32x4*>(bw + b * 2048 + nt * 1024 + boff);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the panel is in registers: the next stage may overwrite it
+      __builtin_amdgcn_sched_barrier(0);
+#if !(defined(WINO_DIAG) && (WINO_DIAG & 4))
+      if (s + 1 < nstages) LOAD_B(s + 1)
+#endif
+#if !(defined(WINO_DIAG) && (WINO_DIAG & 8))
+      if (g == 0 && chunk + 1 < nchunks) LOAD_A(chunk + 1)
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+      const int q16 = (2 * g + lh) << 4;            // this lane half's channel quad inside the chunk, as a byte offset
+      f32x4 P[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const f32x4 d1 = *reinterpret_cast<const f32x4*>(smem + ((pre[2 * c + 0] ^ q16) + aboff));
+        const f32x4 d2 = *reinterpret_cast<const f32x4*>(smem + ((pre[2 * c + 1] ^ q16) + aboff));
+        P[c] = d1 + sigma * d2;
+      }
+      const f32x4 v[4] = {P[0] - P[2], P[1] + P[2], P[2] - P[1], P[1] - P[3]};
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt)
+            acc[b][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[b][j], bfr[b][nt][j], acc[b][nt], 0, 0, 0);
+    }
+  }
+#undef WAIT_VM
+#undef LOAD_A
+#undef LOAD_B
+#undef B_PIECE
+  STAMP(1)
+  __syncthreads();
+
+  // ------------------------------- epilogue -------------------------------
+  // acc[b][nt][r]: tile t = (r&3) + 8*(r>>2) + 4*lh, channel nt*32 + li, frequency (fa, b), without the row sign s1.
+  // Column transform in registers: Z[.][0] = M0 + M1 + M2, Z[.][1] = M1 - M2 - M3; the 4 x 2 planes meet in LDS (64 KB), then
+  // every thread owns two (tile, channel quad) pairs: 8 float4 reads each, the row transform, bias, 2x2 pixels as float4.
+  float* ex = reinterpret_cast<float*>(smem);       // [8 = 2 a + j][32 tiles][64 ch]
+  static_assert(8 * 32 * 64 * 4 <= 2 * W4_A_BYTES + 4 * W4_B_WAVE, "exchange buffer must fit the staging LDS");
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int t = (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const float m0 = acc[0][nt][r], m1 = acc[1][nt][r], m2 = acc[2][nt][r], m3 = acc[3][nt][r];
+      ex[((fa * 2 + 0) * 32 + t) * 64 + nt * 32 + li] = s1 * (m0 + m1 + m2);
+      ex[((fa * 2 + 1) * 32 + t) * 64 + nt * 32 + li] = s1 * (m1 - m2 - m3);
+    }
+  STAMP(4)
+  __syncthreads();
+  STAMP(5)
+  const int oq = tid & 15;
+  const int n0 = nb * 64 + oq * 4;
+  f32x4 outv[2][4];                                 // [item][pixel] x 4 channels
+  const int vrows = min(8, a.H - Y0), vcols = min(16, a.W - X0);
+  f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+  if (a.bias != nullptr) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) if (n0 + c < a.Cout) bias4[c] = a.bias[n0 + c];
+  }
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int ot = (tid >> 4) + 16 * it;            // tile of the workgroup: (ot>>3, ot&7)
+    f32x4 m[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) m[i][j] = *reinterpret_cast<const f32x4*>(ex + ((i * 2 + j) * 32 + ot) * 64 + oq * 4);
+    // Y = A^T Z with A^T = [1 1 1 0; 0 1 -1 -1]
+    f32x4 o[4] = {m[0][0] + m[1][0] + m[2][0], m[0][1] + m[1][1] + m[2][1], m[1][0] - m[2][0] - m[3][0], m[1][1] - m[2][1] - m[3][1]};
+    const int py = 2 * (ot >> 3), px = 2 * (ot & 7);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      f32x4 v = o[k] + bias4;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        if (a.relu) v[c] = fmaxf(v[c], 0.f);
+        if (n0 + c >= a.Cout) v[c] = 0.f;
+      }
+      const int yy = py + (k >> 1), xx = px + (k & 1);
+      const bool ok = yy < vrows && xx < vcols;
+      if (ok && n0 < a.y_cw) {
+        float* dst = a.y + ((size_t)(img * a.H + Y0 + yy) * a.W + X0 + xx) * a.y_cs + a.y_coff + n0;
+        if (a.accumulate) v += *reinterpret_cast<const f32x4*>(dst);
+        *reinterpret_cast<f32x4*>(dst) = v;
+      }
+      const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+      outv[it][k] = ok ? v : zero4;
+    }
+  }
+  STAMP(2)
+  if (a.stats != nullptr) {
+    // two-pass per-tile statistics over the valid pixels: thread (tid>>4, oq) holds 8 pixels of channels 4 oq .. 4 oq + 3
+    __syncthreads();                                // everyone has read the exchange planes
+    float* red = reinterpret_cast<float*>(smem);    // [16][64 ch] + [64] means
+    const float cnt = (float)(vrows * vcols);
+    f32x4 mean4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      f32x4 sacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int ot = (tid >> 4) + 16 * it;
+        const int py = 2 * (ot >> 3), px = 2 * (ot & 7);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const bool ok = (py + (k >> 1)) < vrows && (px + (k & 1)) < vcols;
+          if (pass == 0) sacc += outv[it][k];
+          else if (ok) { const f32x4 d = outv[it][k] - mean4; sacc += d * d; }
+        }
+      }
+      *reinterpret_cast<f32x4*>(red + (tid >> 4) * 64 + oq * 4) = sacc;
+      __syncthreads();
+      if (tid < 64) {                               // channel c = tid: sum over the 16 thread rows
+        float tsum = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) tsum += red[q * 64 + tid];
+        if (pass == 0) red[16 * 64 + tid] = tsum / cnt;
+        else a.stats[(size_t)bx * a.Cout_pad + nb * 64 + tid] = make_float4(red[16 * 64 + tid], tsum, cnt, 0.f);
+      }
+      __syncthreads();
+      if (pass == 0) mean4 = *reinterpret_cast<const f32x4*>(red + 16 * 64 + oq * 4);
+      __syncthreads();
+    }
+  }
+  STAMP(3)
+}
+
+// ---- filter transform: U = G g G^T, packed with k innermost: [Cin_pad/8][16][Ncols_pad][8] ---------------------------------
+// mode 0: forward       g(k = c, col = n)[t] = W[n][c][t]            (W: [Cout][Cin][3][3], src_d1 = Cin)
+// mode 1: data gradient g(k = n, col = c)[t] = W[n][c][8 - t]        (K = Cout, columns = Cin)
+__global__ void wino4_pack_kernel(const float* __restrict__ w, float* __restrict__ up, int mode, int K, int Ncols, int Ncols_pad,
+                                  int stages, int src_d1, const float* __restrict__ colscale) {
+  const size_t total = (size_t)stages * 8 * Ncols_pad;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int kk = (int)(idx % 8);
+    const int col = (int)((idx / 8) % Ncols_pad);
+    const int st = (int)(idx / ((size_t)Ncols_pad * 8));
+    const int k = st * 8 + kk;
+    float g[3][3];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      float v = 0.f;
+      if (k < K && col < Ncols) {
+        v = (mode == 0) ? w[((size_t)col * src_d1 + k) * 9 + t] : w[((size_t)k * src_d1 + col) * 9 + (8 - t)];
+        if (colscale != nullptr) v *= colscale[col];
+      }
+      g[t / 3][t % 3] = v;
+    }
+    float gg[4][3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      gg[0][q] = g[0][q];
+      gg[1][q] = 0.5f * (g[0][q] + g[1][q] + g[2][q]);
+      gg[2][q] = 0.5f * (g[0][q] - g[1][q] + g[2][q]);
+      gg[3][q] = g[2][q];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float u[4] = {gg[i][0], 0.5f * (gg[i][0] + gg[i][1] + gg[i][2]), 0.5f * (gg[i][0] - gg[i][1] + gg[i][2]), gg[i][2]};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) up[(((size_t)st * 16 + i * 4 + j) * Ncols_pad + col) * 8 + kk] = u[j];
+    }
+  }
+}
+
+// Same size as hpri_wino_packed_floats; the layout differs (k innermost).
+extern "C" int hpri_wino4_pack(const float* w, float* up, const float* colscale, int mode, int K, int Ncols, int Ncols_pad,
+                               int src_d1, hipStream_t stream) {
+  HPRI_REQUIRE(w && up, "wino4_pack: null pointer");
+  HPRI_REQUIRE((mode == 0 || mode == 1) && K > 0 && Ncols > 0 && Ncols_pad >= Ncols && Ncols_pad % 64 == 0, "wino4_pack: bad arguments");
+  const int stages = hpri_cdiv(K, 8);
+  const size_t total = (size_t)stages * 8 * Ncols_pad;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(wino4_pack_kernel, dim3(blocks), dim3(256), 0, stream, w, up, mode, K, Ncols, Ncols_pad, stages, src_d1, colscale);
+  HPRI_CHECK_LAUNCH();
+  return HPRI_OK;
+}
+
+static unsigned long long* hpri_wino4_stamps = nullptr;   // diagnostic builds: set through hpri_wino4_set_stamps
+extern "C" int hpri_wino4_set_stamps(unsigned long long* p) { hpri_wino4_stamps = p; return HPRI_OK; }
+
+extern "C" int hpri_conv_wino4_plan(int N, int H, int W, int* stat_tiles) {
+  *stat_tiles = N * hpri_cdiv(H, 8) * hpri_cdiv(W, 16);
+  return HPRI_OK;
+}
+
+// 3x3 / pad 1 / stride 1 convolution, Winograd F(2x2,3x3), fp32.  x: fp32 NHWC view with channels [Cin, Cin_pad) zero
+// (Cin_pad a multiple of 8); up from hpri_wino4_pack; accumulate bit 0: y += result, bit 1: ReLU epilogue; statistics:
+// one (mean, M2, count, 0) record per 16 x 8-pixel tile and channel (hpri_conv_wino4_plan).
+extern "C" int hpri_conv_wino4(const float* x, int x_cs, int x_coff, const float* up, const float* bias, float* y, int y_cs,
+                               int y_coff, float* stats, int N, int H, int W, int Cin_pad, int Cout, int Cout_pad, int y_cw,
+                               int accumulate, hipStream_t stream) {
+  HPRI_REQUIRE(x && up && y, "conv_wino4: null pointer");
+  HPRI_REQUIRE(N > 0 && H > 0 && W > 0, "conv_wino4: empty image");
+  HPRI_REQUIRE(Cin_pad > 0 && Cin_pad % 8 == 0, "conv_wino4: Cin_pad must be a positive multiple of 8");
+  HPRI_REQUIRE(Cout_pad % 64 == 0 && Cout <= Cout_pad && Cout > 0, "conv_wino4: Cout_pad must be a multiple of 64 >= Cout");
+  HPRI_REQUIRE(x_cs % 4 == 0 && x_coff % 4 == 0 && x_coff + Cin_pad <= x_cs, "conv_wino4: input channel stride/offset");
+  HPRI_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)up & 15) == 0, "conv_wino4: pointers must be 16-byte aligned");
+  HPRI_REQUIRE((long long)H * W * x_cs * 4 < (1ll << 32) - 65536, "conv_wino4: one image of the input view exceeds 4 GiB (32-bit buffer offsets)");
+  HPRI_REQUIRE((long long)(Cin_pad / 8) * 16 * 8 * Cout_pad * 4 < (1ll << 31), "conv_wino4: packed weights exceed 2 GiB");
+  HPRI_REQUIRE(!((accumulate & 1) && stats != nullptr), "conv_wino4: statistics are not available together with accumulate");
+  Wino4Args a;
+  a.x = x; a.x_cs = x_cs; a.x_coff = x_coff; a.up = up; a.bias = bias; a.y = y; a.y_cs = y_cs; a.y_coff = y_coff;
+  a.stats = reinterpret_cast<float4*>(stats);
+  a.N = N; a.H = H; a.W = W; a.Cin_pad = Cin_pad; a.Cout = Cout; a.Cout_pad = Cout_pad;
+  a.y_cw = y_cw < Cout ? Cout : y_cw; a.accumulate = accumulate & 1; a.relu = (accumulate >> 1) & 1;
+  HPRI_REQUIRE(a.y_cw + y_coff <= y_cs, "conv_wino4: output channels exceed the channel stride");
+  HPRI_REQUIRE(y_cs % 4 == 0 && y_coff % 4 == 0 && a.y_cw % 4 == 0 && ((uintptr_t)y & 15) == 0,
+               "conv_wino4: the output view must be float4-aligned (stride, offset and written width multiples of 4)");
+  a.tiles_x = hpri_cdiv(W, 16); a.tiles_y = hpri_cdiv(H, 8);
+  a.stamps = hpri_wino4_stamps;
+  dim3 grid((unsigned)(N * a.tiles_x * a.tiles_y * (Cout_pad / 64)), 1u, 1u);
+  hipLaunchKernelGGL(conv_wino4_kernel, grid, dim3(256), 0, stream, a);
+  HPRI_CHECK_LAUNCH();
+  return HPRI_OK;
+}

@@ -146,19 +146,31 @@ WINO_MIN_BLOCKS = 256        # workgroups (16x16-pixel tiles x 64-channel blocks
 
 
 def _wino_ok(x: "Act", ncols: int) -> bool:
-    return WINOGRAD and x.N * ((x.H + 15) // 16) * ((x.W + 15) // 16) * (_rup(ncols, 64) // 64) >= WINO_MIN_BLOCKS
+    th = 8 if WINO4 else 16                  # tile height of the kernel in use (conv_wino4.hip: 16 x 8 pixels)
+    return WINOGRAD and x.N * ((x.H + th - 1) // th) * ((x.W + 15) // 16) * (_rup(ncols, 64) // 64) >= WINO_MIN_BLOCKS
+
+
+# Which of the two fused Winograd kernels: conv_wino4.hip (4-wave workgroups of 16 x 8 pixels, two per CU: the output
+# transform of one runs under the MFMAs of the other) or conv_wino.hip (8 waves, 16 x 16 pixels, one per CU).  Their packed
+# weights differ in layout, so the choice is part of the pack-cache key.  HPRI_WINO4: 1 (default) / 0.
+WINO4 = os.environ.get("HPRI_WINO4", "1") != "0"
+
+
+def _wino_sfx() -> str:
+    return "wino4" if WINO4 else "wino"
 
 
 def _pack_wino(w: torch.Tensor, mode: int, K: int, ncols: int, d1: int) -> Tuple[torch.Tensor, int]:
     ncols_pad = _rup(ncols, 64)
+    kind = _wino_sfx()
 
     def build():
         global PACK_LAUNCHES
         up = torch.empty(_lib.load().hpri_wino_packed_floats(K, ncols_pad), dtype=torch.float32, device=w.device)
-        _lib.call("hpri_wino_pack", _p(w), _p(up), ctypes.c_void_p(0), mode, K, ncols, ncols_pad, d1, _stream())
+        _lib.call(f"hpri_{kind}_pack", _p(w), _p(up), ctypes.c_void_p(0), mode, K, ncols, ncols_pad, d1, _stream())
         PACK_LAUNCHES += 1
         return up
-    return _cached_pack(w, ("wino", mode, K, ncols, d1), build), ncols_pad
+    return _cached_pack(w, (kind, mode, K, ncols, d1), build), ncols_pad
 
 
 def _conv_launch_wino(x: Act, up: torch.Tensor, bias: Optional[torch.Tensor], y: Act, stats: Optional[torch.Tensor],
@@ -168,7 +180,7 @@ def _conv_launch_wino(x: Act, up: torch.Tensor, bias: Optional[torch.Tensor], y:
         tag += f" N{x.N} {x.H}x{x.W} K{x.cw} N{cout}"
     wtiles = x.N * ((x.H + 1) // 2) * ((x.W + 1) // 2)
     with _timed(tag, 2.0 * x.N * x.H * x.W * cin * cout * 9, executed=2.0 * wtiles * 16 * cin * cout):
-        _lib.call("hpri_conv_wino", x.ptr, x.cs, x.coff, _p(up), _p(bias), y.ptr, y.cs, y.coff, _p(stats), x.N, x.H, x.W, x.cw,
+        _lib.call(f"hpri_conv_{_wino_sfx()}", x.ptr, x.cs, x.coff, _p(up), _p(bias), y.ptr, y.cs, y.coff, _p(stats), x.N, x.H, x.W, x.cw,
                   cout, cout_pad, y_cw, accumulate, _stream())
 
 
@@ -537,7 +549,7 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
     if use_batch:
         ksp = ctypes.c_int(); tl = ctypes.c_int(); wsf = ctypes.c_size_t()
         if wino:
-            _lib.call("hpri_conv_wino_plan", x.N, x.H, x.W, ctypes.byref(tl))
+            _lib.call(f"hpri_conv_{_wino_sfx()}_plan", x.N, x.H, x.W, ctypes.byref(tl))
         elif v2:
             _lib.call("hpri_conv_bf16v2_plan", x.N, x.H, x.W, _rup(cin, 32), cout_pad, ctypes.byref(ksp), ctypes.byref(tl),
                       ctypes.byref(wsf))
@@ -672,7 +684,7 @@ def _conv_folded_eval(x: Act, weight: torch.Tensor, bias: Optional[torch.Tensor]
                   _p(fold[:cout]), _p(fold[cout:]), _stream())
         if wino:   # Winograd layout: the filter transform is linear, so the column scale goes in front of it
             wp = torch.empty(_lib.load().hpri_wino_packed_floats(cin, cout_pad), dtype=torch.float32, device=dev)
-            _lib.call("hpri_wino_pack", _p(weight), _p(wp), _p(fold[:cout]), 0, cin, cout, cout_pad, cin, _stream())
+            _lib.call(f"hpri_{_wino_sfx()}_pack", _p(weight), _p(wp), _p(fold[:cout]), 0, cin, cout, cout_pad, cin, _stream())
         elif lowp:   # bf16 / bf16x3 / bf16x6 predict path: the same fold, weights scaled in fp32 and then rounded / split
             wp = torch.empty(((cin + 31) // 32) * T * cout_pad * 32 * (split + 1), dtype=torch.bfloat16, device=dev)
             _lib.call("hpri_pack_weight_bf16_scaled", _p(weight), _p(wp), _p(fold[:cout]), cin, cout, cout_pad, T, cin, split,
@@ -689,7 +701,7 @@ def _conv_folded_eval(x: Act, weight: torch.Tensor, bias: Optional[torch.Tensor]
             return (t.data_ptr(), -1)
     bn_state = (_BN_EPOCH, ver(bn.running_mean), ver(bn.running_var), ver(bn.weight), ver(bn.bias),
                 None if bias is None else ver(bias))
-    wp, fold = _cached_pack(weight, ("fold", prec, ks, wino), build, extra=bn_state)
+    wp, fold = _cached_pack(weight, ("fold", prec, ks, _wino_sfx() if wino else False), build, extra=bn_state)
     fbias = fold[cout:]
     y = Act.new(x.N, x.H, x.W, cout, dev)
     if wino:

@@ -91,6 +91,17 @@ int hpri_conv_wino_plan(int N, int H, int W, int* stat_tiles);
 int hpri_conv_wino(const float* x, int x_cs, int x_coff, const float* up, const float* bias, float* y, int y_cs, int y_coff,
                    float* stats, int N, int H, int W, int Cin_pad, int Cout, int Cout_pad, int y_cw, int accumulate,
                    hipStream_t stream);
+/* Second form of the fused Winograd kernel (conv_wino4.hip): 4-wave workgroups of 16 x 8 pixels, two per CU, wave = frequency
+ * row, weights packed with k innermost (hpri_wino4_pack: same size as hpri_wino_packed_floats, different layout); same
+ * argument contract as hpri_conv_wino; statistics records per 16 x 8-pixel tile (hpri_conv_wino4_plan). */
+int hpri_wino4_pack(const float* w, float* up, const float* colscale, int mode, int K, int Ncols, int Ncols_pad, int src_d1,
+                    hipStream_t stream);
+int hpri_conv_wino4_plan(int N, int H, int W, int* stat_tiles);
+int hpri_conv_wino4(const float* x, int x_cs, int x_coff, const float* up, const float* bias, float* y, int y_cs, int y_coff,
+                    float* stats, int N, int H, int W, int Cin_pad, int Cout, int Cout_pad, int y_cw, int accumulate,
+                    hipStream_t stream);
+int hpri_wino4_set_stamps(unsigned long long* stamps);
+
 
 /* Winograd weight gradient (dU = sum over tiles of V * (A dY A^T), dg = G^T dU G): slabs ws[split][16][Cr][Nr] from
  * hpri_conv_wino_wgrad (sizes: hpri_wino_wgrad_plan), fixed-order sum + inverse filter transform into OIHW by

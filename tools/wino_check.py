@@ -43,7 +43,9 @@ def main():
         assert lib.hpri_pack_weight(P(w), P(wp), mode, K, ncols, cout_pad, 9, 0, 0, d1, st) == 0
         up = torch.empty(lib.hpri_wino_packed_floats(K, cout_pad), device=dev)
         assert lib.hpri_wino_pack(P(w), P(up), P(None), mode, K, ncols, cout_pad, d1, st) == 0
-        return cs, cout_pad, x, w, b, wp, up
+        up4 = torch.empty(lib.hpri_wino_packed_floats(K, cout_pad), device=dev)
+        assert lib.hpri_wino4_pack(P(w), P(up4), P(None), mode, K, ncols, cout_pad, d1, st) == 0
+        return cs, cout_pad, x, w, b, wp, (up, up4)
 
     def run_direct(x, cs, wp, b, y, stats, N, H, W, Cout, cout_pad, acc):
         k, tl, wsf = ctypes.c_int(), ctypes.c_int(), ctypes.c_size_t()
@@ -63,6 +65,14 @@ def main():
         assert rc == 0, lib.hpri_last_error()
         return sts, tl.value
 
+    def run_wino4(x, cs, up, b, y, stats, N, H, W, Cout, cout_pad, acc):
+        tl = ctypes.c_int()
+        lib.hpri_conv_wino4_plan(N, H, W, ctypes.byref(tl))
+        sts = torch.zeros(tl.value * cout_pad * 4, device=dev) if stats else None
+        rc = lib.hpri_conv_wino4(P(x), cs, 0, P(up), P(b), P(y), rup(Cout, 8), 0, P(sts), N, H, W, cs, Cout, cout_pad, rup(Cout, 8), acc, st)
+        assert rc == 0, lib.hpri_last_error()
+        return sts, tl.value
+
     def chan_stats(stats, tiles, cout_pad, Cout):
         s = stats.view(tiles, cout_pad, 4).double()
         n = s[:, :, 2]
@@ -73,7 +83,7 @@ def main():
     ok = True
     for (N, H, W, Cin, Cout) in CHECK:
         for mode in (0, 1):
-            cs, cout_pad, x, w, b, wp, up = setup(N, H, W, Cin, Cout, mode)
+            cs, cout_pad, x, w, b, wp, (up, up4) = setup(N, H, W, Cin, Cout, mode)
             xt = x[:, :Cin].reshape(N, H, W, Cin).permute(0, 3, 1, 2).double()
             wt = w.double() if mode == 0 else w.double().permute(1, 0, 2, 3).flip(2, 3)
             ref = torch.nn.functional.conv2d(xt, wt, b.double(), padding=1).permute(0, 2, 3, 1).reshape(-1, Cout)
@@ -82,6 +92,8 @@ def main():
                 y1 = y0.clone()
                 s0, t0 = run_direct(x, cs, wp, b, y0, acc != 1, N, H, W, Cout, cout_pad, acc)
                 s1, t1 = run_wino(x, cs, up, b, y1, acc != 1, N, H, W, Cout, cout_pad, acc)
+                y4 = torch.full_like(y0, 0.25)
+                s4, t4 = run_wino4(x, cs, up4, b, y4, acc != 1, N, H, W, Cout, cout_pad, acc)
                 want = ref.clamp(min=0) if acc == 2 else (ref + 0.25 if acc == 1 else ref)
                 e0 = float((y0.view(-1, rup(Cout, 8))[:, :Cout].double() - want).abs().max())
                 e1 = float((y1.view(-1, rup(Cout, 8))[:, :Cout].double() - want).abs().max())
@@ -97,6 +109,14 @@ def main():
                 good = e1 < 5e-5 * max(1.0, float(want.abs().max()))
                 ok &= good
                 if not good: line += "   <-- OUTPUT DIFFERS"
+                e4 = float((y4.view(-1, rup(Cout, 8))[:, :Cout].double() - want).abs().max())
+                line += f"  |wino4-fp64| {e4:.2e}"
+                good = e4 < 5e-5 * max(1.0, float(want.abs().max()))
+                if acc != 1:
+                    m4, v4 = chan_stats(s4, t4, cout_pad, Cout)
+                    good &= float((m0 - m4).abs().max()) < 1e-4 and float(((v0 - v4).abs() / (v0 + 1e-3)).max()) < 1e-4
+                ok &= good
+                if not good: line += "   <-- WINO4 DIFFERS"
                 print(line, flush=True)
     # ---- weight gradient ----
     for (N, H, W, Cin, Cout) in CHECK + [(2, 76, 121, 64, 128)]:
@@ -121,16 +141,16 @@ def main():
         ok &= e < 2e-5 * max(1.0, sc) * 2
     print("CHECK", "PASSED" if ok else "FAILED", flush=True)
     for (N, H, W, Cin, Cout) in BENCH:
-        cs, cout_pad, x, w, b, wp, up = setup(N, H, W, Cin, Cout, 0)
+        cs, cout_pad, x, w, b, wp, (up, up4) = setup(N, H, W, Cin, Cout, 0)
         y = torch.empty(N * H * W * rup(Cout, 8), device=dev)
         flops = 2.0 * N * H * W * Cin * Cout * 9
-        res = {"direct": [], "wino": []}
+        res = {"direct": [], "wino": [], "wino4": []}
         for rnd in range(5):
-            for kind in ("direct", "wino"):
+            for kind in ("direct", "wino", "wino4"):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(4):
-                    (run_direct if kind == "direct" else run_wino)(x, cs, wp if kind == "direct" else up, b, y, True, N, H, W, Cout, cout_pad, 0)
+                    {"direct": run_direct, "wino": run_wino, "wino4": run_wino4}[kind](x, cs, {"direct": wp, "wino": up, "wino4": up4}[kind], b, y, True, N, H, W, Cout, cout_pad, 0)
                 e1.record()
                 torch.cuda.synchronize()
                 if rnd:
@@ -164,10 +184,12 @@ def main():
               f"({flops / mw['wino'] / 1e9:.1f} effective TF)  x{mw['direct'] / mw['wino']:.2f}  splits {s_.value}", flush=True)
         del dyb, wsd, wsw
         md = {k: sorted(v)[len(v) // 2] for k, v in res.items()}
-        rows.append({"shape": [N, H, W, Cin, Cout], "direct_ms": md["direct"], "wino_ms": md["wino"],
-                     "direct_tf": flops / md["direct"] / 1e9, "wino_effective_tf": flops / md["wino"] / 1e9})
+        rows.append({"shape": [N, H, W, Cin, Cout], "direct_ms": md["direct"], "wino_ms": md["wino"], "wino4_ms": md["wino4"],
+                     "direct_tf": flops / md["direct"] / 1e9, "wino_effective_tf": flops / md["wino"] / 1e9,
+                     "wino4_effective_tf": flops / md["wino4"] / 1e9})
         print(f"N{N} {H}x{W} {Cin}->{Cout}: direct {md['direct']:.3f} ms ({rows[-1]['direct_tf']:.1f} TF)   winograd {md['wino']:.3f} ms "
-              f"({rows[-1]['wino_effective_tf']:.1f} effective TF)  x{md['direct'] / md['wino']:.2f}", flush=True)
+              f"({rows[-1]['wino_effective_tf']:.1f} effective TF)   wino4 {md['wino4']:.3f} ms ({rows[-1]['wino4_effective_tf']:.1f})  "
+              f"x{md['wino'] / md['wino4']:.3f} vs wino", flush=True)
         del x, y
         torch.cuda.empty_cache()
     if len(sys.argv) > 1:

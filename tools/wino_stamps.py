@@ -45,4 +45,6 @@ for (N, H, W, Cin, Cout) in SHAPES:
     for g in (0, 1):
         d = [t[:, g, i + 1] - t[:, g, i] for i in range(3)]
         tot = t[:, g, 3] - t[:, g, 0]
+        e = [t[:, g, 4] - t[:, g, 1], t[:, g, 5] - t[:, g, 4], t[:, g, 6] - t[:, g, 5], t[:, g, 7] - t[:, g, 6], t[:, g, 2] - t[:, g, 7]]
+        print(f"   waves {4*g}-{4*g+3}: epilogue pass 0: exchange writes {e[0].median():.0f} | barrier {e[1].median():.0f} | reads + A^T M A + stores {e[2].median():.0f} | barrier {e[3].median():.0f} | pass 1 {e[4].median():.0f}")
         print(f"   waves {4*g}-{4*g+3}: total {tot.median():8.0f} | " + " | ".join(f"{n} {v.median():7.0f} ({100 * v.median() / tot.median():4.1f} %)" for n, v in zip(names, d)) + f" | per stage {d[0].median() / (cs // 8):6.0f}")
