@@ -489,9 +489,17 @@ __global__ __launch_bounds__(512, 2) void conv_wino_wgrad_kernel(WinoWgradArgs a
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[e][ct][nt][r] = 0.f;
 
-  const float* zpage = hpri_wino_zero + (lane & 3) * 4;
-  // DMA pieces of a stage: x rows 4 x 9 pieces (4 pixels x 256 B each), dy 2 x 8 pieces; piece p of this wave = p*8 + wave
+  // DMA pieces of a stage: x rows 4 x 9 pieces (4 pixels x 256 B each), dy 2 x 8 pieces; piece p of this wave = p*8 + wave.
+  // buffer_load ... lds: the descriptor base is the unit's first (halo) pixel -- a wave-uniform pointer that may lie before the
+  // tensor for border units --, the piece's row / pixel-group offset goes in as the scalar offset, and the lane part is ONE
+  // per-lane constant; lanes outside the image, beyond the valid channels or in the unused tail of a staged row get an
+  // out-of-range offset, which the hardware range check turns into zeros in LDS (tools/lds_dma_oob.hip).  About 4 vector
+  // instructions per piece instead of ~20 (every one of them costs fp32-MFMA issue time).
   constexpr int NPX = 4 * (WG_XROW / 4), NPY = 2 * 8, NPW = (NPX + NPY + 7) / 8;
+  constexpr unsigned OOB = 0xFFFFFFF0u;
+  const int l4 = lane >> 4;                          // pixel of the piece's group of four
+  const unsigned xlane = (c_blk + (lane & 15) * 4 < a.x_cvalid) ? (unsigned)(l4 * a.x_cs * 4 + (lane & 15) * 16) : OOB;
+  const unsigned ylane = (n_blk + (lane & 15) * 4 < a.dy_cvalid) ? (unsigned)(l4 * a.dy_cs * 4 + (lane & 15) * 16) : OOB;
 #define LOAD_UNIT(u_, buf_)                                                                                            \
   {                                                                                                                    \
     int q_ = (u_);                                                                                                     \
@@ -499,24 +507,24 @@ __global__ __launch_bounds__(512, 2) void conv_wino_wgrad_kernel(WinoWgradArgs a
     const int sy_ = q_ % a.strips_y; const int img_ = q_ / a.strips_y;                                                 \
     const int y0_ = sy_ * 2, x0_ = sx_ * 32;                                                                           \
     unsigned char* lb_ = smem + (buf_) * WG_STAGE_BYTES;                                                               \
+    const float* xu_ = a.x + ((long long)(img_ * a.H + y0_ - 1) * a.W + x0_ - 1) * a.x_cs + a.x_coff + c_blk;          \
+    const float* yu_ = a.dy + ((long long)(img_ * a.H + y0_) * a.W + x0_) * a.dy_cs + a.dy_coff + n_blk;               \
+    const __amdgpu_buffer_rsrc_t rx_ = __builtin_amdgcn_make_buffer_rsrc((void*)xu_, 0, 0x7FFFFF00, 0x00020000);       \
+    const __amdgpu_buffer_rsrc_t ry_ = __builtin_amdgcn_make_buffer_rsrc((void*)yu_, 0, 0x7FFFFF00, 0x00020000);       \
     _Pragma("unroll") for (int p = 0; p < NPW; ++p) {                                                                  \
       const int piece_ = p * 8 + wave;                                                                                 \
-      if (piece_ < NPX + NPY) {                                                                                        \
-        const float* src_ = zpage;                                                                                     \
-        if (piece_ < NPX) {                                                                                            \
-          const int row_ = piece_ / (WG_XROW / 4), px_ = (piece_ % (WG_XROW / 4)) * 4 + (lane >> 4);                   \
-          const int iy_ = y0_ + row_ - 1, ix_ = x0_ + px_ - 1, c_ = c_blk + (lane & 15) * 4;                           \
-          if (px_ < 34 && iy_ >= 0 && iy_ < a.H && ix_ >= 0 && ix_ < a.W && c_ < a.x_cvalid)                           \
-            src_ = a.x + ((size_t)(img_ * a.H + iy_) * a.W + ix_) * a.x_cs + a.x_coff + c_;                            \
-        } else {                                                                                                       \
-          const int pp_ = piece_ - NPX;                                                                                \
-          const int row_ = pp_ >> 3, px_ = (pp_ & 7) * 4 + (lane >> 4);                                                \
-          const int iy_ = y0_ + row_, ix_ = x0_ + px_, n_ = n_blk + (lane & 15) * 4;                                   \
-          if (iy_ < a.H && ix_ < a.W && n_ < a.dy_cvalid)                                                              \
-            src_ = a.dy + ((size_t)(img_ * a.H + iy_) * a.W + ix_) * a.dy_cs + a.dy_coff + n_;                         \
-        }                                                                                                              \
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_,                          \
-                                         (__attribute__((address_space(3))) void*)(lb_ + piece_ * 1024), 16, 0, 0);    \
+      if (piece_ < NPX) {                                                                                              \
+        const int row_ = piece_ / (WG_XROW / 4), pxb_ = (piece_ % (WG_XROW / 4)) * 4;          /* wave-uniform */       \
+        const bool rowok_ = (unsigned)(y0_ + row_ - 1) < (unsigned)a.H;                                                \
+        const bool ok_ = rowok_ && (pxb_ + l4) < 34 && (unsigned)(x0_ + pxb_ + l4 - 1) < (unsigned)a.W;                \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx_, (__attribute__((address_space(3))) void*)(lb_ + piece_ * 1024), 16, \
+                                                 ok_ ? xlane : OOB, (row_ * a.W + pxb_) * a.x_cs * 4, 0, 0);           \
+      } else if (piece_ < NPX + NPY) {                                                                                 \
+        const int pp_ = piece_ - NPX;                                                                                  \
+        const int row_ = pp_ >> 3, pxb_ = (pp_ & 7) * 4;                                                               \
+        const bool ok_ = (y0_ + row_) < a.H && (x0_ + pxb_ + l4) < a.W;                                                \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ry_, (__attribute__((address_space(3))) void*)(lb_ + piece_ * 1024), 16, \
+                                                 ok_ ? ylane : OOB, (row_ * a.W + pxb_) * a.dy_cs * 4, 0, 0);          \
       }                                                                                                                \
     }                                                                                                                  \
   }
@@ -642,6 +650,8 @@ extern "C" int hpri_conv_wino_wgrad(const float* x, int x_cs, int x_coff, int x_
   HPRI_REQUIRE(x_cs % 4 == 0 && x_coff % 4 == 0 && dy_cs % 4 == 0 && dy_coff % 4 == 0 && x_cvalid % 4 == 0 && dy_cvalid % 4 == 0,
                "conv_wino_wgrad: channel strides / offsets / valid counts must be multiples of 4");
   HPRI_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)dy & 15) == 0, "conv_wino_wgrad: pointers must be 16-byte aligned");
+  HPRI_REQUIRE((long long)5 * W * x_cs * 4 < (1ll << 31) && (long long)3 * W * dy_cs * 4 < (1ll << 31),
+               "conv_wino_wgrad: image rows too long for 32-bit buffer offsets");
   WinoWgradArgs a;
   a.x = x; a.x_cs = x_cs; a.x_coff = x_coff; a.x_cvalid = x_cvalid; a.dy = dy; a.dy_cs = dy_cs; a.dy_coff = dy_coff; a.dy_cvalid = dy_cvalid;
   a.ws = ws; a.N = N; a.H = H; a.W = W;
