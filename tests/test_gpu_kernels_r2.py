@@ -45,11 +45,19 @@ GEOM = [(1, 17, 23, 5, 7), (2, 36, 50, 64, 64), (1, 76, 121, 128, 192), (2, 38, 
         (1, 1, 1, 8, 8), (1, 2, 3, 3, 1), (1, 33, 31, 238, 64)]
 
 
+def _wino_fns(lib, kern):
+    """(pack, plan, conv) of one of the two fused Winograd kernels: conv_wino4.hip (the default: 16x8-pixel workgroups, two
+    per CU) or conv_wino.hip (16x16 pixels, one per CU).  Same argument contract, different weight layouts."""
+    return getattr(lib, f"hpri_{kern}_pack"), getattr(lib, f"hpri_conv_{kern}_plan"), getattr(lib, f"hpri_conv_{kern}")
+
+
 @pytest.mark.parametrize("shape", GEOM)
 @pytest.mark.parametrize("mode", [0, 1])
-def test_winograd_forward_and_data_gradient_vs_fp64(lib, shape, mode):
+@pytest.mark.parametrize("kern", ["wino4", "wino"])
+def test_winograd_forward_and_data_gradient_vs_fp64(lib, shape, mode, kern):
     """mode 0: y = conv2d(x, W) + b.  mode 1: the data-gradient form -- the same kernel on the transposed, 180-degree
     rotated weight (pack mode 1), as engine.py uses it for dX."""
+    pack, plan, conv = _wino_fns(lib, kern)
     N, H, W, Cin, Cout = shape
     torch.manual_seed(11 + mode)
     cs, cout_pad, ycs = rup(Cin, 8), rup(Cout, 64), rup(Cout, 8)
@@ -65,21 +73,21 @@ def test_winograd_forward_and_data_gradient_vs_fp64(lib, shape, mode):
         wt = w.double().cpu().permute(1, 0, 2, 3).flip(2, 3)
     b = torch.randn(Cout, device=DEV)
     up = torch.empty(lib.hpri_wino_packed_floats(Cin, cout_pad), device=DEV)
-    assert lib.hpri_wino_pack(P(w), P(up), P(None), mode, Cin, Cout, cout_pad, d1, _st()) == 0
+    assert pack(P(w), P(up), P(None), mode, Cin, Cout, cout_pad, d1, _st()) == 0
     xt = x[:, :Cin].reshape(N, H, W, Cin).permute(0, 3, 1, 2).double().cpu()
     ref = torch.nn.functional.conv2d(xt, wt, b.double().cpu(), padding=1).permute(0, 2, 3, 1).reshape(-1, Cout)
     tl = ctypes.c_int()
-    lib.hpri_conv_wino_plan(N, H, W, ctypes.byref(tl))
+    plan(N, H, W, ctypes.byref(tl))
     for acc, want in ((0, ref), (2, ref.clamp(min=0)), (1, ref + 0.25)):
         y = torch.full((N * H * W, ycs), 0.25, device=DEV)
         stats = torch.zeros(tl.value * cout_pad * 4, device=DEV) if acc != 1 else None
-        rc = lib.hpri_conv_wino(P(x), cs, 0, P(up), P(b), P(y), ycs, 0, P(stats), N, H, W, cs, Cout, cout_pad, ycs, acc, _st())
+        rc = conv(P(x), cs, 0, P(up), P(b), P(y), ycs, 0, P(stats), N, H, W, cs, Cout, cout_pad, ycs, acc, _st())
         assert rc == 0, lib.hpri_last_error()
         torch.cuda.synchronize()
         got = y[:, :Cout].double().cpu()
         scale = max(1.0, float(want.abs().max()))
         err = float((got - want).abs().max())
-        record_margin(f"wino/fwd{mode}/acc{acc}/{N}x{H}x{W}x{Cin}x{Cout}", err, 5e-5 * scale)
+        record_margin(f"{kern}/fwd{mode}/acc{acc}/{N}x{H}x{W}x{Cin}x{Cout}", err, 5e-5 * scale)
         assert err < 5e-5 * scale, (shape, mode, acc, err)
         if Cout < ycs:
             assert float(y[:, Cout:].abs().max()) in (0.0, 0.25)       # pad channels: zero-filled or untouched, never garbage
@@ -90,9 +98,11 @@ def test_winograd_forward_and_data_gradient_vs_fp64(lib, shape, mode):
             assert float((var - want.var(0, unbiased=False)).abs().max()) < 1e-4 * scale * scale
 
 
-def test_winograd_forward_channel_slice_views(lib):
+@pytest.mark.parametrize("kern", ["wino4", "wino"])
+def test_winograd_forward_channel_slice_views(lib, kern):
     """Input and output are channel slices of wider buffers (the skip-concat layout, model_parts.py:87): the kernel
     must read only [coff, coff+Cin) and write only [coff, coff+Cout)."""
+    pack, plan, conv = _wino_fns(lib, kern)
     N, H, W, Cin, Cout = 1, 20, 28, 16, 64
     torch.manual_seed(5)
     xcs, xoff, ycs, yoff = 40, 8, 136, 64
@@ -100,9 +110,9 @@ def test_winograd_forward_channel_slice_views(lib):
     w = torch.randn(Cout, Cin, 3, 3, device=DEV) * 0.1
     cout_pad = rup(Cout, 64)
     up = torch.empty(lib.hpri_wino_packed_floats(Cin, cout_pad), device=DEV)
-    assert lib.hpri_wino_pack(P(w), P(up), P(None), 0, Cin, Cout, cout_pad, Cin, _st()) == 0
+    assert pack(P(w), P(up), P(None), 0, Cin, Cout, cout_pad, Cin, _st()) == 0
     yb = torch.full((N * H * W, ycs), 7.0, device=DEV)
-    rc = lib.hpri_conv_wino(P(xb), xcs, xoff, P(up), P(None), P(yb), ycs, yoff, P(None), N, H, W, Cin, Cout, cout_pad, Cout, 0, _st())
+    rc = conv(P(xb), xcs, xoff, P(up), P(None), P(yb), ycs, yoff, P(None), N, H, W, Cin, Cout, cout_pad, Cout, 0, _st())
     assert rc == 0, lib.hpri_last_error()
     torch.cuda.synchronize()
     xt = xb[:, xoff:xoff + Cin].reshape(N, H, W, Cin).permute(0, 3, 1, 2).double().cpu()
@@ -111,14 +121,16 @@ def test_winograd_forward_channel_slice_views(lib):
     assert torch.all(yb[:, :yoff] == 7.0) and torch.all(yb[:, yoff + Cout:] == 7.0)
 
 
-def test_winograd_rejects_unaligned_output(lib):
+@pytest.mark.parametrize("kern", ["wino4", "wino"])
+def test_winograd_rejects_unaligned_output(lib, kern):
     """The output transform stores float4 channel vectors: a channel stride that is not a multiple of 4 is an error
     return (HPRI_REQUIRE), not a silent scatter over the neighbouring pixels."""
+    pack, plan, conv = _wino_fns(lib, kern)
     N, H, W, Cin, Cout = 1, 8, 8, 8, 7
     x = torch.zeros(N * H * W, 8, device=DEV)
     up = torch.zeros(lib.hpri_wino_packed_floats(Cin, 64), device=DEV)
     y = torch.zeros(N * H * W * 8, device=DEV)
-    rc = lib.hpri_conv_wino(P(x), 8, 0, P(up), P(None), P(y), 7, 0, P(None), N, H, W, 8, Cout, 64, 7, 0, _st())
+    rc = conv(P(x), 8, 0, P(up), P(None), P(y), 7, 0, P(None), N, H, W, 8, Cout, 64, 7, 0, _st())
     assert rc != 0
     assert b"y_cs" in lib.hpri_last_error() or b"align" in lib.hpri_last_error().lower()
 
