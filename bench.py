@@ -384,7 +384,7 @@ def main():
                       "ms": r["bf16_planes"]["ms"], "TF": r["bf16_planes"]["tflops"], "frac_of_2.5PF": r["bf16_planes"]["frac_of_2.5PF"],
                       "hbm_bytes_algorithmic": int(r["bf16_planes"]["algorithmic_hbm_mb"] * 1e6),
                       "hbm_bytes_measured": "profiles/r02_first_conv_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/first_conv.py)",
-                      "fp32_kernel_same_layer": r["fp32"]}
+                      "fp32_kernel_same_layer": r["fp32"], "fp32_winograd_same_layer": r.get("fp32_winograd")}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

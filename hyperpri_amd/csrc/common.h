@@ -51,6 +51,23 @@ __device__ __forceinline__ void plane_store4(const PlaneOut& pl, size_t pix, int
 }
 #endif
 
+// LDS-DMA through a buffer descriptor (buffer_load_dwordx4 ... lds): 16 bytes per lane from base + soffset + voffset into
+// the wave's 1 KB LDS piece.  A lane whose voffset lies beyond the descriptor's range gets ZEROS written into its LDS slot
+// (hardware range check; tools/lds_dma_oob.hip) -- used for halo pixels outside the image.  The instruction's immediate
+// offset would be added to the LDS address as well, so every offset goes through soffset / voffset.  (The host pass of a
+// templated kernel drops the instantiation when it meets the device-only descriptor type: hence the host-side dummies.)
+#define HPRI_DMA_OOB 0xFFFFFFF0u
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __amdgpu_buffer_rsrc_t hpri_rsrc_t;
+#define HPRI_MAKE_RSRC(ptr_, bytes_) __builtin_amdgcn_make_buffer_rsrc((void*)(ptr_), 0, (int)(bytes_), 0x00020000)
+#define HPRI_LDS_DMA16(rs_, lds_, voff_, soff_) \
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_, (__attribute__((address_space(3))) void*)(lds_), 16, voff_, soff_, 0, 0)
+#else
+typedef int hpri_rsrc_t;
+#define HPRI_MAKE_RSRC(ptr_, bytes_) 0
+#define HPRI_LDS_DMA16(rs_, lds_, voff_, soff_) ((void)(rs_))
+#endif
+
 // host: fill a PlaneOut from C-ABI arguments (planes == nullptr: no plane output)
 static inline int hpri_plane_out(PlaneOut* po, void* planes, long long plane_stride, int pl_cs, int pl_coff, int pl_cw, int npl, int C) {
   po->p = reinterpret_cast<__bf16*>(planes); po->plane = plane_stride; po->cs = pl_cs; po->coff = pl_coff; po->cw = pl_cw; po->npl = npl;

@@ -125,22 +125,26 @@ __global__ __launch_bounds__(512, 2) void conv_bf16v2_kernel(ConvV2Args a) {
   };
 
   // per-lane DMA source offsets of the item being loaded (B: packed-weight rows of channel block nb; A: halo pixels)
-  int goff[NIB], aoff[NIA], bpiece[NIB];
+  // (buffer_load ... lds: 32-bit per-lane byte offsets against wave-uniform descriptors; halo pixels outside the image get an
+  // offset beyond the descriptor's range and the hardware range check writes zeros into their LDS slots)
+  constexpr unsigned OOB = 0xFFFFFFF0u;
+  unsigned goff[NIB], aoff[NIA];
+  int bpiece[NIB];
   {
     const bool late_ = wave >= 4;
 #pragma unroll
     for (int q = 0; q < NIB; ++q)      // waves 0-3 take pieces [0, 4*NB_E), waves 4-7 the rest
       bpiece[q] = late_ ? (4 * NB_E + (q < NB_L ? q : 0) * 4 + (wave - 4)) : (q * 4 + wave);
   }
-  const __bf16* ximg = a.xp;
-  const __bf16* zpage = reinterpret_cast<const __bf16*>(hpri_zero_page) + (lane & 3) * 8;
+  const hpri_rsrc_t rs_b = HPRI_MAKE_RSRC(a.wp, 0x7FFFFF00);
+  hpri_rsrc_t rs_a = HPRI_MAKE_RSRC(a.xp, 0x7FFFFF00);
   auto setup_loads = [&](const V2Tile& t) {
 #pragma unroll
     for (int q = 0; q < NIB; ++q) {
       const int R = bpiece[q] * 16 + (lane >> 2);
       const int rb = R / BN, n = R - rb * BN;
       const int ls = (lane & 3) ^ ((n >> 2) & 3);
-      goff[q] = (rb * a.Cout_pad + t.nb * BN + n) * 32 + ls * 8;
+      goff[q] = (unsigned)((rb * a.Cout_pad + t.nb * BN + n) * 32 + ls * 8) * 2u;
     }
     const int TW = 1 << t.twl, TH = 2 * WM * (32 >> t.twl);
     const int HW = TW + KS - 1, HP = (TH + KS - 1) * HW;
@@ -148,35 +152,31 @@ __global__ __launch_bounds__(512, 2) void conv_bf16v2_kernel(ConvV2Args a) {
 #pragma unroll
     for (int q = 0; q < NIA; ++q) {
       const int pix = (q * 8 + wave) * 16 + (lane >> 2);
-      int off = -1;
+      unsigned off = OOB;
       if (pix < HP) {
         const int hy = (int)(((unsigned)pix * hw_inv) >> 16), hx = pix - hy * HW;
         const int iy = t.y0 + hy - PAD, ix = t.x0 + hx - PAD;
         if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
-          off = (iy * a.W + ix) * a.x_cs + (((lane & 3) ^ ((pix >> 2) & 3)) << 3);
+          off = (unsigned)((iy * a.W + ix) * a.x_cs + (((lane & 3) ^ ((pix >> 2) & 3)) << 3)) * 2u;
       }
       aoff[q] = off;
     }
-    ximg = a.xp + (size_t)t.img * a.H * a.W * a.x_cs + a.x_coff;
+    rs_a = HPRI_MAKE_RSRC((a.xp + (size_t)t.img * a.H * a.W * a.x_cs + a.x_coff), 0x7FFFFF00);
   };
 #define LOAD_B(s_)                                                                                                    \
   {                                                                                                                   \
-    const __bf16* pb_ = a.wp + (size_t)(s_) * SR * a.Cout_pad * 32;                                                   \
+    const int sb_ = (s_) * SR * a.Cout_pad * 64;                                  /* bytes */                        \
     unsigned char* lb_ = b_lds + ((s_) % NBB) * B_BYTES;                                                              \
     _Pragma("unroll") for (int q = 0; q < NIB; ++q)                                                                   \
         if (q < NB_L || !late)                                                                                        \
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pb_ + goff[q]),            \
-                                           (__attribute__((address_space(3))) void*)(lb_ + bpiece[q] * 1024), 16, 0, 0); \
+          HPRI_LDS_DMA16(rs_b, lb_ + bpiece[q] * 1024, goff[q], sb_);                                               \
   }
 #define LOAD_A(chunk_)                                                                                                \
   {                                                                                                                   \
     unsigned char* la_ = a_lds + ((chunk_) & 1) * A_BYTES;                                                            \
     _Pragma("unroll") for (int pl = 0; pl < NPL; ++pl)                                                                \
-        _Pragma("unroll") for (int q = 0; q < NIA; ++q) {                                                             \
-          const __bf16* src_ = (aoff[q] >= 0) ? (ximg + (size_t)pl * a.x_plane + (size_t)(unsigned)aoff[q] + (chunk_) * 32) : zpage; \
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_,                       \
-                                           (__attribute__((address_space(3))) void*)(la_ + pl * APIX * 64 + (q * 8 + wave) * 1024), 16, 0, 0); \
-        }                                                                                                             \
+        _Pragma("unroll") for (int q = 0; q < NIA; ++q)                                                               \
+            HPRI_LDS_DMA16(rs_a, la_ + pl * APIX * 64 + (q * 8 + wave) * 1024, aoff[q], (int)(pl * a.x_plane * 2) + (chunk_) * 64);   \
   }
 #define PROLOGUE_LOADS()                       \
   LOAD_A(chunk0)                               \
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(512, 2) void conv_bf16v2_kernel(ConvV2Args a) {
       /* ---------------- MFMA phase ---------------- */                                                               \
       const bool more_b = (s_) + 3 < S, more_a = ((st_) == 0 && chunk + 1 < nchunks);                                  \
       prev_a = more_a;                                                                                                 \
-      const __bf16* pb_ = a.wp + (size_t)((s_) + 3) * SR * a.Cout_pad * 32;                                            \
+      const int sb_ = ((s_) + 3) * SR * a.Cout_pad * 64;                                                               \
       unsigned char* lb_ = b_lds + (((s_) + 3) % NBB) * B_BYTES;                                                       \
       unsigned char* la_ = a_lds + ((chunk + 1) & 1) * A_BYTES;                                                        \
       __builtin_amdgcn_s_setprio(1);                                                                                   \
@@ -278,15 +278,11 @@ __global__ __launch_bounds__(512, 2) void conv_bf16v2_kernel(ConvV2Args a) {
           const int k = m / 3;                                                                                         \
           if (k < NIB) {                                                                                               \
             if (more_b && (k < NB_L || !late))                                                                         \
-              __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pb_ + goff[k < NIB ? k : 0]), \
-                                               (__attribute__((address_space(3))) void*)(lb_ + bpiece[k < NIB ? k : 0] * 1024), 16, 0, 0); \
+              HPRI_LDS_DMA16(rs_b, lb_ + bpiece[k < NIB ? k : 0] * 1024, goff[k < NIB ? k : 0], sb_);                          \
           } else if (k - NIB < NA_W) {                                                                                 \
             const int pl = (k - NIB) / NIA, q = (k - NIB) % NIA;                                                       \
-            if (more_a) {                                                                                              \
-              const __bf16* src_ = (aoff[q] >= 0) ? (ximg + (size_t)pl * a.x_plane + (size_t)(unsigned)aoff[q] + (chunk + 1) * 32) : zpage; \
-              __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_,                    \
-                                               (__attribute__((address_space(3))) void*)(la_ + pl * APIX * 64 + (q * 8 + wave) * 1024), 16, 0, 0); \
-            }                                                                                                          \
+            if (more_a)                                                                                                \
+              HPRI_LDS_DMA16(rs_a, la_ + pl * APIX * 64 + (q * 8 + wave) * 1024, aoff[q], (int)(pl * a.x_plane * 2) + (chunk + 1) * 64); \
           }                                                                                                            \
         }                                                                                                              \
       }                                                                                                                \

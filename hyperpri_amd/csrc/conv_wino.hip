@@ -509,22 +509,20 @@ __global__ __launch_bounds__(512, 2) void conv_wino_wgrad_kernel(WinoWgradArgs a
     unsigned char* lb_ = smem + (buf_) * WG_STAGE_BYTES;                                                               \
     const float* xu_ = a.x + ((long long)(img_ * a.H + y0_ - 1) * a.W + x0_ - 1) * a.x_cs + a.x_coff + c_blk;          \
     const float* yu_ = a.dy + ((long long)(img_ * a.H + y0_) * a.W + x0_) * a.dy_cs + a.dy_coff + n_blk;               \
-    const __amdgpu_buffer_rsrc_t rx_ = __builtin_amdgcn_make_buffer_rsrc((void*)xu_, 0, 0x7FFFFF00, 0x00020000);       \
-    const __amdgpu_buffer_rsrc_t ry_ = __builtin_amdgcn_make_buffer_rsrc((void*)yu_, 0, 0x7FFFFF00, 0x00020000);       \
+    const hpri_rsrc_t rx_ = HPRI_MAKE_RSRC(xu_, 0x7FFFFF00);       \
+    const hpri_rsrc_t ry_ = HPRI_MAKE_RSRC(yu_, 0x7FFFFF00);       \
     _Pragma("unroll") for (int p = 0; p < NPW; ++p) {                                                                  \
       const int piece_ = p * 8 + wave;                                                                                 \
       if (piece_ < NPX) {                                                                                              \
         const int row_ = piece_ / (WG_XROW / 4), pxb_ = (piece_ % (WG_XROW / 4)) * 4;          /* wave-uniform */       \
         const bool rowok_ = (unsigned)(y0_ + row_ - 1) < (unsigned)a.H;                                                \
         const bool ok_ = rowok_ && (pxb_ + l4) < 34 && (unsigned)(x0_ + pxb_ + l4 - 1) < (unsigned)a.W;                \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx_, (__attribute__((address_space(3))) void*)(lb_ + piece_ * 1024), 16, \
-                                                 ok_ ? xlane : OOB, (row_ * a.W + pxb_) * a.x_cs * 4, 0, 0);           \
+        HPRI_LDS_DMA16(rx_, lb_ + piece_ * 1024, ok_ ? xlane : OOB, (row_ * a.W + pxb_) * a.x_cs * 4);           \
       } else if (piece_ < NPX + NPY) {                                                                                 \
         const int pp_ = piece_ - NPX;                                                                                  \
         const int row_ = pp_ >> 3, pxb_ = (pp_ & 7) * 4;                                                               \
         const bool ok_ = (y0_ + row_) < a.H && (x0_ + pxb_ + l4) < a.W;                                                \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(ry_, (__attribute__((address_space(3))) void*)(lb_ + piece_ * 1024), 16, \
-                                                 ok_ ? ylane : OOB, (row_ * a.W + pxb_) * a.dy_cs * 4, 0, 0);          \
+        HPRI_LDS_DMA16(ry_, lb_ + piece_ * 1024, ok_ ? ylane : OOB, (row_ * a.W + pxb_) * a.dy_cs * 4);          \
       }                                                                                                                \
     }                                                                                                                  \
   }

@@ -74,8 +74,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(Wino4Args a) {
   //      the image get an offset beyond the descriptor's range: the hardware range check writes ZEROS into their LDS slots
   //      (tools/lds_dma_oob.hip), so there is no zero page, no select and no 64-bit address arithmetic per piece ----
   const float* ximg = a.x + (size_t)img * a.H * a.W * a.x_cs + a.x_coff;
-  const __amdgpu_buffer_rsrc_t rs_a =
-      __builtin_amdgcn_make_buffer_rsrc((void*)ximg, 0, (int)(((long long)a.H * a.W * a.x_cs - a.x_coff) * 4), 0x00020000);
+  const hpri_rsrc_t rs_a =
+      HPRI_MAKE_RSRC(ximg, (int)(((long long)a.H * a.W * a.x_cs - a.x_coff) * 4));
   constexpr int NIA = (W4_AI + 3) / 4;              // per wave (the last round is partial)
   constexpr unsigned OOB = 0xFFFFFFF0u;
   unsigned aoff[NIA];
@@ -105,8 +105,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(Wino4Args a) {
           const int lquad_ = lq ^ ((slot_ >> 1) & 7);                                                                 \
           if (((chunk_) * 32 + lquad_ * 4) >= a.Cin_pad) vo_ = OOB;                                                   \
         }                                                                                                             \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (__attribute__((address_space(3))) void*)(la_ + inst_ * 1024), 16, vo_, \
-                                                 (chunk_) * 128, 0, 0);                                               \
+        HPRI_LDS_DMA16(rs_a, la_ + inst_ * 1024, vo_, (chunk_) * 128);                                               \
       }                                                                                                               \
     }                                                                                                                 \
   }
@@ -114,8 +113,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(Wino4Args a) {
   //      which holds logical half (lane&1) ^ ((n>>3)&1) (conflict-free ds_read_b128 of a lane's four k values) ----
   const unsigned goff0 = (unsigned)(((fa * 4) * a.Cout_pad + nb * 64 + (lane >> 1)) * 8 + 4 * ((lane & 1) ^ ((lane >> 4) & 1))) * 4u;
   const int gstep_b = a.Cout_pad * 8 * 4;           // bytes between column frequencies
-  const __amdgpu_buffer_rsrc_t rs_b =
-      __builtin_amdgcn_make_buffer_rsrc((void*)a.up, 0, (int)((long long)(a.Cin_pad >> 3) * 16 * 8 * a.Cout_pad * 4), 0x00020000);
+  const hpri_rsrc_t rs_b =
+      HPRI_MAKE_RSRC(a.up, (int)((long long)(a.Cin_pad >> 3) * 16 * 8 * a.Cout_pad * 4));
   unsigned char* bw = b_lds + wave * W4_B_WAVE;
 #define LOAD_B(s_)                                                                                                    \
   {                                                                                                                   \
@@ -124,8 +123,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(Wino4Args a) {
   }
 // NB the instruction's immediate offset is added to the LDS address as well as to the memory address: everything goes through soffset
 #define B_PIECE(p_)                                                                                                   \
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (__attribute__((address_space(3))) void*)(bw + (p_) * 1024), 16, goff0, \
-                                           sb_ + ((p_) >> 1) * gstep_b + ((p_) & 1) * 1024, 0, 0);
+  HPRI_LDS_DMA16(rs_b, bw + (p_) * 1024, goff0, sb_ + ((p_) >> 1) * gstep_b + ((p_) & 1) * 1024);
 
   // lane's tile: (ty, tx) = (li>>3, li&7); halo slot of its input pixel (r, c): (2 ty + r) * 18 + 2 tx + c
   const int hpb = (2 * (li >> 3)) * W4_HW + 2 * (li & 7);

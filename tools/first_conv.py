@@ -72,6 +72,27 @@ def measure(reps=20, modes=("bf16_planes", "fp32")):
             out[mode]["frac_of_2.5PF"] = round(tf / PEAK_BF16, 4)
         else:
             out[mode]["frac_of_157.3TF"] = round(tf / 157.3, 4)
+    # ---- fp32 Winograd F(2x2,3x3) on the same layer (the headline path; conv_wino4.hip) ----
+    if "fp32" in modes:
+        up = torch.empty(lib.hpri_wino_packed_floats(CIN, cout_pad), device=dev)
+        assert lib.hpri_wino4_pack(P(w), P(up), ctypes.c_void_p(0), 0, CIN, COUT, cout_pad, CIN, st) == 0
+        tlw = ctypes.c_int()
+        lib.hpri_conv_wino4_plan(N, H, W, ctypes.byref(tlw))
+        statsw = torch.zeros(tlw.value * cout_pad * 4, device=dev)
+        callw = lambda: lib.hpri_conv_wino4(P(x), cs, 0, P(up), P(b), P(y), COUT, 0, P(statsw), N, H, W, cs, COUT, cout_pad, COUT, 0, st)
+        for _ in range(3):
+            assert callw() == 0, lib.hpri_last_error()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            callw()
+        e1.record()
+        torch.cuda.synchronize()
+        msw = e0.elapsed_time(e1) / reps
+        executed = 2.0 * N * ((H + 1) // 2) * ((W + 1) // 2) * 16 * CIN * COUT
+        out["fp32_winograd"] = {"ms": round(msw, 4), "executed_tflops": round(executed / msw / 1e9, 1),
+                                "direct_equivalent_tflops": round(FLOPS / msw / 1e9, 1),
+                                "frac_of_157.3TF_executed": round(executed / msw / 1e9 / 157.3, 4)}
     return out
 
 
