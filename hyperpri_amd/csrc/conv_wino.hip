@@ -475,8 +475,6 @@ __global__ __launch_bounds__(512, 2) void conv_wino_wgrad_kernel(WinoWgradArgs a
   const int r1 = (fa == 0) ? 0 : 1, r2 = (fa == 3) ? 3 : 2;
   const float s1 = (fa == 2) ? -1.f : 1.f, s2 = (fa == 1 || fa == 2) ? 1.f : -1.f;
   const int c0 = fb;
-  // dM = A dY A^T: row part T[q] = ta0 dY[0][q] + ta1 dY[1][q] with (ta0, ta1) = (1,0) (1,1) (1,-1) (0,-1) for a = 0..3
-  const float ta0 = (fa == 3) ? 0.f : 1.f, ta1 = (fa == 0) ? 0.f : (fa == 1 ? 1.f : -1.f);
   const float sigma = s1 * s2;
 
   f32x16 acc[2][2][2];                              // [frequency e][cin tile ct][cout tile nt]
@@ -527,7 +525,11 @@ __global__ __launch_bounds__(512, 2) void conv_wino_wgrad_kernel(WinoWgradArgs a
     }                                                                                                                  \
   }
 
-#define K_LOOP(FB_)                                                                                                    \
+// The loop body is compiled per (frequency row, column pair): the row part of dM = A dY A^T multiplies by constants that are
+// 0 or +-1 -- a = 0: dY[0], a = 1: dY[0] + dY[1], a = 2: dY[0] - dY[1], a = 3: -dY[1] -- so rows 0 and 3 need no arithmetic at
+// all and rows 1, 2 one add per column; the column part for b = 2 fb + e is t0 | t0 + t1 (fb = 0), t0 - t1 | -t1 (fb = 1).  The
+// two minus signs (row 3, and b = 3) are left out here and applied once to the accumulators when the slab is written.
+#define K_LOOP(FA_, FB_)                                                                                               \
     _Pragma("unroll 2") for (int kk = 0; kk < 8; ++kk) {      /* MFMA k-step: tiles 2 kk + lh of the strip */            \
       const int tile = 2 * kk + lh;                                                                                    \
       float va[2][2], vb[2][2];                     /* [frequency e][cin tile | cout tile] */                          \
@@ -542,35 +544,52 @@ __global__ __launch_bounds__(512, 2) void conv_wino_wgrad_kernel(WinoWgradArgs a
         va[1][ct] = FB_ ? (P[0] - P[2]) : (P[1] + P[2]);                                                               \
       }                                                                                                                \
       _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) {                                                               \
-        const float y00 = ys[(0 * 32 + 2 * tile + 0) * 64 + nt * 32 + li], y01 = ys[(0 * 32 + 2 * tile + 1) * 64 + nt * 32 + li]; \
-        const float y10 = ys[(1 * 32 + 2 * tile + 0) * 64 + nt * 32 + li], y11 = ys[(1 * 32 + 2 * tile + 1) * 64 + nt * 32 + li]; \
-        const float t0 = ta0 * y00 + ta1 * y10, t1 = ta0 * y01 + ta1 * y11;                                            \
-        /* column part for b = 2 fb + e:  b=0: t0 | b=1: t0 + t1 | b=2: t0 - t1 | b=3: -t1 */                          \
+        float t0, t1;                                                                                                  \
+        if (FA_ == 0 || FA_ == 3) {                                                                                    \
+          t0 = ys[(((FA_ == 3) ? 1 : 0) * 32 + 2 * tile + 0) * 64 + nt * 32 + li];                                     \
+          t1 = ys[(((FA_ == 3) ? 1 : 0) * 32 + 2 * tile + 1) * 64 + nt * 32 + li];                                     \
+        } else {                                                                                                       \
+          const float y00 = ys[(0 * 32 + 2 * tile + 0) * 64 + nt * 32 + li], y01 = ys[(0 * 32 + 2 * tile + 1) * 64 + nt * 32 + li]; \
+          const float y10 = ys[(1 * 32 + 2 * tile + 0) * 64 + nt * 32 + li], y11 = ys[(1 * 32 + 2 * tile + 1) * 64 + nt * 32 + li]; \
+          t0 = (FA_ == 1) ? (y00 + y10) : (y00 - y10);                                                                 \
+          t1 = (FA_ == 1) ? (y01 + y11) : (y01 - y11);                                                                 \
+        }                                                                                                              \
         vb[0][nt] = FB_ ? (t0 - t1) : t0;                                                                              \
-        vb[1][nt] = FB_ ? (-t1) : (t0 + t1);                                                                           \
+        vb[1][nt] = FB_ ? t1 : (t0 + t1);                                                                              \
       }                                                                                                                \
       _Pragma("unroll") for (int e = 0; e < 2; ++e)                                                                    \
           _Pragma("unroll") for (int ct = 0; ct < 2; ++ct)                                                             \
               _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                                         \
                   acc[e][ct][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[e][ct], vb[e][nt], acc[e][ct][nt], 0, 0, 0); \
     }
-  // the column-pair variant is chosen once per wave, outside the unit loop (two copies of the loop, no selects inside)
-#define UNIT_LOOP(FB_)                                                                                                 \
+  // the variant is chosen once per wave, outside the unit loop (eight copies of the loop, no selects inside)
+#define UNIT_LOOP(FA_, FB_)                                                                                            \
   for (int u = u0; u < u1; ++u) {                                                                                      \
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                   \
     __builtin_amdgcn_s_barrier();          /* this unit has landed for everyone; the other buffer is free */           \
     if (u + 1 < u1) LOAD_UNIT(u + 1, (u + 1 - u0) & 1)                                                                 \
     const float* xs = reinterpret_cast<const float*>(smem + ((u - u0) & 1) * WG_STAGE_BYTES);                          \
     const float* ys = xs + WG_X_BYTES / 4;                                                                             \
-    K_LOOP(FB_)                                                                                                        \
+    K_LOOP(FA_, FB_)                                                                                                   \
   }
   if (u0 < u1) LOAD_UNIT(u0, 0)
-  if (fb) { UNIT_LOOP(1) } else { UNIT_LOOP(0) }
+  switch (wave) {                          // wave = 2 fa + fb
+    case 0: UNIT_LOOP(0, 0) break;
+    case 1: UNIT_LOOP(0, 1) break;
+    case 2: UNIT_LOOP(1, 0) break;
+    case 3: UNIT_LOOP(1, 1) break;
+    case 4: UNIT_LOOP(2, 0) break;
+    case 5: UNIT_LOOP(2, 1) break;
+    case 6: UNIT_LOOP(3, 0) break;
+    default: UNIT_LOOP(3, 1) break;
+  }
 #undef UNIT_LOOP
 #undef K_LOOP
 #undef LOAD_UNIT
   // slab: ws[split][xi][c][n]; accumulator rows = cin (register index), columns = cout (lane)
   float* slab = a.ws + (size_t)split * 16 * a.Cr * a.Nr;
+  const float sdy = (fa == 3) ? -s1 : s1;                              // input-transform row sign x dY row sign
+  const float sgn[2] = {sdy, (fb == 1) ? -sdy : sdy};                  // ... x the sign of column frequency b = 3
 #pragma unroll
   for (int e = 0; e < 2; ++e) {
     const int xi = fa * 4 + 2 * fb + e;
@@ -582,7 +601,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_wgrad_kernel(WinoWgradArgs a
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int c = c_blk + ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          slab[((size_t)xi * a.Cr + c) * a.Nr + n] = s1 * acc[e][ct][nt][r];    // s1: the transform sign left out of the loop
+          slab[((size_t)xi * a.Cr + c) * a.Nr + n] = sgn[e] * acc[e][ct][nt][r];   // the transform signs left out of the loop
         }
       }
   }
