@@ -192,6 +192,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="skip the per-kernel HIP-event pass")
+    ap.add_argument("--no-optimizer-leg", action="store_true",
+                    help="skip the optimizer-step comparison (its torch.optim.Adam half is the only ATen work of a bench run; "
+                         "profiling passes use this so that their kernel tables show the hot path alone)")
     ap.add_argument("--bf16-steps", type=int, default=5,
                     help="extra steps in each of the precision modes bf16x6, bf16x3 and bf16 (reported as 'bf16x6_mode' / 'bf16x3_mode' / "
                          "'bf16_mode', never as 'value'); 0 = skip")
@@ -270,7 +273,7 @@ def main():
 
     # ---- optimizer step: excluded from the metric, reported beside it ----
     optimizer_step = None
-    if rank == 0:
+    if rank == 0 and not args.no_optimizer_leg:
         def time_opt(opt, n=10):
             for _ in range(2):
                 opt.step()
