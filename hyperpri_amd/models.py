@@ -110,10 +110,6 @@ class SpectralUNET(torch.nn.Module):
                               precision=getattr(self, "hpri_precision", None))
 
     def forward(self, x):
-        if self.n_classes != 1 and x.shape[0] > 0:
-            # models.py:144 reshapes (R*C, n_classes) as (n_classes, R, C): only meaningful for 1 class
-            raise NotImplementedError("hyperpri_amd: SpectralUNET supports n_classes == 1 (as the reference's reshape does)")
-
         def prog(tape, a, need):
             x0 = self._layer(tape, a[0], self.tail, need[0])
             x1 = self._layer(tape, x0, self.down1)
@@ -125,7 +121,14 @@ class SpectralUNET(torch.nn.Module):
             t = self._layer(tape, E.concat_channels(tape, x2, t), self.up3)
             t = self._layer(tape, E.concat_channels(tape, x1, t), self.up4)
             return E.out_conv(tape, E.concat_channels(tape, x0, t), self.outc.weight, self.outc.bias)
-        return run(prog, [x], list(self.parameters()))
+        out = run(prog, [x], list(self.parameters()))
+        if self.n_classes != 1:
+            # models.py:144 stores each image's (R*C, n_classes) result with .reshape(n_classes, R, C): the FLAT order is
+            # pixel-major, class-minor.  `out` holds true class planes (N, K, R, C); re-order to the reference's element order
+            # (a differentiable view + copy of N*K*R*C floats; no BASELINE config has n_classes != 1).
+            n, k, r, c = out.shape
+            out = out.reshape(n, k, r * c).transpose(1, 2).contiguous().reshape(n, k, r, c)
+        return out
 
 
 class CubeNET(torch.nn.Module):

@@ -97,6 +97,7 @@ NETS = [
     ("net_cubenet64_bilinear_tiny", lambda: O.cubenet_shapes(6, 1, 64, True), O.cubenet_forward, {"first_depth": 64, "bilinear": True}, 1241, (2, 1, 6, 36, 50), 4321),
     ("net_spectral_tiny", lambda: O.spectral_shapes(10, 1, 4), O.spectral_forward, {}, 1237, (3, 10, 7, 9), 4322),
     ("net_spectral_f48", lambda: O.spectral_shapes(22, 1, 48), O.spectral_forward, {}, 1238, (2, 22, 12, 20), 4323),
+    ("net_spectral_3class", lambda: O.spectral_shapes(10, 3, 4), O.spectral_forward, {}, 1252, (2, 10, 7, 9), 4332),
     ("net_spectral_f50", lambda: O.spectral_shapes(22, 1, 50), O.spectral_forward, {}, 1242, (2, 22, 9, 14), 4324),
     # the BASELINE configs' exact channel widths at reduced spatial size (tests/golden/make_golden_widths.py)
     ("net_spectral1650_small", lambda: O.spectral_shapes(238, 1, 1650), O.spectral_forward, {}, 1250, (2, 238, 16, 24), 4330),
@@ -112,7 +113,7 @@ def test_tiny_net(name, shapes, fwd, kw, xseed, xshape, mseed):
     sd = O.synth_state_dict(shapes())
     x = _u(xseed, xshape)
     thr = MASK_THR.get(name, 0.9 if "spectral" not in name else 0.7)
-    mask = (_u(mseed, (xshape[0], 1) + tuple(xshape[-2:])) > thr).float()
+    mask = (_u(mseed, (xshape[0], int(z["logits"].shape[1])) + tuple(xshape[-2:])) > thr).float()
     logits, loss, grads = O.train_step(fwd, sd, x, mask, **kw)
     np.testing.assert_allclose(logits.numpy(), z["logits"], rtol=1e-4, atol=2e-6)
     assert abs(loss - float(z["loss"])) < 1e-6
