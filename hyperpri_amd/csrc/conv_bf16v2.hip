@@ -12,7 +12,8 @@
 //   A (input)  halo of (TH+2) x (TW+2) pixels x 32 channels per plane, 64-byte pixel rows, unpadded; the four 16-byte
 //              slots of a pixel are XOR-swizzled with (pixel>>2)&3 (the DMA cannot permute its destination, but every
 //              lane picks WHICH source slot it fetches) -> conflict-free ds_read_b128 fragments for any tap offset;
-//              pixels outside the image are fetched from a 64-byte page of zeros; double-buffered per 32-channel chunk
+//              pixels outside the image get an out-of-range buffer offset (the descriptor's range check writes zeros into
+//              their LDS slots); double-buffered per 32-channel chunk
 //   B (weights) per stage = one kernel row (KS taps x planes x BN rows of 32 k), same swizzle, double-buffered
 //   pipeline   stage s+1 (and, on a chunk's first row, the next chunk's halo) is in flight while stage s multiplies:
 //              one vmcnt(0) + one barrier per stage of 24..48 MFMAs per wave
@@ -26,7 +27,6 @@
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 #define HPRI_MAXSEG 4
-__device__ __attribute__((aligned(64))) unsigned int hpri_zero_page[16];   // DMA source for halo pixels outside the image
 
 struct ConvV2Args {
   const __bf16* xp; long long x_plane;   // activation planes: plane p at xp + p*x_plane (elements)

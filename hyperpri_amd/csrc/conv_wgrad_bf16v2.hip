@@ -30,8 +30,6 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef bf16x4 __attribute__((address_space(3))) * lds_bf16x4_ptr;
 
-__device__ __attribute__((aligned(64))) unsigned int hpri_wg_zero_page[16];   // DMA source for pixels outside the image
-
 struct WgV2Args {
   const __bf16* xp; int x_cs, x_coff, x_cvalid;       // plane 0 of the convolution input; channels >= x_cvalid read as zero
   const __bf16* dyp; int dy_cs, dy_coff, dy_cvalid;   // plane 0 of the gradient w.r.t. the convolution output
@@ -72,29 +70,31 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_bf16v2_kernel(WgV2Args a) {
   // ---- DMA roles.  Instruction i covers LDS pixel rows 8i .. 8i+7; lane -> row 8i + (lane>>3), physical 16-byte slot lane&7,
   //      which holds logical slot (lane&7) ^ 4*((row>>1)&1) of that pixel ----
   const int sl = lane & 7;
-  int xoff[4], xhy[4], xhx[4];                       // source offset (elements) relative to the unit's first pixel; halo (row, column)
+  // (buffer_load ... lds: the descriptor base is the unit's first HALO pixel -- a wave-uniform pointer that may lie before the
+  // tensor for border units; lanes outside the image or beyond the valid channels get an out-of-range offset, which the
+  // range check turns into zeros in LDS)
+  unsigned xoff[4]; int xhy[4], xhx[4];              // byte offset relative to the unit's first halo pixel; halo (row, column)
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int i = wave + 8 * q, r = 8 * i + (lane >> 3);
     const int hy = r / WG_HW, hx = r - hy * WG_HW;
     const int ls = sl ^ (((r >> 1) & 1) << 2);
     const bool ok = i < WG_XI && r < WG_HP && c_blk + ls * 8 < a.x_cvalid;
-    xoff[q] = ((hy - 1) * a.W + (hx - 1)) * a.x_cs + ls * 8;
-    xhy[q] = ok ? hy : (1 << 24);                    // never inside the image: fetched from the zero page
+    xoff[q] = (unsigned)((hy * a.W + hx) * a.x_cs + ls * 8) * 2u;
+    xhy[q] = ok ? hy : (1 << 24);                    // never inside the image: zero-filled
     xhx[q] = hx;
   }
-  int yoff[2], yhy[2], yhx[2];
+  unsigned yoff[2]; int yhy[2], yhx[2];
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
     const int i = wave + 8 * q, r = 8 * i + (lane >> 3);
     const int py = r >> 5, px = r & 31;
     const int ls = sl ^ (((r >> 1) & 1) << 2);
     const bool ok = n_blk + ls * 8 < a.dy_cvalid;
-    yoff[q] = (py * a.W + px) * a.dy_cs + ls * 8;
+    yoff[q] = (unsigned)((py * a.W + px) * a.dy_cs + ls * 8) * 2u;
     yhy[q] = ok ? py : (1 << 24);
     yhx[q] = px;
   }
-  const __bf16* zpage = reinterpret_cast<const __bf16*>(hpri_wg_zero_page) + (lane & 3) * 8;
 
 #define ISSUE_UNIT(u_, buf_)                                                                                           \
   {                                                                                                                    \
@@ -103,26 +103,22 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_bf16v2_kernel(WgV2Args a) {
     const int sy_ = q_ % a.units_y;                                                                                    \
     const int img_ = q_ / a.units_y;                                                                                   \
     const int y0_ = sy_ * 4, x0_ = sx_ * 32;                                                                           \
-    const __bf16* xb_ = a.xp + ((size_t)(img_ * a.H + y0_) * a.W + x0_) * a.x_cs + a.x_coff + c_blk;                   \
-    const __bf16* yb_ = a.dyp + ((size_t)(img_ * a.H + y0_) * a.W + x0_) * a.dy_cs + a.dy_coff + n_blk;                \
+    const hpri_rsrc_t rx_ = HPRI_MAKE_RSRC(a.xp + ((long long)(img_ * a.H + y0_ - 1) * a.W + x0_ - 1) * a.x_cs + a.x_coff + c_blk, 0x7FFFFF00); \
+    const hpri_rsrc_t ry_ = HPRI_MAKE_RSRC(a.dyp + ((long long)(img_ * a.H + y0_) * a.W + x0_) * a.dy_cs + a.dy_coff + n_blk, 0x7FFFFF00);     \
     unsigned char* lx_ = smem + (buf_) * WG_UB;                                                                        \
     _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                                    \
       const int i_ = wave + 8 * q;                                                                                     \
       if (i_ < WG_XI) {                                                                                                \
         const int iy_ = y0_ - 1 + xhy[q], ix_ = x0_ - 1 + xhx[q];                                                      \
         const bool in_ = (unsigned)iy_ < (unsigned)a.H && (unsigned)ix_ < (unsigned)a.W;                               \
-        const __bf16* src_ = in_ ? xb_ + (ptrdiff_t)xoff[q] : zpage;                                                   \
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_,                          \
-                                         (__attribute__((address_space(3))) void*)(lx_ + i_ * 1024), 16, 0, 0);        \
+        HPRI_LDS_DMA16(rx_, lx_ + i_ * 1024, in_ ? xoff[q] : HPRI_DMA_OOB, 0);                                         \
       }                                                                                                                \
     }                                                                                                                  \
     _Pragma("unroll") for (int q = 0; q < 2; ++q) {                                                                    \
       const int i_ = wave + 8 * q;                                                                                     \
       const int iy_ = y0_ + yhy[q], ix_ = x0_ + yhx[q];                                                                \
       const bool in_ = iy_ < a.H && ix_ < a.W;                                                                         \
-      const __bf16* src_ = in_ ? yb_ + (ptrdiff_t)yoff[q] : zpage;                                                     \
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_,                            \
-                                       (__attribute__((address_space(3))) void*)(lx_ + WG_XB + i_ * 1024), 16, 0, 0);  \
+      HPRI_LDS_DMA16(ry_, lx_ + WG_XB + i_ * 1024, in_ ? yoff[q] : HPRI_DMA_OOB, 0);                                   \
     }                                                                                                                  \
   }
 
