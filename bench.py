@@ -67,7 +67,7 @@ def pmc_traffic(tag):
     elif tag.startswith("conv_wgrad<3"):
         key = "conv_wgrad_kernel<3, 1, 1, 0>"
     elif tag.startswith("conv_winograd_f32"):
-        key = "conv_wino_kernel"
+        key = "conv_wino4_kernel" if any("conv_wino4_kernel" in k for k in kern) else "conv_wino_kernel"
     elif tag.startswith("conv_wgrad_winograd_f32"):
         key = "conv_wino_wgrad_kernel"
     else:
