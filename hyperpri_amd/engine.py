@@ -296,6 +296,8 @@ class Tape:
             node(self)
             if sink is not None and len(self.sunk) > seen:
                 # every parameter belongs to exactly one op, so its gradient is final once that op's node has run
+                # (with a sink installed every kernel of the backward pass runs on ONE stream -- see SIDE_STREAM -- so the
+                # bucket's all-reduce, which orders itself behind the current stream, sees all of its gradients)
                 for p in list(self.sunk.values())[seen:]:
                     sink.ready(p)
                 seen = len(self.sunk)
@@ -370,7 +372,12 @@ def event_log_summary():
 # ---- side stream: weight gradients run beside the data gradient of the same layer -------------------------
 # The two GEMMs of a conv's backward are independent; issuing wgrad on a second HIP stream lets its workgroups
 # fill the CUs the dgrad kernel's tail leaves idle (and vice versa).  Joined before gradients leave the node.
-SIDE_STREAM = False   # measured on MI355X: no gain for this workload (58.3 vs 57.8 ms/step); kept as an opt-in
+# Weight gradients on a second stream: a layer's weight gradient and its data gradient only share inputs, and every launch
+# ends in a partial round of workgroups (4.5-18 rounds per launch at one or two workgroups per CU): the other stream's
+# workgroups fill those tails.  34.35 -> 33.25 ms/step (+3.3 %), bit-identical results.  HPRI_SIDE_STREAM=0 disables it.
+# Not used while a gradient sink (ddp.GradSync) is installed: there the buckets' all-reduces order themselves behind the
+# stream that calls sink.ready(), and with them in flight the second stream measured -2 % (1 rank over RCCL).
+SIDE_STREAM = os.environ.get("HPRI_SIDE_STREAM", "1") != "0"
 _side_streams: Dict[int, "torch.cuda.Stream"] = {}
 
 
@@ -625,14 +632,17 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
                 _lib.call("hpri_col_sum", dyr.ptr, dyr.cs, dyr.coff, _p(db), acc_b, _p(ws), ws.numel(), x.P, cout, _stream())
         if not weight.requires_grad:          # frozen (feature_extraction, models.py:17-21): no weight gradient at all
             pass
-        elif SIDE_STREAM and need_dx and _EVENT_LOG is None:
+        elif SIDE_STREAM and need_dx and _EVENT_LOG is None and _GRAD_SINK is None:
             dw, acc_w = tp.param_slot(weight)
             main, side = torch.cuda.current_stream(dev), _side(dev)
             side.wait_stream(main)                      # dyr (and everything before it) is ready
             with torch.cuda.stream(side):
                 _wgrad(x, dyr, dw, acc_w, cin, cout, ks, bf16=lowp, split=split)
-            for t in (x.buf, dyr.buf, dw):               # keep the caching allocator from recycling them early
-                t.record_stream(side)
+            for a_ in (x, dyr):                          # keep the caching allocator from recycling them early
+                a_.buf.record_stream(side)
+                if a_.pl is not None:
+                    a_.pl.buf.record_stream(side)
+            dw.record_stream(side)
             tp.used_side = True
         else:
             dw, acc_w = tp.param_slot(weight)
