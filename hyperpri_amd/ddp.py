@@ -115,6 +115,11 @@ class GradSync:
         b, i = self._where[id(p)]
         self._landed(b, i)
 
+    def completes_bucket(self, p: torch.Tensor) -> bool:
+        """Will ``ready(p)`` issue a bucket's all-reduce?  (The engine joins its second stream first in that case.)"""
+        b, i = self._where[id(p)]
+        return b.pending == 1 and i not in b.landed and self.collective and not self._accumulating
+
     # ---- plain autograd path ----------------------------------------------------------------------------------------
     def _on_grad(self, p: torch.Tensor) -> None:
         if id(p) in self._direct:

@@ -296,9 +296,11 @@ class Tape:
             node(self)
             if sink is not None and len(self.sunk) > seen:
                 # every parameter belongs to exactly one op, so its gradient is final once that op's node has run
-                # (with a sink installed every kernel of the backward pass runs on ONE stream -- see SIDE_STREAM -- so the
-                # bucket's all-reduce, which orders itself behind the current stream, sees all of its gradients)
                 for p in list(self.sunk.values())[seen:]:
+                    # a bucket's all-reduce orders itself behind the CURRENT stream: before the hand-over that completes a
+                    # bucket, the main stream waits for the weight gradients still running on the second one
+                    if self.used_side and getattr(sink, "completes_bucket", lambda q: True)(p):
+                        join_side(p.device)
                     sink.ready(p)
                 seen = len(self.sunk)
         self.nodes.clear()
@@ -378,6 +380,7 @@ def event_log_summary():
 # Not used while a gradient sink (ddp.GradSync) is installed: there the buckets' all-reduces order themselves behind the
 # stream that calls sink.ready(), and with them in flight the second stream measured -2 % (1 rank over RCCL).
 SIDE_STREAM = os.environ.get("HPRI_SIDE_STREAM", "1") != "0"
+SIDE_STREAM_WITH_SINK = os.environ.get("HPRI_SIDE_STREAM_SINK", "0") == "1"
 _side_streams: Dict[int, "torch.cuda.Stream"] = {}
 
 
@@ -632,7 +635,7 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
                 _lib.call("hpri_col_sum", dyr.ptr, dyr.cs, dyr.coff, _p(db), acc_b, _p(ws), ws.numel(), x.P, cout, _stream())
         if not weight.requires_grad:          # frozen (feature_extraction, models.py:17-21): no weight gradient at all
             pass
-        elif SIDE_STREAM and need_dx and _EVENT_LOG is None and _GRAD_SINK is None:
+        elif SIDE_STREAM and need_dx and _EVENT_LOG is None and (_GRAD_SINK is None or SIDE_STREAM_WITH_SINK):
             dw, acc_w = tp.param_slot(weight)
             main, side = torch.cuda.current_stream(dev), _side(dev)
             side.wait_stream(main)                      # dyr (and everything before it) is ready
