@@ -873,8 +873,19 @@ def _upsample_into(tape: Tape, x1: Act, dst: Act, weight: Optional[torch.Tensor]
         bprec = precision or DEFAULT_PRECISION
         if weight.requires_grad:
             dw, acc_w = tp.param_slot(weight)
-            _wgrad(x1, gu, dw, acc_w, cin, 4 * cup, 1, bmode=A_S2D, dst_mode=1, H2=H2, W2=W2, py0=py0, px0=px0, cup=cup,
-                   bf16=bprec in LOWP, split=_SPLIT.get(bprec, 0))
+            if SIDE_STREAM and need_dx1 and _EVENT_LOG is None and (_GRAD_SINK is None or SIDE_STREAM_WITH_SINK):
+                # the weight gradient and the data gradient of the transposed convolution only share inputs: second stream
+                main, side = torch.cuda.current_stream(dev), _side(dev)
+                side.wait_stream(main)                  # gu (pad ring dropped) and everything before it is ready
+                with torch.cuda.stream(side):
+                    _wgrad(x1, gu, dw, acc_w, cin, 4 * cup, 1, bmode=A_S2D, dst_mode=1, H2=H2, W2=W2, py0=py0, px0=px0, cup=cup,
+                           bf16=bprec in LOWP, split=_SPLIT.get(bprec, 0))
+                for t in (x1.buf, gu.buf, dw):
+                    t.record_stream(side)
+                tp.used_side = True
+            else:
+                _wgrad(x1, gu, dw, acc_w, cin, 4 * cup, 1, bmode=A_S2D, dst_mode=1, H2=H2, W2=W2, py0=py0, px0=px0, cup=cup,
+                       bf16=bprec in LOWP, split=_SPLIT.get(bprec, 0))
         if need_dx1:
             gx, acc = tp.grad_slot(x1)
             if bprec in LOWP:

@@ -48,6 +48,8 @@ def main():
                    "kernels": out}, fh, indent=1)
     for f in glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True):
         shutil.copy(f, os.path.join(root, "profiles", f"{tag}_bench_kernel_stats.csv"))
+    for f in glob.glob(os.path.join(src, "stats1", "**", "*kernel_stats.csv"), recursive=True):
+        shutil.copy(f, os.path.join(root, "profiles", f"{tag}_bench_kernel_stats_one_stream.csv"))
     for f in ("bench.json", "bench_prof.json"):
         p = os.path.join(src, f)
         if os.path.exists(p):
