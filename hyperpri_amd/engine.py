@@ -300,8 +300,15 @@ class Tape:
                     # a bucket's all-reduce orders itself behind the CURRENT stream: before the hand-over that completes a
                     # bucket, the main stream waits for the weight gradients still running on the second one
                     if self.used_side and getattr(sink, "completes_bucket", lambda q: True)(p):
-                        join_side(p.device)
-                    sink.ready(p)
+                        # neither compute stream is held up: a third stream waits for both and hands the bucket over
+                        dev = p.device
+                        iss = _issue_stream(dev)
+                        iss.wait_stream(torch.cuda.current_stream(dev))
+                        iss.wait_stream(_side(dev))
+                        with torch.cuda.stream(iss):
+                            sink.ready(p)
+                    else:
+                        sink.ready(p)
                 seen = len(self.sunk)
         self.nodes.clear()
         self.keep.clear()
@@ -389,6 +396,17 @@ def _side(device) -> "torch.cuda.Stream":
     st = _side_streams.get(idx)
     if st is None:
         st = _side_streams[idx] = torch.cuda.Stream(device=device)
+    return st
+
+
+_issue_streams: Dict[int, "torch.cuda.Stream"] = {}
+
+
+def _issue_stream(device) -> "torch.cuda.Stream":
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    st = _issue_streams.get(idx)
+    if st is None:
+        st = _issue_streams[idx] = torch.cuda.Stream(device=device)
     return st
 
 
