@@ -202,6 +202,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(Wino4Args a) {
         P[c] = d1 + sigma * d2;
       }
       const f32x4 v[4] = {P[0] - P[2], P[1] + P[2], P[2] - P[1], P[1] - P[3]};
+#ifndef WINO4_NO_SETPRIO
+      __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -209,6 +212,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(Wino4Args a) {
 #pragma unroll
           for (int nt = 0; nt < 2; ++nt)
             acc[b][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[b][j], bfr[b][nt][j], acc[b][nt], 0, 0, 0);
+#ifndef WINO4_NO_SETPRIO
+      __builtin_amdgcn_s_setprio(0);
+#endif
     }
   }
 #undef WAIT_VM
