@@ -213,6 +213,9 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.dry_launch:
         return dry_launch_rank()
+    # main, weight-gradient, RCCL and hand-over streams each want their own hardware queue (engine.SIDE_STREAM_WITH_SINK);
+    # the runtime reads this when it initialises, i.e. at the first HIP call below
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_pg = world > 1 or args.force_sync

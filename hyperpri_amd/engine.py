@@ -384,10 +384,28 @@ def event_log_summary():
 # Weight gradients on a second stream: a layer's weight gradient and its data gradient only share inputs, and every launch
 # ends in a partial round of workgroups (4.5-18 rounds per launch at one or two workgroups per CU): the other stream's
 # workgroups fill those tails.  34.35 -> 33.25 ms/step (+3.3 %), bit-identical results.  HPRI_SIDE_STREAM=0 disables it.
-# Not used while a gradient sink (ddp.GradSync) is installed: there the buckets' all-reduces order themselves behind the
-# stream that calls sink.ready(), and with them in flight the second stream measured -2 % (1 rank over RCCL).
+# Under a gradient sink (ddp.GradSync) it needs 8 hardware queues, see SIDE_STREAM_WITH_SINK below.
 SIDE_STREAM = os.environ.get("HPRI_SIDE_STREAM", "1") != "0"
-SIDE_STREAM_WITH_SINK = os.environ.get("HPRI_SIDE_STREAM_SINK", "0") == "1"
+# With a gradient sink installed three or four streams are live during backward (main, weight gradients, RCCL, bucket
+# hand-over).  The HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), and streams that share a
+# queue serialise: with 4 queues the second stream measured -1.6 % under a sink (one rank over RCCL), with 8 it keeps its
+# +3.3 % (57.4 vs 60.4 cubes/s).  The variable is read when the runtime initialises, so it can only be raised before the
+# first HIP call: done here if nothing has touched the GPU yet; otherwise the sink path stays on one stream.
+def _hw_queues_ok() -> bool:
+    try:
+        have = int(os.environ.get("GPU_MAX_HW_QUEUES", "0"))
+    except ValueError:
+        have = 0
+    if have >= 8:
+        return True                      # set by the caller before the process started its HIP runtime (bench.py does)
+    if have == 0 and not torch.cuda.is_initialized():
+        os.environ["GPU_MAX_HW_QUEUES"] = "8"
+        return True
+    return False
+
+
+_sink_env = os.environ.get("HPRI_SIDE_STREAM_SINK")
+SIDE_STREAM_WITH_SINK = (_sink_env == "1") if _sink_env is not None else _hw_queues_ok()
 _side_streams: Dict[int, "torch.cuda.Stream"] = {}
 
 
