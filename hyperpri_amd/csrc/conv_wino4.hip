@@ -16,7 +16,7 @@
 //              LDS (the ds_write_b32 rate, 64 B/clk/CU, is what the exchange costs)
 //   DMA        both operands by buffer_load ... lds: 32-bit per-lane offsets against an SGPR descriptor (no 64-bit address
 //              arithmetic per piece), out-of-image halo pixels zero-filled by the descriptor's range check
-// Halo layout, swizzle, statistics and argument contract as conv_wino.hip.
+// Statistics and argument contract as conv_wino.hip; the halo layout is de-interleaved by column parity (below).
 #include "common.h"
 
 struct Wino4Args {
@@ -49,6 +49,11 @@ struct Wino4Args {
 #define W4_AI 23                           // halo DMA instructions (8 slots each; the last one half used)
 #define W4_A_BYTES (W4_AI * 1024)
 #define W4_B_WAVE 8192                     // bytes per wave per stage: 4 frequencies x [64 n][8 k] fp32
+// Halo slots: a row holds its even columns first, then the odd ones (a tile's columns 2 tx + c are then CONSECUTIVE slots over
+// tx), and the eight 16-byte quads of a slot are XOR-swizzled with ((slot >> 1) + row) & 7: brute-forced conflict-free for every
+// ds_read_b128 lane group, input row / column and quad (row-major slots with (slot >> 1) & 7 measured 0.57 conflict cycles per
+// LDS cycle: up to 4-way)
+#define W4_SWZ(slot_, hy_) ((((slot_) >> 1) + (hy_)) & 7)
 
 __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(Wino4Args a) {
   __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * W4_A_BYTES + 4 * W4_B_WAVE];
@@ -84,10 +89,11 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(Wino4Args a) {
     const int slot = (q * 4 + wave) * 8 + (lane >> 3);
     unsigned off = OOB;
     if (slot < W4_SLOTS) {
-      const int hy = slot / W4_HW, hx = slot - hy * W4_HW;
+      const int hy = slot / W4_HW, rem = slot - hy * W4_HW;
+      const int hx = rem < W4_HW / 2 ? 2 * rem : 2 * (rem - W4_HW / 2) + 1;      // even columns first, then the odd ones
       const int iy = Y0 + hy - 1, ix = X0 + hx - 1;
       if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
-        off = (unsigned)((iy * a.W + ix) * a.x_cs + ((((lane & 7) ^ ((slot >> 1) & 7))) << 2)) * 4u;
+        off = (unsigned)((iy * a.W + ix) * a.x_cs + ((((lane & 7) ^ W4_SWZ(slot, hy))) << 2)) * 4u;
     }
     aoff[q] = off;
   }
@@ -102,7 +108,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(Wino4Args a) {
         unsigned vo_ = aoff[q];                                                                                       \
         if (tail_) {                                                                                                  \
           const int slot_ = inst_ * 8 + (lane >> 3);                                                                  \
-          const int lquad_ = lq ^ ((slot_ >> 1) & 7);                                                                 \
+          const int lquad_ = lq ^ W4_SWZ(slot_, slot_ / W4_HW);                                                       \
           if (((chunk_) * 32 + lquad_ * 4) >= a.Cin_pad) vo_ = OOB;                                                   \
         }                                                                                                             \
         HPRI_LDS_DMA16(rs_a, la_ + inst_ * 1024, vo_, (chunk_) * 128);                                               \
@@ -125,14 +131,15 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(Wino4Args a) {
 #define B_PIECE(p_)                                                                                                   \
   HPRI_LDS_DMA16(rs_b, bw + (p_) * 1024, goff0, sb_ + ((p_) >> 1) * gstep_b + ((p_) & 1) * 1024);
 
-  // lane's tile: (ty, tx) = (li>>3, li&7); halo slot of its input pixel (r, c): (2 ty + r) * 18 + 2 tx + c
-  const int hpb = (2 * (li >> 3)) * W4_HW + 2 * (li & 7);
+  // lane's tile: (ty, tx) = (li>>3, li&7); its input pixel (r, c) is halo pixel (hy, hx) = (2 ty + r, 2 tx + c), stored in slot
+  // hy * 18 + (hx & 1) * 9 + (hx >> 1)
   int pre[8];                                       // XOR-form halo addresses: [2 c + (row r1 | r2)]
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
-    const int h1 = hpb + r1 * W4_HW + c, h2 = hpb + r2 * W4_HW + c;
-    pre[2 * c + 0] = h1 * 128 + (((h1 >> 1) & 7) << 4);
-    pre[2 * c + 1] = h2 * 128 + (((h2 >> 1) & 7) << 4);
+    const int hx = 2 * (li & 7) + c, hy1 = 2 * (li >> 3) + r1, hy2 = 2 * (li >> 3) + r2;
+    const int h1 = hy1 * W4_HW + (hx & 1) * (W4_HW / 2) + (hx >> 1), h2 = hy2 * W4_HW + (hx & 1) * (W4_HW / 2) + (hx >> 1);
+    pre[2 * c + 0] = h1 * 128 + (W4_SWZ(h1, hy1) << 4);
+    pre[2 * c + 1] = h2 * 128 + (W4_SWZ(h2, hy2) << 4);
   }
   const int boff = li * 32 + ((lh ^ ((li >> 3) & 1)) << 4);
 
