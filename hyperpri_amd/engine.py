@@ -147,6 +147,8 @@ WINO_MIN_BLOCKS = 256        # workgroups (16x16-pixel tiles x 64-channel blocks
 
 def _wino_ok(x: "Act", ncols: int) -> bool:
     th = 8 if WINO4 else 16                  # tile height of the kernel in use (conv_wino4.hip: 16 x 8 pixels)
+    if x.H * x.W * x.cs * 4 >= (1 << 32) - 65536:      # 32-bit DMA offsets per image (conv_wino4 / wgrad): direct kernels beyond that
+        return False
     return WINOGRAD and x.N * ((x.H + th - 1) // th) * ((x.W + 15) // 16) * (_rup(ncols, 64) // 64) >= WINO_MIN_BLOCKS
 
 
@@ -780,7 +782,8 @@ def _wgrad(x: Act, dy: Act, dw: torch.Tensor, accumulate: int, cin: int, cout: i
     tag = f"conv_wgrad{('_bf16', '_bf16x3', '_bf16x6')[split] if bf16 else ''}<{ks},{'s2d' if bmode == A_S2D else 'direct'}>"
     if SHAPE_TAGS:
         tag += f" N{N} {H}x{W} C{cin_pad} N{cout}"
-    if (not bf16) and ks == 3 and bmode == A_DIRECT and dst_mode == 0 and WINOGRAD and WINO_WGRAD and N * H * W >= 4096:
+    if ((not bf16) and ks == 3 and bmode == A_DIRECT and dst_mode == 0 and WINOGRAD and WINO_WGRAD and N * H * W >= 4096
+            and 5 * W * max(x.cs, dy.cs) * 4 < (1 << 31)):
         # Winograd weight gradient (conv_wino.hip): 16 instead of 36 multiplies per 2x2 pixels and channel pair
         sp = ctypes.c_int(); wcr = ctypes.c_int(); wnr = ctypes.c_int()
         _lib.call("hpri_wino_wgrad_plan", N, H, W, cin_pad, cout_pad, ctypes.byref(sp), ctypes.byref(wcr), ctypes.byref(wnr))
