@@ -558,7 +558,8 @@ extern "C" int hpri_conv_bf16v2_dbg(const void* xp, long long x_plane, int x_cs,
   HPRI_REQUIRE(Cout_pad % 64 == 0 && Cout <= Cout_pad && Cout > 0, "conv_bf16v2: Cout_pad must be a multiple of 64 >= Cout");
   HPRI_REQUIRE(x_cs % 8 == 0 && x_coff % 8 == 0 && x_coff + Cin_pad <= x_cs, "conv_bf16v2: plane channel stride/offset must be multiples of 8 and hold Cin_pad channels");
   HPRI_REQUIRE(((uintptr_t)xp & 15) == 0 && ((uintptr_t)wp & 15) == 0 && (x_plane % 8) == 0, "conv_bf16v2: pointers must be 16-byte aligned");
-  HPRI_REQUIRE((long long)H * W * x_cs < (1ll << 31), "conv_bf16v2: one image of the input view exceeds 2^31 elements");
+  HPRI_REQUIRE((long long)H * W * x_cs * 2 < 0x7FFFFF00ll, "conv_bf16v2: one image of the input planes exceeds 2 GiB (32-bit DMA offsets)");
+  HPRI_REQUIRE((long long)(Cin_pad / 32) * 9 * Cout_pad * 64 < 0x7FFFFF00ll, "conv_bf16v2: packed weights exceed 2 GiB");
   HPRI_REQUIRE(split == 0, "conv_bf16v2: only plain bf16 planes (split 0) are built in this version");
   ConvV2Args a;
   a.xp = reinterpret_cast<const __bf16*>(xp); a.x_plane = x_plane; a.x_cs = x_cs; a.x_coff = x_coff;
