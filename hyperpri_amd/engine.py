@@ -192,6 +192,11 @@ PLANE_PRODUCERS = True       # producers (BN-apply, BN-backward, ...) write the 
 PLANE_CONVERSIONS = 0        # generic fp32 -> planes passes launched (fused producers do not count)
 
 
+def _planes_fit(x: Act, channels: int) -> bool:
+    """One image of bf16 planes of ``channels`` channels stays below the 2 GiB the plane kernels' DMA descriptors cover."""
+    return x.H * x.W * _rup(channels, 32) * 2 < 0x7FFFFF00
+
+
 def new_planes(x: Act, npl: int = 1) -> Planes:
     """Uninitialised plane storage for ``x`` (the producing kernel fills it, pad channels included)."""
     cs16 = _rup(x.C, 32)
@@ -577,7 +582,8 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
         return _conv_folded_eval(x, weight, bias, bn, ks, cin, cout, relu, prec)
     lowp = prec in LOWP
     split = _SPLIT.get(prec, 0)
-    v2 = PLANE_CONV and prec == "bf16" and ks == 3        # operands by LDS-DMA from bf16 planes (conv_bf16v2.hip)
+    # operands by LDS-DMA from bf16 planes (conv_bf16v2.hip); its DMA offsets are 32-bit per image
+    v2 = PLANE_CONV and prec == "bf16" and ks == 3 and _planes_fit(x, max(cin, cout))
     wino = prec == "fp32" and ks == 3 and groups == 1 and _wino_ok(x, cout)
     wino_d = prec == "fp32" and ks == 3 and groups == 1 and _wino_ok(x, cin)     # the data gradient has Cin columns
     if wino:
@@ -757,7 +763,7 @@ def _conv_folded_eval(x: Act, weight: torch.Tensor, bias: Optional[torch.Tensor]
     y = Act.new(x.N, x.H, x.W, cout, dev)
     if wino:
         _conv_launch_wino(x, wp, fbias, y, None, cin, cout, cout_pad, y.cw, accumulate=2 if relu else 0)
-    elif lowp and PLANE_CONV and prec == "bf16" and ks == 3:
+    elif lowp and PLANE_CONV and prec == "bf16" and ks == 3 and _planes_fit(x, max(cin, cout)):
         _conv_launch_v2(x, wp, fbias, y, None, cin, cout, cout_pad, y.cw, accumulate=2 if relu else 0)
     elif lowp:
         _conv_launch_bf16(x, wp, fbias, y, None, x.N, x.H, x.W, x.cw, cout, cout_pad, y.cw, ks, accumulate=2 if relu else 0,
