@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Is the bf16 plane convolution limited by the chip's power management?  The same launch (238->64, 608x968, batch 2) on
+all-zero operands (no switching activity in the matrix pipe, LDS and DMA data paths) and on random operands: the instruction
+stream and the memory traffic are identical, only the data -- and with it the power draw and the clock the chip holds -- differ."""
+import ctypes
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from hyperpri_amd import _lib  # noqa: E402
+
+N, H, W, CIN, COUT = 2, 608, 968, 238, 64
+lib = _lib.load()
+dev = torch.device("cuda", 0)
+st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+P = lambda t: ctypes.c_void_p(t.data_ptr())
+cs16, cout_pad = 256, 64
+flops = 2.0 * N * H * W * CIN * COUT * 9
+out = {}
+for name in ("zeros", "random", "zeros", "random"):
+    planes = torch.zeros(N * H * W * cs16, dtype=torch.bfloat16, device=dev)
+    wp = torch.zeros((cs16 // 32) * 9 * cout_pad * 32, dtype=torch.bfloat16, device=dev)
+    if name == "random":
+        planes.copy_(torch.randn(N * H * W * cs16, device=dev).to(torch.bfloat16))
+        wp.copy_((torch.randn(wp.numel(), device=dev) * 0.05).to(torch.bfloat16))
+    b = torch.zeros(COUT, device=dev)
+    y = torch.empty(N * H * W * COUT, device=dev)
+    k, tl, wsf = ctypes.c_int(), ctypes.c_int(), ctypes.c_size_t()
+    lib.hpri_conv_bf16v2_plan(N, H, W, cs16, cout_pad, ctypes.byref(k), ctypes.byref(tl), ctypes.byref(wsf))
+    stats = torch.empty(tl.value * cout_pad * 4, device=dev)
+    ws = torch.empty(max(wsf.value, 4), device=dev)
+    call = lambda: lib.hpri_conv_bf16v2(P(planes), 0, cs16, 0, P(wp), P(b), P(y), COUT, 0, P(stats), N, H, W, cs16, COUT, cout_pad, COUT, 0, 0,
+                                        P(ws), ws.numel(), st)
+    for _ in range(20):
+        assert call() == 0
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(100):
+        call()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 100
+    out.setdefault(name, []).append(round(flops / ms / 1e9, 1))
+    print(f"{name:7s}: {ms:.4f} ms = {flops / ms / 1e9:.0f} TF", flush=True)
+print(json.dumps(out))
