@@ -46,3 +46,34 @@ for name in ("zeros", "random", "zeros", "random"):
     out.setdefault(name, []).append(round(flops / ms / 1e9, 1))
     print(f"{name:7s}: {ms:.4f} ms = {flops / ms / 1e9:.0f} TF", flush=True)
 print(json.dumps(out))
+
+# ---- the same question for the fp32 Winograd kernel (conv_wino4.hip) on the same layer ----
+cs = 240
+executed = 2.0 * N * ((H + 1) // 2) * ((W + 1) // 2) * 16 * CIN * COUT
+outw = {}
+for name in ("zeros", "random", "zeros", "random"):
+    x = torch.zeros(N * H * W, cs, device=dev)
+    w = torch.zeros(COUT, CIN, 3, 3, device=dev)
+    if name == "random":
+        x[:, :CIN] = torch.randn(N * H * W, CIN, device=dev)
+        w.copy_(torch.randn(COUT, CIN, 3, 3, device=dev) * 0.05)
+    up = torch.empty(lib.hpri_wino_packed_floats(CIN, cout_pad), device=dev)
+    assert lib.hpri_wino4_pack(P(w), P(up), ctypes.c_void_p(0), 0, CIN, COUT, cout_pad, CIN, st) == 0
+    tlw = ctypes.c_int()
+    lib.hpri_conv_wino4_plan(N, H, W, ctypes.byref(tlw))
+    statsw = torch.zeros(tlw.value * cout_pad * 4, device=dev)
+    b = torch.zeros(COUT, device=dev)
+    y = torch.empty(N * H * W * COUT, device=dev)
+    callw = lambda: lib.hpri_conv_wino4(P(x), cs, 0, P(up), P(b), P(y), COUT, 0, P(statsw), N, H, W, cs, COUT, cout_pad, COUT, 0, st)
+    for _ in range(10):
+        assert callw() == 0
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(40):
+        callw()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 40
+    outw.setdefault(name, []).append(round(executed / ms / 1e9, 1))
+    print(f"fp32 Winograd {name:7s}: {ms:.4f} ms = {executed / ms / 1e9:.1f} executed TF", flush=True)
+print(json.dumps({"fp32_winograd_executed_tf": outw}))
