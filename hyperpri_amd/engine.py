@@ -62,11 +62,12 @@ class Act:
 
     Invariant: channels [C, cw) (cw = C rounded up to 8) exist inside the stride and hold zeros, so
     consumers may run their K loop over ``cw`` channels."""
-    __slots__ = ("buf", "N", "H", "W", "C", "cs", "coff", "pl")
+    __slots__ = ("buf", "N", "H", "W", "C", "cs", "coff", "pl", "parent")
 
     def __init__(self, buf: torch.Tensor, N: int, H: int, W: int, C: int, cs: int, coff: int = 0):
         self.buf, self.N, self.H, self.W, self.C, self.cs, self.coff = buf, N, H, W, C, cs, coff
         self.pl: Optional["Planes"] = None      # bf16 plane copy of this activation (bf16 precision modes), see planes_of
+        self.parent: Optional["Act"] = None     # wider buffer this Act is the leading channel slice of (new_with_room)
 
     @property
     def cw(self) -> int:
@@ -84,6 +85,18 @@ class Act:
     def new(N: int, H: int, W: int, C: int, device) -> "Act":
         cs = _rup(C, 8)
         return Act(torch.empty(N * H * W * cs, dtype=torch.float32, device=device), N, H, W, C, cs, 0)
+
+    @staticmethod
+    def new_with_room(N: int, H: int, W: int, C: int, room: int, device) -> "Act":
+        """An Act that is channels [0, C) of a fresh [N,H,W,C+room] buffer: a skip tensor written where the decoder's
+        concat will need it (model_parts.py:87), so that ``up_concat`` has nothing to copy.  C % 8 == 0 keeps the
+        zero-pad invariant trivially true for the slice."""
+        if room <= 0 or C % 8:
+            return Act.new(N, H, W, C, device)
+        parent = Act.new(N, H, W, C + room, device)
+        a = parent.slice(0, C)
+        a.parent = parent
+        return a
 
     def slice(self, c0: int, C: int) -> "Act":
         if c0 % 4:
@@ -564,7 +577,7 @@ def _conv_launch(x: Act, wp: torch.Tensor, bias: Optional[torch.Tensor], y: Act,
 # --------------------------------------------------------------------------------------------------
 def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.Tensor], bn: Optional[BNRef],
                  train: bool, ks: int, groups: int = 1, relu: bool = True, need_dx: bool = True,
-                 precision: Optional[str] = None) -> Act:
+                 precision: Optional[str] = None, room: int = 0) -> Act:
     """Conv2d(k=ks, pad=ks//2) -> BatchNorm -> ReLU  (model_parts.py:22-27; models.py:169-180 with the
     Conv3d weight (F,1,D,3,3) read as (F,D,3,3); models.py:108-114 for Linear -> BatchNorm1d -> ReLU with
     ks = 1 and ``groups`` = images, each image being its own BN batch, models.py:132)."""
@@ -579,7 +592,7 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
     if prec not in PRECISIONS:
         raise RuntimeError(f"hyperpri_amd: unknown precision {prec!r}; choose from {PRECISIONS}")
     if bn is not None and not train and not tape.record and FOLD_EVAL_BN:
-        return _conv_folded_eval(x, weight, bias, bn, ks, cin, cout, relu, prec)
+        return _conv_folded_eval(x, weight, bias, bn, ks, cin, cout, relu, prec, room)
     lowp = prec in LOWP
     split = _SPLIT.get(prec, 0)
     # operands by LDS-DMA from bf16 planes (conv_bf16v2.hip); its DMA offsets are 32-bit per image
@@ -640,7 +653,7 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
         else:
             _lib.call("hpri_bn_eval_prepare", _p(bn.running_mean), _p(bn.running_var), _p(bn.weight), _p(bn.bias),
                       bn.eps, cout, _p(mean), _p(invstd), _p(scale), _p(shift), _stream())
-        y = Act.new(x.N, x.H, x.W, cout, dev)
+        y = Act.new_with_room(x.N, x.H, x.W, cout, room, dev)    # room > 0: a skip tensor, written where its concat needs it
         ppg = (x.P // G)
         # bf16 plane mode: the normalise pass also writes y as bf16 planes -- what the next 3x3 convolution (and the
         # weight gradient) stage by DMA -- so no conversion pass has to read y again
@@ -720,7 +733,7 @@ FOLD_LAUNCHES = 0     # folded conv+BN+ReLU stages executed (tests assert that t
 
 
 def _conv_folded_eval(x: Act, weight: torch.Tensor, bias: Optional[torch.Tensor], bn: BNRef, ks: int, cin: int, cout: int,
-                      relu: bool, prec: str = "fp32") -> Act:
+                      relu: bool, prec: str = "fp32", room: int = 0) -> Act:
     """Eval-mode Conv -> BatchNorm -> ReLU (running statistics) without the normalise pass: w' = w*gamma/sqrt(var+eps),
     b' = (b-mean)*gamma/sqrt(var+eps)+beta, ReLU in the conv epilogue.  Used when nothing is recorded for backward
     (torch.no_grad / inference_mode: PLTrainer.py:530,626)."""
@@ -760,7 +773,7 @@ def _conv_folded_eval(x: Act, weight: torch.Tensor, bias: Optional[torch.Tensor]
                 None if bias is None else ver(bias))
     wp, fold = _cached_pack(weight, ("fold", prec, ks, _wino_sfx() if wino else False), build, extra=bn_state)
     fbias = fold[cout:]
-    y = Act.new(x.N, x.H, x.W, cout, dev)
+    y = Act.new_with_room(x.N, x.H, x.W, cout, room, dev)
     if wino:
         _conv_launch_wino(x, wp, fbias, y, None, cin, cout, cout_pad, y.cw, accumulate=2 if relu else 0)
     elif lowp and PLANE_CONV and prec == "bf16" and ks == 3 and _planes_fit(x, max(cin, cout)):
@@ -956,8 +969,12 @@ def up_concat(tape: Tape, x1: Act, skip: Act, weight: Optional[torch.Tensor], bi
         raise RuntimeError("hyperpri_amd: Up: batch mismatch")
     if skip.C % 4:
         raise RuntimeError("hyperpri_amd: Up: channel counts must be multiples of 4")
-    cat = Act.new(skip.N, skip.H, skip.W, skip.C + cup, dev)
-    _lib.call("hpri_copy_slice", skip.ptr, skip.cs, skip.coff, cat.ptr, cat.cs, cat.coff, cat.P, skip.C, 0, _stream())
+    par = skip.parent
+    if par is not None and par.C == skip.C + cup and par.coff == skip.coff and par.buf is skip.buf:
+        cat = par                  # the skip was produced in place (Act.new_with_room): nothing to copy
+    else:
+        cat = Act.new(skip.N, skip.H, skip.W, skip.C + cup, dev)
+        _lib.call("hpri_copy_slice", skip.ptr, skip.cs, skip.coff, cat.ptr, cat.cs, cat.coff, cat.P, skip.C, 0, _stream())
     if cat.cw > cat.C:
         _lib.call("hpri_fill_pad", cat.ptr, cat.cs, cat.coff + cat.C, cat.N, cat.H, cat.W, cat.cw - cat.C, 0, 0, 0, 0, _stream())
     ups = cat.slice(skip.C, cup)

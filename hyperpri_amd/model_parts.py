@@ -14,13 +14,24 @@ import torch.nn.functional as F  # re-exported: the reference star-imports this 
 from . import engine as E
 from .autograd import run
 
-__all__ = ["DoubleConv", "Down", "Up", "OutConv", "torch", "nn", "F", "set_precision"]
+__all__ = ["DoubleConv", "Down", "Up", "OutConv", "torch", "nn", "F", "set_precision"]     # (skip_room, has_hooks: internal)
 
 
-def _double_conv_ops(tape, x, seq, train, need_dx=True, precision=None):
-    """(conv3x3 -> BN -> ReLU) x 2 on an Act; ``seq`` is the 6-entry nn.Sequential container."""
+def _double_conv_ops(tape, x, seq, train, need_dx=True, precision=None, room=0):
+    """(conv3x3 -> BN -> ReLU) x 2 on an Act; ``seq`` is the 6-entry nn.Sequential container.  ``room``: channels to keep
+    free behind the result (it is a skip tensor: the decoder's concat is then in place)."""
     h = E.conv_bn_relu(tape, x, seq[0].weight, seq[0].bias, E.BNRef(seq[1]), train, 3, need_dx=need_dx, precision=precision)
-    return E.conv_bn_relu(tape, h, seq[3].weight, seq[3].bias, E.BNRef(seq[4]), train, 3, precision=precision)
+    return E.conv_bn_relu(tape, h, seq[3].weight, seq[3].bias, E.BNRef(seq[4]), train, 3, precision=precision, room=room)
+
+
+def skip_room(up):
+    """Channels the decoder stage ``up`` (an ``Up`` module, or a bare ConvTranspose2d) will append behind its skip tensor:
+    known only for the transposed-convolution concat path; 0 = let ``up_concat`` copy."""
+    if isinstance(up, nn.ConvTranspose2d):
+        return up.out_channels
+    if isinstance(up, Up) and not up.bilinear and not up.use_attention:
+        return up.up.out_channels
+    return 0
 
 
 def has_hooks(module):
@@ -53,8 +64,8 @@ class DoubleConv(nn.Module):
                   nn.ReLU(inplace=True)]
         self.double_conv = nn.Sequential(*layers)
 
-    def _ops(self, tape, x, need_dx=True):
-        return _double_conv_ops(tape, x, self.double_conv, self.training, need_dx, getattr(self, "hpri_precision", None))
+    def _ops(self, tape, x, need_dx=True, room=0):
+        return _double_conv_ops(tape, x, self.double_conv, self.training, need_dx, getattr(self, "hpri_precision", None), room)
 
     def forward(self, x):
         return run(lambda tape, a, need: self._ops(tape, a[0], need[0]), [x], list(self.parameters()))
@@ -67,8 +78,8 @@ class Down(nn.Module):
         super().__init__()
         self.maxpool_conv = nn.Sequential(nn.MaxPool2d(2), DoubleConv(in_channels, out_channels))
 
-    def _ops(self, tape, x):
-        return self.maxpool_conv[1]._ops(tape, E.maxpool2(tape, x))
+    def _ops(self, tape, x, room=0):
+        return self.maxpool_conv[1]._ops(tape, E.maxpool2(tape, x), room=room)
 
     def forward(self, x):
         return run(lambda tape, a, need: self._ops(tape, a[0]), [x], list(self.parameters()))

@@ -12,7 +12,7 @@ import torch.nn.functional as F
 from . import engine as E
 from .autograd import run
 from .model_parts import *  # noqa: F401,F403  (the reference's callers star-import everything)
-from .model_parts import DoubleConv, Down, OutConv, Up, has_hooks
+from .model_parts import DoubleConv, Down, OutConv, Up, has_hooks, skip_room
 
 
 def set_parameter_requires_grad(model, feature_extraction):
@@ -49,10 +49,11 @@ class UNet(nn.Module):
     def forward(self, x):
         if self.fused_tape and not has_hooks(self):
             def prog(tape, a, need):
-                x1 = self.inc._ops(tape, a[0], need[0])
-                x2 = self.down1._ops(tape, x1)
-                x3 = self.down2._ops(tape, x2)
-                x4 = self.down3._ops(tape, x3)
+                # the four skip tensors are produced inside the buffers their concats will use (model_parts.py:87)
+                x1 = self.inc._ops(tape, a[0], need[0], room=skip_room(self.up4))
+                x2 = self.down1._ops(tape, x1, room=skip_room(self.up3))
+                x3 = self.down2._ops(tape, x2, room=skip_room(self.up2))
+                x4 = self.down3._ops(tape, x3, room=skip_room(self.up1))
                 x5 = self.down4._ops(tape, x4)
                 y = self.up1._ops(tape, x5, x4)
                 y = self.up2._ops(tape, y, x3)
@@ -163,12 +164,12 @@ class CubeNET(torch.nn.Module):
             self.upconv4 = DoubleConv(64 + first_depth, 64)
         self.outc = OutConv(64, self.n_classes)
 
-    def _stem_ops(self, tape, x, need_dx):
+    def _stem_ops(self, tape, x, need_dx, room=0):
         prec = getattr(self, "hpri_precision", None)
         h = E.conv_bn_relu(tape, x, self.first_conv.weight, self.first_conv.bias, E.BNRef(self.inc[1]),
                            self.training, 3, need_dx=need_dx, precision=prec)
         return E.conv_bn_relu(tape, h, self.inc2[0].weight, self.inc2[0].bias, E.BNRef(self.inc2[1]),
-                              self.training, 3, precision=prec)
+                              self.training, 3, precision=prec, room=room)
 
     def _stem(self, x):
         params = list(self.inc.parameters()) + list(self.inc2.parameters())
@@ -190,10 +191,11 @@ class CubeNET(torch.nn.Module):
             raise ValueError(f"CubeNET expects (N,1,{self.depth},R,C), got {tuple(x.shape)}")
         if self.fused_tape and not has_hooks(self):
             def prog(tape, a, need):
-                x1 = self._stem_ops(tape, a[0], need[0])
-                x2 = self.down1._ops(tape, x1)
-                x3 = self.down2._ops(tape, x2)
-                x4 = self.down3._ops(tape, x3)
+                up4 = self.up4 if self.first_depth == 64 else self.upsample4
+                x1 = self._stem_ops(tape, a[0], need[0], room=skip_room(up4))
+                x2 = self.down1._ops(tape, x1, room=skip_room(self.up3))
+                x3 = self.down2._ops(tape, x2, room=skip_room(self.up2))
+                x4 = self.down3._ops(tape, x3, room=skip_room(self.up1))
                 x5 = self.down4._ops(tape, x4)
                 y = self.up1._ops(tape, x5, x4)
                 y = self.up2._ops(tape, y, x3)
