@@ -199,6 +199,30 @@ __global__ void fill_pad_kernel(float* __restrict__ d, int cs, int coff, int N, 
   }
 }
 
+// F.pad with any mix of positive (zero ring) and negative (crop) widths: d[n][y][x] = s[n][y-oy][x-ox] where that lies
+// inside the Hs x Ws source, 0 elsewhere (model_parts.py:77-80 when the skip is SMALLER than the upsampled tensor).
+__global__ void shift_copy_kernel(const float* __restrict__ s, int s_cs, int s_coff, int Hs, int Ws, float* __restrict__ d,
+                                  int d_cs, int d_coff, int N, int Hd, int Wd, int oy, int ox, int C4, int accumulate) {
+  const long long total = (long long)N * Hd * Wd * C4;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4) * 4;
+    long long r = i / C4;
+    const int ix = (int)(r % Wd); r /= Wd;
+    const int iy = (int)(r % Hd);
+    const int n = (int)(r / Hd);
+    const int sy = iy - oy, sx = ix - ox;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (sy >= 0 && sy < Hs && sx >= 0 && sx < Ws)
+      v = *reinterpret_cast<const float4*>(s + (((long long)n * Hs + sy) * Ws + sx) * s_cs + s_coff + c);
+    float* o = d + (i / C4) * d_cs + d_coff + c;
+    if (accumulate) {
+      const float4 w = *reinterpret_cast<const float4*>(o);
+      v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+    }
+    *reinterpret_cast<float4*>(o) = v;
+  }
+}
+
 __global__ void fill_kernel(float* __restrict__ d, long long n, float v) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) d[i] = v;
 }
@@ -419,6 +443,16 @@ extern "C" int hpri_copy_slice(const float* src, int s_cs, int s_coff, float* ds
   HPRI_REQ_V4(s_cs, s_coff); HPRI_REQ_V4(d_cs, d_coff);
   hipLaunchKernelGGL(copy_slice_kernel, dim3(ew_blocks(P * (C / 4))), dim3(256), 0, stream, src, s_cs, s_coff, dst, d_cs,
                      d_coff, P, C / 4, accumulate);
+  HPRI_CHECK_LAUNCH();
+  return HPRI_OK;
+}
+
+extern "C" int hpri_shift_copy(const float* src, int s_cs, int s_coff, int Hs, int Ws, float* dst, int d_cs, int d_coff, int N,
+                               int Hd, int Wd, int oy, int ox, int C, int accumulate, hipStream_t stream) {
+  HPRI_REQUIRE(src && dst && N > 0 && Hs > 0 && Ws > 0 && Hd > 0 && Wd > 0 && C > 0 && C % 4 == 0, "shift_copy: bad arguments");
+  HPRI_REQ_V4(s_cs, s_coff); HPRI_REQ_V4(d_cs, d_coff);
+  hipLaunchKernelGGL(shift_copy_kernel, dim3(ew_blocks((long long)N * Hd * Wd * (C / 4))), dim3(256), 0, stream, src, s_cs,
+                     s_coff, Hs, Ws, dst, d_cs, d_coff, N, Hd, Wd, oy, ox, C / 4, accumulate);
   HPRI_CHECK_LAUNCH();
   return HPRI_OK;
 }

@@ -877,12 +877,28 @@ def _upsample_into(tape: Tape, x1: Act, dst: Act, weight: Optional[torch.Tensor]
     dev = x1.buf.device
     H2, W2 = dst.H, dst.W
     dY, dX = H2 - 2 * x1.H, W2 - 2 * x1.W
-    if dY < 0 or dX < 0:
-        raise RuntimeError("hyperpri_amd: Up: skip smaller than the upsampled input (negative pad) is not supported")
-    py0, px0 = dY // 2, dX // 2
+    py0, px0 = dY // 2, dX // 2          # Python floor division, as the reference's ``diffY // 2`` (-1 // 2 == -1)
     cup = dst.C
     if cup % 4:
         raise RuntimeError("hyperpri_amd: Up: channel counts must be multiples of 4")
+    if dY < 0 or dX < 0:
+        # skip smaller than the upsampled tensor: F.pad with negative widths crops (model_parts.py:77-80).  Not reached by
+        # the 608 x 968 pyramids (floor pooling makes skips >= 2x), so no fused form: upsample at the natural 2H x 2W size,
+        # then one shift-copy pass that crops / zero-pads each axis; backward is the same pass with the offsets negated.
+        full = Act.new(x1.N, 2 * x1.H, 2 * x1.W, cup, dev)
+        _upsample_into(tape, x1, full, weight, bias, need_dx1, precision)
+        _lib.call("hpri_shift_copy", full.ptr, full.cs, full.coff, full.H, full.W, dst.ptr, dst.cs, dst.coff, dst.N, H2, W2,
+                  py0, px0, cup, 0, _stream())
+        if tape.record:
+            def bwd_crop(tp: Tape) -> None:
+                gu = tp.grads.pop(id(dst), None)
+                if gu is None:
+                    return
+                gf, acc = tp.grad_slot(full)
+                _lib.call("hpri_shift_copy", gu.ptr, gu.cs, gu.coff, H2, W2, gf.ptr, gf.cs, gf.coff, gf.N, full.H, full.W,
+                          -py0, -px0, cup, int(acc), _stream())
+            tape.nodes.append(bwd_crop)
+        return
     if dY or dX:
         _lib.call("hpri_fill_pad", dst.ptr, dst.cs, dst.coff, dst.N, H2, W2, cup, py0, py0 + 2 * x1.H, px0, px0 + 2 * x1.W, _stream())
     if weight is not None:
@@ -961,8 +977,9 @@ def _upsample_into(tape: Tape, x1: Act, dst: Act, weight: Optional[torch.Tensor]
 def up_concat(tape: Tape, x1: Act, skip: Act, weight: Optional[torch.Tensor], bias: Optional[torch.Tensor],
               need_dx1: bool = True, precision: Optional[str] = None) -> Act:
     """cat([skip, pad(up(x1))], dim=1): model_parts.py:63-64,73-87 (and models.py:230-239).  One buffer
-    [N,H,W,Cskip+Cup]: the skip is copied into channels [0,Cskip), the upsampling kernel writes [Cskip,Cskip+Cup)
-    directly; in backward the split is free (channel-slice views of the consumer's input gradient)."""
+    [N,H,W,Cskip+Cup]: the skip already lives in channels [0,Cskip) when its producer allocated the buffer
+    (Act.new_with_room) and is copied there otherwise; the upsampling kernel writes [Cskip,Cskip+Cup) directly; in
+    backward the split is free (channel-slice views of the consumer's input gradient)."""
     dev = x1.buf.device
     cup = weight.shape[1] if weight is not None else x1.C
     if skip.N != x1.N:

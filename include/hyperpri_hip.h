@@ -222,6 +222,10 @@ int hpri_copy_slice_any(const float* src, int s_cs, int s_coff, float* dst, int 
                         int Cz, int accumulate, hipStream_t stream);
 int hpri_fill_pad(float* dst, int cs, int coff, int N, int H, int W, int C, int y0, int y1, int x0, int x1,
                   hipStream_t stream);
+/* F.pad with positive and/or negative widths in one pass (model_parts.py:77-80, the crop case): dst[n][y][x] = src[n][y-oy][x-ox]
+ * inside the Hs x Ws source, 0 outside. */
+int hpri_shift_copy(const float* src, int s_cs, int s_coff, int Hs, int Ws, float* dst, int d_cs, int d_coff, int N, int Hd,
+                    int Wd, int oy, int ox, int C, int accumulate, hipStream_t stream);
 int hpri_fill(float* dst, long long n, float value, hipStream_t stream);
 int hpri_outconv_fwd(const float* x, int x_cs, int x_coff, const float* w, const float* b, float* y, int N,
                      long long P, int C, int K, hipStream_t stream);

@@ -88,6 +88,15 @@ def test_up_variants(name, bil, att, seed):
     _block(name, Up(16, 8, bilinear=bil, use_attention=att), seed, 2)
 
 
+@pytest.mark.parametrize("name,bil,seed", [("block_up_crop", False, 3100), ("block_up_crop_mixed", False, 3200),
+                                           ("block_up_bilinear_crop", True, 3300)])
+def test_up_crop(name, bil, seed):
+    """Skip smaller than the upsampled tensor (F.pad with negative widths crops, model_parts.py:73-80): both axes cropped,
+    one cropped and one padded, uneven crops after bilinear upsampling."""
+    from hyperpri_amd import Up
+    _block(name, Up(16, 8, bilinear=bil), seed, 2)
+
+
 def test_outconv():
     from hyperpri_amd import OutConv
     _block("block_outconv", OutConv(6, 2), 2500, 1)

@@ -82,6 +82,15 @@ def test_block_up_variants(name, bil, att, seed):
     _block(name, sd, lambda s, x1, x2, t: O.up(s, "", x1, x2, t, bil, att), seed, 2)
 
 
+@pytest.mark.parametrize("name,bil,seed", [("block_up_crop", False, 3100), ("block_up_crop_mixed", False, 3200),
+                                           ("block_up_bilinear_crop", True, 3300)])
+def test_block_up_crop(name, bil, seed):
+    """Skip smaller than the upsampled tensor: F.pad crops (model_parts.py:73-80); fixtures from make_golden_crop.py."""
+    sd = OrderedDict()
+    O._up_keys(sd, "", 16, 8, bil, False)
+    _block(name, sd, lambda s, x1, x2, t: O.up(s, "", x1, x2, t, bil, False), seed, 2)
+
+
 def test_block_outconv():
     sd = OrderedDict()
     O._conv_keys(sd, "conv", 2, 6, 1)
