@@ -187,6 +187,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(Wino4Args a) {
       if (g == 1 && chunk + 1 < nchunks) { if (wave < 3) WAIT_VM(6); else WAIT_VM(5); }
       else WAIT_VM(0);
       if (g == 0) __builtin_amdgcn_s_barrier();     // the chunk's halo is visible to all four waves; all have left the previous chunk
+#ifdef HPRI_STAMPS
+      if (s == 0) STAMP(7)                          // end of the prologue: the first halo chunk and weight stage have landed
+#endif
 #pragma unroll
       for (int b = 0; b < 4; ++b)
 #pragma unroll

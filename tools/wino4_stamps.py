@@ -6,6 +6,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 SHAPES = [(2, 608, 968, 238, 64), (2, 304, 484, 128, 128)]
+if os.environ.get("WINO_SHAPES"):      # e.g. "2,608,968,64,64;2,304,484,128,128"
+    SHAPES = [tuple(int(v) for v in q.split(",")) for q in os.environ["WINO_SHAPES"].split(";")]
 def rup(x, m): return (x + m - 1) // m * m
 LIBNAME = os.environ.get("WINO_LIB", "libv2stamps.so")
 print("library", LIBNAME)
@@ -63,6 +65,21 @@ for (N, H, W, Cin, Cout) in SHAPES:
                 cov += max(0, min(s3, o1) - max(s1, o0))
             tot_epi += epi; tot_cov += min(cov, epi)
     print(f"   epilogue time covered by a co-resident workgroup's main loop: {100.0 * tot_cov / max(tot_epi, 1):.1f} %")
+    # what a CU slot spends OUTSIDE a workgroup's stamped region: from one workgroup's last stamp to the first stamp of the next
+    # workgroup that starts on the same CU (dispatch + kernel preamble), and the prologue (first stamp -> first operands landed)
+    gaps = []
+    for k, v in groups.items():
+        starts = sorted(s0 for (s0, s1, s3, i) in v)
+        import bisect
+        for (s0, s1, s3, i) in v:
+            j = bisect.bisect_right(starts, s3)
+            if j < len(starts):
+                gaps.append(starts[j] - s3)
+    gaps.sort()
+    pro = (raw[:, 7] - raw[:, 0]).double()
+    if gaps:
+        print(f"   end of a workgroup -> start of the next one on that CU: median {gaps[len(gaps)//2]} p10 {gaps[len(gaps)//10]} p90 {gaps[9*len(gaps)//10]} ticks;"
+              f" prologue (start -> first operands landed): median {pro.median():.0f} p90 {pro.quantile(0.9):.0f}")
     k0 = sorted(groups)[0]
     print("   first key timeline (start, loop end, end, id):", [(a0 - groups[k0][0][0], a1 - groups[k0][0][0], a3 - groups[k0][0][0], i) for (a0, a1, a3, i) in sorted(groups[k0])[:6]])
     for g in (0, 1):
