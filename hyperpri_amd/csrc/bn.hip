@@ -67,6 +67,72 @@ __global__ void bn_finalize_kernel(const float4* __restrict__ part, int tiles_pe
   }
 }
 
+// The same for MANY tiles per group (a 608 x 968 layer: 9272 tiles x 64 channels = 9.5 MB of partials, which the kernel
+// above read with two workgroups: 80 us).  block = 256 tile slices x 4 channels, grid = (ceil(C/4), G): 16+ workgroups, 64-byte
+// segments; slices meet by a fixed shuffle tree inside a wave, the 16 waves in order through LDS (deterministic).
+__global__ __launch_bounds__(1024) void bn_finalize_wide_kernel(
+    const float4* __restrict__ part, int tiles_per_group, int Cp, int C, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float eps, float* __restrict__ mean, float* __restrict__ invstd,
+    float* __restrict__ var_unbiased, float* __restrict__ scale, float* __restrict__ shift, float momentum,
+    float* __restrict__ rm, float* __restrict__ rv, long long* __restrict__ nbt) {
+  __shared__ double sw[16][4][3];
+  const int cl = threadIdx.x & 3, sl = threadIdx.x >> 2;          // channel of the block, tile slice (0..255)
+  const int c = blockIdx.x * 4 + cl, g = blockIdx.y;
+  double a1 = 0.0, a2 = 0.0, an = 0.0;
+  if (c < C) {
+    const float4* p = part + (size_t)g * tiles_per_group * Cp + c;
+    int t = sl;
+    for (; t + 768 < tiles_per_group; t += 1024) {    // 4 independent loads in flight
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = p[(size_t)(t + 256 * u) * Cp];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const double m = v[u].x, n = v[u].z;
+        a1 += n * m;
+        a2 += (double)v[u].y + n * m * m;
+        an += n;
+      }
+    }
+    for (; t < tiles_per_group; t += 256) {
+      const float4 v = p[(size_t)t * Cp];
+      const double m = v.x, n = v.z;
+      a1 += n * m;
+      a2 += (double)v.y + n * m * m;
+      an += n;
+    }
+  }
+#pragma unroll
+  for (int d = 4; d < 64; d <<= 1) {                  // the 16 slices of a wave that share a channel: lanes cl, cl+4, ...
+    a1 += __shfl_xor(a1, d);
+    a2 += __shfl_xor(a2, d);
+    an += __shfl_xor(an, d);
+  }
+  const int wv = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) < 4) { sw[wv][cl][0] = a1; sw[wv][cl][1] = a2; sw[wv][cl][2] = an; }
+  __syncthreads();
+  if (threadIdx.x < 4 && c < C) {
+    double t1 = 0.0, t2 = 0.0, tn = 0.0;
+    for (int k = 0; k < 16; ++k) { t1 += sw[k][cl][0]; t2 += sw[k][cl][1]; tn += sw[k][cl][2]; }
+    const double mu = t1 / tn;
+    double var = t2 / tn - mu * mu;
+    if (var < 0.0) var = 0.0;
+    const double is = 1.0 / sqrt(var + (double)eps);
+    const int o = g * C + c;
+    mean[o] = (float)mu;
+    invstd[o] = (float)is;
+    var_unbiased[o] = (float)(tn > 1.0 ? var * tn / (tn - 1.0) : var);
+    const float sc = gamma[c] * (float)is;
+    scale[o] = sc;
+    shift[o] = beta[c] - (float)mu * sc;
+    if (rm != nullptr) {
+      rm[c] = (1.f - momentum) * rm[c] + momentum * mean[o];
+      rv[c] = (1.f - momentum) * rv[c] + momentum * var_unbiased[o];
+      if (c == 0 && nbt != nullptr) *nbt += 1;
+    }
+  }
+}
+
 // running = (1-m)*running + m*stat, applied for g = 0..G-1 in order (SpectralUNET advances N times per call)
 __global__ void bn_update_running_kernel(const float* __restrict__ mean, const float* __restrict__ var_unbiased,
                                          int G, int C, float momentum, float* __restrict__ rm, float* __restrict__ rv,
@@ -352,10 +418,16 @@ extern "C" int hpri_bn_finalize(const float* partials, int tiles_per_group, int 
   HPRI_REQUIRE(tiles_per_group > 0 && G > 0 && C > 0 && Cp >= C, "bn_finalize: bad sizes");
   const bool running = running_mean != nullptr && running_var != nullptr;
   const bool fused = running && G == 1;
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(hpri_cdiv(C, 32), G), dim3(1024), 0, stream,
-                     reinterpret_cast<const float4*>(partials), tiles_per_group, Cp, C, gamma, beta, eps, mean, invstd,
-                     var_unbiased, scale, shift, momentum, fused ? running_mean : nullptr, fused ? running_var : nullptr,
-                     fused ? num_batches_tracked : nullptr);
+  if (tiles_per_group >= 512)                       // few channels x many tiles: spread the tiles over more workgroups
+    hipLaunchKernelGGL(bn_finalize_wide_kernel, dim3(hpri_cdiv(C, 4), G), dim3(1024), 0, stream,
+                       reinterpret_cast<const float4*>(partials), tiles_per_group, Cp, C, gamma, beta, eps, mean, invstd,
+                       var_unbiased, scale, shift, momentum, fused ? running_mean : nullptr, fused ? running_var : nullptr,
+                       fused ? num_batches_tracked : nullptr);
+  else
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(hpri_cdiv(C, 32), G), dim3(1024), 0, stream,
+                       reinterpret_cast<const float4*>(partials), tiles_per_group, Cp, C, gamma, beta, eps, mean, invstd,
+                       var_unbiased, scale, shift, momentum, fused ? running_mean : nullptr, fused ? running_var : nullptr,
+                       fused ? num_batches_tracked : nullptr);
   HPRI_CHECK_LAUNCH();
   if (running && !fused) {
     hipLaunchKernelGGL(bn_update_running_kernel, dim3(hpri_cdiv(C, 256)), dim3(256), 0, stream, mean, var_unbiased, G, C,

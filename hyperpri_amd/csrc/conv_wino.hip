@@ -639,6 +639,51 @@ __global__ void wino_wgrad_reduce_kernel(const float* __restrict__ ws, float* __
   }
 }
 
+// The same for MANY slabs (the 608 x 968 layers: 256 slabs of 16 x 64 x 64, 67 MB, which the kernel above reads with 16
+// workgroups): S slab slices x 64 columns per workgroup and ONE input channel; slice s sums slabs s, s + S, ... in order, the
+// slices meet in LDS in order (deterministic).
+template <int S>
+__global__ __launch_bounds__(64 * S) void wino_wgrad_reduce_wide_kernel(const float* __restrict__ ws, float* __restrict__ dw,
+                                                                        int splits, int Cr, int Nr, int Cin, int Cout,
+                                                                        int accumulate) {
+  __shared__ float red[S - 1][16][64];
+  const int ln = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + ln, c = blockIdx.y;            // n < Nr (a multiple of 64), c < Cin <= Cr
+  float u[16];
+#pragma unroll
+  for (int xi = 0; xi < 16; ++xi) u[xi] = 0.f;
+  const size_t slab = (size_t)16 * Cr * Nr;
+  for (int k = sl; k < splits; k += S) {
+    const float* p = ws + (size_t)k * slab + (size_t)c * Nr + n;
+#pragma unroll
+    for (int xi = 0; xi < 16; ++xi) u[xi] += p[(size_t)xi * Cr * Nr];
+  }
+  if (sl > 0) {
+#pragma unroll
+    for (int xi = 0; xi < 16; ++xi) red[sl - 1][xi][ln] = u[xi];
+  }
+  __syncthreads();
+  if (sl > 0 || n >= Cout) return;
+  for (int q = 0; q < S - 1; ++q)
+#pragma unroll
+    for (int xi = 0; xi < 16; ++xi) u[xi] += red[q][xi][ln];
+  float t[3][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    t[0][j] = u[0 * 4 + j] + 0.5f * (u[1 * 4 + j] + u[2 * 4 + j]);
+    t[1][j] = 0.5f * (u[1 * 4 + j] - u[2 * 4 + j]);
+    t[2][j] = 0.5f * (u[1 * 4 + j] + u[2 * 4 + j]) + u[3 * 4 + j];
+  }
+  float* o = dw + ((size_t)n * Cin + c) * 9;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const float g0 = t[i][0] + 0.5f * (t[i][1] + t[i][2]), g1 = 0.5f * (t[i][1] - t[i][2]), g2 = 0.5f * (t[i][1] + t[i][2]) + t[i][3];
+    o[i * 3 + 0] = accumulate ? o[i * 3 + 0] + g0 : g0;
+    o[i * 3 + 1] = accumulate ? o[i * 3 + 1] + g1 : g1;
+    o[i * 3 + 2] = accumulate ? o[i * 3 + 2] + g2 : g2;
+  }
+}
+
 extern "C" int hpri_wino_wgrad_plan(int N, int H, int W, int Cin_pad, int Cout_pad, int* splits, int* Cr, int* Nr) {
   const int cblk = hpri_cdiv(Cin_pad, 64), nblk = hpri_cdiv(Cout_pad, 64);
   const int total = N * hpri_cdiv(H, 2) * hpri_cdiv(W, 32);
@@ -689,8 +734,16 @@ extern "C" int hpri_wino_wgrad_reduce(const float* ws, float* dw, int N, int H, 
   HPRI_REQUIRE(ws && dw && Cin > 0 && Cout > 0, "wino_wgrad_reduce: bad arguments");
   int splits, Cr, Nr;
   hpri_wino_wgrad_plan(N, H, W, Cin_pad, Cout_pad, &splits, &Cr, &Nr);
-  dim3 grid((unsigned)hpri_cdiv(Cout, 64), (unsigned)hpri_cdiv(Cin, 4));
-  hipLaunchKernelGGL(wino_wgrad_reduce_kernel, grid, dim3(256), 0, stream, ws, dw, splits, Cr, Nr, Cin, Cout, accumulate);
+  if (splits >= 64) {                               // many slabs, few (c, n) pairs: spread the slabs over the workgroup too
+    dim3 grid((unsigned)hpri_cdiv(Cout, 64), (unsigned)Cin);
+    hipLaunchKernelGGL(wino_wgrad_reduce_wide_kernel<16>, grid, dim3(1024), 0, stream, ws, dw, splits, Cr, Nr, Cin, Cout, accumulate);
+  } else if (splits >= 8) {
+    dim3 grid((unsigned)hpri_cdiv(Cout, 64), (unsigned)Cin);
+    hipLaunchKernelGGL(wino_wgrad_reduce_wide_kernel<8>, grid, dim3(512), 0, stream, ws, dw, splits, Cr, Nr, Cin, Cout, accumulate);
+  } else {
+    dim3 grid((unsigned)hpri_cdiv(Cout, 64), (unsigned)hpri_cdiv(Cin, 4));
+    hipLaunchKernelGGL(wino_wgrad_reduce_kernel, grid, dim3(256), 0, stream, ws, dw, splits, Cr, Nr, Cin, Cout, accumulate);
+  }
   HPRI_CHECK_LAUNCH();
   return HPRI_OK;
 }
