@@ -20,6 +20,7 @@ post-accumulate-grad hook and are copied into the bucket instead.  Works with an
 from __future__ import annotations
 
 import contextlib
+import os
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -50,24 +51,42 @@ class _Bucket:
 
 
 class GradSync:
-    def __init__(self, module: torch.nn.Module, bucket_mb: float = 48.0, process_group=None,
-                 broadcast_buffers: bool = False, force: bool = False):
+    def __init__(self, module: torch.nn.Module, bucket_mb: Optional[float] = None, process_group=None,
+                 broadcast_buffers: bool = False, force: bool = False, tail_mb: Optional[float] = None):
+        if bucket_mb is None:
+            bucket_mb = float(os.environ.get("HPRI_BUCKET_MB", "24"))
+        if tail_mb is None:
+            tail_mb = float(os.environ.get("HPRI_TAIL_MB", "2"))
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.collective = self.world > 1 or (force and dist.is_initialized())   # force: rehearse with one rank
+        # RCCL averages inside the collective (ncclAvg); gloo (the CPU tests) sums and finish() divides
+        self._avg = dist.is_initialized() and dist.get_backend(process_group) == "nccl"
         params = [p for p in module.parameters() if p.requires_grad]
+        ready = list(reversed(params))       # backward produces gradients in reverse registration order
+        nbytes = [p.numel() * p.element_size() for p in ready]
+        # The all-reduce of the LAST bucket cannot overlap with anything: keep it small.  The gradients that land last (the
+        # first layers: a few hundred KB each in the U-Nets) form a tail bucket of at most tail_mb; the bucket before it is
+        # issued while those layers' backward -- the largest feature maps, several ms -- still runs.
         cap = int(bucket_mb * (1 << 20))
+        tail_cap = min(int(tail_mb * (1 << 20)), cap)
+        ntail, tsize = 0, 0
+        while ntail < len(ready) - 1 and tsize + nbytes[len(ready) - 1 - ntail] <= tail_cap:
+            tsize += nbytes[len(ready) - 1 - ntail]
+            ntail += 1
         self.buckets: List[_Bucket] = []
         cur: List[torch.nn.Parameter] = []
         size = 0
-        for p in reversed(params):           # backward produces gradients in reverse registration order
+        for p, nb in zip(ready[:len(ready) - ntail], nbytes):
             cur.append(p)
-            size += p.numel() * p.element_size()
+            size += nb
             if size >= cap:
                 self.buckets.append(_Bucket(cur))
                 cur, size = [], 0
         if cur:
             self.buckets.append(_Bucket(cur))
+        if ntail:
+            self.buckets.append(_Bucket(ready[len(ready) - ntail:]))
         self._where: Dict[int, Tuple[_Bucket, int]] = {}
         self._hooks = []
         for b in self.buckets:
@@ -147,7 +166,7 @@ class GradSync:
         if b.flat.is_cuda:
             b.t_issue = torch.cuda.Event(enable_timing=True)
             b.t_issue.record()
-        b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def end_micro_batch(self) -> None:
         """Close an accumulation micro-batch (called by the user after each backward inside ``no_sync``)."""
@@ -174,7 +193,7 @@ class GradSync:
             if b.work is not None:
                 b.work.wait()
                 b.work = None
-            if self.world > 1:
+            if self.world > 1 and not self._avg:
                 b.flat.div_(self.world)
             for i, p in enumerate(b.params):
                 p.grad = b.view(i)

@@ -112,3 +112,21 @@ def test_gradsync_world2_micro_batches_and_guard():
     for a0, a1, x0, x1 in zip(g0, g1, l0, l1):
         assert torch.equal(a0, a1)
         torch.testing.assert_close(a0, (x0 + x1) / 2, rtol=1e-5, atol=1e-6)
+
+
+def test_bucket_plan_keeps_the_last_bucket_small():
+    """The all-reduce of the last bucket cannot overlap with backward: the gradients that land last form a small tail."""
+    from hyperpri_amd.ddp import GradSync
+    net = torch.nn.Sequential(torch.nn.Linear(64, 64), torch.nn.Linear(64, 2048), torch.nn.Linear(2048, 1024), torch.nn.Linear(1024, 1024),
+                              torch.nn.Linear(1024, 64), torch.nn.Linear(64, 1))
+    sync = GradSync(net, bucket_mb=4.0, tail_mb=1.0)
+    try:
+        sizes = [b.flat.numel() * 4 for b in sync.buckets]
+        assert len(sizes) >= 3 and sizes[-1] <= 1 << 20
+        # ready order = reverse registration order, every parameter exactly once
+        flat = [id(p) for b in sync.buckets for p in b.params]
+        assert flat == [id(p) for p in reversed(list(net.parameters()))]
+        # the tail holds the first layers (whose gradients land last)
+        assert id(net[0].weight) in {id(p) for p in sync.buckets[-1].params}
+    finally:
+        sync.remove()
