@@ -372,7 +372,7 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, int dy_cs, int
         o[j] = (c + j < C) ? sc[j] * (gj - k1[j] - xh * k2[j]) : 0.f;   // pad channels stay exactly zero
         acc[j] += o[j];
       }
-      *reinterpret_cast<float4*>(dx + p * dx_cs + dx_coff + c) = make_float4(o[0], o[1], o[2], o[3]);
+      if (dx != nullptr) *reinterpret_cast<float4*>(dx + p * dx_cs + dx_coff + c) = make_float4(o[0], o[1], o[2], o[3]);
       if (in_p) plane_store4(pl, p, c, o[0], o[1], o[2], o[3]);
     }
   }
@@ -520,7 +520,9 @@ extern "C" int hpri_bn_relu_bwd_pl(const float* dy, int dy_cs, int dy_coff, cons
                                    size_t ws_floats, long long P, long long pix_per_group, int C, int Cw, int relu,
                                    int use_batch_stats, void* planes, long long plane_stride, int pl_cs, int pl_coff,
                                    int pl_cw, int npl, hipStream_t stream) {
-  HPRI_REQUIRE(dy && x && dx && mean && invstd && scale && shift && workspace, "bn_relu_bwd: null pointer");
+  // dx == nullptr with planes given: the gradient is wanted as bf16 planes only (both consumers, the data-gradient and the
+  // weight-gradient kernel of the plane mode, read nothing else): one fp32 tensor write less
+  HPRI_REQUIRE(dy && x && (dx || planes) && mean && invstd && scale && shift && workspace, "bn_relu_bwd: null pointer");
   PlaneOut po;
   { const int rc_ = hpri_plane_out(&po, planes, plane_stride, pl_cs, pl_coff, pl_cw, npl, C); if (rc_ != HPRI_OK) return rc_; }
   HPRI_REQUIRE(Cw % 4 == 0 && Cw >= C && dy_cs % 4 == 0 && x_cs % 4 == 0 && dx_cs % 4 == 0 && dy_coff % 4 == 0 &&

@@ -201,6 +201,9 @@ def _conv_launch_wino(x: Act, up: torch.Tensor, bias: Optional[torch.Tensor], y:
 
 PLANE_CONV = os.environ.get("HPRI_PLANE_CONV", "1") != "0"   # bf16 mode: 3x3 convs on bf16 planes (0: round-1 kernel)
 PLANE_WGRAD = os.environ.get("HPRI_PLANE_WGRAD", "1") != "0"  # ... and their weight gradients (0: round-1 kernel)
+# the BatchNorm backward of a plane-mode layer writes its result as bf16 planes ONLY when both consumers read planes (one fp32
+# tensor write less per layer and step).  HPRI_PLANES_ONLY_GRAD: 1 (default) / 0.
+PLANES_ONLY_GRAD = os.environ.get("HPRI_PLANES_ONLY_GRAD", "1") != "0"
 PLANE_PRODUCERS = True       # producers (BN-apply, BN-backward, ...) write the planes themselves; False: generic pass only
 PLANE_CONVERSIONS = 0        # generic fp32 -> planes passes launched (fused producers do not count)
 
@@ -679,7 +682,11 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
             mean, invstd, varu, scale, shift = (st[i * G * cout:(i + 1) * G * cout] for i in range(5))
             # read by the data gradient and by the weight gradient
             dpl = new_planes(dyr, 1) if (v2 and (need_dx or (PLANE_WGRAD and weight.requires_grad)) and PLANE_PRODUCERS) else None
-            _lib.call("hpri_bn_relu_bwd_pl", g.ptr, g.cs, g.coff, yr.ptr, yr.cs, yr.coff, dyr.ptr, dyr.cs, dyr.coff,
+            # plane mode: when the weight gradient and the data gradient both read the bf16 planes, nobody reads the fp32 form
+            f32_dead = (dpl is not None and ks == 3 and split == 0 and PLANE_CONV and PLANE_WGRAD and PLANES_ONLY_GRAD
+                        and (need_dx or weight.requires_grad))
+            _lib.call("hpri_bn_relu_bwd_pl", g.ptr, g.cs, g.coff, yr.ptr, yr.cs, yr.coff,
+                      ctypes.c_void_p(0) if f32_dead else dyr.ptr, dyr.cs, dyr.coff,
                       _p(mean), _p(invstd), _p(scale), _p(shift), _p(dgam), _p(dbet), acc_g, _p(db), acc_b,
                       _p(ws), ws.numel(), x.P, x.P // G, cout, dyr.cw, int(relu), int(use_batch), *_pl_args(dpl), _stream())
         else:

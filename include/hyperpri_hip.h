@@ -197,6 +197,7 @@ int hpri_maxpool2_fwd_pl(const float* x, int x_cs, int x_coff, float* y, int y_c
 int hpri_bn_apply_relu_pl(const float* x, int x_cs, int x_coff, float* y, int y_cs, int y_coff, const float* scale,
                           const float* shift, long long P, long long pix_per_group, int C, int Cw, int relu, void* planes,
                           long long plane_stride, int pl_cs, int pl_coff, int pl_cw, int npl, hipStream_t stream);
+/* dx may be NULL when planes are given: the gradient is then written as bf16 planes only (plane-mode consumers read nothing else). */
 int hpri_bn_relu_bwd_pl(const float* dy, int dy_cs, int dy_coff, const float* x, int x_cs, int x_coff, float* dx,
                         int dx_cs, int dx_coff, const float* mean, const float* invstd, const float* scale,
                         const float* shift, float* dgamma, float* dbeta, int accumulate_param_grads, float* dbias,
