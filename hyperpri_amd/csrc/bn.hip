@@ -207,7 +207,7 @@ __global__ void bn_apply_relu_kernel(const float* __restrict__ x, int x_cs, int 
       const float4 v = *reinterpret_cast<const float4*>(x + p * x_cs + x_coff + c);
       o.x = v.x * sc[0] + sh[0]; o.y = v.y * sc[1] + sh[1]; o.z = v.z * sc[2] + sh[2]; o.w = v.w * sc[3] + sh[3];
       if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
-      *reinterpret_cast<float4*>(y + p * y_cs + y_coff + c) = o;
+      if (y != nullptr) *reinterpret_cast<float4*>(y + p * y_cs + y_coff + c) = o;
     }
     if (in_p) plane_store4(pl, p, c, o.x, o.y, o.z, o.w);
   }
@@ -468,7 +468,9 @@ extern "C" int hpri_bn_apply_relu_pl(const float* x, int x_cs, int x_coff, float
                                      const float* scale, const float* shift, long long P, long long pix_per_group,
                                      int C, int Cw, int relu, void* planes, long long plane_stride, int pl_cs, int pl_coff,
                                      int pl_cw, int npl, hipStream_t stream) {
-  HPRI_REQUIRE(x && y && scale && shift, "bn_apply_relu: null pointer");
+  // y == nullptr with planes given: the activation is wanted as bf16 planes only (the inner tensor of a DoubleConv in the plane
+  // mode: the next convolution and its weight gradient read nothing else)
+  HPRI_REQUIRE(x && (y || planes) && scale && shift, "bn_apply_relu: null pointer");
   PlaneOut po;
   { const int rc_ = hpri_plane_out(&po, planes, plane_stride, pl_cs, pl_coff, pl_cw, npl, C); if (rc_ != HPRI_OK) return rc_; }
   HPRI_REQUIRE(Cw % 4 == 0 && Cw >= C && x_cs % 4 == 0 && y_cs % 4 == 0 && x_coff % 4 == 0 && y_coff % 4 == 0 &&

@@ -62,12 +62,13 @@ class Act:
 
     Invariant: channels [C, cw) (cw = C rounded up to 8) exist inside the stride and hold zeros, so
     consumers may run their K loop over ``cw`` channels."""
-    __slots__ = ("buf", "N", "H", "W", "C", "cs", "coff", "pl", "parent")
+    __slots__ = ("buf", "N", "H", "W", "C", "cs", "coff", "pl", "parent", "f32_valid")
 
     def __init__(self, buf: torch.Tensor, N: int, H: int, W: int, C: int, cs: int, coff: int = 0):
         self.buf, self.N, self.H, self.W, self.C, self.cs, self.coff = buf, N, H, W, C, cs, coff
         self.pl: Optional["Planes"] = None      # bf16 plane copy of this activation (bf16 precision modes), see planes_of
         self.parent: Optional["Act"] = None     # wider buffer this Act is the leading channel slice of (new_with_room)
+        self.f32_valid = True                   # False: only the bf16 planes were written (plane mode, inner tensor of a DoubleConv)
 
     @property
     def cw(self) -> int:
@@ -204,6 +205,8 @@ PLANE_WGRAD = os.environ.get("HPRI_PLANE_WGRAD", "1") != "0"  # ... and their we
 # the BatchNorm backward of a plane-mode layer writes its result as bf16 planes ONLY when both consumers read planes (one fp32
 # tensor write less per layer and step).  HPRI_PLANES_ONLY_GRAD: 1 (default) / 0.
 PLANES_ONLY_GRAD = os.environ.get("HPRI_PLANES_ONLY_GRAD", "1") != "0"
+# ... and the inner tensor of a DoubleConv (conv -> BN -> ReLU -> [here] -> conv) likewise.  HPRI_PLANES_ONLY_ACT: 1 (default) / 0.
+PLANES_ONLY_ACT = os.environ.get("HPRI_PLANES_ONLY_ACT", "1") != "0"
 PLANE_PRODUCERS = True       # producers (BN-apply, BN-backward, ...) write the planes themselves; False: generic pass only
 PLANE_CONVERSIONS = 0        # generic fp32 -> planes passes launched (fused producers do not count)
 
@@ -580,7 +583,7 @@ def _conv_launch(x: Act, wp: torch.Tensor, bias: Optional[torch.Tensor], y: Act,
 # --------------------------------------------------------------------------------------------------
 def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.Tensor], bn: Optional[BNRef],
                  train: bool, ks: int, groups: int = 1, relu: bool = True, need_dx: bool = True,
-                 precision: Optional[str] = None, room: int = 0) -> Act:
+                 precision: Optional[str] = None, room: int = 0, next_cout: int = 0) -> Act:
     """Conv2d(k=ks, pad=ks//2) -> BatchNorm -> ReLU  (model_parts.py:22-27; models.py:169-180 with the
     Conv3d weight (F,1,D,3,3) read as (F,D,3,3); models.py:108-114 for Linear -> BatchNorm1d -> ReLU with
     ks = 1 and ``groups`` = images, each image being its own BN batch, models.py:132)."""
@@ -600,6 +603,8 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
     split = _SPLIT.get(prec, 0)
     # operands by LDS-DMA from bf16 planes (conv_bf16v2.hip); its DMA offsets are 32-bit per image
     v2 = PLANE_CONV and prec == "bf16" and ks == 3 and _planes_fit(x, max(cin, cout))
+    if not x.f32_valid and not (v2 and x.pl is not None):
+        raise RuntimeError("hyperpri_amd: internal error: a planes-only activation reached a kernel that reads fp32")
     wino = prec == "fp32" and ks == 3 and groups == 1 and _wino_ok(x, cout)
     wino_d = prec == "fp32" and ks == 3 and groups == 1 and _wino_ok(x, cin)     # the data gradient has Cin columns
     if wino:
@@ -661,7 +666,13 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
         # bf16 plane mode: the normalise pass also writes y as bf16 planes -- what the next 3x3 convolution (and the
         # weight gradient) stage by DMA -- so no conversion pass has to read y again
         ypl = new_planes(y, 1) if (v2 and PLANE_PRODUCERS) else None
-        _lib.call("hpri_bn_apply_relu_pl", yr.ptr, yr.cs, yr.coff, y.ptr, y.cs, y.coff, _p(scale), _p(shift),
+        # ``next_cout`` > 0: y is the inner tensor of a DoubleConv (the caller says so), read only by the next 3x3 convolution
+        # of ``next_cout`` columns and by that convolution's weight gradient.  When those read planes, nobody reads fp32.
+        if (ypl is not None and next_cout > 0 and PLANES_ONLY_ACT and PLANE_WGRAD and room == 0
+                and _planes_fit(y, max(cout, next_cout))):
+            y.f32_valid = False
+        _lib.call("hpri_bn_apply_relu_pl", yr.ptr, yr.cs, yr.coff, y.ptr if y.f32_valid else ctypes.c_void_p(0), y.cs, y.coff,
+                  _p(scale), _p(shift),
                   x.P, ppg, cout, y.cw, int(relu), *_pl_args(ypl), _stream())
     if not tape.record:
         return y

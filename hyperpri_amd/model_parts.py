@@ -20,7 +20,8 @@ __all__ = ["DoubleConv", "Down", "Up", "OutConv", "torch", "nn", "F", "set_preci
 def _double_conv_ops(tape, x, seq, train, need_dx=True, precision=None, room=0):
     """(conv3x3 -> BN -> ReLU) x 2 on an Act; ``seq`` is the 6-entry nn.Sequential container.  ``room``: channels to keep
     free behind the result (it is a skip tensor: the decoder's concat is then in place)."""
-    h = E.conv_bn_relu(tape, x, seq[0].weight, seq[0].bias, E.BNRef(seq[1]), train, 3, need_dx=need_dx, precision=precision)
+    h = E.conv_bn_relu(tape, x, seq[0].weight, seq[0].bias, E.BNRef(seq[1]), train, 3, need_dx=need_dx, precision=precision,
+                       next_cout=seq[3].weight.shape[0])       # h is read by the second convolution only
     return E.conv_bn_relu(tape, h, seq[3].weight, seq[3].bias, E.BNRef(seq[4]), train, 3, precision=precision, room=room)
 
 

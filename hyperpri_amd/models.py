@@ -167,7 +167,7 @@ class CubeNET(torch.nn.Module):
     def _stem_ops(self, tape, x, need_dx, room=0):
         prec = getattr(self, "hpri_precision", None)
         h = E.conv_bn_relu(tape, x, self.first_conv.weight, self.first_conv.bias, E.BNRef(self.inc[1]),
-                           self.training, 3, need_dx=need_dx, precision=prec)
+                           self.training, 3, need_dx=need_dx, precision=prec, next_cout=self.inc2[0].weight.shape[0])
         return E.conv_bn_relu(tape, h, self.inc2[0].weight, self.inc2[0].bias, E.BNRef(self.inc2[1]),
                               self.training, 3, precision=prec, room=room)
 
