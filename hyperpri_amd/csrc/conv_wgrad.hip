@@ -415,6 +415,37 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restr
   }
 }
 
+// ConvTranspose2d(k2, s2) weights (dst mode 1, T == 1): dW[c][co][tap] from slab rows n = tap * Cup + co.  One workgroup owns
+// 64 channels x 16 co x 4 taps: every thread sums its four (row, channel) pairs over the slabs in order (256-byte row segments),
+// the 64 x 64 tile turns in LDS, and each channel's 16 co x 4 taps leave as 256 contiguous bytes (the generic kernel above wrote
+// them as scattered 4-byte stores from 32-lane row segments, with 24 of its 32 slices idle at 8 slabs: 118 us for up1).
+__global__ __launch_bounds__(1024) void wgrad_reduce_convt_kernel(const float* __restrict__ ws, float* __restrict__ dw, int splits,
+                                                                  int Cr, int Nr, int Cin, int Cup, int accumulate) {
+  __shared__ float tile[64][65];
+  const int cl = threadIdx.x & 63, r = threadIdx.x >> 6;          // channel lane, row group (0..15)
+  const int c0 = blockIdx.x * 64, co0 = blockIdx.y * 16;
+  const size_t slab = (size_t)Cr * Nr;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int rr = r + 16 * j;                                     // tile row: tap = rr >> 4, co = co0 + (rr & 15)
+    const int n = (rr >> 4) * Cup + co0 + (rr & 15);
+    float acc = 0.f;
+    if (c0 + cl < Cin) {
+      const float* p = ws + (size_t)n * Cr + c0 + cl;
+      for (int k = 0; k < splits; ++k) acc += p[(size_t)k * slab];
+    }
+    tile[rr][cl] = acc;
+  }
+  __syncthreads();
+  const int c = threadIdx.x >> 4, q = threadIdx.x & 15;            // output: channel c0 + c, co0 + q, taps 0..3 as one float4
+  if (c0 + c < Cin) {
+    float4 v = make_float4(tile[q][c], tile[16 + q][c], tile[32 + q][c], tile[48 + q][c]);
+    float4* o = reinterpret_cast<float4*>(dw + ((size_t)(c0 + c) * Cup + co0 + q) * 4);
+    if (accumulate) { const float4 w = *o; v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w; }
+    *o = v;
+  }
+}
+
 // XCD-aware grid (wgrad_block_ids) from this many (C, N) tiles on: at least two XCDs' worth of resident workgroups,
 // and enough pixel strips that 8k splits still amortise the slab write.  Options "wgrad_xcd_min_tiles" (0 = never) and
 // "wgrad_xcd_min_strips" (api.cpp).
@@ -561,7 +592,10 @@ extern "C" int hpri_wgrad_reduce(const float* ws, float* dw, int N, int H, int W
   int splits, Cr, Nr;
   hpri_wgrad_plan(N, H, W, Cin_pad, Cout_pad, KS, &splits, &Cr, &Nr);
   dim3 grid((unsigned)hpri_cdiv(Cin, 32), (unsigned)Cout);
-  if (KS == 3) hipLaunchKernelGGL((wgrad_reduce_kernel<9>), grid, dim3(1024), 0, stream, ws, dw, splits, Cr, Nr, Cin, Cout, dst_mode, Cup, accumulate);
+  if (KS == 1 && dst_mode == 1 && Cup % 16 == 0 && ((uintptr_t)dw & 15) == 0)
+    hipLaunchKernelGGL(wgrad_reduce_convt_kernel, dim3((unsigned)hpri_cdiv(Cin, 64), (unsigned)(Cup / 16)), dim3(1024), 0, stream, ws, dw,
+                       splits, Cr, Nr, Cin, Cup, accumulate);
+  else if (KS == 3) hipLaunchKernelGGL((wgrad_reduce_kernel<9>), grid, dim3(1024), 0, stream, ws, dw, splits, Cr, Nr, Cin, Cout, dst_mode, Cup, accumulate);
   else hipLaunchKernelGGL((wgrad_reduce_kernel<1>), grid, dim3(1024), 0, stream, ws, dw, splits, Cr, Nr, Cin, Cout, dst_mode, Cup, accumulate);
   HPRI_CHECK_LAUNCH();
   return HPRI_OK;
