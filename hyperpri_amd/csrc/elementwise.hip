@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_v4_kernel(const float* __res
       const int ro = r >> 5;
       f32x4 v = {tile[r][(cq * 4 + 0 + ro) & 63], tile[r][(cq * 4 + 1 + ro) & 63], tile[r][(cq * 4 + 2 + ro) & 63],
                  tile[r][(cq * 4 + 3 + ro) & 63]};           // channels >= C were staged as zeros
-      if (c < Cw) *reinterpret_cast<f32x4*>(dst + ((long long)n * P + p) * cs + coff + c) = v;
+      if (dst != nullptr && c < Cw) *reinterpret_cast<f32x4*>(dst + ((long long)n * P + p) * cs + coff + c) = v;
       if (c < pl.cw) plane_store4(pl, (size_t)((long long)n * P + p), c, v[0], v[1], v[2], v[3]);
     }
   }
@@ -379,7 +379,8 @@ extern "C" int hpri_nchw_to_nhwc(const float* src, float* dst, int N, int C, lon
 extern "C" int hpri_nchw_to_nhwc_pl(const float* src, float* dst, int N, int C, long long P, int cs, int coff, int Cw,
                                     void* planes, long long plane_stride, int pl_cs, int pl_coff, int pl_cw, int npl,
                                     hipStream_t stream) {
-  HPRI_REQUIRE(src && dst && N > 0 && C > 0 && P > 0 && Cw >= C && Cw + coff <= cs, "nchw_to_nhwc: bad arguments");
+  // dst == NULL with planes given: bf16 planes only (the plane-mode first convolution and its weight gradient read nothing else)
+  HPRI_REQUIRE(src && (dst || planes) && N > 0 && C > 0 && P > 0 && Cw >= C && Cw + coff <= cs, "nchw_to_nhwc: bad arguments");
   PlaneOut po;
   { const int rc_ = hpri_plane_out(&po, planes, plane_stride, pl_cs, pl_coff, pl_cw, npl, C); if (rc_ != HPRI_OK) return rc_; }
   if (P % 4 == 0 && cs % 4 == 0 && coff % 4 == 0 && Cw % 4 == 0 && ((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0) {
@@ -388,7 +389,7 @@ extern "C" int hpri_nchw_to_nhwc_pl(const float* src, float* dst, int N, int C, 
     HPRI_CHECK_LAUNCH();
     return HPRI_OK;
   }
-  if (planes != nullptr) return hpri_set_error(HPRI_ERR_UNSUPPORTED, "nchw_to_nhwc_pl: plane output needs the 16-byte aligned form");
+  if (planes != nullptr || dst == nullptr) return hpri_set_error(HPRI_ERR_UNSUPPORTED, "nchw_to_nhwc_pl: plane output needs the 16-byte aligned form");
   dim3 grid((unsigned)hpri_cdiv64(P, 64), (unsigned)hpri_cdiv(Cw, 32), (unsigned)N);
   hipLaunchKernelGGL(nchw_to_nhwc_kernel, grid, dim3(256), 0, stream, src, dst, C, P, cs, coff, Cw);
   HPRI_CHECK_LAUNCH();

@@ -113,7 +113,8 @@ class Act:
     def from_tensor(t: torch.Tensor, npl: int = 0) -> "Act":
         """(N,C,H,W) tensor -> Act.  Zero-copy when t is channels-last with a stride that already
         provides the zero pad; otherwise one nchw->nhwc HIP transpose (dataset.py:267-271 hands NCHW), which for
-        ``npl`` > 0 also writes the bf16 planes the bf16-mode first convolution stages by DMA."""
+        ``npl`` > 0 also writes the bf16 planes the bf16-mode first convolution stages by DMA (``npl`` < 0: |npl| planes and
+        no fp32 copy at all)."""
         _require_cuda(t, "input tensor")
         N, C, H, W = t.shape
         st = t.stride()
@@ -128,10 +129,15 @@ class Act:
             return a
         if not t.is_contiguous():
             t = t.contiguous()   # rare: arbitrary strides from the caller
+        planes_only = npl < 0          # the caller's first layer and its weight gradient read bf16 planes and nothing else
+        npl = abs(npl)
         a = Act.new(N, H, W, C, t.device)
         if npl > 0 and PLANE_PRODUCERS and (H * W) % 4 == 0 and t.data_ptr() % 16 == 0:
             pl = new_planes(a, npl)
-            _lib.call("hpri_nchw_to_nhwc_pl", _p(t), a.ptr, N, C, H * W, a.cs, 0, a.cw, *_pl_args(pl), _stream())
+            if planes_only and H * W * max(_rup(C, 32), 128) * 2 < 0x7FFFFF00:     # (as _planes_fit for a first layer <= 128 wide)
+                a.f32_valid = False
+            _lib.call("hpri_nchw_to_nhwc_pl", _p(t), a.ptr if a.f32_valid else ctypes.c_void_p(0), N, C, H * W, a.cs, 0, a.cw,
+                      *_pl_args(pl), _stream())
         else:
             _lib.call("hpri_nchw_to_nhwc", _p(t), a.ptr, N, C, H * W, a.cs, 0, a.cw, _stream())
         return a
@@ -234,7 +240,9 @@ def _pl_args(pl: Optional[Planes]):
 def input_planes_for(module) -> int:
     """Planes the input layout pass should write for a network whose first layer is a 3x3 convolution."""
     prec = getattr(module, "hpri_precision", None) or DEFAULT_PRECISION
-    return 1 if (PLANE_CONV and PLANE_PRODUCERS and prec == "bf16") else 0
+    if not (PLANE_CONV and PLANE_PRODUCERS and prec == "bf16"):
+        return 0
+    return -1 if (PLANES_ONLY_ACT and PLANE_WGRAD) else 1      # -1: one plane and NO fp32 copy (Act.from_tensor)
 
 
 def planes_of(x: Act, npl: int = 1) -> Planes:
@@ -763,6 +771,8 @@ def _conv_folded_eval(x: Act, weight: torch.Tensor, bias: Optional[torch.Tensor]
     lowp = prec in LOWP
     split = _SPLIT.get(prec, 0)
     wino = prec == "fp32" and ks == 3 and _wino_ok(x, cout)
+    if not x.f32_valid and not (lowp and PLANE_CONV and prec == "bf16" and ks == 3 and x.pl is not None and _planes_fit(x, max(cin, cout))):
+        raise RuntimeError("hyperpri_amd: internal error: a planes-only activation reached a kernel that reads fp32")
 
     def build():
         global PACK_LAUNCHES
