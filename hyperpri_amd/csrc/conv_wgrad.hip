@@ -418,24 +418,36 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restr
 // ConvTranspose2d(k2, s2) weights (dst mode 1, T == 1): dW[c][co][tap] from slab rows n = tap * Cup + co.  One workgroup owns
 // 64 channels x 16 co x 4 taps: every thread sums its four (row, channel) pairs over the slabs in order (256-byte row segments),
 // the 64 x 64 tile turns in LDS, and each channel's 16 co x 4 taps leave as 256 contiguous bytes (the generic kernel above wrote
-// them as scattered 4-byte stores from 32-lane row segments, with 24 of its 32 slices idle at 8 slabs: 118 us for up1).
+// them as scattered 4-byte stores from 32-lane row segments, with most of its 32 slices idle at 4-16 slabs: 118 -> 9 us for
+// up1; used for <= 16 slabs).
 __global__ __launch_bounds__(1024) void wgrad_reduce_convt_kernel(const float* __restrict__ ws, float* __restrict__ dw, int splits,
                                                                   int Cr, int Nr, int Cin, int Cup, int accumulate) {
   __shared__ float tile[64][65];
   const int cl = threadIdx.x & 63, r = threadIdx.x >> 6;          // channel lane, row group (0..15)
   const int c0 = blockIdx.x * 64, co0 = blockIdx.y * 16;
   const size_t slab = (size_t)Cr * Nr;
+  // tile rows of this thread: rr = r + 16 j (tap = j, co = co0 + r), i.e. slab rows n_j = j * Cup + co0 + r
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  if (c0 + cl < Cin) {
+    const float* p = ws + (size_t)(co0 + r) * Cr + c0 + cl;
+    const size_t tapstep = (size_t)Cup * Cr;
+    int k = 0;
+    for (; k + 2 <= splits; k += 2) {               // 8 independent loads in flight; each (n, c) still sums its slabs in order
+      float v[8];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int rr = r + 16 * j;                                     // tile row: tap = rr >> 4, co = co0 + (rr & 15)
-    const int n = (rr >> 4) * Cup + co0 + (rr & 15);
-    float acc = 0.f;
-    if (c0 + cl < Cin) {
-      const float* p = ws + (size_t)n * Cr + c0 + cl;
-      for (int k = 0; k < splits; ++k) acc += p[(size_t)k * slab];
+      for (int j = 0; j < 4; ++j) {
+        v[j] = p[(size_t)k * slab + j * tapstep];
+        v[4 + j] = p[(size_t)(k + 1) * slab + j * tapstep];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { acc[j] += v[j]; acc[j] += v[4 + j]; }
     }
-    tile[rr][cl] = acc;
+    for (; k < splits; ++k)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] += p[(size_t)k * slab + j * tapstep];
   }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) tile[r + 16 * j][cl] = acc[j];
   __syncthreads();
   const int c = threadIdx.x >> 4, q = threadIdx.x & 15;            // output: channel c0 + c, co0 + q, taps 0..3 as one float4
   if (c0 + c < Cin) {
@@ -592,7 +604,9 @@ extern "C" int hpri_wgrad_reduce(const float* ws, float* dw, int N, int H, int W
   int splits, Cr, Nr;
   hpri_wgrad_plan(N, H, W, Cin_pad, Cout_pad, KS, &splits, &Cr, &Nr);
   dim3 grid((unsigned)hpri_cdiv(Cin, 32), (unsigned)Cout);
-  if (KS == 1 && dst_mode == 1 && Cup % 16 == 0 && ((uintptr_t)dw & 15) == 0)
+  // few slabs x many outputs (up1: 4 x 2 M): the transposing kernel, one thread per four outputs; many slabs x few outputs
+  // (up4: 256 x 32 K) keep the slice-parallel generic kernel
+  if (KS == 1 && dst_mode == 1 && Cup % 16 == 0 && ((uintptr_t)dw & 15) == 0 && splits <= 16)
     hipLaunchKernelGGL(wgrad_reduce_convt_kernel, dim3((unsigned)hpri_cdiv(Cin, 64), (unsigned)(Cup / 16)), dim3(1024), 0, stream, ws, dw,
                        splits, Cr, Nr, Cin, Cup, accumulate);
   else if (KS == 3) hipLaunchKernelGGL((wgrad_reduce_kernel<9>), grid, dim3(1024), 0, stream, ws, dw, splits, Cr, Nr, Cin, Cout, dst_mode, Cup, accumulate);
