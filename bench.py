@@ -216,8 +216,12 @@ def main():
     # main, weight-gradient, RCCL and hand-over streams each want their own hardware queue (engine.SIDE_STREAM_WITH_SINK);
     # the runtime reads this when it initialises, i.e. at the first HIP call below
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # HPRI_BENCH_ONE_GPU=1: rehearsal of the N > 1 control flow on a ONE-GPU box -- every rank computes on cuda:0 and the
+    # collective runs over gloo (RCCL refuses two ranks on one device).  Not a measurement: the line says so.
+    one_gpu = os.environ.get("HPRI_BENCH_ONE_GPU") == "1"
+    dev_index = 0 if one_gpu else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     use_pg = world > 1 or args.force_sync
     if use_pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -227,7 +231,10 @@ def main():
         saved_fd = os.dup(1)
         os.dup2(2, 1)
         try:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            if one_gpu:
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+            else:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
             dist.barrier()                        # communicator creation (eager with device_id, but make sure)
             torch.cuda.synchronize()
         finally:
@@ -280,7 +287,15 @@ def main():
     grad_sync = None
     if sync is not None:
         ov = sync.overlap_ms()           # last timed step: per bucket, all-reduce issue -> finish() return (stream time)
-        grad_sync = {"backend": "nccl (RCCL)", "grad_mb": round(sum(b.flat.numel() for b in sync.buckets) * 4 / 2 ** 20, 1),
+        equal = None
+        if one_gpu and world > 1:
+            # rehearsal check: after finish() every rank must hold the same (averaged) gradients
+            cs = torch.stack([torch.stack([p.grad.double().abs().sum(), p.grad.double().sum()]) for p in net.parameters()]).sum(0)
+            lo, hi = cs.clone(), cs.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            equal = bool(torch.equal(lo, hi))
+        grad_sync = {"backend": "gloo on one GPU (REHEARSAL, not a measurement)" if one_gpu else "nccl (RCCL)",
+                     "ranks_hold_equal_gradients": equal, "grad_mb": round(sum(b.flat.numel() for b in sync.buckets) * 4 / 2 ** 20, 1),
                      "gradients_written_in_place": True, "overlap": ov,
                      "note": "buckets are issued from inside the backward tape as their last gradient lands; "
                              "issue_to_finish_ms[0] is the window in which communication ran beside the rest of backward"}
