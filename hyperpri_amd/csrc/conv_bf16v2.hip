@@ -486,18 +486,27 @@ static inline int v2_wn(int Cout_pad) { return (Cout_pad % 128 == 0) ? 2 : 1; }
 
 // Split-K (host only): one workgroup per CU, so a grid that is not close to a multiple of 256 workgroups wastes whole
 // rounds; K is cut (<= 4 ways, >= 4 chunks per slice) where that brings workgroups per CU closer to an integer.
+// K slices for layers with few items.  A slice costs HBM traffic, not only a launch: the convolution writes k fp32 slabs
+// instead of one output and splitk_finish reads them back and writes the output (2 k output sizes more than k = 1), against
+// the whole rounds of 256 workgroups it buys.  Measured on the C2 step, interleaved on one box: the round-efficiency rule
+// alone (k = 3-4 on every layer below 304 x 484: more slab traffic than arithmetic at 152 x 242) 138.7 cubes/s, slices priced
+// at 850 TFLOP/s and 5 TB/s 145.2, no slices at all 147.7 -- with half a round or more of items (38 x 60: 144) the idle CUs
+// of the last round are cheaper than the slabs, and in backward the weight gradients of the second stream use them anyway.
+// Slices remain for problems below half a round, priced as above.
 static int v2_ksplit(int N, int H, int W, int Cin_pad, int Cout_pad) {
   const int wn = v2_wn(Cout_pad);
   const long long blocks = (long long)N * v2_segments(H, W, 8 / wn).tiles_img * (Cout_pad / (64 * wn));
   const int nchunks = Cin_pad / 32;
-  if (blocks >= 1024) return 1;
-  int best = 1; double best_eff = 0.0;
+  if (blocks >= 128) return 1;
+  const double t_compute = 2.0 * N * H * W * (double)Cin_pad * Cout_pad * 9.0 / 850e12;
+  const double out_bytes = 4.0 * N * H * W * (double)Cout_pad;
+  int best = 1; double best_t = 1e30;
   for (int k = 1; k <= 4; ++k) {
     if (k > 1 && nchunks / k < 4) break;
     const double per_cu = (double)blocks * k / 256.0;
     double eff = per_cu / (double)((long long)(per_cu + 0.999999));
-    if (k > 1) eff *= 0.97;
-    if (eff > best_eff + 1e-9) { best_eff = eff; best = k; }
+    const double t = t_compute / eff + (k > 1 ? 2.0 * k * out_bytes / 5e12 + 4e-6 : 0.0);
+    if (t < best_t - 1e-12) { best_t = t; best = k; }
   }
   return best;
 }
