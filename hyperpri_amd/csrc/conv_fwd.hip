@@ -626,21 +626,26 @@ static int launch_conv(const ConvFwdArgs& a0, hipStream_t stream) {
   return HPRI_OK;
 }
 
-// Split-K plan (host only).  A layer whose natural grid leaves CUs idle or badly balanced (38x60 and 76x121 levels)
-// is cut along K so that the number of equal-sized workgroups per CU is close to an integer.
+// Split-K plan (host only).  A layer whose natural grid leaves CUs idle or badly balanced (38x60 and 76x121 levels) is cut
+// along K so that the number of equal-sized workgroups per CU is close to an integer -- when that is worth its HBM traffic:
+// the kernel writes k fp32 slabs instead of one output and splitk_finish reads them back (2 k output sizes more than k = 1).
+// Priced with the rate the kernel family reaches (fp32 120, bf16 600, bf16x3 200, bf16x6 100 TFLOP/s) and 5 TB/s.
 static inline int conv_ksplit(int N, int H, int W, int Cin_pad, int Cout_pad, int KS, int epi, int amode, int prec = 0) {
   if (epi != HPRI_E_DIRECT) return 1;
   int wm, wn; conv_cfg(Cout_pad, &wm, &wn, prec);
   const long long blocks = (long long)N * conv_segments(H, W, wm).tiles_img * (Cout_pad / (64 * wn));
   const int nchunks = hpri_cdiv(Cin_pad, 32);
   if (blocks >= 2048) return 1;                       // >= 8 workgroups per CU: balance is already fine
-  int best = 1; double best_eff = 0.0;
+  const double rate = prec == 0 ? 120e12 : prec == 1 ? 600e12 : prec == 2 ? 200e12 : 100e12;
+  const double t_compute = 2.0 * N * H * W * (double)Cin_pad * Cout_pad * KS * KS / rate;
+  const double out_bytes = 4.0 * N * H * W * (double)Cout_pad;
+  int best = 1; double best_t = 1e30;
   for (int k = 1; k <= 4; ++k) {
     if (k > 1 && nchunks / k < 4) break;              // keep >= 4 chunks (128 channels x taps) per split
     const double per_cu = (double)blocks * k / 256.0;
-    double eff = per_cu / (double)((long long)(per_cu + 0.999999));
-    if (k > 1) eff *= 0.97;                           // price of the extra partial-sum round trip
-    if (eff > best_eff + 1e-9) { best_eff = eff; best = k; }
+    const double eff = per_cu / (double)((long long)(per_cu + 0.999999));
+    const double t = t_compute / eff + (k > 1 ? 2.0 * k * out_bytes / 5e12 + 4e-6 : 0.0);
+    if (t < best_t - 1e-12) { best_t = t; best = k; }
   }
   return best;
 }
