@@ -62,13 +62,14 @@ class Act:
 
     Invariant: channels [C, cw) (cw = C rounded up to 8) exist inside the stride and hold zeros, so
     consumers may run their K loop over ``cw`` channels."""
-    __slots__ = ("buf", "N", "H", "W", "C", "cs", "coff", "pl", "parent", "f32_valid")
+    __slots__ = ("buf", "N", "H", "W", "C", "cs", "coff", "pl", "parent", "f32_valid", "want_pl")
 
     def __init__(self, buf: torch.Tensor, N: int, H: int, W: int, C: int, cs: int, coff: int = 0):
         self.buf, self.N, self.H, self.W, self.C, self.cs, self.coff = buf, N, H, W, C, cs, coff
         self.pl: Optional["Planes"] = None      # bf16 plane copy of this activation (bf16 precision modes), see planes_of
         self.parent: Optional["Act"] = None     # wider buffer this Act is the leading channel slice of (new_with_room)
         self.f32_valid = True                   # False: only the bf16 planes were written (plane mode, inner tensor of a DoubleConv)
+        self.want_pl = 0                        # plane mode marker: planes a 3x3 consumer of this tensor (or of its pooled map) would read
 
     @property
     def cw(self) -> int:
@@ -213,6 +214,8 @@ PLANE_WGRAD = os.environ.get("HPRI_PLANE_WGRAD", "1") != "0"  # ... and their we
 PLANES_ONLY_GRAD = os.environ.get("HPRI_PLANES_ONLY_GRAD", "1") != "0"
 # ... and the inner tensor of a DoubleConv (conv -> BN -> ReLU -> [here] -> conv) likewise.  HPRI_PLANES_ONLY_ACT: 1 (default) / 0.
 PLANES_ONLY_ACT = os.environ.get("HPRI_PLANES_ONLY_ACT", "1") != "0"
+# no planes for tensors whose readers inside these networks are all fp32 (the output of a DoubleConv).  HPRI_PLANES_LAZY: 1 / 0.
+PLANES_LAZY = os.environ.get("HPRI_PLANES_LAZY", "1") != "0"
 PLANE_PRODUCERS = True       # producers (BN-apply, BN-backward, ...) write the planes themselves; False: generic pass only
 PLANE_CONVERSIONS = 0        # generic fp32 -> planes passes launched (fused producers do not count)
 
@@ -673,7 +676,11 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
         ppg = (x.P // G)
         # bf16 plane mode: the normalise pass also writes y as bf16 planes -- what the next 3x3 convolution (and the
         # weight gradient) stage by DMA -- so no conversion pass has to read y again
-        ypl = new_planes(y, 1) if (v2 and PLANE_PRODUCERS) else None
+        # -- for the inner tensor of a DoubleConv (``next_cout`` > 0).  The OUTPUT of a DoubleConv is read by max-pooling, the
+        # transposed convolution, the concat and the 1x1 output layer, all fp32 readers: no planes for it (573 MB of writes per
+        # C2 step that nobody read); ``want_pl`` still tells the pooling pass to write ITS result as planes.
+        y.want_pl = 1 if (v2 and PLANE_PRODUCERS) else 0
+        ypl = new_planes(y, 1) if (y.want_pl and (next_cout > 0 or not PLANES_LAZY)) else None
         # ``next_cout`` > 0: y is the inner tensor of a DoubleConv (the caller says so), read only by the next 3x3 convolution
         # of ``next_cout`` columns and by that convolution's weight gradient.  When those read planes, nobody reads fp32.
         if (ypl is not None and next_cout > 0 and PLANES_ONLY_ACT and PLANE_WGRAD and room == 0
@@ -880,7 +887,9 @@ def maxpool2(tape: Tape, x: Act) -> Act:
         raise RuntimeError("hyperpri_amd: MaxPool2d(2) needs H, W >= 2")
     y = Act.new(x.N, x.H // 2, x.W // 2, x.C, x.buf.device)
     # plane mode (the input carries bf16 planes): the pooled map is written as planes too, for the next 3x3 convolution
-    ypl = new_planes(y, x.pl.npl) if (x.pl is not None and PLANE_PRODUCERS) else None
+    npl = x.pl.npl if x.pl is not None else x.want_pl
+    ypl = new_planes(y, npl) if (npl > 0 and PLANE_PRODUCERS) else None
+    y.want_pl = npl
     _lib.call("hpri_maxpool2_fwd_pl", x.ptr, x.cs, x.coff, y.ptr, y.cs, y.coff, x.N, x.H, x.W, x.cw, *_pl_args(ypl), _stream())
     if tape.record:
         def bwd(tp: Tape) -> None:
