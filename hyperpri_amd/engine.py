@@ -62,13 +62,14 @@ class Act:
 
     Invariant: channels [C, cw) (cw = C rounded up to 8) exist inside the stride and hold zeros, so
     consumers may run their K loop over ``cw`` channels."""
-    __slots__ = ("buf", "N", "H", "W", "C", "cs", "coff", "pl", "parent", "f32_valid", "want_pl")
+    __slots__ = ("buf", "N", "H", "W", "C", "cs", "coff", "pl", "parent", "f32_valid", "want_pl", "pl_part")
 
     def __init__(self, buf: torch.Tensor, N: int, H: int, W: int, C: int, cs: int, coff: int = 0):
         self.buf, self.N, self.H, self.W, self.C, self.cs, self.coff = buf, N, H, W, C, cs, coff
         self.pl: Optional["Planes"] = None      # bf16 plane copy of this activation (bf16 precision modes), see planes_of
         self.parent: Optional["Act"] = None     # wider buffer this Act is the leading channel slice of (new_with_room)
         self.f32_valid = True                   # False: only the bf16 planes were written (plane mode, inner tensor of a DoubleConv)
+        self.pl_part = None                     # (Planes, channels filled so far): a concat buffer whose skip half is already in planes
         self.want_pl = 0                        # plane mode marker: planes a 3x3 consumer of this tensor (or of its pooled map) would read
 
     @property
@@ -216,6 +217,8 @@ PLANES_ONLY_GRAD = os.environ.get("HPRI_PLANES_ONLY_GRAD", "1") != "0"
 PLANES_ONLY_ACT = os.environ.get("HPRI_PLANES_ONLY_ACT", "1") != "0"
 # no planes for tensors whose readers inside these networks are all fp32 (the output of a DoubleConv).  HPRI_PLANES_LAZY: 1 / 0.
 PLANES_LAZY = os.environ.get("HPRI_PLANES_LAZY", "1") != "0"
+# a skip tensor's planes are written straight into the plane buffer of the decoder's concat.  HPRI_PLANES_CONCAT: 1 / 0.
+PLANES_CONCAT = os.environ.get("HPRI_PLANES_CONCAT", "1") != "0"
 PLANE_PRODUCERS = True       # producers (BN-apply, BN-backward, ...) write the planes themselves; False: generic pass only
 PLANE_CONVERSIONS = 0        # generic fp32 -> planes passes launched (fused producers do not count)
 
@@ -681,6 +684,14 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
         # C2 step that nobody read); ``want_pl`` still tells the pooling pass to write ITS result as planes.
         y.want_pl = 1 if (v2 and PLANE_PRODUCERS) else 0
         ypl = new_planes(y, 1) if (y.want_pl and (next_cout > 0 or not PLANES_LAZY)) else None
+        cpl = None
+        if ypl is None and y.want_pl and y.parent is not None and PLANES_CONCAT and y.C % 8 == 0:
+            # a skip tensor: its planes go where the decoder's concat will want them -- channels [0, Cskip) of a plane buffer of the
+            # concat's width; up_concat converts only the upsampled half afterwards (half the traffic of converting the concat)
+            par = y.parent
+            cs16 = _rup(par.C, 32)
+            cpl = Planes(torch.empty(par.P * cs16, dtype=torch.bfloat16, device=dev), par.P * cs16, cs16, 0, 1)
+            par.pl_part = (cpl, y.C)
         # ``next_cout`` > 0: y is the inner tensor of a DoubleConv (the caller says so), read only by the next 3x3 convolution
         # of ``next_cout`` columns and by that convolution's weight gradient.  When those read planes, nobody reads fp32.
         if (ypl is not None and next_cout > 0 and PLANES_ONLY_ACT and PLANE_WGRAD and room == 0
@@ -688,7 +699,8 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
             y.f32_valid = False
         _lib.call("hpri_bn_apply_relu_pl", yr.ptr, yr.cs, yr.coff, y.ptr if y.f32_valid else ctypes.c_void_p(0), y.cs, y.coff,
                   _p(scale), _p(shift),
-                  x.P, ppg, cout, y.cw, int(relu), *_pl_args(ypl), _stream())
+                  x.P, ppg, cout, y.cw, int(relu),
+                  *(_pl_args(ypl) if cpl is None else (_p(cpl.buf), cpl.plane, cpl.cs, 0, y.C, 1)), _stream())
     if not tape.record:
         return y
 
@@ -1033,6 +1045,14 @@ def up_concat(tape: Tape, x1: Act, skip: Act, weight: Optional[torch.Tensor], bi
         _lib.call("hpri_fill_pad", cat.ptr, cat.cs, cat.coff + cat.C, cat.N, cat.H, cat.W, cat.cw - cat.C, 0, 0, 0, 0, _stream())
     ups = cat.slice(skip.C, cup)
     _upsample_into(tape, x1, ups, weight, bias, need_dx1, precision)
+    if cat.pl_part is not None and cat.pl_part[1] == skip.C and cat.pl is None:
+        # plane mode: the skip half of the concat's planes was written by the skip's producer; convert the upsampled half only
+        global PLANE_CONVERSIONS
+        pl = cat.pl_part[0]
+        _lib.call("hpri_to_planes", ups.ptr, ups.cs, ups.coff, _p(pl.buf), pl.plane, pl.cs, skip.C, ups.P, cup, pl.cs - skip.C, 1,
+                  _stream())
+        PLANE_CONVERSIONS += 1
+        cat.pl, cat.pl_part = pl, None
     if tape.record:
         def bwd(tp: Tape) -> None:
             g = tp.grads.pop(id(cat), None)
