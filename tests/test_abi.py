@@ -78,3 +78,17 @@ def test_cpu_inputs_fail_loudly():
     import hyperpri_amd as H
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         H.OutConv(4, 1)(torch.zeros(1, 4, 2, 2))
+
+
+def test_split_k_is_priced_by_its_slab_traffic():
+    """Host-side planning (no GPU): the bf16 plane convolution takes K slices only below half a round of work items (every
+    CubeNET-64 layer from 38x60 up runs unsliced), and the direct kernels stop slicing where the slabs outweigh whole rounds."""
+    import ctypes
+    from hyperpri_amd import _lib
+    lib = _lib.load()
+    k = ctypes.c_int(); tl = ctypes.c_int(); ws = ctypes.c_size_t()
+    for (N, H, W, cin, cout) in [(2, 38, 60, 512, 1024), (2, 76, 121, 1024, 512), (2, 152, 242, 256, 256), (2, 608, 968, 256, 64)]:
+        assert lib.hpri_conv_bf16v2_plan(N, H, W, cin, cout, ctypes.byref(k), ctypes.byref(tl), ctypes.byref(ws)) == 0
+        assert k.value == 1 and ws.value == 0, (H, W, cin, cout, k.value)
+    assert lib.hpri_conv_bf16v2_plan(1, 16, 24, 1024, 64, ctypes.byref(k), ctypes.byref(tl), ctypes.byref(ws)) == 0
+    assert k.value > 1 and ws.value == k.value * 16 * 24 * 64       # a tiny problem: slices fill the chip
