@@ -367,7 +367,7 @@ def main():
         bf16_mode.update({
             "dtype": "bf16 operands / f32 accumulate (v_mfma_f32_32x32x16_bf16); activations, BN, pooling f32",
             "parity": "Dice/IoU level only (max |dlogit| 4.0e-2, <=0.35 % sign flips, |dDice| <= 1.5e-4 vs the fp32 oracle: "
-                      "profiles/r01_bf16_dice_parity.json); NOT the headline value"})
+                      "profiles/r02_bf16_dice_parity.json, plane kernels); NOT the headline value"})
 
     roofline = None
     if rank == 0 and not args.no_roofline:
