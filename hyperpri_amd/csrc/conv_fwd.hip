@@ -38,6 +38,7 @@ struct ConvFwdArgs {
   int H2, W2, py0, px0, Cup;  // S2D / D2S geometry: hi-res image dims, pad offsets, channels per tap
   int ksplit;            // >1: blockIdx.z takes a slice of the K chunks and stores raw partial sums to ws
   float* ws;             // [ksplit][N*H*W][Cout_pad] partial sums (split-K only)
+  __bf16* plp; int pl_cs, pl_coff;   // D2S only: the scattered result ALSO (y != nullptr) or ONLY (y == nullptr) as one bf16 plane
   // Tile segments: the image width is cut into column bands of tile width 32, 16, 8 or 4 (tile height grows as the
   // width shrinks, pixels per tile stay constant) so that W = 484 / 242 / 121 does not round up to 512 / 256 / 128.
   int nseg, tiles_img;
@@ -693,12 +694,15 @@ static int launch_conv_bf16(const ConvFwdArgs& a0, hipStream_t stream) {
 }
 
 // bf16-operand variant of hpri_conv_fwd (same modes); wp from hpri_pack_weight_bf16.
-extern "C" int hpri_conv_fwd_bf16(const float* x, int x_cs, int x_coff, const void* wp, const float* bias,
-                                  float* y, int y_cs, int y_coff, float* stats,
-                                  int N, int H, int W, int Cin_pad, int Cout, int Cout_pad, int y_cw,
-                                  int KS, int amode, int epi, int accumulate, int H2, int W2, int py0, int px0, int Cup,
-                                  int split, float* ws, size_t ws_floats, hipStream_t stream) {
-  HPRI_REQUIRE(x && wp && y, "conv_fwd_bf16: null pointer");
+static int conv_fwd_bf16_impl(const float* x, int x_cs, int x_coff, const void* wp, const float* bias,
+                              float* y, int y_cs, int y_coff, float* stats,
+                              int N, int H, int W, int Cin_pad, int Cout, int Cout_pad, int y_cw,
+                              int KS, int amode, int epi, int accumulate, int H2, int W2, int py0, int px0, int Cup,
+                              int split, float* ws, size_t ws_floats, void* planes, int pl_cs, int pl_coff, hipStream_t stream) {
+  HPRI_REQUIRE(x && wp && (y || planes), "conv_fwd_bf16: null pointer");
+  if (planes != nullptr)
+    HPRI_REQUIRE(epi == HPRI_E_D2S && split == 0 && !(accumulate & 1) && pl_cs % 8 == 0 && pl_coff % 8 == 0 && pl_coff + Cup <= pl_cs &&
+                     ((uintptr_t)planes & 15) == 0, "conv_fwd_bf16: plane output is for the plain-bf16 transposed convolution (D2S), not accumulating");
   HPRI_REQUIRE(N > 0 && H > 0 && W > 0, "conv_fwd_bf16: empty image");
   HPRI_REQUIRE(Cin_pad > 0 && Cin_pad % 8 == 0, "conv_fwd_bf16: Cin_pad must be a positive multiple of 8");
   HPRI_REQUIRE(Cout_pad % 64 == 0 && Cout <= Cout_pad && Cout > 0, "conv_fwd_bf16: Cout_pad must be a multiple of 64 >= Cout");
@@ -712,6 +716,7 @@ extern "C" int hpri_conv_fwd_bf16(const float* x, int x_cs, int x_coff, const vo
   a.N = N; a.H = H; a.W = W; a.Cin_pad = Cin_pad; a.Cout = Cout; a.Cout_pad = Cout_pad;
   a.y_cw = y_cw < Cout ? Cout : y_cw; a.accumulate = accumulate & 1; a.relu = (accumulate >> 1) & 1;
   a.H2 = H2; a.W2 = W2; a.py0 = py0; a.px0 = px0; a.Cup = Cup;
+  a.plp = reinterpret_cast<__bf16*>(planes); a.pl_cs = pl_cs; a.pl_coff = pl_coff;
   if (epi == HPRI_E_DIRECT) HPRI_REQUIRE(a.y_cw + y_coff <= y_cs, "conv_fwd_bf16: output channels exceed the channel stride");
   if (amode == HPRI_A_S2D || epi == HPRI_E_D2S) {
     HPRI_REQUIRE(KS == 1, "conv_fwd_bf16: S2D/D2S need KS == 1");
@@ -746,6 +751,26 @@ extern "C" int hpri_conv_fwd_bf16(const float* x, int x_cs, int x_coff, const vo
   return hpri_splitk_finish(ws, a.ksplit, Cout_pad, bias, y, y_cs, y_coff, stats, N, H * W, Cout, a.y_cw, accumulate & 1, a.relu, stream);
 }
 
+extern "C" int hpri_conv_fwd_bf16(const float* x, int x_cs, int x_coff, const void* wp, const float* bias,
+                                  float* y, int y_cs, int y_coff, float* stats,
+                                  int N, int H, int W, int Cin_pad, int Cout, int Cout_pad, int y_cw,
+                                  int KS, int amode, int epi, int accumulate, int H2, int W2, int py0, int px0, int Cup,
+                                  int split, float* ws, size_t ws_floats, hipStream_t stream) {
+  return conv_fwd_bf16_impl(x, x_cs, x_coff, wp, bias, y, y_cs, y_coff, stats, N, H, W, Cin_pad, Cout, Cout_pad, y_cw, KS, amode, epi,
+                            accumulate, H2, W2, py0, px0, Cup, split, ws, ws_floats, nullptr, 0, 0, stream);
+}
+
+// ConvTranspose2d(k2, s2) forward in the plain bf16 mode with the result written as ONE bf16 plane (channels [pl_coff, pl_coff +
+// Cup) of a plane buffer with pl_cs elements per hi-res pixel: the decoder's concat planes) -- also as fp32 when y != NULL.
+extern "C" int hpri_convt_fwd_bf16_pl(const float* x, int x_cs, int x_coff, const void* wp, const float* bias,
+                                      float* y, int y_cs, int y_coff, int N, int H, int W, int Cin_pad, int Cout, int Cout_pad,
+                                      int H2, int W2, int py0, int px0, int Cup, void* planes, int pl_cs, int pl_coff,
+                                      hipStream_t stream) {
+  HPRI_REQUIRE(planes != nullptr, "convt_fwd_bf16_pl: null plane pointer");
+  return conv_fwd_bf16_impl(x, x_cs, x_coff, wp, bias, y, y_cs, y_coff, nullptr, N, H, W, Cin_pad, Cout, Cout_pad, Cout, 1,
+                            HPRI_A_DIRECT, HPRI_E_D2S, 0, H2, W2, py0, px0, Cup, 0, nullptr, 0, planes, pl_cs, pl_coff, stream);
+}
+
 extern "C" int hpri_conv_fwd(const float* x, int x_cs, int x_coff, const float* wp, const float* bias,
                              float* y, int y_cs, int y_coff, float* stats,
                              int N, int H, int W, int Cin_pad, int Cout, int Cout_pad, int y_cw,
@@ -766,6 +791,7 @@ extern "C" int hpri_conv_fwd(const float* x, int x_cs, int x_coff, const float* 
   a.N = N; a.H = H; a.W = W; a.Cin_pad = Cin_pad; a.Cout = Cout; a.Cout_pad = Cout_pad;
   a.y_cw = y_cw < Cout ? Cout : y_cw; a.accumulate = accumulate & 1; a.relu = (accumulate >> 1) & 1;
   a.H2 = H2; a.W2 = W2; a.py0 = py0; a.px0 = px0; a.Cup = Cup;
+  a.plp = nullptr; a.pl_cs = 0; a.pl_coff = 0;
   a.ksplit = conv_ksplit(N, H, W, Cin_pad, Cout_pad, KS, epi, amode);
   a.ws = ws;
   if (a.ksplit > 1) {

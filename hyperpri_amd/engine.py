@@ -219,6 +219,8 @@ PLANES_ONLY_ACT = os.environ.get("HPRI_PLANES_ONLY_ACT", "1") != "0"
 PLANES_LAZY = os.environ.get("HPRI_PLANES_LAZY", "1") != "0"
 # a skip tensor's planes are written straight into the plane buffer of the decoder's concat.  HPRI_PLANES_CONCAT: 1 / 0.
 PLANES_CONCAT = os.environ.get("HPRI_PLANES_CONCAT", "1") != "0"
+# ... and the transposed convolution writes its half of those planes itself (no fp32 form, no conversion).  HPRI_PLANES_CONVT: 1 / 0.
+PLANES_CONVT = os.environ.get("HPRI_PLANES_CONVT", "1") != "0"
 PLANE_PRODUCERS = True       # producers (BN-apply, BN-backward, ...) write the planes themselves; False: generic pass only
 PLANE_CONVERSIONS = 0        # generic fp32 -> planes passes launched (fused producers do not count)
 
@@ -919,7 +921,7 @@ def maxpool2(tape: Tape, x: Act) -> Act:
 # upsample (ConvTranspose2d k2 s2 | bilinear x2) -> zero-pad -> concat with / multiply by the skip
 # --------------------------------------------------------------------------------------------------
 def _upsample_into(tape: Tape, x1: Act, dst: Act, weight: Optional[torch.Tensor], bias: Optional[torch.Tensor],
-                   need_dx1: bool, precision: Optional[str] = None) -> None:
+                   need_dx1: bool, precision: Optional[str] = None, dst_planes=None) -> bool:
     """Write up(x1), zero-padded to dst's H x W (left = floor(d/2), model_parts.py:73-80), into the view ``dst``.
     ``weight`` given: ConvTranspose2d(k2,s2) as one GEMM per input pixel (Cin -> 4*Cup) whose epilogue scatters the
     2x2 patches (model_parts.py:63-64); ``weight`` None: nn.Upsample(2, 'bilinear', align_corners=True) (:57)."""
@@ -947,7 +949,8 @@ def _upsample_into(tape: Tape, x1: Act, dst: Act, weight: Optional[torch.Tensor]
                 _lib.call("hpri_shift_copy", gu.ptr, gu.cs, gu.coff, H2, W2, gf.ptr, gf.cs, gf.coff, gf.N, full.H, full.W,
                           -py0, -px0, cup, int(acc), _stream())
             tape.nodes.append(bwd_crop)
-        return
+        return False
+    planes_written = False
     if dY or dX:
         _lib.call("hpri_fill_pad", dst.ptr, dst.cs, dst.coff, dst.N, H2, W2, cup, py0, py0 + 2 * x1.H, px0, px0 + 2 * x1.W, _stream())
     if weight is not None:
@@ -957,7 +960,16 @@ def _upsample_into(tape: Tape, x1: Act, dst: Act, weight: Optional[torch.Tensor]
         uprec = precision or DEFAULT_PRECISION
         bf16 = uprec in LOWP
         usplit = _SPLIT.get(uprec, 0)
-        if bf16:
+        if bf16 and usplit == 0 and dst_planes is not None and not (dY or dX) and PLANES_CONVT:
+            # plane mode: the 2x2 patches go straight into the concat's bf16 planes (``dst_planes`` = (Planes, first channel)); the
+            # fp32 form of the upsampled half has no reader (the next convolution and its weight gradient read planes)
+            wp, ncols_pad = _pack_bf16(weight, 2, cin, 4 * cup, 1, cup, cup, split=0)
+            pl, pc0 = dst_planes
+            with _timed("conv_fwd_bf16<1,4x1,direct,d2s+planes>", 2.0 * x1.N * x1.H * x1.W * cin * 4 * cup):
+                _lib.call("hpri_convt_fwd_bf16_pl", x1.ptr, x1.cs, x1.coff, _p(wp), _p(bias), ctypes.c_void_p(0), dst.cs, dst.coff,
+                          x1.N, x1.H, x1.W, x1.cw, 4 * cup, ncols_pad, H2, W2, py0, px0, cup, _p(pl.buf), pl.cs, pc0, _stream())
+            planes_written = True
+        elif bf16:
             wp, ncols_pad = _pack_bf16(weight, 2, cin, 4 * cup, 1, cup, cup, split=usplit)
             _conv_launch_bf16(x1, wp, bias, dst, None, x1.N, x1.H, x1.W, x1.cw, 4 * cup, ncols_pad, 4 * cup, 1,
                               epi=E_D2S, H2=H2, W2=W2, py0=py0, px0=px0, cup=cup, cin_true=cin, split=usplit)
@@ -972,7 +984,7 @@ def _upsample_into(tape: Tape, x1: Act, dst: Act, weight: Optional[torch.Tensor]
         _lib.call("hpri_upsample2x_fwd", x1.ptr, x1.cs, x1.coff, dst.ptr, dst.cs, dst.coff, x1.N, x1.H, x1.W, H2, W2,
                   py0, px0, cup, _stream())
     if not tape.record:
-        return
+        return planes_written
 
     def bwd(tp: Tape) -> None:
         gu = tp.grads.pop(id(dst), None)
@@ -1021,6 +1033,7 @@ def _upsample_into(tape: Tape, x1: Act, dst: Act, weight: Optional[torch.Tensor]
                 _conv_launch(gu, wpd, None, gx, None, x1.N, x1.H, x1.W, 4 * cup, cin, cols_pad, gx.cw, 1,
                              amode=A_S2D, accumulate=int(acc), H2=H2, W2=W2, py0=py0, px0=px0, cup=cup, cin_true=4 * cup)
     tape.nodes.append(bwd)
+    return planes_written
 
 
 def up_concat(tape: Tape, x1: Act, skip: Act, weight: Optional[torch.Tensor], bias: Optional[torch.Tensor],
@@ -1044,14 +1057,21 @@ def up_concat(tape: Tape, x1: Act, skip: Act, weight: Optional[torch.Tensor], bi
     if cat.cw > cat.C:
         _lib.call("hpri_fill_pad", cat.ptr, cat.cs, cat.coff + cat.C, cat.N, cat.H, cat.W, cat.cw - cat.C, 0, 0, 0, 0, _stream())
     ups = cat.slice(skip.C, cup)
-    _upsample_into(tape, x1, ups, weight, bias, need_dx1, precision)
-    if cat.pl_part is not None and cat.pl_part[1] == skip.C and cat.pl is None:
-        # plane mode: the skip half of the concat's planes was written by the skip's producer; convert the upsampled half only
+    part = cat.pl_part is not None and cat.pl_part[1] == skip.C and cat.pl is None
+    direct = part and cat.pl_part[0].cs == skip.C + cup       # no pad channels behind the concat's planes to zero
+    wrote = _upsample_into(tape, x1, ups, weight, bias, need_dx1, precision,
+                           dst_planes=(cat.pl_part[0], skip.C) if direct else None)
+    if part:
+        # plane mode: the skip half of the concat's planes was written by the skip's producer; the upsampled half by the transposed
+        # convolution itself, or -- pad ring, other precisions, bilinear -- by a conversion of that half only
         global PLANE_CONVERSIONS
         pl = cat.pl_part[0]
-        _lib.call("hpri_to_planes", ups.ptr, ups.cs, ups.coff, _p(pl.buf), pl.plane, pl.cs, skip.C, ups.P, cup, pl.cs - skip.C, 1,
-                  _stream())
-        PLANE_CONVERSIONS += 1
+        if wrote:
+            cat.f32_valid = False                   # channels [Cskip, Cskip + Cup) exist as planes only
+        else:
+            _lib.call("hpri_to_planes", ups.ptr, ups.cs, ups.coff, _p(pl.buf), pl.plane, pl.cs, skip.C, ups.P, cup, pl.cs - skip.C, 1,
+                      _stream())
+            PLANE_CONVERSIONS += 1
         cat.pl, cat.pl_part = pl, None
     if tape.record:
         def bwd(tp: Tape) -> None:

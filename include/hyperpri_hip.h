@@ -127,6 +127,11 @@ int hpri_conv_fwd_bf16(const float* x, int x_cs, int x_coff, const void* wp, con
                        int y_coff, float* stats, int N, int H, int W, int Cin_pad, int Cout, int Cout_pad, int y_cw,
                        int KS, int amode, int epi, int accumulate, int H2, int W2, int py0, int px0, int Cup, int split,
                        float* ws, size_t ws_floats, hipStream_t stream);
+/* ConvTranspose2d(k2,s2) forward (model_parts.py:63-64) in the plain bf16 mode, result as ONE bf16 plane: channels [pl_coff,
+ * pl_coff + Cup) of a plane buffer with pl_cs elements per hi-res pixel (the decoder's concat planes); also fp32 when y != NULL. */
+int hpri_convt_fwd_bf16_pl(const float* x, int x_cs, int x_coff, const void* wp, const float* bias, float* y, int y_cs,
+                           int y_coff, int N, int H, int W, int Cin_pad, int Cout, int Cout_pad, int H2, int W2, int py0, int px0,
+                           int Cup, void* planes, int pl_cs, int pl_coff, hipStream_t stream);
 
 /* bf16 activation PLANES (conv_bf16v2.hip): in the bf16 modes the producer of an activation writes it as bf16 NHWC
  * planes (plane 0 = bf16(x), plane 1 = bf16(x - hi), ...; `plane_stride` elements apart, `cs16` elements per pixel,

@@ -209,14 +209,14 @@ def test_held_out_split_dice_parity_slice():
 def test_plane_mode_traffic_savings_do_not_change_results(kind):
     """bf16 plane mode: tensors whose readers all read planes are written as planes ONLY (network input, inner tensor of a
     DoubleConv, BatchNorm-backward output), a DoubleConv's output gets no planes, and a skip's planes go into the concat's
-    plane buffer.  None of that touches a value any kernel reads: logits and every gradient are bit-identical with all
-    five switches off, and BN buffers too."""
+    plane buffer, whose other half the transposed convolution writes itself.  None of that touches a value any kernel reads:
+    logits and every gradient are bit-identical with all the switches off, and BN buffers too."""
     import hyperpri_amd as H
     from hyperpri_amd import engine as E
     net, x, m = _net(kind)
     H.set_precision(net, "bf16")
     sd = {k: v.clone() for k, v in net.state_dict().items()}
-    names = ["PLANES_ONLY_GRAD", "PLANES_ONLY_ACT", "PLANES_LAZY", "PLANES_CONCAT"]
+    names = ["PLANES_ONLY_GRAD", "PLANES_ONLY_ACT", "PLANES_LAZY", "PLANES_CONCAT", "PLANES_CONVT"]
     assert all(getattr(E, n) for n in names)          # the defaults under test
     lg1, g1 = _step(net, x, m)
     bufs1 = {k: v.clone() for k, v in net.named_buffers()}
