@@ -470,6 +470,28 @@ def _issue_stream(device) -> "torch.cuda.Stream":
     return st
 
 
+# Steps in flight.  A training loop that never reads a value back lets the host run many steps ahead of the GPU (a step is
+# enqueued in ~5 ms and runs for 13-33 ms).  Every step in flight holds its activations, so the caching allocator keeps asking
+# the driver for memory (12 allocations per step measured in a 10-step unfenced loop, 33 GiB reserved and growing) -- and the
+# first process after another one has left the GPU twice spent 190 ms per step in that state.  The networks therefore wait, at
+# the start of a forward, until the GPU has STARTED the previous forward (= finished the step before it): two steps in flight,
+# the host still a whole step ahead, memory bounded.  HPRI_STEPS_IN_FLIGHT: 2 (default); 0 = no limit.
+STEPS_IN_FLIGHT = int(os.environ.get("HPRI_STEPS_IN_FLIGHT", "2"))
+_flight: Dict[int, list] = {}
+
+
+def throttle(device) -> None:
+    if STEPS_IN_FLIGHT <= 0 or device.type != "cuda":
+        return
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    q = _flight.setdefault(idx, [])
+    while len(q) >= STEPS_IN_FLIGHT - 1 and q:
+        q.pop(0).synchronize()
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(device))
+    q.append(ev)
+
+
 def join_side(device) -> None:
     idx = device.index if device.index is not None else torch.cuda.current_device()
     st = _side_streams.get(idx)

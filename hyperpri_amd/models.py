@@ -47,6 +47,7 @@ class UNet(nn.Module):
     fused_tape = True
 
     def forward(self, x):
+        E.throttle(x.device)
         if self.fused_tape and not has_hooks(self):
             def prog(tape, a, need):
                 # the four skip tensors are produced inside the buffers their concats will use (model_parts.py:87)
@@ -111,6 +112,7 @@ class SpectralUNET(torch.nn.Module):
                               precision=getattr(self, "hpri_precision", None))
 
     def forward(self, x):
+        E.throttle(x.device)
         def prog(tape, a, need):
             x0 = self._layer(tape, a[0], self.tail, need[0])
             x1 = self._layer(tape, x0, self.down1)
@@ -189,6 +191,7 @@ class CubeNET(torch.nn.Module):
     def forward(self, x):
         if x.dim() != 5 or x.shape[2] != self.depth:
             raise ValueError(f"CubeNET expects (N,1,{self.depth},R,C), got {tuple(x.shape)}")
+        E.throttle(x.device)
         if self.fused_tape and not has_hooks(self):
             def prog(tape, a, need):
                 up4 = self.up4 if self.first_depth == 64 else self.upsample4
