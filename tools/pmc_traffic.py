@@ -41,6 +41,8 @@ def main():
         wr = w * 1024.0 / max(nw, 1)
         out[k] = {"launches": max(nf, nw), "read_bytes_per_launch": rd, "write_bytes_per_launch": wr,
                   "hbm_bytes_per_launch": rd + wr}
+    if not out:
+        raise SystemExit(f"no FETCH_SIZE / WRITE_SIZE rows under {src}: nothing written (bench.py replays profiles/{tag}_pmc_traffic.json)")
     os.makedirs(os.path.join(root, "profiles"), exist_ok=True)
     with open(os.path.join(root, "profiles", f"{tag}_pmc_traffic.json"), "w") as fh:
         json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on bench.py --steps 2 --warmup 1; "
