@@ -281,7 +281,7 @@ def main():
     #      until two bursts in a row are within 8 % of the fastest burst seen, for at most --settle-seconds; the number of bursts
     #      is agreed across ranks (every step holds collectives).  Allocator counters before / after are reported.
     settle = {"bursts": 0}
-    if args.settle_seconds > 0:
+    if args.settle_seconds > 0 and not one_gpu:       # (the one-GPU gloo rehearsal takes 44 s per step: no settle there)
         burst = max(1, min(args.steps, 5))
         ms0 = torch.cuda.memory_stats(dev)
         seen = []
