@@ -295,7 +295,7 @@ def main():
             seen.append((time.perf_counter() - s0) / burst)
             calm = len(seen) >= 2 and max(seen[-2:]) <= 1.08 * min(seen)
             stop = calm or (time.perf_counter() - t_begin) > args.settle_seconds or len(seen) >= 200
-            if world > 1:
+            if use_pg:                          # (also with one rank under --force-sync, so that this path runs on a one-GPU box)
                 flag = torch.tensor([0.0 if stop else 1.0], device=dev)
                 dist.all_reduce(flag, op=dist.ReduceOp.MAX)
                 stop = float(flag.item()) == 0.0
