@@ -95,6 +95,11 @@ class GradSync:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
         self.module = module
         self.broadcast_buffers = broadcast_buffers
+        # torch DDP's default (broadcast_buffers=True): rank 0's buffers (BN running statistics) replace everyone's at the start of
+        # every forward.  A pre-hook on the TOP-LEVEL module: the fused tape only steps aside for hooks on children.
+        self._buf_hook = None
+        if broadcast_buffers and self.world > 1:
+            self._buf_hook = module.register_forward_pre_hook(lambda m, inp: self.sync_buffers())
         self._accumulating = False      # inside no_sync(): gradients add up locally, no collective
         self._micro = 0                 # backward passes since the last finish()
         self._direct: set = set()       # ids of parameters whose gradient the engine wrote into the bucket this step
@@ -223,5 +228,8 @@ class GradSync:
         for h in self._hooks:
             h.remove()
         self._hooks.clear()
+        if self._buf_hook is not None:
+            self._buf_hook.remove()
+            self._buf_hook = None
         if engine._GRAD_SINK is self:
             engine.set_grad_sink(None)

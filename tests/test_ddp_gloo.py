@@ -130,3 +130,28 @@ def test_bucket_plan_keeps_the_last_bucket_small():
         assert id(net[0].weight) in {id(p) for p in sync.buckets[-1].params}
     finally:
         sync.remove()
+
+
+def _buf_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from hyperpri_amd.ddp import GradSync
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(4, 4), torch.nn.BatchNorm1d(4))
+    with torch.no_grad():
+        net[1].running_mean.fill_(float(rank + 1))          # the ranks' statistics have drifted apart
+    sync = GradSync(net, broadcast_buffers=True)
+    net.eval()
+    net(torch.randn(3, 4))                                  # the forward pre-hook broadcasts rank 0's buffers first
+    out[rank] = net[1].running_mean.clone()
+    sync.remove()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_broadcast_buffers_like_torch_ddp():
+    """GradSync(broadcast_buffers=True): rank 0's BN buffers replace everyone's at the start of a forward (torch DDP's default)."""
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_buf_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert torch.equal(out[0], torch.full((4,), 1.0)) and torch.equal(out[1], out[0])
