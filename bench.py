@@ -78,6 +78,25 @@ def pmc_traffic(tag):
     return None, src
 
 
+def first_conv_traffic():
+    """(measured HBM bytes per launch of the bf16-plane 238->64 convolution, source file), REPLAYED from the newest committed
+    profiles/rNN_first_conv_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/first_conv.py, gfx950
+    correction applied by tools/pmc_traffic.py); (None, None) if no such file is committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_first_conv_pmc_traffic.json")))
+    if not files:
+        return None, None
+    try:
+        kern = json.load(open(files[-1]))["kernels"]
+    except Exception:
+        return None, None
+    src = os.path.relpath(files[-1], ROOT) + " (replayed: rocprofv3 --pmc passes of tools/first_conv.py, not measured in this run)"
+    for k, v in kern.items():
+        if k.startswith("void conv_bf16v") or k.startswith("conv_bf16v"):
+            return round(v["hbm_bytes_per_launch"]), src
+    return None, src
+
+
 def host_cores():
     """Cores this process may actually use: scheduler affinity capped by the cgroup CPU quota (the GPU box
     exposes all host CPUs in the affinity mask but grants a share of them)."""
@@ -195,6 +214,8 @@ def main():
     ap.add_argument("--no-optimizer-leg", action="store_true",
                     help="skip the optimizer-step comparison (its torch.optim.Adam half is the only ATen work of a bench run; "
                          "profiling passes use this so that their kernel tables show the hot path alone)")
+    ap.add_argument("--no-training-shaped", action="store_true",
+                    help="skip the `value_training_shaped` leg (the same loop with FusedAdam.step() after every backward)")
     ap.add_argument("--bf16-steps", type=int, default=5,
                     help="extra steps in each of the precision modes bf16x6, bf16x3 and bf16 (reported as 'bf16x6_mode' / 'bf16x3_mode' / "
                          "'bf16_mode', never as 'value'); 0 = skip")
@@ -332,9 +353,44 @@ def main():
             equal = bool(torch.equal(lo, hi))
         grad_sync = {"backend": "gloo on one GPU (REHEARSAL, not a measurement)" if one_gpu else "nccl (RCCL)",
                      "ranks_hold_equal_gradients": equal, "grad_mb": round(sum(b.flat.numel() for b in sync.buckets) * 4 / 2 ** 20, 1),
-                     "gradients_written_in_place": True, "overlap": ov,
+                     "gradients_written_in_place": True, "overlap": ov, "buckets_issued_by": dict(sync.issued),
                      "note": "buckets are issued from inside the backward tape as their last gradient lands; "
                              "issue_to_finish_ms[0] is the window in which communication ran beside the rest of backward"}
+
+    # ---- the same loop as a training run shapes it: FusedAdam.step() after every backward, so every parameter changes every
+    #      step and the packed-weight caches (Winograd U, data-gradient panels) are REBUILT every step -- `value`'s loop keeps the
+    #      parameters frozen and therefore pays 0 pack launches.  Reported beside `value`, never as it (SURVEY.md 8d excludes the
+    #      optimizer from the metric).  All ranks take part (a step holds collectives); parameters are restored afterwards.
+    training_shaped = None
+    if not args.no_training_shaped:
+        with torch.no_grad():
+            saved = [p.detach().clone() for p in net.parameters()]
+        opt = HP.FusedAdam(net.parameters(), lr=1e-3)
+        packs0 = engine.PACK_LAUNCHES
+        for _ in range(2):
+            step(); opt.step()
+        fence()
+        packs1 = engine.PACK_LAUNCHES
+        tt = time.perf_counter()
+        for _ in range(args.steps):
+            loss_t = step(); opt.step()
+        fence()
+        dtt = time.perf_counter() - tt
+        if world > 1:
+            t = torch.tensor([dtt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dtt = float(t.item())
+        training_shaped = {"value": round(world * BATCH * args.steps / dtt, 4), "unit": "cubes/s", "steps": args.steps,
+                           "ms_per_step": round(dtt / args.steps * 1e3, 3), "final_loss": round(float(loss_t.detach()), 6),
+                           "pack_launches_per_step": (engine.PACK_LAUNCHES - packs1) / args.steps,
+                           "what": "forward + loss + backward" + (" + gradient all-reduce" if world > 1 else "") +
+                                   " + FusedAdam(lr=1e-3).step(): weights change every step, packed copies rebuilt every step"}
+        with torch.no_grad():
+            for p, q in zip(net.parameters(), saved):
+                p.copy_(q)
+        del saved, opt
+        engine.bump_param_epoch()
+        step(); fence()                    # re-pack outside anything timed below
 
     # ---- optimizer step: excluded from the metric, reported beside it ----
     optimizer_step = None
@@ -446,12 +502,13 @@ def main():
         import first_conv as FC
         torch.cuda.empty_cache()
         r = FC.measure(reps=10)
+        fc_bytes, fc_src = first_conv_traffic()
         first_conv = {"layer": "CubeNET-64 first_conv 238->64, 3x3, batch 2, forward (bias + BN partial statistics in the epilogue)",
                       "mode": "bf16 operand planes resident in HBM, both operands by LDS-DMA, v_mfma_f32_32x32x16_bf16, f32 accumulate "
                               "and f32 output (precision mode 'bf16'; the layout pass that writes the planes is a separate kernel)",
                       "ms": r["bf16_planes"]["ms"], "TF": r["bf16_planes"]["tflops"], "frac_of_2.5PF": r["bf16_planes"]["frac_of_2.5PF"],
                       "hbm_bytes_algorithmic": int(r["bf16_planes"]["algorithmic_hbm_mb"] * 1e6),
-                      "hbm_bytes_measured": "profiles/r02_first_conv_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/first_conv.py)",
+                      "hbm_bytes_measured": fc_bytes, "hbm_bytes_measured_source": fc_src,
                       "fp32_kernel_same_layer": r["fp32"], "fp32_winograd_same_layer": r.get("fp32_winograd")}
 
     cpu = None
@@ -477,6 +534,7 @@ def main():
             "model_tflops": round(value * GFLOP_PER_CUBE / 1e3 / world, 2),
             "model_tflops_note": "value x 2910.17 GFLOP/cube (direct-convolution flops of the reference graph, SURVEY.md 8d) per GPU; "
                                  "the fp32 path executes fewer multiplies than that (Winograd), so this can exceed the fp32 MFMA peak",
+            "value_training_shaped": training_shaped,
             "roofline": roofline, "roofline_238to64": first_conv, "cpu_baseline": cpu, "optimizer_step": optimizer_step, "bf16x6_mode": bf16x6_mode, "bf16x3_mode": bf16x3_mode, "bf16_mode": bf16_mode,
         }
         print(json.dumps(out), flush=True)

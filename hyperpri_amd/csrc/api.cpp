@@ -19,28 +19,54 @@ extern "C" int hpri_version(void) { return 100; }  // 0.1.0
 //                         0 = never                                                          (HPRI_WGRAD_XCD_MIN, 128)
 //   wgrad_xcd_min_strips  ... and only with at least this many 64-pixel strips                (HPRI_WGRAD_XCD_STRIPS, 2048)
 #include <stdlib.h>
-static int g_opt[3] = {-1, -1, -1};
+#include <atomic>
+#include <mutex>
+// Re-entrancy (include/hyperpri_hip.h: launchers may be called from any thread -- forward on the main thread, backward on
+// autograd's worker threads): the options are atomics initialised exactly once, from the environment, under std::call_once;
+// hpri_set_option stores with release order and the launchers' reads are relaxed loads of an int (a plan option changes
+// block order only, never results).
+static std::atomic<int> g_opt[3];
+static std::once_flag g_opt_once;
 static const char* const g_opt_name[3] = {"conv_nbx_min", "wgrad_xcd_min_tiles", "wgrad_xcd_min_strips"};
 static const char* const g_opt_env[3] = {"HPRI_NBX_MIN", "HPRI_WGRAD_XCD_MIN", "HPRI_WGRAD_XCD_STRIPS"};
 static const int g_opt_default[3] = {9, 128, 2048};
 
-int hpri_option(int idx) {
-  if (g_opt[idx] < 0) {
-    const char* e = getenv(g_opt_env[idx]);
-    g_opt[idx] = e ? atoi(e) : g_opt_default[idx];
-    if (g_opt[idx] < 0) g_opt[idx] = g_opt_default[idx];
+static void opt_init() {
+  for (int i = 0; i < 3; ++i) {
+    const char* e = getenv(g_opt_env[i]);
+    int v = e ? atoi(e) : g_opt_default[i];
+    if (v < 0) v = g_opt_default[i];
+    g_opt[i].store(v, std::memory_order_relaxed);
   }
-  return g_opt[idx];
+}
+
+int hpri_option(int idx) {
+  std::call_once(g_opt_once, opt_init);
+  return g_opt[idx].load(std::memory_order_relaxed);
 }
 
 extern "C" int hpri_set_option(const char* name, int value) {
+  std::call_once(g_opt_once, opt_init);
   for (int i = 0; i < 3; ++i)
     if (name && strcmp(name, g_opt_name[i]) == 0) {
       if (value < 0) return hpri_set_error(HPRI_ERR_ARG, "set_option: value must be >= 0");
-      g_opt[i] = value;
+      g_opt[i].store(value, std::memory_order_release);
       return HPRI_OK;
     }
   return hpri_set_error(HPRI_ERR_ARG, "set_option: unknown option");
+}
+
+// Compute units of the device the calling thread has current (hipDeviceProp_t.multiProcessorCount), cached per device:
+// launch plans and the two-workgroups-per-CU stagger of the Winograd kernel size themselves by it instead of assuming 256.
+static std::atomic<int> g_cus[16];
+int hpri_cu_count() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 256;
+  int n = g_cus[dev].load(std::memory_order_relaxed);
+  if (n > 0) return n;
+  if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+  g_cus[dev].store(n, std::memory_order_relaxed);
+  return n;
 }
 
 extern "C" int hpri_get_option(const char* name) {

@@ -34,7 +34,9 @@ struct WinoArgs {
   float4* stats;                // [N*tiles_img][Cout_pad] (mean, M2, count, 0) or nullptr
   int N, H, W, Cin_pad, Cout, Cout_pad, y_cw, accumulate, relu;
   int tiles_x, tiles_y;
-  unsigned long long* stamps;   // diagnostic builds (-DHPRI_STAMPS) only
+#ifdef HPRI_STAMPS
+  unsigned long long* stamps;   // diagnostic builds only (tools/build_wino_diag.sh)
+#endif
 };
 
 #ifdef HPRI_STAMPS
@@ -399,8 +401,11 @@ extern "C" int hpri_wino_pack(const float* w, float* up, const float* colscale, 
   return HPRI_OK;
 }
 
-static unsigned long long* hpri_wino_stamps = nullptr;   // diagnostic builds: set through hpri_wino_set_stamps
+// stamp buffer: diagnostic builds (-DHPRI_STAMPS) only; the product library keeps no state (re-entrant, include/hyperpri_hip.h)
+#ifdef HPRI_STAMPS
+static unsigned long long* hpri_wino_stamps = nullptr;
 extern "C" int hpri_wino_set_stamps(unsigned long long* p) { hpri_wino_stamps = p; return HPRI_OK; }
+#endif
 
 extern "C" int hpri_conv_wino_plan(int N, int H, int W, int* stat_tiles) {
   *stat_tiles = N * hpri_cdiv(H, 16) * hpri_cdiv(W, 16);
@@ -429,7 +434,9 @@ extern "C" int hpri_conv_wino(const float* x, int x_cs, int x_coff, const float*
   HPRI_REQUIRE(y_cs % 4 == 0 && y_coff % 4 == 0 && a.y_cw % 4 == 0 && ((uintptr_t)y & 15) == 0,
                "conv_wino: the output view must be float4-aligned (stride, offset and written width multiples of 4)");
   a.tiles_x = hpri_cdiv(W, 16); a.tiles_y = hpri_cdiv(H, 16);
+#ifdef HPRI_STAMPS
   a.stamps = hpri_wino_stamps;
+#endif
   dim3 grid((unsigned)(N * a.tiles_x * a.tiles_y * (Cout_pad / 64)), 1u, 1u);
   hipLaunchKernelGGL(conv_wino_kernel, grid, dim3(512), 0, stream, a);
   HPRI_CHECK_LAUNCH();

@@ -27,7 +27,11 @@ struct Wino4Args {
   float4* stats;                // [N*tiles_img][Cout_pad] (mean, M2, count, 0) or nullptr
   int N, H, W, Cin_pad, Cout, Cout_pad, y_cw, accumulate, relu;
   int tiles_x, tiles_y;
-  unsigned long long* stamps;   // diagnostic builds (-DHPRI_STAMPS) only
+  int ncu, stagger_cycles;      // compute units of the device (host: hipDeviceProp_t.multiProcessorCount) and the one-off delay of
+                                // each CU's second occupant (below); 0 cycles = no stagger
+#ifdef HPRI_STAMPS
+  unsigned long long* stamps;   // diagnostic builds only (tools/build_wino4_diag.sh)
+#endif
 };
 
 #ifdef HPRI_STAMPS
@@ -156,11 +160,12 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(Wino4Args a) {
 #ifndef WINO4_NO_STAGGER
   // Two workgroups share a CU, and all workgroups of a launch take the same time: without help both run their output
   // transform (no MFMAs) at the same moment, for the whole launch.  The SECOND occupants of the first round (the dispatcher
-  // hands workgroups 0-255 to 256 different CUs, 256-511 to the same CUs again) sleep once for a little more than an epilogue
-  // (exchange + output transform + statistics: ~16.4 k cycles when shared); from then on each CU's two slots stay that far
-  // apart and one's epilogue runs under the other's main loop (tools/wino4_stamps.py: 97-99 % of the epilogue time covered).
-  if ((blockIdx.x >> 8) == 1) {
-    const long long wait = 20000;
+  // hands workgroups [0, ncu) to ncu different CUs, [ncu, 2 ncu) to the same CUs again) sleep once for a little more than
+  // an epilogue (exchange + output transform + statistics: ~16.4 k cycles when shared); from then on each CU's two slots stay
+  // that far apart and one's epilogue runs under the other's main loop (tools/wino4_stamps.py: 97-99 % of the epilogue time
+  // covered).  Placement is not promised by HIP: a different dispatch order costs the overlap, never correctness.
+  if ((unsigned)(blockIdx.x - a.ncu) < (unsigned)a.ncu && a.stagger_cycles > 0) {
+    const long long wait = a.stagger_cycles;
     const long long t0 = (long long)__builtin_amdgcn_s_memtime();
     while ((long long)__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(32);
   }
@@ -381,8 +386,17 @@ extern "C" int hpri_wino4_pack(const float* w, float* up, const float* colscale,
   return HPRI_OK;
 }
 
-static unsigned long long* hpri_wino4_stamps = nullptr;   // diagnostic builds: set through hpri_wino4_set_stamps
+// Stamp buffer of the diagnostic build (-DHPRI_STAMPS, tools/build_wino4_diag.sh).  The product library keeps no state: the
+// entry point exists (the header declares it) and refuses.
+#ifdef HPRI_STAMPS
+static unsigned long long* hpri_wino4_stamps = nullptr;
 extern "C" int hpri_wino4_set_stamps(unsigned long long* p) { hpri_wino4_stamps = p; return HPRI_OK; }
+#else
+extern "C" int hpri_wino4_set_stamps(unsigned long long*) {
+  return hpri_set_error(HPRI_ERR_UNSUPPORTED, "wino4_set_stamps: this library was built without -DHPRI_STAMPS");
+}
+#endif
+#define W4_STAGGER_CYCLES 20000   // a little more than one epilogue with a partner on the CU (16.4 k cycles, tools/wino4_stamps.py)
 
 extern "C" int hpri_conv_wino4_plan(int N, int H, int W, int* stat_tiles) {
   *stat_tiles = N * hpri_cdiv(H, 8) * hpri_cdiv(W, 16);
@@ -413,7 +427,10 @@ extern "C" int hpri_conv_wino4(const float* x, int x_cs, int x_coff, const float
   HPRI_REQUIRE(y_cs % 4 == 0 && y_coff % 4 == 0 && a.y_cw % 4 == 0 && ((uintptr_t)y & 15) == 0,
                "conv_wino4: the output view must be float4-aligned (stride, offset and written width multiples of 4)");
   a.tiles_x = hpri_cdiv(W, 16); a.tiles_y = hpri_cdiv(H, 8);
+  a.ncu = hpri_cu_count(); a.stagger_cycles = W4_STAGGER_CYCLES;
+#ifdef HPRI_STAMPS
   a.stamps = hpri_wino4_stamps;
+#endif
   dim3 grid((unsigned)(N * a.tiles_x * a.tiles_y * (Cout_pad / 64)), 1u, 1u);
   hipLaunchKernelGGL(conv_wino4_kernel, grid, dim3(256), 0, stream, a);
   HPRI_CHECK_LAUNCH();

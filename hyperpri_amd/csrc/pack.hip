@@ -138,3 +138,29 @@ extern "C" int hpri_pack_weight_bf16_scaled(const float* w, void* wp, const floa
   HPRI_CHECK_LAUNCH();
   return HPRI_OK;
 }
+
+// ---- content fingerprint of a parameter tensor (engine.py: HPRI_PACK_VERIFY / engine.verify_packs) ----------------------
+// The packed panels are caches keyed on torch's version counter, which writes through `p.data` do not advance.  The verify
+// mode of the cache compares this 64-bit fingerprint of the fp32 bits (sum of word * odd multiplier of its index: integer
+// adds, so the result does not depend on the order the workgroups finish in) against the one taken when the pack was built.
+__global__ void fingerprint_kernel(const unsigned* __restrict__ w, long long n, unsigned long long* __restrict__ out) {
+  unsigned long long acc = 0ull;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    acc += (unsigned long long)w[i] * (2ull * (unsigned long long)i + 0x9E3779B97F4A7C15ull);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if ((threadIdx.x & 63) == 0) atomicAdd(out, acc);
+}
+
+extern "C" int hpri_fingerprint(const void* w, long long n_words, unsigned long long* out, hipStream_t stream) {
+  HPRI_REQUIRE(w && out && n_words > 0, "fingerprint: null pointer or empty tensor");
+  HPRI_REQUIRE(((uintptr_t)w & 3) == 0 && ((uintptr_t)out & 7) == 0, "fingerprint: misaligned pointer");
+  if (hipMemsetAsync(out, 0, sizeof(unsigned long long), stream) != hipSuccess)
+    return hpri_set_error(HPRI_ERR_LAUNCH, "fingerprint: hipMemsetAsync failed");
+  long long blocks = (n_words + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(fingerprint_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, reinterpret_cast<const unsigned*>(w),
+                     n_words, out);
+  HPRI_CHECK_LAUNCH();
+  return HPRI_OK;
+}

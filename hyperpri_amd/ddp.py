@@ -99,19 +99,51 @@ class GradSync:
         # every forward.  A pre-hook on the TOP-LEVEL module: the fused tape only steps aside for hooks on children.
         self._buf_hook = None
         if broadcast_buffers and self.world > 1:
-            self._buf_hook = module.register_forward_pre_hook(lambda m, inp: self.sync_buffers())
+            # training-mode forwards only: an eval / validation forward that runs on a subset of the ranks (rank-0-only
+            # validation) must not enter a collective the other ranks never join
+            self._buf_hook = module.register_forward_pre_hook(lambda m, inp: self.sync_buffers() if m.training else None)
+        if self.collective and engine.SIDE_STREAM and not engine.SIDE_STREAM_WITH_SINK and not GradSync._warned_queues:
+            GradSync._warned_queues = True
+            import sys
+            print("hyperpri_amd.GradSync: GPU_MAX_HW_QUEUES could not be raised to 8 any more (the HIP runtime was initialised "
+                  "before hyperpri_amd was imported); weight gradients stay on the main stream under the gradient sink "
+                  "(~3 % slower backward).  Export GPU_MAX_HW_QUEUES=8 before the process starts.", file=sys.stderr, flush=True)
         self._accumulating = False      # inside no_sync(): gradients add up locally, no collective
         self._micro = 0                 # backward passes since the last finish()
         self._direct: set = set()       # ids of parameters whose gradient the engine wrote into the bucket this step
         self._events = None             # (per-bucket issue events, end-of-finish event) of the last step
+        # who issued the all-reduces since construction: "tape" = from inside the engine's backward tape (ready()), "hook" = from a
+        # post-accumulate-grad hook (plain autograd), "finish" = left over for finish() (no overlap): tests and the bench line read it
+        self.issued = {"tape": 0, "hook": 0, "finish": 0}
+        self._issuer = "finish"
         engine.set_grad_sink(self)
 
-    # torch DDP broadcasts BN buffers from rank 0 every forward (broadcast_buffers=True default);
-    # call this before eval/checkpoint to mimic it
+    _warned_queues = False
+
+    # torch DDP broadcasts BN buffers from rank 0 every forward (broadcast_buffers=True default): ONE coalesced broadcast there,
+    # and one here -- the float buffers (running_mean / running_var) travel as one flat tensor per dtype, the integer ones
+    # (num_batches_tracked) as another: 2 collectives per call instead of 54 for CubeNET.  Call it yourself before an
+    # eval / checkpoint on all ranks to mimic DDP when broadcast_buffers is off.
     def sync_buffers(self) -> None:
-        if self.world > 1:
-            for b in self.module.buffers():
-                dist.broadcast(b, 0, group=self.group)
+        if self.world <= 1:
+            return
+        by_type: Dict[Tuple[torch.dtype, torch.device], List[torch.Tensor]] = {}
+        for b in self.module.buffers():
+            by_type.setdefault((b.dtype, b.device), []).append(b)
+        for bufs in by_type.values():
+            if len(bufs) == 1:
+                dist.broadcast(bufs[0], 0, group=self.group)
+                continue
+            flat = torch.cat([b.reshape(-1) for b in bufs])
+            dist.broadcast(flat, 0, group=self.group)
+            off, views = 0, []
+            for b in bufs:
+                views.append(flat[off:off + b.numel()].view_as(b))
+                off += b.numel()
+            with torch.no_grad():
+                torch._foreach_copy_(bufs, views)       # one multi-tensor launch back into the modules' buffers
+        if any(b.is_cuda for b in self.module.buffers()):
+            engine.bump_bn_epoch()          # folded eval packs depend on the running statistics
 
     @contextlib.contextmanager
     def no_sync(self):
@@ -137,7 +169,11 @@ class GradSync:
 
     def ready(self, p: torch.Tensor) -> None:
         b, i = self._where[id(p)]
-        self._landed(b, i)
+        self._issuer = "tape"
+        try:
+            self._landed(b, i)
+        finally:
+            self._issuer = "finish"
 
     def completes_bucket(self, p: torch.Tensor) -> bool:
         """Will ``ready(p)`` issue a bucket's all-reduce?  (The engine joins its second stream first in that case.)"""
@@ -153,7 +189,11 @@ class GradSync:
         v = b.view(i)
         if p.grad.data_ptr() != v.data_ptr():     # (p.grad may BE the view: installed by the previous finish())
             v.copy_(p.grad)                       # with micro-batches autograd has already summed them into p.grad
-        self._landed(b, i)
+        self._issuer = "hook"
+        try:
+            self._landed(b, i)
+        finally:
+            self._issuer = "finish"
 
     def _guard(self, b: _Bucket, i: int) -> None:
         if b.work is not None or i in b.landed:
@@ -168,6 +208,7 @@ class GradSync:
             self._issue(b)
 
     def _issue(self, b: _Bucket) -> None:
+        self.issued[self._issuer] += 1
         if b.flat.is_cuda:
             b.t_issue = torch.cuda.Event(enable_timing=True)
             b.t_issue.record()

@@ -295,6 +295,17 @@ class Tape:
         self.keep: List[object] = []
         self.used_side = False
         self.sunk: Dict[int, torch.Tensor] = {}     # parameters whose gradient was written into the grad sink's storage
+        self.uses: Dict[int, int] = {}              # id(parameter) -> ops recorded on this tape that will produce a gradient for it
+        self._touched: List[int] = []               # parameters the running node asked a gradient slot for
+
+    def note_params(self, *params: Optional[torch.Tensor]) -> None:
+        """Called by an op while it records its backward node: it will contribute to these parameters' gradients.  A
+        parameter used by several nodes (tied weights, a module called twice inside one tape) is handed to the gradient sink
+        only after the LAST of them has run."""
+        if self.record:
+            for p in params:
+                if p is not None and p.requires_grad:
+                    self.uses[id(p)] = self.uses.get(id(p), 0) + 1
 
     def grad_slot(self, a: Act) -> Tuple[Act, bool]:
         """(gradient view for ``a``, accumulate?) -- allocates a fresh buffer the first time."""
@@ -315,6 +326,7 @@ class Tape:
             _lib.call("hpri_copy_slice", view.ptr, view.cs, view.coff, g.ptr, g.cs, g.coff, g.P, _rup(a.C, 4), 1, _stream())
 
     def param_slot(self, p: torch.Tensor) -> Tuple[torch.Tensor, int]:
+        self._touched.append(id(p))
         g = self.param_grads.get(id(p))
         if g is not None:
             return g, 1
@@ -333,27 +345,32 @@ class Tape:
 
     def backward(self) -> None:
         sink = _GRAD_SINK
-        seen = 0
         for node in reversed(self.nodes):
+            self._touched.clear()
             node(self)
-            if sink is not None and len(self.sunk) > seen:
-                # every parameter belongs to exactly one op, so its gradient is final once that op's node has run
-                for p in list(self.sunk.values())[seen:]:
-                    # a bucket's all-reduce orders itself behind the CURRENT stream: before the hand-over that completes a
-                    # bucket, the main stream waits for the weight gradients still running on the second one
-                    if self.used_side and getattr(sink, "completes_bucket", lambda q: True)(p):
-                        # neither compute stream is held up: a third stream waits for both and hands the bucket over
-                        dev = p.device
-                        iss = _issue_stream(dev)
-                        iss.wait_stream(torch.cuda.current_stream(dev))
-                        iss.wait_stream(_side(dev))
-                        with torch.cuda.stream(iss):
-                            sink.ready(p)
-                    else:
+            if sink is None or not self._touched:
+                continue
+            for pid in dict.fromkeys(self._touched):        # each parameter once per node, in the order the node asked
+                left = self.uses.get(pid, 1) - 1            # (an op that did not announce itself counts as the only user)
+                self.uses[pid] = left
+                p = self.sunk.get(pid)
+                if p is None or left > 0:
+                    continue                                # not in a bucket, or another node still adds to this gradient
+                # a bucket's all-reduce orders itself behind the CURRENT stream: before the hand-over that completes a
+                # bucket, the main stream waits for the weight gradients still running on the second one
+                if self.used_side and getattr(sink, "completes_bucket", lambda q: True)(p):
+                    # neither compute stream is held up: a third stream waits for both and hands the bucket over
+                    dev = p.device
+                    iss = _issue_stream(dev)
+                    iss.wait_stream(torch.cuda.current_stream(dev))
+                    iss.wait_stream(_side(dev))
+                    with torch.cuda.stream(iss):
                         sink.ready(p)
-                seen = len(self.sunk)
+                else:
+                    sink.ready(p)
         self.nodes.clear()
         self.keep.clear()
+        self.uses.clear()
 
 
 class BNRef:
@@ -475,7 +492,7 @@ def _issue_stream(device) -> "torch.cuda.Stream":
 # the driver for memory (12 allocations per step measured in a 10-step unfenced loop, 33 GiB reserved and growing) -- and the
 # first process after another one has left the GPU twice spent 190 ms per step in that state.  The networks therefore wait, at
 # the start of a forward, until the GPU has STARTED the previous forward (= finished the step before it): two steps in flight,
-# the host still a whole step ahead, memory bounded.  HPRI_STEPS_IN_FLIGHT: 2 (default); 0 = no limit.
+# the host still a whole step ahead, memory bounded.  HPRI_STEPS_IN_FLIGHT: 2 (default); 1 = serialised; 0 = no limit.
 STEPS_IN_FLIGHT = int(os.environ.get("HPRI_STEPS_IN_FLIGHT", "2"))
 _flight: Dict[int, list] = {}
 
@@ -485,6 +502,11 @@ def throttle(device) -> None:
         return
     idx = device.index if device.index is not None else torch.cuda.current_device()
     q = _flight.setdefault(idx, [])
+    if STEPS_IN_FLIGHT == 1:                 # fully serialised: the previous step has FINISHED before this one is enqueued
+        torch.cuda.current_stream(device).synchronize()
+        q.clear()
+        return
+    # an event marks the START of a forward: with N - 1 of them outstanding, N steps are in flight once this one is enqueued
     while len(q) >= STEPS_IN_FLIGHT - 1 and q:
         q.pop(0).synchronize()
     ev = torch.cuda.Event()
@@ -522,18 +544,78 @@ def set_grad_sink(sink) -> None:
 _PARAM_EPOCH = 0
 _BN_EPOCH = 0               # bumped whenever a training-mode forward updates running statistics (raw-pointer writes)
 _PACK_CACHE: Dict[int, Dict[tuple, tuple]] = {}
-PACK_CACHE = True
+# What the key CANNOT see: writes through ``p.data`` (p.data.copy_/mul_/clamp_/normal_: EMA swaps, weight clipping, .data-style
+# init) leave ``p._version`` where it was.  After such a write call ``bump_param_epoch()``, or run with
+#   HPRI_PACK_CACHE=0   / ``with engine.pack_cache(False):``   -- no cache: every forward repacks (~0.3 ms per C2 step), or
+#   HPRI_PACK_VERIFY=1  / ``with engine.verify_packs():``      -- every cache hit is checked against a 64-bit content
+#                          fingerprint of the parameter (hpri_fingerprint; one small kernel and a host read-back per hit: a
+#                          debugging mode, it serialises host and device); a mismatch rebuilds the pack and counts in
+#                          PACK_VERIFY_MISSES.
+PACK_CACHE = os.environ.get("HPRI_PACK_CACHE", "1") != "0"
+PACK_VERIFY = os.environ.get("HPRI_PACK_VERIFY", "0") == "1"
+PACK_VERIFY_MISSES = 0      # stale packs the verify mode caught (a caller wrote parameter memory behind the version counter)
 PACK_LAUNCHES = 0           # pack kernels launched (tests / profiles)
 
 
+def bump_bn_epoch() -> None:
+    """BatchNorm running statistics were rewritten (a broadcast from rank 0, a raw-pointer kernel)."""
+    global _BN_EPOCH
+    _BN_EPOCH += 1
+
+
 def bump_param_epoch() -> None:
-    """Tell the engine that parameter memory was modified behind torch's back (raw-pointer kernels)."""
+    """Tell the engine that parameter memory was modified behind torch's back (raw-pointer kernels, ``p.data`` writes)."""
     global _PARAM_EPOCH
     _PARAM_EPOCH += 1
 
 
-def _cached_pack(w: torch.Tensor, key: tuple, build, extra=None):
-    """``extra``: further state the packed copy depends on (BN statistics of a folded conv); a mismatch rebuilds."""
+class pack_cache:
+    """``with engine.pack_cache(False):`` -- run the enclosed forwards without the packed-weight cache."""
+
+    def __init__(self, on: bool):
+        self.on = bool(on)
+
+    def __enter__(self):
+        global PACK_CACHE
+        self.old, PACK_CACHE = PACK_CACHE, self.on
+        return self
+
+    def __exit__(self, *exc):
+        global PACK_CACHE
+        PACK_CACHE = self.old
+        return False
+
+
+class verify_packs:
+    """``with engine.verify_packs():`` -- check every packed-weight cache hit against the parameter's content fingerprint."""
+
+    def __init__(self, on: bool = True):
+        self.on = bool(on)
+
+    def __enter__(self):
+        global PACK_VERIFY
+        self.old, PACK_VERIFY = PACK_VERIFY, self.on
+        return self
+
+    def __exit__(self, *exc):
+        global PACK_VERIFY
+        PACK_VERIFY = self.old
+        return False
+
+
+def _fingerprint(*tensors: Optional[torch.Tensor]) -> tuple:
+    """Content fingerprints (host integers; synchronises) of the given device tensors."""
+    live = [t for t in tensors if t is not None]
+    out = torch.empty(len(live), dtype=torch.int64, device=live[0].device)
+    for i, t in enumerate(live):
+        _lib.call("hpri_fingerprint", _p(t), t.numel() * t.element_size() // 4, ctypes.c_void_p(out.data_ptr() + 8 * i), _stream())
+    return tuple(out.tolist())
+
+
+def _cached_pack(w: torch.Tensor, key: tuple, build, extra=None, also=()):
+    """``extra``: further state the packed copy depends on (BN statistics of a folded conv); a mismatch rebuilds.
+    ``also``: further tensors whose CONTENT the pack depends on (verify mode fingerprints them together with ``w``)."""
+    global PACK_VERIFY_MISSES
     if not PACK_CACHE:
         return build()
     ent = _PACK_CACHE.get(id(w))
@@ -549,8 +631,14 @@ def _cached_pack(w: torch.Tensor, key: tuple, build, extra=None):
             weakref.finalize(w, _PACK_CACHE.pop, wid, None)
         ent = _PACK_CACHE[id(w)] = {"stamp": stamp, "packs": {}}
     got = ent["packs"].get(key)
+    fp = _fingerprint(w, *also) if PACK_VERIFY else None
+    if got is not None and got[0] == extra and fp is not None and got[2] is not None and got[2] != fp:
+        PACK_VERIFY_MISSES += 1     # same version counter, different bytes: the parameter was written through .data
+        got = None
     if got is None or got[0] != extra:
-        got = ent["packs"][key] = (extra, build())
+        got = ent["packs"][key] = (extra, build(), fp)
+    elif fp is not None and got[2] is None:
+        got = ent["packs"][key] = (got[0], got[1], fp)       # first verified use of a pack built with verification off
     return got[1]
 
 
@@ -747,6 +835,7 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
             # plane mode: when the weight gradient and the data gradient both read the bf16 planes, nobody reads the fp32 form
             f32_dead = (dpl is not None and ks == 3 and split == 0 and PLANE_CONV and PLANE_WGRAD and PLANES_ONLY_GRAD
                         and (need_dx or weight.requires_grad))
+            dyr.f32_valid = not f32_dead
             _lib.call("hpri_bn_relu_bwd_pl", g.ptr, g.cs, g.coff, yr.ptr, yr.cs, yr.coff,
                       ctypes.c_void_p(0) if f32_dead else dyr.ptr, dyr.cs, dyr.coff,
                       _p(mean), _p(invstd), _p(scale), _p(shift), _p(dgam), _p(dbet), acc_g, _p(db), acc_b,
@@ -793,6 +882,7 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
                 _conv_launch(dyr, wpd, None, gx, None, x.N, x.H, x.W, dyr.cw, cin, cin_cols_pad, gx.cw, ks, accumulate=int(acc),
                              cin_true=cout)
 
+    tape.note_params(weight, bias, *((bn.weight, bn.bias) if bn is not None else ()))
     tape.nodes.append(bwd)
     return y
 
@@ -842,7 +932,8 @@ def _conv_folded_eval(x: Act, weight: torch.Tensor, bias: Optional[torch.Tensor]
             return (t.data_ptr(), -1)
     bn_state = (_BN_EPOCH, ver(bn.running_mean), ver(bn.running_var), ver(bn.weight), ver(bn.bias),
                 None if bias is None else ver(bias))
-    wp, fold = _cached_pack(weight, ("fold", prec, ks, _wino_sfx() if wino else False), build, extra=bn_state)
+    wp, fold = _cached_pack(weight, ("fold", prec, ks, _wino_sfx() if wino else False), build, extra=bn_state,
+                            also=(bn.running_mean, bn.running_var, bn.weight, bn.bias, bias))
     fbias = fold[cout:]
     y = Act.new_with_room(x.N, x.H, x.W, cout, room, dev)
     if wino:
@@ -865,6 +956,10 @@ def _wgrad(x: Act, dy: Act, dw: torch.Tensor, accumulate: int, cin: int, cout: i
     N, H, W = (N or x.N), (H or x.H), (W or x.W)
     cin_pad = x.cw
     cout_pad = _rup(cout, 64)
+    plane_route = bf16 and split == 0 and ks == 3 and bmode == A_DIRECT and dst_mode == 0 and PLANE_CONV and PLANE_WGRAD
+    if not plane_route and not (x.f32_valid and dy.f32_valid):
+        # every kernel below reads fp32: a planes-only operand (bf16 plane mode) would be read as uninitialised memory
+        raise RuntimeError("hyperpri_amd: internal error: a planes-only activation reached a weight-gradient kernel that reads fp32")
     splits = ctypes.c_int(); cr = ctypes.c_int(); nr = ctypes.c_int()
     _lib.call("hpri_wgrad_plan", N, H, W, cin_pad, cout_pad, ks, ctypes.byref(splits), ctypes.byref(cr), ctypes.byref(nr))
     ws = _ws(splits.value * ks * ks * cr.value * nr.value, x.buf.device)
@@ -886,7 +981,7 @@ def _wgrad(x: Act, dy: Act, dw: torch.Tensor, accumulate: int, cin: int, cout: i
                       N, H, W, cin_pad, cout_pad, _stream())
         _lib.call("hpri_wino_wgrad_reduce", _p(wws), _p(dw), N, H, W, cin, cin_pad, cout, cout_pad, accumulate, _stream())
         return
-    if bf16 and split == 0 and ks == 3 and bmode == A_DIRECT and dst_mode == 0 and PLANE_CONV and PLANE_WGRAD:
+    if plane_route:
         # bf16 planes of both operands (written by their producers) -> LDS by DMA (conv_wgrad_bf16v2.hip)
         xpl, dpl = planes_of(x, 1), planes_of(dy, 1)
         sp = ctypes.c_int(); pcr = ctypes.c_int(); pnr = ctypes.c_int()
@@ -982,7 +1077,7 @@ def _upsample_into(tape: Tape, x1: Act, dst: Act, weight: Optional[torch.Tensor]
         uprec = precision or DEFAULT_PRECISION
         bf16 = uprec in LOWP
         usplit = _SPLIT.get(uprec, 0)
-        if bf16 and usplit == 0 and dst_planes is not None and not (dY or dX) and PLANES_CONVT:
+        if bf16 and usplit == 0 and dst_planes is not None and not (dY or dX) and PLANES_CONVT and PLANE_CONV and PLANE_WGRAD:
             # plane mode: the 2x2 patches go straight into the concat's bf16 planes (``dst_planes`` = (Planes, first channel)); the
             # fp32 form of the upsampled half has no reader (the next convolution and its weight gradient read planes)
             wp, ncols_pad = _pack_bf16(weight, 2, cin, 4 * cup, 1, cup, cup, split=0)
@@ -1054,6 +1149,7 @@ def _upsample_into(tape: Tape, x1: Act, dst: Act, weight: Optional[torch.Tensor]
                 wpd, cols_pad = _pack(weight, 3, 4 * cup, cin, 1, cup, cup)
                 _conv_launch(gu, wpd, None, gx, None, x1.N, x1.H, x1.W, 4 * cup, cin, cols_pad, gx.cw, 1,
                              amode=A_S2D, accumulate=int(acc), H2=H2, W2=W2, py0=py0, px0=px0, cup=cup, cin_true=4 * cup)
+    tape.note_params(weight, bias)
     tape.nodes.append(bwd)
     return planes_written
 
@@ -1080,7 +1176,10 @@ def up_concat(tape: Tape, x1: Act, skip: Act, weight: Optional[torch.Tensor], bi
         _lib.call("hpri_fill_pad", cat.ptr, cat.cs, cat.coff + cat.C, cat.N, cat.H, cat.W, cat.cw - cat.C, 0, 0, 0, 0, _stream())
     ups = cat.slice(skip.C, cup)
     part = cat.pl_part is not None and cat.pl_part[1] == skip.C and cat.pl is None
-    direct = part and cat.pl_part[0].cs == skip.C + cup       # no pad channels behind the concat's planes to zero
+    # ... and only when every reader of the upsampled half reads planes: the next 3x3 convolution (PLANE_CONV) AND its weight
+    # gradient (PLANE_WGRAD); with either switched off the round-1 kernels read the fp32 form, which must then exist
+    direct = (part and cat.pl_part[0].cs == skip.C + cup       # no pad channels behind the concat's planes to zero
+              and PLANE_CONV and PLANE_WGRAD)
     wrote = _upsample_into(tape, x1, ups, weight, bias, need_dx1, precision,
                            dst_planes=(cat.pl_part[0], skip.C) if direct else None)
     if part:
@@ -1202,6 +1301,7 @@ def out_conv(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.Tens
                 gxp, gcs, gco, gcw, acc = ctypes.c_void_p(0), 0, 0, 0, False
             _lib.call("hpri_outconv_bwd", _p(gy), x.ptr, x.cs, x.coff, _p(weight), gxp, gcs, gco, gcw, int(acc),
                       _p(dw), _p(db), acc_w, _p(ws), ws.numel(), x.N, x.H * x.W, C, K, _stream())
+        tape.note_params(weight, bias)
         tape.nodes.append(bwd)
     return y, holder
 

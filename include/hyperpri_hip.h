@@ -15,7 +15,10 @@
  *     library never allocates, frees or synchronises.  All launches go to the given hipStream_t.
  *   - Return value: 0 = ok, <0 = error (HPRI_ERR_*); hpri_last_error() returns the thread's message.
  *     Nothing throws across the ABI.
- *   - Launchers are re-entrant and hold no state (autograd calls them from worker threads).
+ *   - Launchers are re-entrant (autograd calls them from worker threads).  The only process-wide state is immutable after
+ *     its first use or atomic: the three launch-plan options (read once from the environment under std::call_once, then
+ *     atomics; hpri_set_option) and a per-device cache of the compute-unit count; the error message is thread-local.  Stamp
+ *     buffers exist in the diagnostic builds (-DHPRI_STAMPS) only.
  */
 #ifndef HYPERPRI_HIP_H
 #define HYPERPRI_HIP_H
@@ -67,6 +70,12 @@ int hpri_pack_weight_scaled(const float* w, float* wp, const float* colscale, in
 int hpri_pack_weight_bf16_scaled(const float* w, void* wp, const float* colscale, int K, int Ncols, int Ncols_pad, int T,
                                  int src_d1, int split, hipStream_t stream);
 
+/* 64-bit content fingerprint of n_words 32-bit words (order-independent integer sum; `out` is zeroed by the call, on the
+ * stream).  Used by the verify mode of the packed-weight cache (hyperpri_amd/engine.py: HPRI_PACK_VERIFY=1), which catches
+ * parameters rewritten through `p.data` -- writes the nn.Parameter version counter (the cache key that stands in for
+ * model_parts.py:22's weight tensor) does not see. */
+int hpri_fingerprint(const void* w, long long n_words, unsigned long long* out, hipStream_t stream);
+
 /* ---- implicit-GEMM convolution, fp32 MFMA (conv_fwd.hip) ----------------------------------------
  * Replaces F.conv2d / F.conv3d / F.linear / F.conv_transpose2d forward and their data gradients
  * (model_parts.py:22,25,63,96; models.py:108,169,177,198).  hpri_conv_fwd_plan (host only) returns the split-K
@@ -100,6 +109,7 @@ int hpri_conv_wino4_plan(int N, int H, int W, int* stat_tiles);
 int hpri_conv_wino4(const float* x, int x_cs, int x_coff, const float* up, const float* bias, float* y, int y_cs, int y_coff,
                     float* stats, int N, int H, int W, int Cin_pad, int Cout, int Cout_pad, int y_cw, int accumulate,
                     hipStream_t stream);
+/* diagnostic builds (-DHPRI_STAMPS, tools/build_wino4_diag.sh) only; the product library returns HPRI_ERR_UNSUPPORTED */
 int hpri_wino4_set_stamps(unsigned long long* stamps);
 
 

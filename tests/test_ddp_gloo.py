@@ -142,16 +142,25 @@ def _buf_worker(rank, world, port, out):
         net[1].running_mean.fill_(float(rank + 1))          # the ranks' statistics have drifted apart
     sync = GradSync(net, broadcast_buffers=True)
     net.eval()
-    net(torch.randn(3, 4))                                  # the forward pre-hook broadcasts rank 0's buffers first
-    out[rank] = net[1].running_mean.clone()
+    if rank == 0:
+        net(torch.randn(3, 4))                              # validation on rank 0 only: an eval forward enters no collective
+    assert torch.equal(net[1].running_mean, torch.full((4,), float(rank + 1)))
+    net.train()
+    with torch.no_grad():
+        net[1].momentum = 0.0                               # keep the statistics as broadcast
+        net(torch.randn(3, 4))                              # the forward pre-hook broadcasts rank 0's buffers first (ONE flat
+    out[rank] = net[1].running_mean.clone()                 # tensor per dtype: float statistics, int64 counters)
+    out[10 + rank] = int(net[1].num_batches_tracked)
     sync.remove()
     dist.barrier()
     dist.destroy_process_group()
 
 
 def test_broadcast_buffers_like_torch_ddp():
-    """GradSync(broadcast_buffers=True): rank 0's BN buffers replace everyone's at the start of a forward (torch DDP's default)."""
+    """GradSync(broadcast_buffers=True): rank 0's BN buffers replace everyone's at the start of a training-mode forward (torch DDP's
+    default), as one coalesced broadcast per dtype; eval-mode forwards do not communicate."""
     mgr = mp.Manager()
     out = mgr.dict()
     mp.spawn(_buf_worker, args=(2, _free_port(), out), nprocs=2, join=True)
     assert torch.equal(out[0], torch.full((4,), 1.0)) and torch.equal(out[1], out[0])
+    assert out[10] == out[11] == 1

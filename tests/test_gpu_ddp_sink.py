@@ -1,0 +1,80 @@
+"""N > 1 through the ENGINE SINK (PLTrainer.py:434-442's DDP step): two ranks as fresh child processes, both
+on cuda:0, gloo collective, tiny CubeNET(6,1,64) as ONE autograd node.  After finish() both ranks hold identical gradients,
+equal to the mean of the two per-rank ORACLE gradients; the buckets' all-reduces were issued from inside the backward tape
+(not by autograd hooks, not left for finish()).  Needs a real MI355X: ``-m gpu``."""
+import os
+import socket
+import subprocess
+import sys
+from collections import OrderedDict
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import record_margin
+from oracle import hyperpri_oracle as O
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _u(seed, shape):
+    return torch.from_numpy(O._u(seed, int(np.prod(shape))).reshape(shape).copy())
+
+
+def _oracle_grads(rank):
+    sd = O.synth_state_dict(O.cubenet_shapes(6, 1, 64))
+    x = _u(1235 + rank, (2, 1, 6, 36, 50))
+    m = (_u(4321 + rank, (2, 1, 36, 50)) > 0.9).float()
+    _, loss, grads = O.train_step(O.cubenet_forward, sd, x, m, first_depth=64)
+    return loss, grads
+
+
+def test_two_ranks_engine_sink_equals_mean_of_oracle_gradients(tmp_path):
+    world, port = 2, str(_free_port())
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4", GPU_MAX_HW_QUEUES="8")
+    outs = [str(tmp_path / f"rank{r}.npz") for r in range(world)]
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_ddp_sink_rank.py"), str(r), str(world), port, outs[r]],
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    logs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=420)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        logs.append(o)
+    for r, p in enumerate(procs):
+        assert p.returncode == 0, f"rank {r} failed:\n{logs[r][-3000:]}"
+    z = [np.load(o) for o in outs]
+    # ---- control flow: several buckets, every one issued from inside the tape, on both steps ----
+    for r in range(world):
+        nb = int(z[r]["buckets"])
+        assert nb >= 2
+        assert int(z[r]["issued_tape"]) == 2 * nb, (int(z[r]["issued_tape"]), int(z[r]["issued_hook"]), int(z[r]["issued_finish"]))
+        assert int(z[r]["issued_hook"]) == 0 and int(z[r]["issued_finish"]) == 0
+        assert int(z[r]["left_for_finish0"]) == 0 and int(z[r]["left_for_finish1"]) == 0
+        assert len(z[r]["issue_to_finish_ms"]) == nb          # overlap_ms(): one issue event per bucket
+    # ---- values: identical on both ranks, and the mean of the per-rank oracle gradients ----
+    ora = [_oracle_grads(r) for r in range(world)]
+    for r in range(world):
+        assert abs(float(z[r]["loss0"]) - ora[r][0]) < 1e-5
+    worst = 0.0
+    for k in ora[0][1]:
+        a0, a1 = z[0]["g/" + k], z[1]["g/" + k]
+        assert np.array_equal(a0, a1), k                      # one all-reduce result, two holders
+        want = (ora[0][1][k].double() + ora[1][1][k].double()).numpy() / 2
+        err = float(np.linalg.norm(a0.astype(np.float64) - want))
+        ref = float(np.linalg.norm(want))
+        if ref < 1e-6:                                        # conv biases in front of a training-mode BN: zero up to rounding
+            assert err < 1e-5, k
+            continue
+        worst = max(worst, err / ref)
+        assert err <= 2e-3 * ref, (k, err, ref)
+    record_margin("ddp_sink/world2/grad_rel_l2", worst, 2e-3)

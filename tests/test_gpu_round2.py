@@ -234,3 +234,60 @@ def test_plane_mode_traffic_savings_do_not_change_results(kind):
         assert torch.equal(a, b)
     for k, v in net.named_buffers():
         assert torch.equal(v, bufs1[k]), k
+
+
+@pytest.mark.parametrize("off", ["PLANE_WGRAD", "PLANE_CONV"])
+def test_plane_mode_with_round1_kernels_reads_valid_fp32(off):
+    """HPRI_PLANE_WGRAD=0 / HPRI_PLANE_CONV=0: the round-1 kernels read fp32 activations, so no tensor they
+    read may exist as planes only (round 2: the transposed convolution wrote the upsampled half of a concat as planes
+    only and the round-1 weight gradient then read uninitialised fp32 -- silently wrong dW).  Gradients with the switch
+    off must agree with the all-planes run to bf16 level, tensor by tensor."""
+    import hyperpri_amd as H
+    from hyperpri_amd import engine as E
+    net, x, m = _net("cube64")
+    H.set_precision(net, "bf16")
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    lg1, g1 = _step(net, x, m)
+    old = getattr(E, off)
+    try:
+        setattr(E, off, False)
+        net.load_state_dict(sd)
+        lg2, g2 = _step(net, x, m)
+    finally:
+        setattr(E, off, old)
+    assert float((lg1 - lg2).abs().max()) < 0.1
+    for (k, _), a, b in zip(net.named_parameters(), g1, g2):
+        ref = float(a.double().norm())
+        err = float((a.double() - b.double()).norm())
+        assert torch.isfinite(b).all(), k
+        assert err <= 0.05 * ref + 1e-6, (k, err, ref)      # same bf16 products, different summation order / kernels
+
+
+def test_packed_weight_cache_and_data_writes():
+    """``p.data`` writes do not advance ``p._version`` (the cache key): the documented remedies -- bump_param_epoch(), the
+    pack_cache(False) context, the verify mode's content fingerprint -- all make the next forward use the new weights."""
+    import hyperpri_amd as H
+    from hyperpri_amd import engine as E
+    net, x, m = _net("cube64")
+    net.eval()
+    with torch.no_grad():
+        l0 = net(x).clone()
+        w = net.inc2[0].weight
+        v0 = w._version
+        w.data.mul_(2.0)
+        assert w._version == v0                       # the hole this test is about
+        stale = net(x).clone()
+        with E.pack_cache(False):
+            fresh = net(x).clone()
+        assert torch.equal(stale, l0) and not torch.equal(fresh, l0)
+        miss0 = E.PACK_VERIFY_MISSES
+        with E.verify_packs():
+            ver = net(x).clone()                      # first verified use: fingerprints are taken of the CURRENT bytes ...
+            w.data.mul_(0.5)
+            back = net(x).clone()                     # ... so this hit sees different bytes and rebuilds
+        assert E.PACK_VERIFY_MISSES > miss0
+        assert torch.equal(back, l0)
+        w.data.mul_(2.0)
+        E.bump_param_epoch()
+        assert torch.equal(net(x), fresh)
+        del ver

@@ -1,0 +1,69 @@
+"""The reverse-mode tape's hand-over of parameter gradients to a gradient sink (engine.Tape.backward): a parameter that
+several recorded ops contribute to (tied weights, a module called twice inside one fused tape) is handed over only after
+the LAST of them has run -- a bucket's all-reduce must not start while a later node still accumulates into its slot.
+Host logic only: fake nodes, a fake sink, CPU tensors."""
+import torch
+
+from hyperpri_amd import engine
+
+
+class _Sink:
+    def __init__(self, params):
+        self.store = {id(p): torch.zeros_like(p) for p in params}
+        self.order = []
+        self.seen_at_ready = {}
+
+    def slot(self, p):
+        return self.store[id(p)], False
+
+    def ready(self, p):
+        self.order.append(id(p))
+        self.seen_at_ready[id(p)] = self.store[id(p)].clone()
+
+
+def test_shared_parameter_is_handed_over_after_its_last_node():
+    w_shared = torch.nn.Parameter(torch.zeros(3))
+    w_single = torch.nn.Parameter(torch.zeros(3))
+    sink = _Sink([w_shared, w_single])
+    engine.set_grad_sink(sink)
+    try:
+        tape = engine.Tape(True)
+
+        def node(params, value):
+            def bwd(tp):
+                for p in params:
+                    g, acc = tp.param_slot(p)
+                    if acc:
+                        g += value
+                    else:
+                        g.fill_(value)
+            tape.note_params(*params)
+            tape.nodes.append(bwd)
+        node([w_shared], 1.0)               # forward order: shared, single, shared again
+        node([w_single], 5.0)
+        node([w_shared], 2.0)
+        tape.backward()
+    finally:
+        engine.set_grad_sink(None)
+    # backward order: second use of the shared weight (not final yet), the single-use weight, first use of the shared weight
+    assert sink.order == [id(w_single), id(w_shared)]
+    assert torch.equal(sink.seen_at_ready[id(w_shared)], torch.full((3,), 3.0))     # both contributions were in
+    assert torch.equal(sink.seen_at_ready[id(w_single)], torch.full((3,), 5.0))
+
+
+def test_unannounced_parameter_counts_as_single_use():
+    w = torch.nn.Parameter(torch.zeros(2))
+    sink = _Sink([w])
+    engine.set_grad_sink(sink)
+    try:
+        tape = engine.Tape(True)
+        tape.nodes.append(lambda tp: tp.param_slot(w)[0].fill_(1.0))
+        tape.backward()
+    finally:
+        engine.set_grad_sink(None)
+    assert sink.order == [id(w)]
+
+
+def test_throttle_is_a_no_op_on_cpu_and_parses_its_bound():
+    engine.throttle(torch.device("cpu"))
+    assert engine.STEPS_IN_FLIGHT >= 0
