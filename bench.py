@@ -371,6 +371,7 @@ def main():
             step(); opt.step()
         fence()
         packs1 = engine.PACK_LAUNCHES
+        mall_t = torch.cuda.memory_stats(dev).get("num_device_alloc", 0)
         tt = time.perf_counter()
         for _ in range(args.steps):
             loss_t = step(); opt.step()
@@ -383,6 +384,7 @@ def main():
         training_shaped = {"value": round(world * BATCH * args.steps / dtt, 4), "unit": "cubes/s", "steps": args.steps,
                            "ms_per_step": round(dtt / args.steps * 1e3, 3), "final_loss": round(float(loss_t.detach()), 6),
                            "pack_launches_per_step": (engine.PACK_LAUNCHES - packs1) / args.steps,
+                           "device_mallocs": int(torch.cuda.memory_stats(dev).get("num_device_alloc", 0) - mall_t),
                            "what": "forward + loss + backward" + (" + gradient all-reduce" if world > 1 else "") +
                                    " + FusedAdam(lr=1e-3).step(): weights change every step, packed copies rebuilt every step"}
         with torch.no_grad():
