@@ -92,7 +92,7 @@ def first_conv_traffic():
         return None, None
     src = os.path.relpath(files[-1], ROOT) + " (replayed: rocprofv3 --pmc passes of tools/first_conv.py, not measured in this run)"
     for k, v in kern.items():
-        if k.startswith("void conv_bf16v") or k.startswith("conv_bf16v"):
+        if "conv_bf16v3" in k or (("conv_bf16v2" in k) and not any("conv_bf16v3" in q for q in kern)):
             return round(v["hbm_bytes_per_launch"]), src
     return None, src
 
@@ -506,8 +506,9 @@ def main():
         r = FC.measure(reps=10)
         fc_bytes, fc_src = first_conv_traffic()
         first_conv = {"layer": "CubeNET-64 first_conv 238->64, 3x3, batch 2, forward (bias + BN partial statistics in the epilogue)",
-                      "mode": "bf16 operand planes resident in HBM, both operands by LDS-DMA, v_mfma_f32_32x32x16_bf16, f32 accumulate "
-                              "and f32 output (precision mode 'bf16'; the layout pass that writes the planes is a separate kernel)",
+                      "mode": "bf16 operand planes resident in HBM, both operands by LDS-DMA, " + r.get("bf16_kernel", "") + ", f32 accumulate "
+                              "and f32 output (precision mode 'bf16'; the layout pass that writes the planes is a separate kernel); "
+                              "operands: the workload's synthetic cube u in [0,1) and default-bound weights",
                       "ms": r["bf16_planes"]["ms"], "TF": r["bf16_planes"]["tflops"], "frac_of_2.5PF": r["bf16_planes"]["frac_of_2.5PF"],
                       "hbm_bytes_algorithmic": int(r["bf16_planes"]["algorithmic_hbm_mb"] * 1e6),
                       "hbm_bytes_measured": fc_bytes, "hbm_bytes_measured_source": fc_src,

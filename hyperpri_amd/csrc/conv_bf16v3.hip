@@ -1,0 +1,640 @@
+// 3x3 implicit-GEMM convolution on bf16 activation PLANES, third form (precision mode "bf16"; forward, and data gradient with the
+// mode-1 pack; reference model_parts.py:22,25; models.py:169,177 and their autograd) -- conv_bf16v2.hip rebuilt on the occupancy
+// recipe that worked for the fp32 Winograd kernel (conv_wino4.hip):
+//
+//   workgroup  256 threads = 4 waves, 256 pixels x 64 output channels, 72 KB of LDS: TWO independent workgroups per CU (one wave
+//              of each on every SIMD).  v2 ran one 8-wave workgroup per CU: every barrier and the whole store + statistics
+//              epilogue (~10 k cycles per item) stalled the CU's matrix pipes; here they run under the partner workgroup's
+//              MFMAs.  Persistent (2 x CUs workgroups walking fixed item lists): a first, non-persistent form paid ~9 k cycles
+//              of dispatch gap and ~5 k of exposed prologue per item (tools/v3_stamps.py); now the next item's first halo and
+//              weight stage are in flight while the current item's results are written out.  Workgroup id mod 8 walks one
+//              XCD's band of the image in raster order, so halos shared by neighbouring tiles meet in that XCD's L2.
+//   MFMA       v_mfma_f32_16x16x32_bf16 (same cycles per flop as 32x32x16, but the chip holds a higher clock on it:
+//              MI355X_MICROARCH.md, DVFS give-back 7), wave tile 64 px x 64 ch = 4 x 4 accumulator tiles (64 VGPRs).  The
+//              WEIGHTS are the A operand and the pixels the B operand: D = W X^T has the channel on the register index and the
+//              pixel on the lane, so a lane's four accumulator registers are four CONSECUTIVE channels of one pixel and go out
+//              as one 16-byte store -- no transposition through LDS in the epilogue at all.
+//   A (input)  halo of (TH+2) x (TW+2) pixels x 32 channels, 64-byte pixel rows, by LDS-DMA (buffer_load ... lds, out-of-image
+//              pixels zero-filled by the descriptor's range check); the four 16-byte k-slots of a pixel are XOR-swizzled with
+//              2*((pixel>>2)&1) through the DMA source address: conflict-free ds_read_b128 for the 16x16x32 fragment lane
+//              groups at every tap offset (brute-forced over all halo positions; v2's (pixel>>2)&3 is 2-way conflicted for
+//              this lane map).  Double-buffered per 32-channel chunk, the next chunk's halo issued in two halves.
+//   B (weights) one kernel row (3 taps x 64 ch x 32 k = 12 KB) per stage, same swizzle, double-buffered, one stage ahead.
+//   pipeline   one counted vmcnt + ONE barrier per stage of 48 MFMAs per wave; DMA pieces issued between the MFMAs.
+//   statistics per-tile BatchNorm partials (exact two-pass per wave, Chan merge of the four waves) with DPP row reductions:
+//              the 16 pixels of an accumulator column live on the 16 lanes of a DPP row.
+// Epilogue contract (bias, ReLU, accumulate, split-K raw slabs, statistics records) as conv_bf16v2.hip.
+#include "common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+#define V3_MAXSEG 4
+#define V3_A_PIECES 24                       // 1-KB DMA pieces per halo buffer: 384 pixel slots (largest halo: 10 x 34 = 340)
+#define V3_A_BYTES (V3_A_PIECES * 1024)
+#define V3_B_BYTES (12 * 1024)               // 3 taps x 64 channels x 32 k x 2 B
+
+struct ConvV3Args {
+  const __bf16* xp; int x_cs, x_coff;        // activation plane: elements per pixel (multiple of 32), first channel (multiple of 8)
+  const __bf16* wp;                          // packed weights [chunk][tap][Cout_pad][32] (hpri_pack_weight_bf16)
+  const float* bias;
+  float* y; int y_cs, y_coff;
+  float4* stats;
+  int N, H, W, Cin_pad, Cout, Cout_pad, y_cw, accumulate, relu;
+  int ksplit; float* ws;
+  int nseg, tiles_img, ntiles, nb_count, per_xcd;
+  int seg_twl[V3_MAXSEG], seg_xbeg[V3_MAXSEG], seg_ntx[V3_MAXSEG], seg_first[V3_MAXSEG];
+  int ncu, stagger_cycles;                   // compute units of the device; one-off delay of each CU's second occupant
+#ifdef HPRI_STAMPS
+  unsigned long long* stamps;                // diagnostic builds only: [workgroup][16] stamps of wave 0 (tools/v3_stamps.py)
+#endif
+};
+
+#ifdef HPRI_STAMPS
+#define V3_STAMP(i_)                                                                                     \
+  {                                                                                                      \
+    unsigned long long t_;                                                                               \
+    __builtin_amdgcn_sched_barrier(0);                                                                   \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                          \
+    __builtin_amdgcn_sched_barrier(0);                                                                   \
+    if (a.stamps != nullptr && threadIdx.x == 0)                                                         \
+      a.stamps[((size_t)blockIdx.z * gridDim.x + blockIdx.x) * 16 + (i_)] = t_;                           \
+  }
+#else
+#define V3_STAMP(i_)
+#endif
+
+// sum over the 16 lanes of a DPP row (= the 16 pixels of one accumulator column group); every lane gets the total
+__device__ __forceinline__ float v3_row_sum(float v) {
+#define V3_DPP_ADD(ctrl_)                                                                                \
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl_, 0xF, 0xF, true))
+  V3_DPP_ADD(0xB1);    // quad_perm [1,0,3,2]
+  V3_DPP_ADD(0x4E);    // quad_perm [2,3,0,1]
+  V3_DPP_ADD(0x141);   // row_half_mirror
+  V3_DPP_ADD(0x140);   // row_mirror
+#undef V3_DPP_ADD
+  return v;
+}
+
+// Geometry of one work item (256-pixel tile x 64-channel block); wave-uniform.
+struct V3Tile { int img, y0, x0, xlim, twl, nb, bx; };
+
+__global__ __launch_bounds__(256, 2) void conv_bf16v3_kernel(ConvV3Args a) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * V3_A_BYTES + 2 * V3_B_BYTES + 512];
+  unsigned char* a_lds = smem;
+  unsigned char* b_lds = smem + 2 * V3_A_BYTES;
+  float* bias_lds = reinterpret_cast<float*>(smem + 2 * V3_A_BYTES + 2 * V3_B_BYTES);   // [2 slots][64]: a block's biases (0 beyond Cout)
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lq = lane >> 4;
+
+  // ---- persistent work list: workgroup id mod 8 labels the XCD (round-robin dispatch; speed only), XCD x owns the items
+  //      [x*per_xcd, (x+1)*per_xcd) -- channel blocks of a pixel tile back to back, pixel tiles in raster order -- and its
+  //      workgroups (two per CU) walk that band interleaved: neighbouring tiles run at the same time on one XCD, so the halo
+  //      columns / rows they share meet in that XCD's L2.  Every workgroup runs a fixed list: the grid drains by itself. ----
+  const int xcd = blockIdx.x & 7, nloc = (int)(gridDim.x >> 3);
+  const int items_all = a.ntiles * a.nb_count;
+  auto tile_of = [&](int k, V3Tile& t) -> bool {
+    const int item = xcd * a.per_xcd + k;
+    if (k >= a.per_xcd || item >= items_all) return false;
+    t.bx = item / a.nb_count; t.nb = item - t.bx * a.nb_count;
+    t.img = t.bx / a.tiles_img;
+    const int tin = t.bx - t.img * a.tiles_img;
+    int seg = 0;
+#pragma unroll
+    for (int q = 1; q < V3_MAXSEG; ++q)
+      if (q < a.nseg && tin >= a.seg_first[q]) seg = q;
+    t.twl = a.seg_twl[seg];
+    const int TW = 1 << t.twl, TH = 256 >> t.twl;
+    const int tt = tin - a.seg_first[seg];
+    const int ty = tt / a.seg_ntx[seg], tx = tt - ty * a.seg_ntx[seg];
+    t.y0 = ty * TH; t.x0 = a.seg_xbeg[seg] + tx * TW;
+    t.xlim = min(a.W, a.seg_xbeg[seg] + a.seg_ntx[seg] * TW);
+    return true;
+  };
+
+  const int nchunks_all = a.Cin_pad >> 5;
+  const int cps = (nchunks_all + a.ksplit - 1) / a.ksplit;
+  const int chunk0 = blockIdx.z * cps;
+  const int nchunks = min(nchunks_all, chunk0 + cps);
+  if (chunk0 >= nchunks) return;
+  const int S0 = chunk0 * 3, S = nchunks * 3;
+
+  // ---- DMA source offsets of the item being LOADED (32-bit per-lane byte offsets against wave-uniform buffer descriptors;
+  //      halo pixels outside the image get an offset beyond the descriptor's range: the hardware writes zeros) ----
+  constexpr unsigned OOB = HPRI_DMA_OOB;
+  unsigned aoff[6];                            // halo piece q*4 + wave: pixel slot 16*(q*4 + wave) + (lane>>2), k-slot lane&3
+  unsigned goff;                               // weight piece q*4 + wave of a stage: tap q, rows wave*16 + (lane>>2) of the block
+  hpri_rsrc_t rs_a = HPRI_MAKE_RSRC(a.xp, 0x7FFFFF00);
+  const hpri_rsrc_t rs_b = HPRI_MAKE_RSRC(a.wp, 0x7FFFFF00);
+  const int tap_bytes = a.Cout_pad * 64;       // one tap of one chunk in the packed weights
+  auto setup_dma = [&](const V3Tile& t) {
+    const int TW = 1 << t.twl, TH = 256 >> t.twl, HW = TW + 2, HP = (TH + 2) * HW;
+    const unsigned hw_inv = (65536u + (unsigned)HW - 1u) / (unsigned)HW;   // exact quotient for pix < 2048
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      const int pix = (q * 4 + wave) * 16 + (lane >> 2);
+      unsigned off = OOB;
+      if (pix < HP) {
+        const int hy = (int)(((unsigned)pix * hw_inv) >> 16), hx = pix - hy * HW;
+        const int iy = t.y0 + hy - 1, ix = t.x0 + hx - 1;
+        if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
+          off = (unsigned)((iy * a.W + ix) * a.x_cs + (((lane & 3) ^ (((pix >> 2) & 1) << 1)) << 3)) * 2u;
+      }
+      aoff[q] = off;
+    }
+    const int n = wave * 16 + (lane >> 2);
+    goff = (unsigned)((t.nb * 64 + n) * 32 + (((lane & 3) ^ (((n >> 2) & 1) << 1)) << 3)) * 2u;
+    // (the descriptor must be PROVABLY wave-uniform, or hipcc wraps every DMA that uses it in a waterfall loop:
+    // cdna_hip_programming.md T20 -- readfirstlane on the two halves of the base pointer says so)
+    const unsigned long long pb = (unsigned long long)(uintptr_t)(a.xp + (size_t)t.img * a.H * a.W * a.x_cs + a.x_coff);
+    const unsigned plo = __builtin_amdgcn_readfirstlane((unsigned)pb), phi = __builtin_amdgcn_readfirstlane((unsigned)(pb >> 32));
+    (void)plo; (void)phi;
+    rs_a = HPRI_MAKE_RSRC((((unsigned long long)phi << 32) | plo), 0x7FFFFF00);
+  };
+  (void)goff; (void)tap_bytes; (void)rs_b;
+// Diagnostic builds (tools/build_v3_diag.sh; results are wrong by construction, only cycles matter): V3_DIAG bit 0 no weight
+// DMA inside the loop, bit 1 no halo DMA inside the loop, bit 2 fragments read once per stage only (tap 0), bit 3 no waits and
+// no barriers inside the loop.
+#ifndef V3_DIAG
+#define V3_DIAG 0
+#endif
+// (buffer indices are compile-time: the chunk loop is unrolled by two, so LDS addresses are immediates of the reads)
+#define V3_DMA_B_(buf_, s_, q_)                                                                                       \
+  HPRI_LDS_DMA16(rs_b, b_lds + (buf_) * V3_B_BYTES + ((q_) * 4 + wave) * 1024, goff, ((s_) * 3 + (q_)) * tap_bytes)
+#define V3_DMA_A_(buf_, c_, q_)                                                                                       \
+  HPRI_LDS_DMA16(rs_a, a_lds + (buf_) * V3_A_BYTES + ((q_) * 4 + wave) * 1024, aoff[q_], (c_) * 64)
+#define V3_DMA_B(buf_, s_, q_) { if (!(V3_DIAG & 1) || !in_loop) { V3_DMA_B_(buf_, s_, q_); } }
+#define V3_DMA_A(buf_, c_, q_) { if (!(V3_DIAG & 2) || !in_loop) { V3_DMA_A_(buf_, c_, q_); } }
+#define V3_WAIT_VM(n_) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n_) : "memory")
+#define V3_BARRIER()                         \
+  __builtin_amdgcn_sched_barrier(0);         \
+  __builtin_amdgcn_s_barrier();              \
+  __builtin_amdgcn_sched_barrier(0)
+// the first halo (six pieces per wave) and the first weight stage of an item: halo buffer 0, weight buffer 0
+#define V3_PROLOGUE_LOADS()                                                   \
+  {                                                                           \
+    constexpr bool in_loop = false;                                           \
+    _Pragma("unroll") for (int q = 0; q < 6; ++q) V3_DMA_A(0, chunk0, q);     \
+    _Pragma("unroll") for (int q = 0; q < 3; ++q) V3_DMA_B(0, S0, q);         \
+  }
+
+  // ---- fragment addresses.  B operand of the MFMA (pixels): lane (li, lq) reads k-slot lq of pixel li of M-tile mt at tap
+  //      (dy, dx); the swizzle depends on the halo pixel, so the nine tap offsets of each M-tile are tabulated -- once per tile
+  //      SHAPE (they do not depend on where the tile lies) ----
+  int aofs[4][9];
+  auto build_aofs = [&](int twl) {
+    const int TW = 1 << twl, HW = TW + 2;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      const int p = (wave * 4 + mt) * 16 + li;
+      const int row = p >> twl, col = p & (TW - 1);
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int hp = (row + t / 3) * HW + col + (t % 3);
+        aofs[mt][t] = hp * 64 + ((lq ^ (((hp >> 2) & 1) << 1)) << 4);
+      }
+    }
+  };
+  // A operand (weights): k-slot lq of channel row nt*16 + li; nt and the tap are immediates
+  const int bofs = li * 64 + ((lq ^ (((li >> 2) & 1) << 1)) << 4);
+
+  V3Tile cur, nxt;
+  int k = (int)(blockIdx.x >> 3);
+  bool have = tile_of(k, cur);
+  if (!have) return;
+  setup_dma(cur);
+  build_aofs(cur.twl);
+  // the channel block's biases go through LDS (16 scalar loads per lane in the epilogue were 16 serialized round trips: hipcc
+  // waits vmcnt(0) behind every conditional load): wave 0 loads the NEXT item's 64 values while the current item's results are
+  // written out and stores them at the top of that item (two slots: no wave is more than one item behind)
+  float bias_next = 0.f;
+  if (tid < 64) {
+    const int n = cur.nb * 64 + tid;
+    bias_next = (a.bias != nullptr && a.ksplit == 1 && n < a.Cout) ? a.bias[n] : 0.f;
+  }
+
+  // Two workgroups share a CU and every workgroup of a launch runs the same program on items of the same size: the second
+  // occupants (workgroups [ncu, 2 ncu) in dispatch order) start late once, so that from then on one workgroup's epilogue runs
+  // under the other's main loop.  Placement is not promised by HIP: another dispatch order costs the overlap, never correctness.
+  if ((unsigned)(blockIdx.x - a.ncu) < (unsigned)a.ncu && a.stagger_cycles > 0) {
+    const long long t0 = (long long)__builtin_amdgcn_s_memtime();
+    while ((long long)__builtin_amdgcn_s_memtime() - t0 < (long long)a.stagger_cycles) __builtin_amdgcn_s_sleep(32);
+  }
+#ifdef HPRI_STAMPS
+  if (a.stamps != nullptr && threadIdx.x == 0) a.stamps[((size_t)blockIdx.z * gridDim.x + blockIdx.x) * 16 + 7] = __builtin_amdgcn_s_memrealtime();
+  long long wait_cycles = 0;                   // cycles wave 0 spent between the top of a stage and the end of its barrier
+  int ntiles_done = 0;
+#endif
+  V3_STAMP(0)
+  V3_PROLOGUE_LOADS()
+  constexpr bool in_loop = true;
+  int slot = 0;
+
+  // One stage = one kernel row of one 32-channel chunk: 3 taps x (4 pixel + 4 weight fragments, 16 MFMAs) per wave.
+  //   top     wait for this wave's pieces of stage s (vmcnt counts in issue order: what the previous stage issued AFTER them --
+  //           half a halo -- may stay in flight), then the barrier: every wave's pieces are visible, and every wave has left
+  //           stage s-1, whose weight buffer (and, on dy = 0, the halo buffer of chunk c-1) may now be refilled
+  //   body    weight pieces of stage s+1 first, then (dy = 0, 1) one half of the next chunk's halo, issued between the MFMAs
+  // A fragment is read one tap ahead of its MFMAs.
+#define V3_READ_TAP(fa_, fb_, ab_, bb_, dy_, dx_)                                                                     \
+  _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                                                    \
+      fa_[mt] = *reinterpret_cast<const bf16x8*>((ab_) + aofs[mt][(dy_) * 3 + (dx_)]);                                \
+  _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                                    \
+      fb_[nt] = *reinterpret_cast<const bf16x8*>((bb_) + (dx_) * 4096 + nt * 1024);
+#define V3_MFMA_TAP(fa_, fb_, dma0_, dma1_)                                                                           \
+  _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) {                                                                  \
+    _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                                  \
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb_[nt], fa_[mt], acc[mt][nt], 0, 0, 0);                \
+    if (mt == 0) { dma0_ }                                                                                            \
+    if (mt == 2) { dma1_ }                                                                                            \
+  }
+#define V3_STAGE(par_, dy_)    /* par_: parity of the chunk relative to chunk0 = its halo buffer; stage buffer (3 par_ + dy_) & 1 */ \
+  {                                                                                                                   \
+    const int s_ = c * 3 + (dy_);                                                                                     \
+    constexpr int bb_i = ((par_) * 3 + (dy_)) & 1;                                                                    \
+    V3_TOP_BEGIN()                                                                                                    \
+    if (!(V3_DIAG & 8) || s_ == S0) {                                                                                 \
+      if ((dy_) == 0 || !more_c) V3_WAIT_VM(0); else V3_WAIT_VM(3);                                                   \
+      V3_BARRIER();                                                                                                   \
+    }                                                                                                                 \
+    V3_TOP_END()                                                                                                      \
+    const unsigned char* ab_ = a_lds + (par_) * V3_A_BYTES;                                                           \
+    const unsigned char* bb_ = b_lds + bb_i * V3_B_BYTES + bofs;                                                      \
+    const bool more_b = s_ + 1 < S;                                                                                   \
+    const bool more_a = (dy_) < 2 && more_c;                                                                          \
+    bf16x8 fa0[4], fb0[4], fa1[4], fb1[4];                                                                            \
+    V3_READ_TAP(fa0, fb0, ab_, bb_, dy_, 0)                                                                           \
+    if (!(V3_DIAG & 4)) { V3_READ_TAP(fa1, fb1, ab_, bb_, dy_, 1) }                                                   \
+    else { _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) { fa1[i_] = fa0[i_]; fb1[i_] = fb0[i_]; } }                \
+    V3_ISSUE_FIRST(V3_I0 V3_I1 V3_I2 V3_I3(par_, dy_) V3_I4(par_, dy_) V3_I5(par_, dy_))                              \
+    V3_SETPRIO(1);                                                                                                    \
+    V3_MFMA_TAP(fa0, fb0, V3_ISSUE_MID(V3_I0), V3_ISSUE_MID(V3_I1))                                                   \
+    if (!(V3_DIAG & 4)) { V3_READ_TAP(fa0, fb0, ab_, bb_, dy_, 2) }                                                   \
+    V3_MFMA_TAP(fa1, fb1, V3_ISSUE_MID(V3_I2), V3_ISSUE_MID(V3_I3(par_, dy_)))                                        \
+    V3_MFMA_TAP(fa0, fb0, V3_ISSUE_MID(V3_I4(par_, dy_)), V3_ISSUE_MID(V3_I5(par_, dy_)))                             \
+    V3_SETPRIO(0);                                                                                                    \
+  }
+// the six DMA slots of a stage, in issue order: the weight pieces of stage s+1, then half of the next chunk's halo
+#define V3_I0 if (more_b) { V3_DMA_B(bb_i ^ 1, s_ + 1, 0); }
+#define V3_I1 if (more_b) { V3_DMA_B(bb_i ^ 1, s_ + 1, 1); }
+#define V3_I2 if (more_b) { V3_DMA_B(bb_i ^ 1, s_ + 1, 2); }
+#define V3_I3(par_, dy_) if (more_a) { V3_DMA_A((par_) ^ 1, c + 1, ((dy_) & 1) * 3 + 0); }
+#define V3_I4(par_, dy_) if (more_a) { V3_DMA_A((par_) ^ 1, c + 1, ((dy_) & 1) * 3 + 1); }
+#define V3_I5(par_, dy_) if (more_a) { V3_DMA_A((par_) ^ 1, c + 1, ((dy_) & 1) * 3 + 2); }
+#ifdef V3_DMA_FIRST      /* A/B switch: all six right behind the barrier instead of between the MFMAs */
+#define V3_ISSUE_FIRST(x_) x_
+#define V3_ISSUE_MID(x_)
+#else
+#define V3_ISSUE_FIRST(x_)
+#define V3_ISSUE_MID(x_) x_
+#endif
+#ifdef V3_NO_SETPRIO
+#define V3_SETPRIO(p_)
+#else
+#define V3_SETPRIO(p_) __builtin_amdgcn_s_setprio(p_)
+#endif
+#ifdef HPRI_STAMPS
+#define V3_TOP_BEGIN() long long tb_; { __builtin_amdgcn_sched_barrier(0); tb_ = (long long)__builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+#define V3_TOP_END() { __builtin_amdgcn_sched_barrier(0); wait_cycles += (long long)__builtin_amdgcn_s_memtime() - tb_; __builtin_amdgcn_sched_barrier(0); }
+#else
+#define V3_TOP_BEGIN()
+#define V3_TOP_END()
+#endif
+
+  while (have) {
+    const int twl = cur.twl, TW = 1 << twl;
+    if (tid < 64) bias_lds[slot * 64 + tid] = bias_next;      // visible to everyone behind the first stage's barrier
+
+    f32x4 acc[4][4];                           // [pixel tile mt][channel tile nt]: channels nt*16 + 4*lq + r, pixel mt*16 + li
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int c = chunk0; c < nchunks; ++c) {
+      {
+        const bool more_c = c + 1 < nchunks;
+        V3_STAGE(0, 0)
+        V3_STAGE(0, 1)
+        V3_STAGE(0, 2)
+        if (!more_c) break;
+      }
+      ++c;
+      {
+        const bool more_c = c + 1 < nchunks;
+        V3_STAGE(1, 0)
+        V3_STAGE(1, 1)
+        V3_STAGE(1, 2)
+      }
+    }
+#ifdef HPRI_STAMPS
+    if (ntiles_done == 0) { V3_STAMP(1) }
+#endif
+
+    // ---- the next item's first halo and weight stage start to load now and land while this item's results are written out:
+    //      every wave has left the main loop (barrier), so halo buffer 0 and weight buffer 0 are free whatever the chunk parity;
+    //      the statistics scratch below lives in halo buffer 1 ----
+    V3_BARRIER();
+#ifdef V3_EPI_PRIO
+    // the epilogue is ~600 vector instructions and 16 stores per wave: at the main loop's priority or below it only gets the
+    // issue slots the partner workgroup's MFMA stream leaves over and takes 3-5 x as long, during which this workgroup's
+    // share of the matrix pipe is idle -- so it runs ABOVE the partner's main loop
+    __builtin_amdgcn_s_setprio(V3_EPI_PRIO);
+#endif
+    k += nloc;
+    have = tile_of(k, nxt);
+    if (have) {
+      setup_dma(nxt);
+      V3_PROLOGUE_LOADS()
+      if (tid < 64) {
+        const int n = nxt.nb * 64 + tid;
+        bias_next = (a.bias != nullptr && a.ksplit == 1 && n < a.Cout) ? a.bias[n] : 0.f;
+      }
+    }
+
+    // ------------------------------- epilogue -------------------------------
+    // acc[mt][nt][r]: pixel (wave*4 + mt)*16 + li of the tile, channel nb*64 + nt*16 + 4*lq + r
+    const bool raw = a.ksplit > 1;             // split-K: raw partial sums into the workspace slab of this K slice
+    float* dst = raw ? a.ws + (size_t)blockIdx.z * ((size_t)a.N * a.H * a.W) * a.Cout_pad : a.y;
+    const int dcs = raw ? a.Cout_pad : a.y_cs, dco = raw ? 0 : a.y_coff, dcw = raw ? a.Cout_pad : a.y_cw;
+    const int nlane = cur.nb * 64 + 4 * lq;    // first channel of this lane in channel tile 0
+    if (!raw) {
+      // pad channels need no mask: their weights are zero (pack) and their bias slot is zero, so their sums are exact zeros
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias_lds + slot * 64 + nt * 16 + 4 * lq);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          f32x4 v = acc[mt][nt] + b4;
+          if (a.relu) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+          }
+          acc[mt][nt] = v;
+        }
+      }
+    }
+    unsigned vmask = 0u;                       // bit mt: this lane's pixel of M-tile mt lies inside the image
+    float* prow[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      const int p = (wave * 4 + mt) * 16 + li;
+      const int iy = cur.y0 + (p >> twl), ix = cur.x0 + (p & (TW - 1));
+      if (iy < a.H && ix < cur.xlim) vmask |= 1u << mt;
+      prow[mt] = dst + ((size_t)(cur.img * a.H + min(iy, a.H - 1)) * a.W + min(ix, a.W - 1)) * dcs + dco + nlane;
+    }
+    // The accumulate / plain decision is taken ONCE, outside the store sequence: a conditional load in front of each store
+    // makes hipcc wait vmcnt(0) at the join, which also waits for every earlier STORE (16 serialized write round trips per
+    // wave: 10.7 k cycles in the first version of this epilogue, tools/v3_stamps.py).  So is "all 64 channels of the block lie
+    // inside the written width" (everywhere except the last block of a narrow tensor): the common path has no per-store
+    // condition at all.
+    const bool full = cur.nb * 64 + 64 <= dcw;
+#define V3_STORE_LOOP(ACC_, COND_)                                                                                    \
+  if (ACC_) {               /* all loads first: a wait for a load behind a store would wait for the store as well */  \
+    f32x4 old_[4][4];                                                                                                 \
+    _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                                                  \
+        _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                              \
+            old_[mt][nt] = (((vmask >> mt) & 1u) && (COND_)) ? *reinterpret_cast<const f32x4*>(prow[mt] + nt * 16)    \
+                                                             : f32x4{0.f, 0.f, 0.f, 0.f};                             \
+    _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                                                  \
+        _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) acc[mt][nt] += old_[mt][nt];                                 \
+  }                                                                                                                   \
+  _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) {                                                                  \
+    if ((vmask >> mt) & 1u) {                                                                                         \
+      _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                                \
+          if (COND_) *reinterpret_cast<f32x4*>(prow[mt] + nt * 16) = acc[mt][nt];                                     \
+    }                                                                                                                 \
+  }
+    if (!raw && a.accumulate) {
+      if (full) { V3_STORE_LOOP(true, true) } else { V3_STORE_LOOP(true, nlane + nt * 16 < dcw) }
+    } else {
+      if (full) { V3_STORE_LOOP(false, true) } else { V3_STORE_LOOP(false, nlane + nt * 16 < dcw) }
+    }
+#undef V3_STORE_LOOP
+#ifdef HPRI_STAMPS
+    if (ntiles_done == 0) { V3_STAMP(2) }
+#endif
+    if (!raw && a.stats != nullptr) {
+      // per-tile, per-channel (mean, M2, count): each wave makes an exact two-pass record of its own 64 pixels (sum, then
+      // squared deviations from its own mean); the four wave records of a channel are merged with Chan's update after one
+      // barrier.  (raw barriers: __syncthreads() would also wait for the output stores above.)
+      float cntl = (float)__builtin_popcount(vmask);
+      const float cntw = v3_row_sum(cntl);     // valid pixels of this wave's 64 (each DPP row holds all 16 pixel columns)
+      const float inv = cntw > 0.f ? 1.f / cntw : 0.f;
+      float* red = reinterpret_cast<float*>(smem + V3_A_BYTES);         // [4 waves][64 channels][2] + [4] counts
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        f32x4 s1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+          if ((vmask >> mt) & 1u) s1 += acc[mt][nt];
+        f32x4 mw, s2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mw[r] = v3_row_sum(s1[r]) * inv;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+          if ((vmask >> mt) & 1u) { const f32x4 d = acc[mt][nt] - mw; s2 += d * d; }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s2[r] = v3_row_sum(s2[r]);
+        if (li == 0) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            red[(wave * 64 + nt * 16 + 4 * lq + r) * 2 + 0] = mw[r];
+            red[(wave * 64 + nt * 16 + 4 * lq + r) * 2 + 1] = s2[r];
+          }
+        }
+      }
+      if (lane == 0) red[4 * 128 + wave] = cntw;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      V3_BARRIER();
+      if (tid < 64) {
+        float n = 0.f, mean = 0.f, m2 = 0.f;
+#pragma unroll
+        for (int w2 = 0; w2 < 4; ++w2) {
+          const float nb_ = red[4 * 128 + w2];
+          if (nb_ > 0.f) {
+            const float mb = red[(w2 * 64 + tid) * 2 + 0], qb = red[(w2 * 64 + tid) * 2 + 1];
+            const float tot = n + nb_, delta = mb - mean, f = __builtin_amdgcn_rcpf(tot) * nb_;
+            mean += delta * f;
+            m2 += qb + delta * delta * (n * f);
+            n = tot;
+          }
+        }
+        a.stats[(size_t)cur.bx * a.Cout_pad + cur.nb * 64 + tid] = make_float4(mean, m2, n, 0.f);
+      }
+      // (the scratch is rewritten only after the next item's main loop, i.e. behind many barriers)
+    }
+#ifdef HPRI_STAMPS
+    if (ntiles_done == 0) { V3_STAMP(3) }
+    ++ntiles_done;
+#endif
+#ifdef V3_EPI_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
+    if (have && nxt.twl != cur.twl) build_aofs(nxt.twl);
+    cur = nxt;
+    slot ^= 1;
+  }
+#ifdef HPRI_STAMPS
+  if (a.stamps != nullptr && threadIdx.x == 0) {
+    unsigned long long* sp = a.stamps + ((size_t)blockIdx.z * gridDim.x + blockIdx.x) * 16;
+    sp[4] = (unsigned long long)wait_cycles;
+    sp[5] = __builtin_amdgcn_s_memrealtime();
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    sp[6] = ((unsigned long long)xcc << 32) | hw;
+    sp[8] = __builtin_amdgcn_s_memtime();
+    sp[9] = (unsigned long long)ntiles_done;
+  }
+#endif
+#undef V3_STAGE
+#undef V3_I0
+#undef V3_I1
+#undef V3_I2
+#undef V3_I3
+#undef V3_I4
+#undef V3_I5
+#undef V3_ISSUE_FIRST
+#undef V3_ISSUE_MID
+#undef V3_MFMA_TAP
+#undef V3_READ_TAP
+#undef V3_SETPRIO
+#undef V3_PROLOGUE_LOADS
+#undef V3_DMA_A
+#undef V3_DMA_B
+#undef V3_DMA_A_
+#undef V3_DMA_B_
+#undef V3_TOP_BEGIN
+#undef V3_TOP_END
+#undef V3_WAIT_VM
+#undef V3_BARRIER
+}
+
+// ---- host side -------------------------------------------------------------------------------------------------------
+// column bands of tile width 32 / 16 (tile height 8 / 16: 256 pixels either way), as conv_bf16v2.hip's; 16 is the narrowest
+// tile (the fragment swizzle is conflict-free for runs of 16 consecutive halo pixels)
+struct V3Segs { int nseg, tiles_img, twl[V3_MAXSEG], xbeg[V3_MAXSEG], ntx[V3_MAXSEG], first[V3_MAXSEG]; };
+static V3Segs v3_segments(int H, int W) {
+  auto th = [&](int tw) { return 256 / tw; };
+  auto slots = [&](int tw, int ntx) { return (long long)hpri_cdiv(H, th(tw)) * th(tw) * tw * ntx; };
+  V3Segs best{};
+  long long best_cost = -1;
+  // candidates: n32 columns of 32-wide tiles, the rest in 16-wide tiles
+  const int max32 = hpri_cdiv(W, 32);
+  for (int n32 = 0; n32 <= max32; ++n32) {
+    const int rem = W - n32 * 32;
+    const int n16 = rem > 0 ? hpri_cdiv(rem, 16) : 0;
+    if (rem <= 0 && n32 * 32 - W >= 32) continue;
+    const long long cost = (n32 ? slots(32, n32) : 0) + (n16 ? slots(16, n16) : 0);
+    if (best_cost < 0 || cost < best_cost || (cost == best_cost && n16 == 0)) {
+      V3Segs g{};
+      if (n32) { g.twl[g.nseg] = 5; g.xbeg[g.nseg] = 0; g.ntx[g.nseg] = n32; g.nseg++; }
+      if (n16) { g.twl[g.nseg] = 4; g.xbeg[g.nseg] = n32 * 32; g.ntx[g.nseg] = n16; g.nseg++; }
+      best = g; best_cost = cost;
+    }
+  }
+  int first = 0;
+  for (int k = 0; k < best.nseg; ++k) { best.first[k] = first; first += hpri_cdiv(H, th(1 << best.twl[k])) * best.ntx[k]; }
+  best.tiles_img = first;
+  return best;
+}
+
+// Split-K (host only), priced as in conv_bf16v2.hip: a slice costs 2 k output sizes of fp32 slab traffic against the partial
+// round of workgroup slots (two per CU) it fills; only problems below half a round are cut.
+static int v3_ksplit(int N, int H, int W, int Cin_pad, int Cout_pad) {
+  const int ncu = hpri_cu_count();
+  const long long blocks = (long long)N * v3_segments(H, W).tiles_img * (Cout_pad / 64);
+  const int nchunks = Cin_pad / 32;
+  if (blocks >= ncu) return 1;
+  const double t_compute = 2.0 * N * H * W * (double)Cin_pad * Cout_pad * 9.0 / 900e12;
+  const double out_bytes = 4.0 * N * H * W * (double)Cout_pad;
+  int best = 1; double best_t = 1e30;
+  for (int k = 1; k <= 4; ++k) {
+    if (k > 1 && nchunks / k < 4) break;
+    const double per_slot = (double)blocks * k / (2.0 * ncu);
+    const double eff = per_slot / (double)((long long)(per_slot + 0.999999));
+    const double t = t_compute / eff + (k > 1 ? 2.0 * k * out_bytes / 5e12 + 4e-6 : 0.0);
+    if (t < best_t - 1e-12) { best_t = t; best = k; }
+  }
+  return best;
+}
+
+#define V3_SK_PIX 64
+extern "C" int hpri_conv_bf16v3_plan(int N, int H, int W, int Cin_pad, int Cout_pad, int* ksplit, int* stat_tiles,
+                                     size_t* ws_floats) {
+  const int k = v3_ksplit(N, H, W, Cin_pad, Cout_pad);
+  *ksplit = k;
+  if (k > 1) { *stat_tiles = N * hpri_cdiv(H * W, V3_SK_PIX); *ws_floats = (size_t)k * N * H * W * Cout_pad; }
+  else { *stat_tiles = N * v3_segments(H, W).tiles_img; *ws_floats = 0; }
+  return HPRI_OK;
+}
+
+// conv_fwd.hip
+extern "C" int hpri_splitk_finish(const float* ws, int ksplit, int Cout_pad, const float* bias, float* y, int y_cs, int y_coff,
+                                  float* stats, int N, int HW, int Cout, int y_cw, int accumulate, int relu, hipStream_t stream);
+
+#define V3_STAGGER_CYCLES 6000      // about one store + statistics epilogue with a partner on the CU
+
+extern "C" int hpri_conv_bf16v3_dbg(const void* xp, long long x_plane, int x_cs, int x_coff, const void* wp, const float* bias,
+                                    float* y, int y_cs, int y_coff, float* stats, int N, int H, int W, int Cin_pad, int Cout,
+                                    int Cout_pad, int y_cw, int accumulate, int split, float* ws, size_t ws_floats,
+                                    unsigned long long* stamps, int stagger_cycles, hipStream_t stream) {
+  HPRI_REQUIRE(xp && wp && y, "conv_bf16v3: null pointer");
+  HPRI_REQUIRE(N > 0 && H > 0 && W > 0, "conv_bf16v3: empty image");
+  HPRI_REQUIRE(Cin_pad > 0 && Cin_pad % 32 == 0, "conv_bf16v3: Cin_pad must be a positive multiple of 32");
+  HPRI_REQUIRE(Cout_pad % 64 == 0 && Cout <= Cout_pad && Cout > 0, "conv_bf16v3: Cout_pad must be a multiple of 64 >= Cout");
+  HPRI_REQUIRE(x_cs % 8 == 0 && x_coff % 8 == 0 && x_coff + Cin_pad <= x_cs, "conv_bf16v3: plane channel stride/offset must be multiples of 8 and hold Cin_pad channels");
+  HPRI_REQUIRE(((uintptr_t)xp & 15) == 0 && ((uintptr_t)wp & 15) == 0, "conv_bf16v3: pointers must be 16-byte aligned");
+  HPRI_REQUIRE((long long)H * W * x_cs * 2 < 0x7FFFFF00ll, "conv_bf16v3: one image of the input planes exceeds 2 GiB (32-bit DMA offsets)");
+  HPRI_REQUIRE((long long)(Cin_pad / 32) * 9 * Cout_pad * 64 < 0x7FFFFF00ll, "conv_bf16v3: packed weights exceed 2 GiB");
+  HPRI_REQUIRE(split == 0, "conv_bf16v3: only plain bf16 planes (split 0) are built");
+  (void)x_plane;
+  ConvV3Args a;
+  a.xp = reinterpret_cast<const __bf16*>(xp); a.x_cs = x_cs; a.x_coff = x_coff;
+  a.wp = reinterpret_cast<const __bf16*>(wp); a.bias = bias; a.y = y; a.y_cs = y_cs; a.y_coff = y_coff;
+  a.stats = reinterpret_cast<float4*>(stats);
+  a.N = N; a.H = H; a.W = W; a.Cin_pad = Cin_pad; a.Cout = Cout; a.Cout_pad = Cout_pad;
+  a.y_cw = y_cw < Cout ? Cout : y_cw; a.accumulate = accumulate & 1; a.relu = (accumulate >> 1) & 1;
+  HPRI_REQUIRE(a.y_cw + y_coff <= y_cs, "conv_bf16v3: output channels exceed the channel stride");
+  HPRI_REQUIRE(y_cs % 4 == 0 && y_coff % 4 == 0 && a.y_cw % 4 == 0 && ((uintptr_t)y & 15) == 0,
+               "conv_bf16v3: the output view must be float4-aligned (stride, offset and written width multiples of 4)");
+  a.ksplit = v3_ksplit(N, H, W, Cin_pad, Cout_pad);
+  a.ws = ws;
+  if (a.ksplit > 1) {
+    if (ws == nullptr || (size_t)a.ksplit * N * H * W * Cout_pad > ws_floats)
+      return hpri_set_error(HPRI_ERR_WORKSPACE, "conv_bf16v3: split-K workspace too small (see hpri_conv_bf16v3_plan)");
+    a.stats = nullptr; a.accumulate = 0;
+  }
+  const V3Segs sg = v3_segments(H, W);
+  a.nseg = sg.nseg; a.tiles_img = sg.tiles_img; a.ntiles = N * sg.tiles_img; a.nb_count = Cout_pad / 64;
+  for (int k = 0; k < V3_MAXSEG; ++k) { a.seg_twl[k] = sg.twl[k]; a.seg_xbeg[k] = sg.xbeg[k]; a.seg_ntx[k] = sg.ntx[k]; a.seg_first[k] = sg.first[k]; }
+  const long long items = (long long)a.ntiles * a.nb_count;
+  HPRI_REQUIRE(items < (1ll << 28), "conv_bf16v3: too many work items");
+  a.per_xcd = (int)((items + 7) / 8);
+  a.ncu = hpri_cu_count(); a.stagger_cycles = stagger_cycles;
+#ifdef HPRI_STAMPS
+  a.stamps = stamps;
+#else
+  (void)stamps;
+#endif
+  // persistent workgroups: two per CU (fewer when there are fewer items), a multiple of 8 so that id mod 8 labels the XCD
+  int nloc = (2 * a.ncu / a.ksplit) / 8;
+  if (nloc < 1) nloc = 1;
+  if (nloc > a.per_xcd) nloc = a.per_xcd;
+  dim3 grid((unsigned)(nloc * 8), 1u, (unsigned)a.ksplit);
+  hipLaunchKernelGGL(conv_bf16v3_kernel, grid, dim3(256), 0, stream, a);
+  HPRI_CHECK_LAUNCH();
+  if (a.ksplit == 1) return HPRI_OK;
+  return hpri_splitk_finish(ws, a.ksplit, Cout_pad, bias, y, y_cs, y_coff, stats, N, H * W, Cout, a.y_cw, accumulate & 1, a.relu, stream);
+}
+
+// 3x3 pad-1 convolution (forward, or data gradient with the flipped pack) over bf16 activation planes: same argument
+// contract as hpri_conv_bf16v2 (x_plane is unused: one plane); statistics records per 256-pixel tile (hpri_conv_bf16v3_plan).
+extern "C" int hpri_conv_bf16v3(const void* xp, long long x_plane, int x_cs, int x_coff, const void* wp, const float* bias,
+                                float* y, int y_cs, int y_coff, float* stats, int N, int H, int W, int Cin_pad, int Cout,
+                                int Cout_pad, int y_cw, int accumulate, int split, float* ws, size_t ws_floats,
+                                hipStream_t stream) {
+  return hpri_conv_bf16v3_dbg(xp, x_plane, x_cs, x_coff, wp, bias, y, y_cs, y_coff, stats, N, H, W, Cin_pad, Cout, Cout_pad,
+                              y_cw, accumulate, split, ws, ws_floats, nullptr, V3_STAGGER_CYCLES, stream);
+}

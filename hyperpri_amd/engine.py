@@ -225,6 +225,16 @@ PLANE_PRODUCERS = True       # producers (BN-apply, BN-backward, ...) write the 
 PLANE_CONVERSIONS = 0        # generic fp32 -> planes passes launched (fused producers do not count)
 
 
+# Which plane convolution: conv_bf16v3.hip (4-wave workgroups of 256 px x 64 ch, two per CU, v_mfma_f32_16x16x32_bf16, stores
+# straight from the accumulators) or conv_bf16v2.hip (one persistent 8-wave workgroup per CU).  Same packed weights, same
+# arguments; the statistics tiles differ (plan).  HPRI_BF16_V3: 1 (default) / 0.
+BF16_V3 = os.environ.get("HPRI_BF16_V3", "1") != "0"
+
+
+def _plane_conv() -> str:
+    return "hpri_conv_bf16v3" if BF16_V3 else "hpri_conv_bf16v2"
+
+
 def _planes_fit(x: Act, channels: int) -> bool:
     """One image of bf16 planes of ``channels`` channels stays below the 2 GiB the plane kernels' DMA descriptors cover."""
     return x.H * x.W * _rup(channels, 32) * 2 < 0x7FFFFF00
@@ -273,13 +283,13 @@ def _conv_launch_v2(x: Act, wp: torch.Tensor, bias: Optional[torch.Tensor], y: A
     pl = planes_of(x, 1)
     cin_pad = _rup(cin, 32)
     ksplit = ctypes.c_int(); tiles = ctypes.c_int(); wsf = ctypes.c_size_t()
-    _lib.call("hpri_conv_bf16v2_plan", x.N, x.H, x.W, cin_pad, cout_pad, ctypes.byref(ksplit), ctypes.byref(tiles), ctypes.byref(wsf))
+    _lib.call(_plane_conv() + "_plan", x.N, x.H, x.W, cin_pad, cout_pad, ctypes.byref(ksplit), ctypes.byref(tiles), ctypes.byref(wsf))
     ws = _ws(wsf.value, x.buf.device) if wsf.value else None
-    tag = f"conv_planes_bf16<3,{'4x2' if cout_pad % 128 == 0 else '8x1'}>"
+    tag = "conv_planes_bf16<3,v3 256x64>" if BF16_V3 else f"conv_planes_bf16<3,{'4x2' if cout_pad % 128 == 0 else '8x1'}>"
     if SHAPE_TAGS:
         tag += f" N{x.N} {x.H}x{x.W} K{cin_pad} N{cout}"
     with _timed(tag, 2.0 * x.N * x.H * x.W * cin * cout * 9):
-        _lib.call("hpri_conv_bf16v2", _p(pl.buf), pl.plane, pl.cs, pl.coff, _p(wp), _p(bias), y.ptr, y.cs, y.coff, _p(stats),
+        _lib.call(_plane_conv(), _p(pl.buf), pl.plane, pl.cs, pl.coff, _p(wp), _p(bias), y.ptr, y.cs, y.coff, _p(stats),
                   x.N, x.H, x.W, cin_pad, cout, cout_pad, y_cw, accumulate, 0, _p(ws), wsf.value, _stream())
 
 
@@ -752,7 +762,7 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
         if wino:
             _lib.call(f"hpri_conv_{_wino_sfx()}_plan", x.N, x.H, x.W, ctypes.byref(tl))
         elif v2:
-            _lib.call("hpri_conv_bf16v2_plan", x.N, x.H, x.W, _rup(cin, 32), cout_pad, ctypes.byref(ksp), ctypes.byref(tl),
+            _lib.call(_plane_conv() + "_plan", x.N, x.H, x.W, _rup(cin, 32), cout_pad, ctypes.byref(ksp), ctypes.byref(tl),
                       ctypes.byref(wsf))
         elif lowp:
             _lib.call("hpri_conv_fwd_bf16_plan", x.N, x.H, x.W, cin_pad, cout_pad, ks, A_DIRECT, E_DIRECT, split,

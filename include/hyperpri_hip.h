@@ -157,6 +157,21 @@ int hpri_conv_bf16v2(const void* xp, long long x_plane, int x_cs, int x_coff, co
                      int accumulate, int split, float* ws, size_t ws_floats, hipStream_t stream);
 int hpri_splitk_finish(const float* ws, int ksplit, int Cout_pad, const float* bias, float* y, int y_cs, int y_coff,
                        float* stats, int N, int HW, int Cout, int y_cw, int accumulate, int relu, hipStream_t stream);
+/* Third form of the plane convolution (conv_bf16v3.hip): 4-wave workgroups of 256 pixels x 64 channels, TWO per CU (one's
+ * prologue / store + statistics epilogue runs under the other's MFMAs), v_mfma_f32_16x16x32_bf16 with the weights as the A
+ * operand (a lane's accumulator registers are consecutive channels of one pixel: 16-byte stores without an LDS transpose).
+ * Same argument, workspace and statistics contract as hpri_conv_bf16v2 (records per 256-pixel tile: hpri_conv_bf16v3_plan);
+ * the output view must be float4-aligned.  _dbg: the same with the one-off delay of each CU's second occupant (cycles) given by
+ * the caller and, in -DHPRI_STAMPS builds, a stamp buffer ([workgroups][8] u64; ignored otherwise). */
+int hpri_conv_bf16v3_plan(int N, int H, int W, int Cin_pad, int Cout_pad, int* ksplit, int* stat_tiles,
+                          size_t* ws_floats);
+int hpri_conv_bf16v3(const void* xp, long long x_plane, int x_cs, int x_coff, const void* wp, const float* bias, float* y,
+                     int y_cs, int y_coff, float* stats, int N, int H, int W, int Cin_pad, int Cout, int Cout_pad, int y_cw,
+                     int accumulate, int split, float* ws, size_t ws_floats, hipStream_t stream);
+int hpri_conv_bf16v3_dbg(const void* xp, long long x_plane, int x_cs, int x_coff, const void* wp, const float* bias, float* y,
+                         int y_cs, int y_coff, float* stats, int N, int H, int W, int Cin_pad, int Cout, int Cout_pad, int y_cw,
+                         int accumulate, int split, float* ws, size_t ws_floats, unsigned long long* stamps,
+                         int stagger_cycles, hipStream_t stream);
 
 /* ---- weight gradients, fp32 MFMA, deterministic split-K (conv_wgrad.hip) --------------------------
  * Replaces the wgrad half of autograd for the same layers.  dst_mode 0 writes OIHW / (out,in),

@@ -168,11 +168,14 @@ def test_winograd_weight_gradient_vs_fp64(lib, shape):
 
 
 @pytest.mark.parametrize("shape", [(2, 36, 50, 64, 64), (1, 76, 121, 128, 192), (1, 17, 23, 40, 64), (1, 33, 31, 238, 64),
-                                   (2, 38, 60, 256, 128)])
-def test_bf16_plane_conv_vs_fp64_of_rounded_operands(lib, shape):
-    """conv_bf16v2: operands are bf16 planes in HBM (written by hpri_to_planes), products accumulate in fp32.  The
-    reference is conv2d in fp64 of the SAME bf16-rounded operands, so the only difference is fp32 summation order."""
+                                   (2, 38, 60, 256, 128), (1, 1, 1, 32, 64), (1, 9, 100, 6, 64), (3, 16, 16, 32, 320)])
+@pytest.mark.parametrize("kern", ["bf16v3", "bf16v2"])
+def test_bf16_plane_conv_vs_fp64_of_rounded_operands(lib, shape, kern):
+    """conv_bf16v3 (the default: 4-wave workgroups, two per CU, 16x16x32 MFMA) / conv_bf16v2: operands are bf16 planes in HBM
+    (written by hpri_to_planes), products accumulate in fp32.  The reference is conv2d in fp64 of the SAME bf16-rounded
+    operands, so the only difference is fp32 summation order."""
     N, H, W, Cin, Cout = shape
+    plan_fn, conv_fn = getattr(lib, f"hpri_conv_{kern}_plan"), getattr(lib, f"hpri_conv_{kern}")
     torch.manual_seed(31)
     cs, cs16, cout_pad = rup(Cin, 8), rup(Cin, 32), rup(Cout, 64)
     x = torch.zeros(N * H * W, cs, device=DEV)
@@ -184,12 +187,12 @@ def test_bf16_plane_conv_vs_fp64_of_rounded_operands(lib, shape):
     wpb = torch.empty(((Cin + 31) // 32) * 9 * cout_pad * 32, dtype=torch.bfloat16, device=DEV)
     assert lib.hpri_pack_weight_bf16(P(w), P(wpb), 0, Cin, Cout, cout_pad, 9, Cin, 0, 0, _st()) == 0
     k, tl, wsf = ctypes.c_int(), ctypes.c_int(), ctypes.c_size_t()
-    lib.hpri_conv_bf16v2_plan(N, H, W, cs16, cout_pad, ctypes.byref(k), ctypes.byref(tl), ctypes.byref(wsf))
+    plan_fn(N, H, W, cs16, cout_pad, ctypes.byref(k), ctypes.byref(tl), ctypes.byref(wsf))
     ws = torch.empty(max(wsf.value, 4), device=DEV)
     stats = torch.zeros(tl.value * cout_pad * 4, device=DEV)
     y = torch.zeros(N * H * W, Cout, device=DEV)
-    rc = lib.hpri_conv_bf16v2(P(planes), 0, cs16, 0, P(wpb), P(b), P(y), Cout, 0, P(stats), N, H, W, cs16, Cout, cout_pad, Cout, 0, 0,
-                              P(ws), ws.numel(), _st())
+    rc = conv_fn(P(planes), 0, cs16, 0, P(wpb), P(b), P(y), Cout, 0, P(stats), N, H, W, cs16, Cout, cout_pad, Cout, 0, 0,
+                 P(ws), ws.numel(), _st())
     assert rc == 0, lib.hpri_last_error()
     torch.cuda.synchronize()
     # the plane pass rounds to nearest-even bf16 and zero-fills the channel pad
@@ -201,12 +204,69 @@ def test_bf16_plane_conv_vs_fp64_of_rounded_operands(lib, shape):
     ref = torch.nn.functional.conv2d(xr, wr, b.double().cpu(), padding=1).permute(0, 2, 3, 1).reshape(-1, Cout)
     sc = max(1.0, float(ref.abs().max()))
     err = float((y.double().cpu() - ref).abs().max())
-    record_margin(f"bf16v2/{N}x{H}x{W}x{Cin}x{Cout}", err, 2e-5 * sc)
+    record_margin(f"{kern}/{N}x{H}x{W}x{Cin}x{Cout}", err, 2e-5 * sc)
     assert err < 2e-5 * sc, (shape, err)
     mean, var, cnt = _chan_stats(stats, tl.value, cout_pad, Cout)
     assert torch.all(cnt == N * H * W)
     assert float((mean - ref.mean(0)).abs().max()) < 1e-4 * sc
     assert float((var - ref.var(0, unbiased=False)).abs().max()) < 1e-4 * sc * sc
+
+
+@pytest.mark.parametrize("shape", [(2, 36, 50, 64, 6), (1, 19, 40, 128, 72), (2, 38, 60, 256, 128)])
+def test_bf16_plane_conv_v3_data_gradient_views_and_epilogues(lib, shape):
+    """conv_bf16v3 as the data gradient (mode-1 pack: K = Cout of the layer, columns = its Cin, rotated taps) writing a
+    channel-slice VIEW of a wider gradient buffer, accumulating into what is there (a skip gradient), with the columns' zero
+    pad kept zero; then the ReLU epilogue of the folded predict path; then the error returns of the boundary."""
+    N, H, W, K, Cols = shape                   # dy has K channels, the result Cols channels
+    torch.manual_seed(7)
+    cs16, cols_pad, cw = rup(K, 32), rup(Cols, 64), rup(Cols, 8)
+    dy = torch.randn(N * H * W, K, device=DEV)
+    planes = torch.zeros(N * H * W, cs16, dtype=torch.bfloat16, device=DEV)
+    planes[:, :K] = dy.to(torch.bfloat16)
+    w = torch.randn(K, Cols, 3, 3, device=DEV) * 0.05                       # the layer's weight [Cout = K][Cin = Cols]
+    wpd = torch.empty(((K + 31) // 32) * 9 * cols_pad * 32, dtype=torch.bfloat16, device=DEV)
+    assert lib.hpri_pack_weight_bf16(P(w), P(wpd), 1, K, Cols, cols_pad, 9, Cols, 0, 0, _st()) == 0
+    k, tl, wsf = ctypes.c_int(), ctypes.c_int(), ctypes.c_size_t()
+    lib.hpri_conv_bf16v3_plan(N, H, W, cs16, cols_pad, ctypes.byref(k), ctypes.byref(tl), ctypes.byref(wsf))
+    ws = torch.empty(max(wsf.value, 4), device=DEV)
+    ycs, yoff = cw + 16, 8                                                  # a view inside a wider buffer
+    prior = torch.randn(N * H * W, ycs, device=DEV)
+    ybuf = prior.clone()
+    rc = lib.hpri_conv_bf16v3(P(planes), 0, cs16, 0, P(wpd), P(None), P(ybuf), ycs, yoff, P(None), N, H, W, cs16, Cols, cols_pad, cw, 1, 0,
+                              P(ws), ws.numel(), _st())
+    assert rc == 0, lib.hpri_last_error()
+    torch.cuda.synchronize()
+    xr = planes[:, :K].double().cpu().reshape(N, H, W, K).permute(0, 3, 1, 2)
+    wr = w.to(torch.bfloat16).double().cpu()
+    ref = torch.nn.functional.conv_transpose2d(xr, wr, padding=1).permute(0, 2, 3, 1).reshape(-1, Cols)     # = dX of conv2d(pad 1)
+    sc = max(1.0, float(ref.abs().max()))
+    got = ybuf.double().cpu()
+    err = float((got[:, yoff:yoff + Cols] - (prior.double().cpu()[:, yoff:yoff + Cols] + ref)).abs().max())
+    record_margin(f"bf16v3/dgrad/{N}x{H}x{W}x{K}x{Cols}", err, 2e-5 * sc)
+    assert err < 2e-5 * sc, (shape, err)
+    # pad columns [Cols, cw) of the view: accumulate adds exact zeros; everything outside the view is untouched
+    assert torch.equal(got[:, yoff + Cols:yoff + cw], prior.double().cpu()[:, yoff + Cols:yoff + cw])
+    assert torch.equal(got[:, :yoff], prior.double().cpu()[:, :yoff]) and torch.equal(got[:, yoff + cw:], prior.double().cpu()[:, yoff + cw:])
+    # ReLU epilogue (accumulate bit 1), bias, no statistics: the folded predict path
+    b = torch.randn(Cols, device=DEV)
+    y2 = torch.full((N * H * W, cw), 7.0, device=DEV)
+    rc = lib.hpri_conv_bf16v3(P(planes), 0, cs16, 0, P(wpd), P(b), P(y2), cw, 0, P(None), N, H, W, cs16, Cols, cols_pad, cw, 2, 0,
+                              P(ws), ws.numel(), _st())
+    assert rc == 0, lib.hpri_last_error()
+    torch.cuda.synchronize()
+    ref2 = torch.relu(ref + b.double().cpu())
+    assert float((y2.double().cpu()[:, :Cols] - ref2).abs().max()) < 2e-5 * sc
+    assert float(y2[:, Cols:].abs().max()) == 0.0 if cw > Cols else True
+    # boundary errors: unaligned output view, channel stride too small, split planes, missing split-K workspace
+    assert lib.hpri_conv_bf16v3(P(planes), 0, cs16, 0, P(wpd), P(b), P(y2), cw, 2, P(None), N, H, W, cs16, Cols, cols_pad, cw, 0, 0,
+                                P(ws), ws.numel(), _st()) != 0
+    assert lib.hpri_conv_bf16v3(P(planes), 0, cs16 - 8, 0, P(wpd), P(b), P(y2), cw, 0, P(None), N, H, W, cs16, Cols, cols_pad, cw, 0, 0,
+                                P(ws), ws.numel(), _st()) != 0
+    assert lib.hpri_conv_bf16v3(P(planes), 0, cs16, 0, P(wpd), P(b), P(y2), cw, 0, P(None), N, H, W, cs16, Cols, cols_pad, cw, 0, 1,
+                                P(ws), ws.numel(), _st()) != 0
+    if k.value > 1:
+        assert lib.hpri_conv_bf16v3(P(planes), 0, cs16, 0, P(wpd), P(b), P(y2), cw, 0, P(None), N, H, W, cs16, Cols, cols_pad, cw, 0, 0,
+                                    P(None), 0, _st()) != 0
 
 
 @pytest.mark.parametrize("shape", [(1, 17, 23, 5, 7), (2, 36, 50, 64, 64), (1, 76, 121, 128, 192), (2, 38, 60, 40, 64), (1, 4, 32, 64, 64),

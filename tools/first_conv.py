@@ -28,10 +28,19 @@ def measure(reps=20, modes=("bf16_planes", "fp32")):
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     P = lambda t: ctypes.c_void_p(t.data_ptr())
     cs, cs16, cout_pad = 240, 256, 64
+    # operand statistics move the clock the chip holds (DVFS: MI355X_MICROARCH.md), so the layer is measured on what it reads in
+    # the benched workload: the synthetic cube u in [0, 1) (x = u(1234 + n, .)) and PyTorch-default-bound weights
+    # w = (2u - 1) / sqrt(fan_in), fan_in = 238 * 9 (bench.py: synth_init_), both from the device generator
+    from hyperpri_amd.engine import synth_fill_
     x = torch.zeros(N * H * W, cs, device=dev)
-    x[:, :CIN] = torch.rand(N * H * W, CIN, device=dev) - 0.5
-    w = (torch.rand(COUT * CIN * 9, device=dev) - 0.5) * 0.1
-    b = torch.rand(COUT, device=dev)
+    xv = torch.empty(N * H * W * CIN, device=dev)
+    synth_fill_(xv, 1234, mode=0)
+    x[:, :CIN] = xv.view(N * H * W, CIN)
+    del xv
+    w = torch.empty(COUT * CIN * 9, device=dev)
+    synth_fill_(w, 1000, mode=2, scale=1.0 / (CIN * 9) ** 0.5)
+    b = torch.empty(COUT, device=dev)
+    synth_fill_(b, 1001, mode=2, scale=1.0 / (CIN * 9) ** 0.5)
     y = torch.empty(N * H * W * COUT, device=dev)
     out = {"shape": {"N": N, "H": H, "W": W, "Cin": CIN, "Cout": COUT, "ks": 3}, "gflop_per_launch": FLOPS / 1e9}
     for mode in modes:
@@ -41,11 +50,15 @@ def measure(reps=20, modes=("bf16_planes", "fp32")):
             assert lib.hpri_to_planes(P(x), cs, 0, P(planes), 0, cs16, 0, N * H * W, CIN, cs16, 1, st) == 0
             wp = torch.empty((cs16 // 32) * 9 * cout_pad * 32, dtype=torch.bfloat16, device=dev)
             assert lib.hpri_pack_weight_bf16(P(w), P(wp), 0, CIN, COUT, cout_pad, 9, CIN, 0, 0, st) == 0
-            lib.hpri_conv_bf16v2_plan(N, H, W, cs16, cout_pad, ctypes.byref(k), ctypes.byref(tl), ctypes.byref(wsf))
+            from hyperpri_amd import engine as _E
+            kern = "hpri_conv_bf16v3" if _E.BF16_V3 else "hpri_conv_bf16v2"        # the kernel the bf16 mode runs (HPRI_BF16_V3)
+            getattr(lib, kern + "_plan")(N, H, W, cs16, cout_pad, ctypes.byref(k), ctypes.byref(tl), ctypes.byref(wsf))
             stats = torch.empty(tl.value * cout_pad * 4, device=dev)
             ws = torch.empty(max(wsf.value, 4), device=dev)
-            call = lambda: lib.hpri_conv_bf16v2(P(planes), 0, cs16, 0, P(wp), P(b), P(y), COUT, 0, P(stats), N, H, W, cs16, COUT,
-                                                cout_pad, COUT, 0, 0, P(ws), ws.numel(), st)
+            conv = getattr(lib, kern)
+            call = lambda: conv(P(planes), 0, cs16, 0, P(wp), P(b), P(y), COUT, 0, P(stats), N, H, W, cs16, COUT,
+                                cout_pad, COUT, 0, 0, P(ws), ws.numel(), st)
+            out["bf16_kernel"] = kern
             alg_bytes = N * H * W * (cs16 * 2 + COUT * 4) + wp.numel() * 2
         else:
             wp = torch.empty(lib.hpri_packed_weight_floats(CIN, cout_pad, 9), device=dev)
