@@ -244,7 +244,35 @@ __global__ void col_reduce_kernel(const float* __restrict__ dy, int dy_cs, int d
       sc[j] = ok ? scale[g * C + c + j] : 0.f;
       sh[j] = ok ? shift[g * C + c + j] : 0.f;
     }
-    for (long long p = p0 + pr; p < p1; p += rows) {
+    // four pixels per thread and iteration, all eight loads issued before the first use: with one pixel per iteration a
+    // thread had two 16-byte loads in flight and the pass ran at 56 % of the HBM rate of its two tensor sweeps (round 2: 1.57 ms
+    // per bf16-mode step against 0.88); the summation order per thread is unchanged (pixels in ascending order)
+    long long p = p0 + pr;
+    for (; p + 3 * rows < p1; p += 4 * rows) {
+      float4 dv[4], xv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        dv[u] = *reinterpret_cast<const float4*>(dy + (p + u * rows) * dy_cs + dy_coff + c);
+        if (MODE == 0) xv[u] = *reinterpret_cast<const float4*>(x + (p + u * rows) * x_cs + x_coff + c);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float d[4] = {dv[u].x, dv[u].y, dv[u].z, dv[u].w};
+        if (MODE == 0) {
+          const float xx[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float gj = (!relu || (xx[j] * sc[j] + sh[j] > 0.f)) ? d[j] : 0.f;
+            s1[j] += gj;
+            s2[j] += gj * ((xx[j] - mu[j]) * is[j]);
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) s1[j] += d[j];
+        }
+      }
+    }
+    for (; p < p1; p += rows) {
       const float4 dv = *reinterpret_cast<const float4*>(dy + p * dy_cs + dy_coff + c);
       const float d[4] = {dv.x, dv.y, dv.z, dv.w};
       if (MODE == 0) {
@@ -280,7 +308,8 @@ __global__ void col_reduce_kernel(const float* __restrict__ dy, int dy_cs, int d
 
 // stage 2: sums[g][k][c] = sum over blocks (double accumulation, fixed order); k in {0,1}
 __global__ void col_finalize_kernel(const float* __restrict__ part, int nblk, int Cpart, int C, float* __restrict__ sums,
-                                    float* __restrict__ out1, float* __restrict__ out2, int accumulate) {
+                                    float* __restrict__ out1, float* __restrict__ out2, int accumulate,
+                                    float* __restrict__ zero_out = nullptr) {
   __shared__ double s[2][32][32];
   const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cl, g = blockIdx.y;
@@ -307,6 +336,7 @@ __global__ void col_finalize_kernel(const float* __restrict__ part, int nblk, in
     // one group only: the parameter gradients ride along (out1 (+)= first sum, out2 (+)= second sum)
     if (out1 != nullptr) out1[c] = accumulate ? out1[c] + (float)t1 : (float)t1;
     if (out2 != nullptr) out2[c] = accumulate ? out2[c] + (float)t2 : (float)t2;
+    if (zero_out != nullptr) zero_out[c] = 0.f;      // (g == 0 only: the caller passes it for one group)
   }
 }
 
@@ -544,9 +574,20 @@ extern "C" int hpri_bn_relu_bwd_pl(const float* dy, int dy_cs, int dy_coff, cons
                      x_cs, x_coff, mean, invstd, scale, shift, pix_per_group, C, cq, relu, part, Cpart);
   HPRI_CHECK_LAUNCH();
   const bool pg = dgamma != nullptr && dbeta != nullptr;
+  // The bias of the convolution in front of a TRAINING-mode BatchNorm has an exactly zero gradient: sum_p dx = scale * (sum g -
+  // Np * mean(g) - mean(g xhat) * sum xhat) and sum xhat = 0.  The reference holds rounding noise there (~1e-9 of the other
+  // gradients; the fixtures compare it against zero); round 1-2 reproduced that noise with a column sum inside the apply kernel
+  // and a second finalize launch per layer.  Now: exact zeros, written by the finalize launch that exists anyway (and nothing at
+  // all when the caller accumulates).  Eval-mode statistics (use_batch_stats = 0) keep the computed sum: it is not zero there.
+  const bool dbias_zero = dbias != nullptr && use_batch_stats;
+  float* zero_out = (dbias_zero && !accumulate_dbias && G == 1) ? dbias : nullptr;
   hipLaunchKernelGGL(col_finalize_kernel, dim3(hpri_cdiv(C, 32), G), dim3(1024), 0, stream, part, nblk, Cpart, C, sums,
-                     (pg && G == 1) ? dbeta : nullptr, (pg && G == 1) ? dgamma : nullptr, accumulate_param_grads);
+                     (pg && G == 1) ? dbeta : nullptr, (pg && G == 1) ? dgamma : nullptr, accumulate_param_grads, zero_out);
   HPRI_CHECK_LAUNCH();
+  if (dbias_zero && !accumulate_dbias && G > 1) {
+    if (hipMemsetAsync(dbias, 0, (size_t)C * sizeof(float), stream) != hipSuccess) return hpri_set_error(HPRI_ERR_LAUNCH, "bn_relu_bwd: memset failed");
+  }
+  if (dbias_zero) dbias = nullptr;          // nothing left to compute for it
   if (pg && G > 1) {
     hipLaunchKernelGGL(bn_param_grad_kernel, dim3(hpri_cdiv(C, 256)), dim3(256), 0, stream, sums, G, C, dgamma, dbeta,
                        accumulate_param_grads);

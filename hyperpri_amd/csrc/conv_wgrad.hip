@@ -415,6 +415,58 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restr
   }
 }
 
+// 3x3 slabs ws[splits][9][Nr][Cr] -> dW[n][c][9] (OIHW), bandwidth-shaped (round 3).  The generic kernel above gives one
+// 1024-thread block 32 channels of one output row and reads 128-byte pieces with splits/32 of its threads: 0.5 TB/s on the
+// 37.7 MB of slabs every layer of a C2 step leaves (1.1 ms per step in the bf16 mode).  Here a block owns ONE output row n and a
+// run of 1024 / S channels; its 256 threads are (256 / S channel quads) x (S slab slices): every thread streams float4s of its
+// slices for all nine taps (all loads independent), the slices meet in LDS in slice order (fixed: deterministic), and the
+// block writes its [channel][tap] run of dW contiguously.  S = 16 / 4 / 1 by the number of slabs.
+template <int S>
+__global__ __launch_bounds__(256) void wgrad_reduce9_wide_kernel(const float* __restrict__ ws, float* __restrict__ dw, int splits,
+                                                                 int Cr, int Nr, int Cin, int Cout, int accumulate) {
+  constexpr int CQ = 256 / S, CR = CQ * 4;               // channel quads / channels per block
+  __shared__ float red[S][9][CR];
+  const int cq = threadIdx.x % CQ, sl = threadIdx.x / CQ;
+  const int n = blockIdx.y, c0 = blockIdx.x * CR, c = c0 + cq * 4;
+  f32x4 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (c < Cr) {
+    const size_t slab = (size_t)9 * Cr * Nr, row = (size_t)Nr * Cr;
+    const float* p = ws + (size_t)n * Cr + c;
+    for (int k = sl; k < splits; k += S) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t) acc[t] += *reinterpret_cast<const f32x4*>(p + (size_t)k * slab + (size_t)t * row);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 9; ++t) *reinterpret_cast<f32x4*>(&red[sl][t][cq * 4]) = acc[t];
+  __syncthreads();
+  const int nout = min(CR, Cin - c0) * 9;                // this block's run of dW: [channel][tap], contiguous
+  float* o = dw + ((size_t)n * Cin + c0) * 9;
+  for (int i = threadIdx.x; i < nout; i += 256) {
+    const int cl = i / 9, t = i - cl * 9;
+    float v = red[0][t][cl];
+#pragma unroll
+    for (int q = 1; q < S; ++q) v += red[q][t][cl];
+    o[i] = accumulate ? o[i] + v : v;
+  }
+}
+
+static void launch_wgrad_reduce9_wide(const float* ws, float* dw, int splits, int Cr, int Nr, int Cin, int Cout, int accumulate,
+                                      hipStream_t stream) {
+  if (splits >= 16)
+    hipLaunchKernelGGL((wgrad_reduce9_wide_kernel<16>), dim3((unsigned)hpri_cdiv(Cin, 64), (unsigned)Cout), dim3(256), 0, stream, ws, dw,
+                       splits, Cr, Nr, Cin, Cout, accumulate);
+  else if (splits >= 3)
+    hipLaunchKernelGGL((wgrad_reduce9_wide_kernel<4>), dim3((unsigned)hpri_cdiv(Cin, 256), (unsigned)Cout), dim3(256), 0, stream, ws, dw,
+                       splits, Cr, Nr, Cin, Cout, accumulate);
+  else
+    hipLaunchKernelGGL((wgrad_reduce9_wide_kernel<1>), dim3((unsigned)hpri_cdiv(Cin, 1024), (unsigned)Cout), dim3(256), 0, stream, ws, dw,
+                       splits, Cr, Nr, Cin, Cout, accumulate);
+}
+
+
 // ConvTranspose2d(k2, s2) weights (dst mode 1, T == 1): dW[c][co][tap] from slab rows n = tap * Cup + co.  One workgroup owns
 // 64 channels x 16 co x 4 taps: every thread sums its four (row, channel) pairs over the slabs in order (256-byte row segments),
 // the 64 x 64 tile turns in LDS, and each channel's 16 co x 4 taps leave as 256 contiguous bytes (the generic kernel above wrote
@@ -609,6 +661,7 @@ extern "C" int hpri_wgrad_reduce(const float* ws, float* dw, int N, int H, int W
   if (KS == 1 && dst_mode == 1 && Cup % 16 == 0 && ((uintptr_t)dw & 15) == 0 && splits <= 16)
     hipLaunchKernelGGL(wgrad_reduce_convt_kernel, dim3((unsigned)hpri_cdiv(Cin, 64), (unsigned)(Cup / 16)), dim3(1024), 0, stream, ws, dw,
                        splits, Cr, Nr, Cin, Cup, accumulate);
+  else if (KS == 3 && dst_mode == 0 && Cr % 4 == 0) launch_wgrad_reduce9_wide(ws, dw, splits, Cr, Nr, Cin, Cout, accumulate, stream);
   else if (KS == 3) hipLaunchKernelGGL((wgrad_reduce_kernel<9>), grid, dim3(1024), 0, stream, ws, dw, splits, Cr, Nr, Cin, Cout, dst_mode, Cup, accumulate);
   else hipLaunchKernelGGL((wgrad_reduce_kernel<1>), grid, dim3(1024), 0, stream, ws, dw, splits, Cr, Nr, Cin, Cout, dst_mode, Cup, accumulate);
   HPRI_CHECK_LAUNCH();
@@ -624,7 +677,8 @@ extern "C" int hpri_wgrad_reduce_ex(const float* ws, float* dw, int splits, int 
   HPRI_REQUIRE(Cin <= Cr && Cout <= Nr, "wgrad_reduce_ex: slab smaller than the gradient");
   if (dst_mode == 1) HPRI_REQUIRE(Cup > 0 && Cout == 4 * Cup, "wgrad_reduce_ex: convT layout needs Cout == 4*Cup");
   dim3 grid((unsigned)hpri_cdiv(Cin, 32), (unsigned)Cout);
-  if (KS == 3) hipLaunchKernelGGL((wgrad_reduce_kernel<9>), grid, dim3(1024), 0, stream, ws, dw, splits, Cr, Nr, Cin, Cout, dst_mode, Cup, accumulate);
+  if (KS == 3 && dst_mode == 0 && Cr % 4 == 0) launch_wgrad_reduce9_wide(ws, dw, splits, Cr, Nr, Cin, Cout, accumulate, stream);
+  else if (KS == 3) hipLaunchKernelGGL((wgrad_reduce_kernel<9>), grid, dim3(1024), 0, stream, ws, dw, splits, Cr, Nr, Cin, Cout, dst_mode, Cup, accumulate);
   else hipLaunchKernelGGL((wgrad_reduce_kernel<1>), grid, dim3(1024), 0, stream, ws, dw, splits, Cr, Nr, Cin, Cout, dst_mode, Cup, accumulate);
   HPRI_CHECK_LAUNCH();
   return HPRI_OK;

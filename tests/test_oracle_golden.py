@@ -178,3 +178,27 @@ def test_generator_known_answer():
     v = O._u(0, 2)
     assert v[0] == 0.0  # mix(0) == 0
     assert O._u(1, 1)[0] == np.float32((0xE220A8397B1DCDAF >> 40) / 2.0 ** 24)
+
+
+def test_oracle_gradients_vs_fp64_reference_samples():
+    """The deep gradient fixtures (tests/golden/make_golden_grads.py): the oracle's fp32 gradients of the tiny CubeNET-64, sampled at
+    the fixture's positions, equal the reference modules' fp32 samples to rounding, and both sit within the recorded distance of the
+    fp64 samples -- so the GPU test that measures the HIP path against fp64 is anchored on the reference, not on the oracle."""
+    import numpy as np
+    z = np.load(os.path.join(G, "grads_cubenet64_tiny.npz"))
+    sd = O.synth_state_dict(O.cubenet_shapes(6, 1, 64))
+    x = torch.from_numpy(O._u(1235, 2 * 6 * 36 * 50).reshape(2, 1, 6, 36, 50).copy())
+    m = (torch.from_numpy(O._u(4321, 2 * 36 * 50).reshape(2, 1, 36, 50).copy()) > 0.9).float()
+    _, loss, grads = O.train_step(O.cubenet_forward, sd, x, m, first_depth=64)
+    assert abs(loss - float(z["loss32"])) < 1e-6
+    names = list(z["grad_names"])
+    ns = int(z["ns"])
+    for k, nm in enumerate(names):
+        g = grads[nm if nm in grads else nm.replace("inc.0.", "first_conv.")].reshape(-1)
+        numel = g.numel()
+        idx = np.arange(numel) if numel <= ns else np.minimum((O._u(9000 + k, ns).astype(np.float64) * numel).astype(np.int64), numel - 1)
+        cnt = int(z["grad_sample_count"][k])
+        got = g[torch.from_numpy(idx)].double().numpy()
+        ref32 = z["grad_sample32"][k, :cnt].astype(np.float64)
+        scale = max(float(np.abs(ref32).max()), 1e-6)
+        assert float(np.abs(got - ref32).max()) <= 2e-3 * scale + 1e-7, nm
