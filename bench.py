@@ -219,8 +219,10 @@ def main():
     ap.add_argument("--bf16-steps", type=int, default=5,
                     help="extra steps in each of the precision modes bf16x6, bf16x3 and bf16 (reported as 'bf16x6_mode' / 'bf16x3_mode' / "
                          "'bf16_mode', never as 'value'); 0 = skip")
-    ap.add_argument("--settle-seconds", type=float, default=10.0,
-                    help="upper bound of the untimed settle phase in front of the warm-up steps (0 = none); see the comment at the loop")
+    ap.add_argument("--settle-seconds", type=float, default=0.0,
+                    help="upper bound of an untimed settle phase in front of the warm-up steps (0 = none, the default since round 3: "
+                         "five driver-shaped sequences -- GPU tests, then this script -- with engine.throttle alone gave 62.37-62.64 "
+                         "cubes/s, none slow: profiles/r03_no_settle_sequences.txt); see the comment at the loop")
     ap.add_argument("--force-sync", action="store_true",
                     help="rehearsal: run the RCCL GradSync path (process group, hooks, all-reduce) even with one rank")
     ap.add_argument("--dry-launch", action="store_true",
@@ -294,7 +296,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # ---- settle (untimed, before the W warm-up steps).  Twice this round the first process on a box that had just run the GPU
+    # ---- settle (OFF by default since round 3; kept as an option).  Round 2's finding: twice the first process on a box that had just run the GPU
     #      test suite measured 190-200 ms/step in the timed loop while every later leg of the same process, and single FENCED
     #      steps before it, ran at the normal 32 ms: the slowness belongs to the first seconds of back-to-back (host running
     #      ahead) steps of a fresh process, i.e. to the caching allocator growing its pool while blocks are still held by queued

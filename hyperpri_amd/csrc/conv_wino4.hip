@@ -27,6 +27,7 @@ struct Wino4Args {
   float4* stats;                // [N*tiles_img][Cout_pad] (mean, M2, count, 0) or nullptr
   int N, H, W, Cin_pad, Cout, Cout_pad, y_cw, accumulate, relu;
   int tiles_x, tiles_y;
+  int items, per_xcd;           // work items (pixel tiles x channel blocks) and items per XCD band
   int ncu, stagger_cycles;      // compute units of the device (host: hipDeviceProp_t.multiProcessorCount) and the one-off delay of
                                 // each CU's second occupant (below); 0 cycles = no stagger
 #ifdef HPRI_STAMPS
@@ -67,8 +68,16 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(Wino4Args a) {
   const int li = lane & 31, lh = lane >> 5;
   const int fa = wave;                              // frequency row
   const int tiles_img = a.tiles_x * a.tiles_y;
-  const int nbc = a.Cout_pad >> 6;                  // channel blocks of one pixel tile are adjacent in launch order
-  const int bx = blockIdx.x / nbc, nb = blockIdx.x - bx * nbc;
+  const int nbc = a.Cout_pad >> 6;
+  // XCD-aware order (round 3): workgroup id mod 8 labels the XCD (round-robin dispatch; speed only), and XCD x owns the items
+  // [x * per_xcd, (x+1) * per_xcd) -- the channel blocks of one pixel tile back to back, pixel tiles in raster order.  With the
+  // plain order (item = workgroup id) the nbc channel blocks of a tile landed on nbc DIFFERENT XCDs and every one of them
+  // fetched the tile's halo into its own L2: measured read traffic 1.41 x nbc x the input (profiles/
+  // r03_wino4_layer_traffic_before_xcd.json: 2.8 x at 2 blocks, 5.0 x at 4, 6.6 x at 8); the halo columns / rows shared by
+  // neighbouring tiles (the 1.41) never met in one L2 either.
+  const int item = (int)(blockIdx.x & 7) * a.per_xcd + (int)(blockIdx.x >> 3);
+  if (item >= a.items) return;
+  const int bx = item / nbc, nb = item - bx * nbc;
   const int img = bx / tiles_img, tin = bx - img * tiles_img;
   const int ty0 = tin / a.tiles_x, tx0 = tin - ty0 * a.tiles_x;
   const int Y0 = ty0 * 8, X0 = tx0 * 16;
@@ -431,7 +440,10 @@ extern "C" int hpri_conv_wino4(const float* x, int x_cs, int x_coff, const float
 #ifdef HPRI_STAMPS
   a.stamps = hpri_wino4_stamps;
 #endif
-  dim3 grid((unsigned)(N * a.tiles_x * a.tiles_y * (Cout_pad / 64)), 1u, 1u);
+  const long long items = (long long)N * a.tiles_x * a.tiles_y * (Cout_pad / 64);
+  HPRI_REQUIRE(items < (1ll << 28), "conv_wino4: too many work items");
+  a.items = (int)items; a.per_xcd = (int)((items + 7) / 8);
+  dim3 grid((unsigned)(a.per_xcd * 8), 1u, 1u);
   hipLaunchKernelGGL(conv_wino4_kernel, grid, dim3(256), 0, stream, a);
   HPRI_CHECK_LAUNCH();
   return HPRI_OK;

@@ -62,7 +62,7 @@ class Act:
 
     Invariant: channels [C, cw) (cw = C rounded up to 8) exist inside the stride and hold zeros, so
     consumers may run their K loop over ``cw`` channels."""
-    __slots__ = ("buf", "N", "H", "W", "C", "cs", "coff", "pl", "parent", "f32_valid", "want_pl", "pl_part")
+    __slots__ = ("buf", "N", "H", "W", "C", "cs", "coff", "pl", "parent", "f32_valid", "want_pl", "pl_part", "colsum_req")
 
     def __init__(self, buf: torch.Tensor, N: int, H: int, W: int, C: int, cs: int, coff: int = 0):
         self.buf, self.N, self.H, self.W, self.C, self.cs, self.coff = buf, N, H, W, C, cs, coff
@@ -71,6 +71,7 @@ class Act:
         self.f32_valid = True                   # False: only the bf16 planes were written (plane mode, inner tensor of a DoubleConv)
         self.pl_part = None                     # (Planes, channels filled so far): a concat buffer whose skip half is already in planes
         self.want_pl = 0                        # plane mode marker: planes a 3x3 consumer of this tensor (or of its pooled map) would read
+        self.colsum_req = None                  # (c0, C): somebody wants the column sums of channels [c0, c0+C) of this tensor's GRADIENT
 
     @property
     def cw(self) -> int:
@@ -305,6 +306,7 @@ class Tape:
         self.keep: List[object] = []
         self.used_side = False
         self.sunk: Dict[int, torch.Tensor] = {}     # parameters whose gradient was written into the grad sink's storage
+        self.colsum: Dict[int, tuple] = {}          # id(Act) -> (stats records, tiles, Cpad, c0) left by the data-gradient kernel that wrote its gradient
         self.uses: Dict[int, int] = {}              # id(parameter) -> ops recorded on this tape that will produce a gradient for it
         self._touched: List[int] = []               # parameters the running node asked a gradient slot for
 
@@ -381,6 +383,7 @@ class Tape:
         self.nodes.clear()
         self.keep.clear()
         self.uses.clear()
+        self.colsum.clear()
 
 
 class BNRef:
@@ -877,12 +880,27 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
             _wgrad(x, dyr, dw, acc_w, cin, cout, ks, bf16=lowp, split=split)
         if need_dx:
             gx, acc = tp.grad_slot(x)
+            # the column sums of (a channel range of) this gradient are wanted -- the bias gradient of the ConvTranspose2d that
+            # produced half of a concat: the data-gradient kernel records them per tile in its epilogue (the BatchNorm statistics
+            # machinery) instead of a dedicated pass over the tensor afterwards
+            gstats, gtiles = None, 0
+            if COLSUM_FROM_STATS and x.colsum_req is not None and not acc and (wino_d or v2):
+                tl = ctypes.c_int(); ksp = ctypes.c_int(); wsf_ = ctypes.c_size_t()
+                if wino_d:
+                    _lib.call(f"hpri_conv_{_wino_sfx()}_plan", x.N, x.H, x.W, ctypes.byref(tl))
+                else:
+                    _lib.call(_plane_conv() + "_plan", x.N, x.H, x.W, _rup(cout, 32), _rup(cin, 64), ctypes.byref(ksp), ctypes.byref(tl),
+                              ctypes.byref(wsf_))
+                gtiles = tl.value
+                gstats = torch.empty(gtiles * _rup(cin, 64) * 4, dtype=torch.float32, device=dev)
             if wino_d:
                 upd, cin_cols_pad = _pack_wino(weight, 1, cout, cin, cin)
-                _conv_launch_wino(dyr, upd, None, gx, None, cout, cin, cin_cols_pad, gx.cw, accumulate=int(acc))
+                _conv_launch_wino(dyr, upd, None, gx, gstats, cout, cin, cin_cols_pad, gx.cw, accumulate=int(acc))
             elif v2:
                 wpd, cin_cols_pad = _pack_bf16(weight, 1, cout, cin, T, cin, split=0)
-                _conv_launch_v2(dyr, wpd, None, gx, None, cout, cin, cin_cols_pad, gx.cw, accumulate=int(acc))
+                _conv_launch_v2(dyr, wpd, None, gx, gstats, cout, cin, cin_cols_pad, gx.cw, accumulate=int(acc))
+            if gstats is not None:
+                tp.colsum[id(x)] = (gstats, gtiles, cin_cols_pad)
             elif lowp:
                 wpd, cin_cols_pad = _pack_bf16(weight, 1, cout, cin, T, cin, split=split)
                 _conv_launch_bf16(dyr, wpd, None, gx, None, x.N, x.H, x.W, dyr.cw, cin, cin_cols_pad, gx.cw, ks,
@@ -897,6 +915,9 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
     return y
 
 
+# the ConvTranspose2d bias gradient from the epilogue records of the data-gradient kernel that wrote the concat's gradient
+# (hpri_colsum_from_stats) instead of a pass over that tensor (hpri_col_sum).  HPRI_COLSUM_FROM_STATS: 1 (default) / 0.
+COLSUM_FROM_STATS = os.environ.get("HPRI_COLSUM_FROM_STATS", "1") != "0"
 FOLD_EVAL_BN = True   # inference only (no tape): conv + eval-mode BN + ReLU as ONE kernel with BN folded into w and b
 FOLD_LAUNCHES = 0     # folded conv+BN+ReLU stages executed (tests assert that the predict path really takes them)
 
@@ -1126,12 +1147,17 @@ def _upsample_into(tape: Tape, x1: Act, dst: Act, weight: Optional[torch.Tensor]
         cin = weight.shape[0]
         if dY or dX:   # F.pad's backward drops the ring
             _lib.call("hpri_fill_pad", gu.ptr, gu.cs, gu.coff, gu.N, H2, W2, cup, py0, py0 + 2 * x1.H, px0, px0 + 2 * x1.W, _stream())
+        cs = tp.colsum.pop(id(dst), None)
         if bias is not None:
             db, acc_b = tp.param_slot(bias)
-            nblk = ctypes.c_int(); cpart = ctypes.c_int()
-            _lib.call("hpri_col_reduce_plan", gu.P, 1, cup, ctypes.byref(nblk), ctypes.byref(cpart))
-            ws = _ws(nblk.value * 2 * cpart.value + 2 * cup, dev)
-            _lib.call("hpri_col_sum", gu.ptr, gu.cs, gu.coff, _p(db), acc_b, _p(ws), ws.numel(), gu.P, cup, _stream())
+            if cs is not None and len(cs) == 4:
+                gstats, gtiles, cpad, c0 = cs
+                _lib.call("hpri_colsum_from_stats", _p(gstats), gtiles, cpad, c0, cup, _p(db), acc_b, _stream())
+            else:
+                nblk = ctypes.c_int(); cpart = ctypes.c_int()
+                _lib.call("hpri_col_reduce_plan", gu.P, 1, cup, ctypes.byref(nblk), ctypes.byref(cpart))
+                ws = _ws(nblk.value * 2 * cpart.value + 2 * cup, dev)
+                _lib.call("hpri_col_sum", gu.ptr, gu.cs, gu.coff, _p(db), acc_b, _p(ws), ws.numel(), gu.P, cup, _stream())
         bprec = precision or DEFAULT_PRECISION
         if weight.requires_grad:
             dw, acc_w = tp.param_slot(weight)
@@ -1205,12 +1231,18 @@ def up_concat(tape: Tape, x1: Act, skip: Act, weight: Optional[torch.Tensor], bi
             PLANE_CONVERSIONS += 1
         cat.pl, cat.pl_part = pl, None
     if tape.record:
+        if weight is not None and bias is not None and bias.requires_grad and cat.H == 2 * x1.H and cat.W == 2 * x1.W:
+            cat.colsum_req = (skip.C, cup)     # (no pad ring: F.pad's backward would have to drop ring pixels from the sums)
+
         def bwd(tp: Tape) -> None:
             g = tp.grads.pop(id(cat), None)
             if g is None:
                 return
             tp.set_grad_view(skip, g.slice(0, skip.C))
             tp.grads[id(ups)] = g.slice(skip.C, cup)
+            cs = tp.colsum.pop(id(cat), None)
+            if cs is not None:
+                tp.colsum[id(ups)] = cs + (skip.C,)
         tape.nodes.append(bwd)
     return cat
 

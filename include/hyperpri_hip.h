@@ -217,6 +217,11 @@ int hpri_bn_relu_bwd(const float* dy, int dy_cs, int dy_coff, const float* x, in
                      int C, int Cw, int relu, int use_batch_stats, hipStream_t stream);
 int hpri_col_sum(const float* src, int cs, int coff, float* out, int accumulate, float* workspace, size_t ws_floats,
                  long long P, int C, hipStream_t stream);
+/* the same sum taken from the per-tile (mean, M2, count, 0) records a convolution epilogue leaves (`stats` of hpri_conv_wino4 /
+ * hpri_conv_bf16v3 / hpri_conv_fwd): out[c] (+)= sum over tiles of mean * count of channel c0 + c.  The ConvTranspose2d bias gradient
+ * (model_parts.py:63-64) without a pass over the gradient tensor: the data-gradient kernel that wrote it recorded its columns. */
+int hpri_colsum_from_stats(const float* stats, int tiles, int Cpad, int c0, int C, float* out, int accumulate,
+                           hipStream_t stream);
 /* the same two passes, also writing their output as bf16 planes (hpri_to_planes layout; channels [C, pl_cw) zero) for
  * the bf16-mode convolutions: the producer writes the planes, so no conversion pass reads the fp32 tensor again */
 int hpri_nchw_to_nhwc_pl(const float* src, float* dst, int N, int C, long long P, int cs, int coff, int Cw, void* planes,

@@ -73,6 +73,69 @@ void run_mix(const char* name, const char* vname, int blocks, int threads, int i
   hipFree(d);
 }
 
+// Instruction mix of a fused fp32 Winograd main loop, per group of FOUR v_mfma_f32_32x32x2_f32: NV vector-ALU instructions
+// (the input transform) and NL ds_read_b128 (halo + transformed-weight fragments), two or one waves per SIMD.
+//   F(2x2,3x3) as built (conv_wino4.hip):          4 VALU + 2 reads per 4 MFMAs (32 + 16 per 32-MFMA stage)
+//   mixed F(2,3) x F(4,3), 8 waves x 3 frequencies: 11 VALU + 3 reads per 4 MFMAs (64 + 18 per 24-MFMA stage), 0.75 x the MFMAs
+// The quotient of the two ticks-per-MFMA figures times 0.75 is the most the mixed form's main loop can gain.
+template <int NV, int NL>
+__global__ __launch_bounds__(512) void wino_mix_kernel(unsigned long long* out, int iters, float seed) {
+  __shared__ float4 lds[4096];
+  for (int i = threadIdx.x; i < 4096; i += blockDim.x) lds[i] = make_float4(seed, seed + i, seed - i, 1.f);
+  f32x16 acc[4];
+  for (int i = 0; i < 4; ++i)
+    for (int r = 0; r < 16; ++r) acc[i][r] = seed * (float)(threadIdx.x + i + r);
+  float x[12];
+  for (int i = 0; i < 12; ++i) x[i] = seed + i;
+  const float m = seed, c = seed * 0.5f;
+  float4 f[3] = {lds[threadIdx.x], lds[threadIdx.x + 512], lds[threadIdx.x + 1024]};
+  unsigned long long t0, t1;
+  __syncthreads();
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+      for (int l = 0; l < NL; ++l) f[l] = lds[(threadIdx.x + 64 * (it + u + l)) & 4095];     // conflict-free b128, address varies
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(f[i % NL].x + x[i], f[(i + 1) % NL].y, acc[i], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int v = (i * NV) / 4; v < ((i + 1) * NV) / 4; ++v) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(x[v % 12]) : "v"(m), "v"(c));
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  asm volatile("s_nop 0" ::: "memory");
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
+  float s = 0.f;
+  for (int i = 0; i < 4; ++i)
+    for (int r = 0; r < 16; ++r) s += acc[i][r];
+  for (int i = 0; i < 12; ++i) s += x[i];
+  if (s == 12345.678f) out[0] = 1;
+  if ((threadIdx.x & 63) == 0) out[1 + blockIdx.x * 8 + (threadIdx.x >> 6)] = t1 - t0;
+}
+
+template <int NV, int NL>
+void run_wino_mix(const char* name, int blocks, int threads, int iters) {
+  unsigned long long* d;
+  hipMalloc(&d, (1 + (size_t)blocks * 8) * 8);
+  hipMemset(d, 0, (1 + (size_t)blocks * 8) * 8);
+  for (int w = 0; w < 2; ++w) wino_mix_kernel<NV, NL><<<blocks, threads>>>(d, iters, 0.25f);
+  hipDeviceSynchronize();
+  const int waves = threads / 64;
+  std::vector<unsigned long long> h(1 + (size_t)blocks * 8);
+  hipMemcpy(h.data(), d, h.size() * 8, hipMemcpyDeviceToHost);
+  std::vector<double> v;
+  for (int b = 0; b < blocks; ++b) for (int w = 0; w < waves; ++w) v.push_back((double)h[1 + b * 8 + w]);
+  std::sort(v.begin(), v.end());
+  const double per_simd = (double)iters * 16 * (waves / 4.0);
+  printf("{\"winograd_mix\": \"%s\", \"valu_per_4_mfma\": %d, \"ds_read_b128_per_4_mfma\": %d, \"workgroups\": %d, \"waves_per_simd\": %.1f, "
+         "\"ticks_per_mfma\": %.2f, \"documented\": 64}\n", name, NV, NL, blocks, waves / 4.0, v[v.size() / 2] / per_simd);
+  hipFree(d);
+}
+
 __device__ __forceinline__ float rnd(unsigned x) {      // hash -> uniform in (-1, 1) * 2^-6
   x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
   return ((float)(x & 0xffffff) / 8388608.f - 1.f) * 0.015625f;
@@ -135,7 +198,16 @@ void run(const char* name, int blocks, int threads, int iters, double ideal, flo
   hipFree(d);
 }
 
-int main() {
+int main(int argc, char** argv) {
+  if (argc > 1 && argv[1][0] == 'w') {           // the Winograd instruction-mix model only
+    for (int threads : {256, 512}) {
+      run_wino_mix<4, 2>("F(2x2,3x3) as built", 256, threads, 4000);
+      run_wino_mix<11, 3>("mixed F(2,3)xF(4,3)", 256, threads, 4000);
+      run_wino_mix<0, 2>("no transform, 2 reads", 256, threads, 4000);
+      run_wino_mix<0, 1>("no transform, 1 read", 256, threads, 4000);
+    }
+    return 0;
+  }
   const int iters = 20000;
   for (int blocks : {8, 64, 256}) {
     for (int threads : {256, 512}) {
