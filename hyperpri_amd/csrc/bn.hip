@@ -179,6 +179,19 @@ __global__ void bn_fold_kernel(const float* __restrict__ rm, const float* __rest
 // -------------------------------------------------------------------------------------------------
 // grid = (pixel blocks, ceil(Cw4/CQ), G); block = 256 = ROWS x CQ channel quads; per-channel constants live in
 // registers for the whole pixel loop (no integer division, no per-element parameter loads)
+
+// The pre-BatchNorm tensor x (a convolution's output) is fp32, or -- bf16 precision mode with HPRI_YR_BF16, conv_bf16v3.hip --
+// stored as bf16: XB selects the element type of `x`; the arithmetic is fp32 either way.
+template <bool XB>
+__device__ __forceinline__ float4 bn_load_x4(const float* __restrict__ x, size_t idx) {
+  if (XB) {
+    const bf16x4_t v = *reinterpret_cast<const bf16x4_t*>(reinterpret_cast<const __bf16*>(x) + idx);
+    return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+  }
+  return *reinterpret_cast<const float4*>(x + idx);
+}
+
+template <bool XB>
 __global__ void bn_apply_relu_kernel(const float* __restrict__ x, int x_cs, int x_coff, float* __restrict__ y,
                                      int y_cs, int y_coff, const float* __restrict__ scale,
                                      const float* __restrict__ shift, int pix_per_group, int C, int Cw, int CQ,
@@ -204,7 +217,7 @@ __global__ void bn_apply_relu_kernel(const float* __restrict__ x, int x_cs, int 
     const size_t p = base + q;
     float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
     if (in_f) {
-      const float4 v = *reinterpret_cast<const float4*>(x + p * x_cs + x_coff + c);
+      const float4 v = bn_load_x4<XB>(x, p * x_cs + x_coff + c);
       o.x = v.x * sc[0] + sh[0]; o.y = v.y * sc[1] + sh[1]; o.z = v.z * sc[2] + sh[2]; o.w = v.w * sc[3] + sh[3];
       if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
       if (y != nullptr) *reinterpret_cast<float4*>(y + p * y_cs + y_coff + c) = o;
@@ -217,7 +230,7 @@ __global__ void bn_apply_relu_kernel(const float* __restrict__ x, int x_cs, int 
 // backward, stage 1: per-channel partial sums of g = dy * [y > 0] and g * xhat over pixel ranges
 // -------------------------------------------------------------------------------------------------
 // grid = (nblk, ceil(C4/CQ), G); block = 256 = ROWS x CQ; partial layout [G][nblk][2][Cq4*4]
-template <int MODE>  // 0: BN+ReLU backward sums (s1 = sum g, s2 = sum g*xhat); 1: plain column sum of dy
+template <int MODE, bool XB = false>  // 0: BN+ReLU backward sums (s1 = sum g, s2 = sum g*xhat); 1: plain column sum of dy
 __global__ void col_reduce_kernel(const float* __restrict__ dy, int dy_cs, int dy_coff, const float* __restrict__ x,
                                   int x_cs, int x_coff, const float* __restrict__ mean,
                                   const float* __restrict__ invstd, const float* __restrict__ scale,
@@ -253,7 +266,7 @@ __global__ void col_reduce_kernel(const float* __restrict__ dy, int dy_cs, int d
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         dv[u] = *reinterpret_cast<const float4*>(dy + (p + u * rows) * dy_cs + dy_coff + c);
-        if (MODE == 0) xv[u] = *reinterpret_cast<const float4*>(x + (p + u * rows) * x_cs + x_coff + c);
+        if (MODE == 0) xv[u] = bn_load_x4<XB>(x, (p + u * rows) * x_cs + x_coff + c);
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -276,7 +289,7 @@ __global__ void col_reduce_kernel(const float* __restrict__ dy, int dy_cs, int d
       const float4 dv = *reinterpret_cast<const float4*>(dy + p * dy_cs + dy_coff + c);
       const float d[4] = {dv.x, dv.y, dv.z, dv.w};
       if (MODE == 0) {
-        const float4 xv = *reinterpret_cast<const float4*>(x + p * x_cs + x_coff + c);
+        const float4 xv = bn_load_x4<XB>(x, p * x_cs + x_coff + c);
         const float xx[4] = {xv.x, xv.y, xv.z, xv.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -353,6 +366,7 @@ __global__ void bn_param_grad_kernel(const float* __restrict__ sums, int G, int 
 
 // dx = scale * (g - s1/Np - xhat * s2/Np)   (training) ;  dx = scale * g  (eval: use_batch_stats = 0)
 // same 2-D mapping as bn_apply_relu_kernel; also emits per-block column sums of dx (the conv-bias gradient)
+template <bool XB>
 __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, int dy_cs, int dy_coff, const float* __restrict__ x,
                                     int x_cs, int x_coff, float* __restrict__ dx, int dx_cs, int dx_coff,
                                     const float* __restrict__ mean, const float* __restrict__ invstd,
@@ -392,7 +406,7 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, int dy_cs, int
     for (int q = q0 + pr; q < q1; q += rows) {
       const size_t p = base + q;
       const float4 dv = *reinterpret_cast<const float4*>(dy + p * dy_cs + dy_coff + c);
-      const float4 xv = *reinterpret_cast<const float4*>(x + p * x_cs + x_coff + c);
+      const float4 xv = bn_load_x4<XB>(x, p * x_cs + x_coff + c);
       const float d[4] = {dv.x, dv.y, dv.z, dv.w}, xx[4] = {xv.x, xv.y, xv.z, xv.w};
       float o[4];
 #pragma unroll
@@ -494,10 +508,10 @@ extern "C" int hpri_bn_apply_relu(const float* x, int x_cs, int x_coff, float* y
 }
 
 // the same pass, also writing the result as bf16 planes (planes == nullptr: fp32 only); see PlaneOut
-extern "C" int hpri_bn_apply_relu_pl(const float* x, int x_cs, int x_coff, float* y, int y_cs, int y_coff,
-                                     const float* scale, const float* shift, long long P, long long pix_per_group,
-                                     int C, int Cw, int relu, void* planes, long long plane_stride, int pl_cs, int pl_coff,
-                                     int pl_cw, int npl, hipStream_t stream) {
+static int bn_apply_relu_impl(const float* x, bool x16, int x_cs, int x_coff, float* y, int y_cs, int y_coff,
+                              const float* scale, const float* shift, long long P, long long pix_per_group,
+                              int C, int Cw, int relu, void* planes, long long plane_stride, int pl_cs, int pl_coff,
+                              int pl_cw, int npl, hipStream_t stream) {
   // y == nullptr with planes given: the activation is wanted as bf16 planes only (the inner tensor of a DoubleConv in the plane
   // mode: the next convolution and its weight gradient read nothing else)
   HPRI_REQUIRE(x && (y || planes) && scale && shift, "bn_apply_relu: null pointer");
@@ -513,10 +527,33 @@ extern "C" int hpri_bn_apply_relu_pl(const float* x, int x_cs, int x_coff, float
   const long long maxb = (pix_per_group + rows * 4 - 1) / (rows * 4);
   if (nbx > maxb) nbx = maxb;
   if (nbx < 1) nbx = 1;
-  hipLaunchKernelGGL(bn_apply_relu_kernel, dim3((unsigned)nbx, ycols, G), dim3(256), 0, stream, x, x_cs, x_coff, y, y_cs,
-                     y_coff, scale, shift, (int)pix_per_group, C, Cw, cq, relu, po);
+  if (x16)
+    hipLaunchKernelGGL(bn_apply_relu_kernel<true>, dim3((unsigned)nbx, ycols, G), dim3(256), 0, stream, x, x_cs, x_coff, y, y_cs,
+                       y_coff, scale, shift, (int)pix_per_group, C, Cw, cq, relu, po);
+  else
+    hipLaunchKernelGGL(bn_apply_relu_kernel<false>, dim3((unsigned)nbx, ycols, G), dim3(256), 0, stream, x, x_cs, x_coff, y, y_cs,
+                       y_coff, scale, shift, (int)pix_per_group, C, Cw, cq, relu, po);
   HPRI_CHECK_LAUNCH();
   return HPRI_OK;
+}
+
+extern "C" int hpri_bn_apply_relu_pl(const float* x, int x_cs, int x_coff, float* y, int y_cs, int y_coff,
+                                     const float* scale, const float* shift, long long P, long long pix_per_group,
+                                     int C, int Cw, int relu, void* planes, long long plane_stride, int pl_cs, int pl_coff,
+                                     int pl_cw, int npl, hipStream_t stream) {
+  return bn_apply_relu_impl(x, false, x_cs, x_coff, y, y_cs, y_coff, scale, shift, P, pix_per_group, C, Cw, relu, planes, plane_stride,
+                            pl_cs, pl_coff, pl_cw, npl, stream);
+}
+
+// the same with the pre-BN tensor stored as bf16 (x16: element (p, c) at x16[p * x_cs + x_coff + c]; hpri_conv_bf16v3 with bit 2 of
+// `accumulate` writes it)
+extern "C" int hpri_bn_apply_relu_x16(const void* x16, int x_cs, int x_coff, float* y, int y_cs, int y_coff,
+                                      const float* scale, const float* shift, long long P, long long pix_per_group,
+                                      int C, int Cw, int relu, void* planes, long long plane_stride, int pl_cs, int pl_coff,
+                                      int pl_cw, int npl, hipStream_t stream) {
+  HPRI_REQUIRE(((uintptr_t)x16 & 7) == 0, "bn_apply_relu_x16: the bf16 tensor must be 8-byte aligned");
+  return bn_apply_relu_impl(reinterpret_cast<const float*>(x16), true, x_cs, x_coff, y, y_cs, y_coff, scale, shift, P, pix_per_group, C,
+                            Cw, relu, planes, plane_stride, pl_cs, pl_coff, pl_cw, npl, stream);
 }
 
 extern "C" int hpri_col_reduce_plan(long long pix_per_group, int G, int C, int* nblk, int* Cpart) {
@@ -545,13 +582,13 @@ extern "C" int hpri_bn_relu_bwd(const float* dy, int dy_cs, int dy_coff, const f
 }
 
 // the same, with dx also written as bf16 planes for the data-gradient / weight-gradient kernels of the bf16 modes
-extern "C" int hpri_bn_relu_bwd_pl(const float* dy, int dy_cs, int dy_coff, const float* x, int x_cs, int x_coff,
-                                   float* dx, int dx_cs, int dx_coff, const float* mean, const float* invstd,
-                                   const float* scale, const float* shift, float* dgamma, float* dbeta,
-                                   int accumulate_param_grads, float* dbias, int accumulate_dbias, float* workspace,
-                                   size_t ws_floats, long long P, long long pix_per_group, int C, int Cw, int relu,
-                                   int use_batch_stats, void* planes, long long plane_stride, int pl_cs, int pl_coff,
-                                   int pl_cw, int npl, hipStream_t stream) {
+static int bn_relu_bwd_impl(const float* dy, int dy_cs, int dy_coff, const float* x, bool x16, int x_cs, int x_coff,
+                            float* dx, int dx_cs, int dx_coff, const float* mean, const float* invstd,
+                            const float* scale, const float* shift, float* dgamma, float* dbeta,
+                            int accumulate_param_grads, float* dbias, int accumulate_dbias, float* workspace,
+                            size_t ws_floats, long long P, long long pix_per_group, int C, int Cw, int relu,
+                            int use_batch_stats, void* planes, long long plane_stride, int pl_cs, int pl_coff,
+                            int pl_cw, int npl, hipStream_t stream) {
   // dx == nullptr with planes given: the gradient is wanted as bf16 planes only (both consumers, the data-gradient and the
   // weight-gradient kernel of the plane mode, read nothing else): one fp32 tensor write less
   HPRI_REQUIRE(dy && x && (dx || planes) && mean && invstd && scale && shift && workspace, "bn_relu_bwd: null pointer");
@@ -570,8 +607,12 @@ extern "C" int hpri_bn_relu_bwd_pl(const float* dy, int dy_cs, int dy_coff, cons
   float* dxpart = workspace + half;
   float* dxsums = dxpart + (size_t)G * nblk * 2 * Cpart;
   const int c4 = hpri_cdiv(C, 4), cq = pick_cq(c4), ycols = hpri_cdiv(c4, cq);
-  hipLaunchKernelGGL((col_reduce_kernel<0>), dim3(nblk, ycols, G), dim3(256), 0, stream, dy, dy_cs, dy_coff, x,
-                     x_cs, x_coff, mean, invstd, scale, shift, pix_per_group, C, cq, relu, part, Cpart);
+  if (x16)
+    hipLaunchKernelGGL((col_reduce_kernel<0, true>), dim3(nblk, ycols, G), dim3(256), 0, stream, dy, dy_cs, dy_coff, x,
+                       x_cs, x_coff, mean, invstd, scale, shift, pix_per_group, C, cq, relu, part, Cpart);
+  else
+    hipLaunchKernelGGL((col_reduce_kernel<0, false>), dim3(nblk, ycols, G), dim3(256), 0, stream, dy, dy_cs, dy_coff, x,
+                       x_cs, x_coff, mean, invstd, scale, shift, pix_per_group, C, cq, relu, part, Cpart);
   HPRI_CHECK_LAUNCH();
   const bool pg = dgamma != nullptr && dbeta != nullptr;
   // The bias of the convolution in front of a TRAINING-mode BatchNorm has an exactly zero gradient: sum_p dx = scale * (sum g -
@@ -596,9 +637,14 @@ extern "C" int hpri_bn_relu_bwd_pl(const float* dy, int dy_cs, int dy_coff, cons
   // the apply kernel uses the same (pixel blocks x channel columns x groups) grid as the reduce, so its dx column
   // partials have the reduce's layout; Cw may add one more channel column than C (zero pads)
   const int ycols_w = hpri_cdiv((Cw > po.cw ? Cw : po.cw) >> 2, cq);
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nblk, ycols_w, G), dim3(256), 0, stream, dy, dy_cs, dy_coff, x, x_cs,
-                     x_coff, dx, dx_cs, dx_coff, mean, invstd, scale, shift, sums, (int)pix_per_group, C, Cw, cq, relu,
-                     use_batch_stats, dbias != nullptr ? dxpart : nullptr, Cpart, po);
+  if (x16)
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(nblk, ycols_w, G), dim3(256), 0, stream, dy, dy_cs, dy_coff, x, x_cs,
+                       x_coff, dx, dx_cs, dx_coff, mean, invstd, scale, shift, sums, (int)pix_per_group, C, Cw, cq, relu,
+                       use_batch_stats, dbias != nullptr ? dxpart : nullptr, Cpart, po);
+  else
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(nblk, ycols_w, G), dim3(256), 0, stream, dy, dy_cs, dy_coff, x, x_cs,
+                       x_coff, dx, dx_cs, dx_coff, mean, invstd, scale, shift, sums, (int)pix_per_group, C, Cw, cq, relu,
+                       use_batch_stats, dbias != nullptr ? dxpart : nullptr, Cpart, po);
   HPRI_CHECK_LAUNCH();
   if (dbias != nullptr) {
     hipLaunchKernelGGL(col_finalize_kernel, dim3(hpri_cdiv(C, 32), G), dim3(1024), 0, stream, dxpart, nblk, Cpart, C, dxsums,
@@ -611,6 +657,32 @@ extern "C" int hpri_bn_relu_bwd_pl(const float* dy, int dy_cs, int dy_coff, cons
     }
   }
   return HPRI_OK;
+}
+
+extern "C" int hpri_bn_relu_bwd_pl(const float* dy, int dy_cs, int dy_coff, const float* x, int x_cs, int x_coff,
+                                   float* dx, int dx_cs, int dx_coff, const float* mean, const float* invstd,
+                                   const float* scale, const float* shift, float* dgamma, float* dbeta,
+                                   int accumulate_param_grads, float* dbias, int accumulate_dbias, float* workspace,
+                                   size_t ws_floats, long long P, long long pix_per_group, int C, int Cw, int relu,
+                                   int use_batch_stats, void* planes, long long plane_stride, int pl_cs, int pl_coff,
+                                   int pl_cw, int npl, hipStream_t stream) {
+  return bn_relu_bwd_impl(dy, dy_cs, dy_coff, x, false, x_cs, x_coff, dx, dx_cs, dx_coff, mean, invstd, scale, shift, dgamma, dbeta,
+                          accumulate_param_grads, dbias, accumulate_dbias, workspace, ws_floats, P, pix_per_group, C, Cw, relu,
+                          use_batch_stats, planes, plane_stride, pl_cs, pl_coff, pl_cw, npl, stream);
+}
+
+// the same with the pre-BN tensor stored as bf16 (see hpri_bn_apply_relu_x16)
+extern "C" int hpri_bn_relu_bwd_x16(const float* dy, int dy_cs, int dy_coff, const void* x16, int x_cs, int x_coff,
+                                    float* dx, int dx_cs, int dx_coff, const float* mean, const float* invstd,
+                                    const float* scale, const float* shift, float* dgamma, float* dbeta,
+                                    int accumulate_param_grads, float* dbias, int accumulate_dbias, float* workspace,
+                                    size_t ws_floats, long long P, long long pix_per_group, int C, int Cw, int relu,
+                                    int use_batch_stats, void* planes, long long plane_stride, int pl_cs, int pl_coff,
+                                    int pl_cw, int npl, hipStream_t stream) {
+  HPRI_REQUIRE(((uintptr_t)x16 & 7) == 0, "bn_relu_bwd_x16: the bf16 tensor must be 8-byte aligned");
+  return bn_relu_bwd_impl(dy, dy_cs, dy_coff, reinterpret_cast<const float*>(x16), true, x_cs, x_coff, dx, dx_cs, dx_coff, mean,
+                          invstd, scale, shift, dgamma, dbeta, accumulate_param_grads, dbias, accumulate_dbias, workspace, ws_floats,
+                          P, pix_per_group, C, Cw, relu, use_batch_stats, planes, plane_stride, pl_cs, pl_coff, pl_cw, npl, stream);
 }
 
 // out[c] (+)= sum over all P pixels of src[p][coff + c]   (conv / linear bias gradients)

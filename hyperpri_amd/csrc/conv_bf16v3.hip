@@ -40,6 +40,8 @@ struct ConvV3Args {
   float* y; int y_cs, y_coff;
   float4* stats;
   int N, H, W, Cin_pad, Cout, Cout_pad, y_cw, accumulate, relu;
+  int y16;                                   // the output view is bf16 (y points at __bf16, y_cs / y_coff in elements): the pre-BN tensor of
+                                             // the bf16 mode at 2 bytes per element (statistics still from the fp32 sums)
   int ksplit; float* ws;
   int nseg, tiles_img, ntiles, nb_count, per_xcd;
   int seg_twl[V3_MAXSEG], seg_xbeg[V3_MAXSEG], seg_ntx[V3_MAXSEG], seg_first[V3_MAXSEG];
@@ -405,7 +407,24 @@ __global__ __launch_bounds__(256, 2) void conv_bf16v3_kernel(ConvV3Args a) {
           if (COND_) *reinterpret_cast<f32x4*>(prow[mt] + nt * 16) = acc[mt][nt];                                     \
     }                                                                                                                 \
   }
-    if (!raw && a.accumulate) {
+    if (!raw && a.y16) {
+      // bf16 output: a lane's four channels are one 8-byte store (round-to-nearest-even, v_cvt_pk_bf16_f32)
+      __bf16* d16 = reinterpret_cast<__bf16*>(a.y);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        if ((vmask >> mt) & 1u) {
+          __bf16* q = d16 + (prow[mt] - dst);
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt)
+            if (full || nlane + nt * 16 < dcw) {
+              bf16x4_t h;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) h[r] = (__bf16)acc[mt][nt][r];
+              *reinterpret_cast<bf16x4_t*>(q + nt * 16) = h;
+            }
+        }
+      }
+    } else if (!raw && a.accumulate) {
       if (full) { V3_STORE_LOOP(true, true) } else { V3_STORE_LOOP(true, nlane + nt * 16 < dcw) }
     } else {
       if (full) { V3_STORE_LOOP(false, true) } else { V3_STORE_LOOP(false, nlane + nt * 16 < dcw) }
@@ -595,12 +614,14 @@ extern "C" int hpri_conv_bf16v3_dbg(const void* xp, long long x_plane, int x_cs,
   a.wp = reinterpret_cast<const __bf16*>(wp); a.bias = bias; a.y = y; a.y_cs = y_cs; a.y_coff = y_coff;
   a.stats = reinterpret_cast<float4*>(stats);
   a.N = N; a.H = H; a.W = W; a.Cin_pad = Cin_pad; a.Cout = Cout; a.Cout_pad = Cout_pad;
-  a.y_cw = y_cw < Cout ? Cout : y_cw; a.accumulate = accumulate & 1; a.relu = (accumulate >> 1) & 1;
+  a.y_cw = y_cw < Cout ? Cout : y_cw; a.accumulate = accumulate & 1; a.relu = (accumulate >> 1) & 1; a.y16 = (accumulate >> 2) & 1;
   HPRI_REQUIRE(a.y_cw + y_coff <= y_cs, "conv_bf16v3: output channels exceed the channel stride");
+  HPRI_REQUIRE(!(a.y16 && a.accumulate), "conv_bf16v3: a bf16 output cannot accumulate");
   HPRI_REQUIRE(y_cs % 4 == 0 && y_coff % 4 == 0 && a.y_cw % 4 == 0 && ((uintptr_t)y & 15) == 0,
                "conv_bf16v3: the output view must be float4-aligned (stride, offset and written width multiples of 4)");
   a.ksplit = v3_ksplit(N, H, W, Cin_pad, Cout_pad);
   a.ws = ws;
+  HPRI_REQUIRE(!(a.y16 && a.ksplit > 1), "conv_bf16v3: a bf16 output is not available for split-K problems (hpri_conv_bf16v3_plan: ksplit > 1)");
   if (a.ksplit > 1) {
     if (ws == nullptr || (size_t)a.ksplit * N * H * W * Cout_pad > ws_floats)
       return hpri_set_error(HPRI_ERR_WORKSPACE, "conv_bf16v3: split-K workspace too small (see hpri_conv_bf16v3_plan)");

@@ -62,7 +62,7 @@ class Act:
 
     Invariant: channels [C, cw) (cw = C rounded up to 8) exist inside the stride and hold zeros, so
     consumers may run their K loop over ``cw`` channels."""
-    __slots__ = ("buf", "N", "H", "W", "C", "cs", "coff", "pl", "parent", "f32_valid", "want_pl", "pl_part", "colsum_req")
+    __slots__ = ("buf", "N", "H", "W", "C", "cs", "coff", "pl", "parent", "f32_valid", "want_pl", "pl_part", "colsum_req", "b16")
 
     def __init__(self, buf: torch.Tensor, N: int, H: int, W: int, C: int, cs: int, coff: int = 0):
         self.buf, self.N, self.H, self.W, self.C, self.cs, self.coff = buf, N, H, W, C, cs, coff
@@ -72,6 +72,7 @@ class Act:
         self.pl_part = None                     # (Planes, channels filled so far): a concat buffer whose skip half is already in planes
         self.want_pl = 0                        # plane mode marker: planes a 3x3 consumer of this tensor (or of its pooled map) would read
         self.colsum_req = None                  # (c0, C): somebody wants the column sums of channels [c0, c0+C) of this tensor's GRADIENT
+        self.b16 = False                        # the buffer holds bf16 elements (a pre-BN tensor of the bf16 mode; read by the *_x16 BN passes only)
 
     @property
     def cw(self) -> int:
@@ -230,6 +231,13 @@ PLANE_CONVERSIONS = 0        # generic fp32 -> planes passes launched (fused pro
 # straight from the accumulators) or conv_bf16v2.hip (one persistent 8-wave workgroup per CU).  Same packed weights, same
 # arguments; the statistics tiles differ (plan).  HPRI_BF16_V3: 1 (default) / 0.
 BF16_V3 = os.environ.get("HPRI_BF16_V3", "1") != "0"
+
+
+# bf16 mode with the v3 plane convolution: the PRE-BatchNorm tensor of a conv -> BN -> ReLU stage (written by the convolution, read
+# by the normalise pass and twice by the BatchNorm backward, by nobody else) is stored as bf16: 2 instead of 4 bytes per element on
+# four tensor sweeps per layer and step.  The statistics still come from the fp32 accumulators.  Dice-level parity re-run:
+# profiles/r03_bf16_dice_parity.json.  HPRI_YR_BF16: 1 (default) / 0.
+YR_BF16 = os.environ.get("HPRI_YR_BF16", "1") != "0"
 
 
 def _plane_conv() -> str:
@@ -753,11 +761,20 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
     else:
         wp, cout_pad = _pack(weight, 0, cin, cout, T, 0, cin)
     use_batch = bn is not None and train
+    yr16 = False
+    if v2 and BF16_V3 and YR_BF16 and bn is not None and groups == 1:
+        ksp_ = ctypes.c_int(); tl_ = ctypes.c_int(); wsf_ = ctypes.c_size_t()
+        _lib.call("hpri_conv_bf16v3_plan", x.N, x.H, x.W, _rup(cin, 32), _rup(cout, 64), ctypes.byref(ksp_), ctypes.byref(tl_), ctypes.byref(wsf_))
+        yr16 = ksp_.value == 1            # (split-K problems finish in fp32: hpri_splitk_finish)
     if use_batch and (x.N * x.H * x.W) // max(groups, 1) <= 1:
         # torch.nn.functional.batch_norm's own check (_verify_batch_size): same error, same message
         raise ValueError("Expected more than 1 value per channel when training, got input size "
                          f"torch.Size([{x.N // max(groups, 1)}, {cout}, {x.H}, {x.W}])")
-    yr = Act.new(x.N, x.H, x.W, cout, dev)
+    if yr16:
+        yr = Act(torch.empty(x.P * _rup(cout, 8), dtype=torch.bfloat16, device=dev), x.N, x.H, x.W, cout, _rup(cout, 8), 0)
+        yr.b16, yr.f32_valid = True, False
+    else:
+        yr = Act.new(x.N, x.H, x.W, cout, dev)
     stats = None
     tiles = 0
     if use_batch:
@@ -778,7 +795,7 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
     if wino:
         _conv_launch_wino(x, wp, bias, yr, stats, cin, cout, cout_pad, yr.cw)
     elif v2:
-        _conv_launch_v2(x, wp, bias, yr, stats, cin, cout, cout_pad, yr.cw)
+        _conv_launch_v2(x, wp, bias, yr, stats, cin, cout, cout_pad, yr.cw, accumulate=4 if yr16 else 0)
     elif lowp:
         _conv_launch_bf16(x, wp, bias, yr, stats, x.N, x.H, x.W, cin_pad, cout, cout_pad, yr.cw, ks, cin_true=cin, split=split)
     else:
@@ -822,7 +839,8 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
         if (ypl is not None and next_cout > 0 and PLANES_ONLY_ACT and PLANE_WGRAD and room == 0
                 and _planes_fit(y, max(cout, next_cout))):
             y.f32_valid = False
-        _lib.call("hpri_bn_apply_relu_pl", yr.ptr, yr.cs, yr.coff, y.ptr if y.f32_valid else ctypes.c_void_p(0), y.cs, y.coff,
+        _lib.call("hpri_bn_apply_relu_x16" if yr16 else "hpri_bn_apply_relu_pl", yr.ptr, yr.cs, yr.coff,
+                  y.ptr if y.f32_valid else ctypes.c_void_p(0), y.cs, y.coff,
                   _p(scale), _p(shift),
                   x.P, ppg, cout, y.cw, int(relu),
                   *(_pl_args(ypl) if cpl is None else (_p(cpl.buf), cpl.plane, cpl.cs, 0, y.C, 1)), _stream())
@@ -849,7 +867,7 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
             f32_dead = (dpl is not None and ks == 3 and split == 0 and PLANE_CONV and PLANE_WGRAD and PLANES_ONLY_GRAD
                         and (need_dx or weight.requires_grad))
             dyr.f32_valid = not f32_dead
-            _lib.call("hpri_bn_relu_bwd_pl", g.ptr, g.cs, g.coff, yr.ptr, yr.cs, yr.coff,
+            _lib.call("hpri_bn_relu_bwd_x16" if yr16 else "hpri_bn_relu_bwd_pl", g.ptr, g.cs, g.coff, yr.ptr, yr.cs, yr.coff,
                       ctypes.c_void_p(0) if f32_dead else dyr.ptr, dyr.cs, dyr.coff,
                       _p(mean), _p(invstd), _p(scale), _p(shift), _p(dgam), _p(dbet), acc_g, _p(db), acc_b,
                       _p(ws), ws.numel(), x.P, x.P // G, cout, dyr.cw, int(relu), int(use_batch), *_pl_args(dpl), _stream())
@@ -899,8 +917,6 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
             elif v2:
                 wpd, cin_cols_pad = _pack_bf16(weight, 1, cout, cin, T, cin, split=0)
                 _conv_launch_v2(dyr, wpd, None, gx, gstats, cout, cin, cin_cols_pad, gx.cw, accumulate=int(acc))
-            if gstats is not None:
-                tp.colsum[id(x)] = (gstats, gtiles, cin_cols_pad)
             elif lowp:
                 wpd, cin_cols_pad = _pack_bf16(weight, 1, cout, cin, T, cin, split=split)
                 _conv_launch_bf16(dyr, wpd, None, gx, None, x.N, x.H, x.W, dyr.cw, cin, cin_cols_pad, gx.cw, ks,
@@ -909,6 +925,8 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
                 wpd, cin_cols_pad = _pack(weight, 1, cout, cin, T, 0, cin)
                 _conv_launch(dyr, wpd, None, gx, None, x.N, x.H, x.W, dyr.cw, cin, cin_cols_pad, gx.cw, ks, accumulate=int(acc),
                              cin_true=cout)
+            if gstats is not None:
+                tp.colsum[id(x)] = (gstats, gtiles, cin_cols_pad)
 
     tape.note_params(weight, bias, *((bn.weight, bn.bias) if bn is not None else ()))
     tape.nodes.append(bwd)

@@ -161,7 +161,9 @@ int hpri_splitk_finish(const float* ws, int ksplit, int Cout_pad, const float* b
  * prologue / store + statistics epilogue runs under the other's MFMAs), v_mfma_f32_16x16x32_bf16 with the weights as the A
  * operand (a lane's accumulator registers are consecutive channels of one pixel: 16-byte stores without an LDS transpose).
  * Same argument, workspace and statistics contract as hpri_conv_bf16v2 (records per 256-pixel tile: hpri_conv_bf16v3_plan);
- * the output view must be float4-aligned.  _dbg: the same with the one-off delay of each CU's second occupant (cycles) given by
+ * the output view must be float4-aligned.  Bit 2 of `accumulate` (value 4): the output view is bf16 (y points at bf16 elements,
+ * y_cs / y_coff in elements; not with bit 0, not for split-K problems) -- the pre-BN tensor at 2 bytes per element, read by
+ * hpri_bn_apply_relu_x16 / hpri_bn_relu_bwd_x16.  _dbg: the same with the one-off delay of each CU's second occupant (cycles) given by
  * the caller and, in -DHPRI_STAMPS builds, a stamp buffer ([workgroups][8] u64; ignored otherwise). */
 int hpri_conv_bf16v3_plan(int N, int H, int W, int Cin_pad, int Cout_pad, int* ksplit, int* stat_tiles,
                           size_t* ws_floats);
@@ -239,6 +241,18 @@ int hpri_bn_relu_bwd_pl(const float* dy, int dy_cs, int dy_coff, const float* x,
                         int accumulate_dbias, float* workspace, size_t ws_floats, long long P, long long pix_per_group,
                         int C, int Cw, int relu, int use_batch_stats, void* planes, long long plane_stride, int pl_cs,
                         int pl_coff, int pl_cw, int npl, hipStream_t stream);
+/* The pre-BatchNorm tensor stored as bf16 (bf16 precision mode, HPRI_YR_BF16: hpri_conv_bf16v3 with bit 2 of `accumulate` writes
+ * it; x16[p * x_cs + x_coff + c], 8-byte aligned channel quads): the normalise pass and the backward read 2 instead of 4 bytes
+ * per element of model_parts.py:23,26's input; arithmetic and every other argument as the fp32 forms. */
+int hpri_bn_apply_relu_x16(const void* x16, int x_cs, int x_coff, float* y, int y_cs, int y_coff, const float* scale,
+                           const float* shift, long long P, long long pix_per_group, int C, int Cw, int relu, void* planes,
+                           long long plane_stride, int pl_cs, int pl_coff, int pl_cw, int npl, hipStream_t stream);
+int hpri_bn_relu_bwd_x16(const float* dy, int dy_cs, int dy_coff, const void* x16, int x_cs, int x_coff, float* dx,
+                         int dx_cs, int dx_coff, const float* mean, const float* invstd, const float* scale,
+                         const float* shift, float* dgamma, float* dbeta, int accumulate_param_grads, float* dbias,
+                         int accumulate_dbias, float* workspace, size_t ws_floats, long long P, long long pix_per_group,
+                         int C, int Cw, int relu, int use_batch_stats, void* planes, long long plane_stride, int pl_cs,
+                         int pl_coff, int pl_cw, int npl, hipStream_t stream);
 
 /* ---- bandwidth-bound ops (elementwise.hip) ---------------------------------------------------------
  * layout change at the module boundary (dataset.py:267-271 hands NC(D)HW), nn.MaxPool2d(2)

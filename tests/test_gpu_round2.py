@@ -247,14 +247,18 @@ def test_plane_mode_with_round1_kernels_reads_valid_fp32(off):
     net, x, m = _net("cube64")
     H.set_precision(net, "bf16")
     sd = {k: v.clone() for k, v in net.state_dict().items()}
-    lg1, g1 = _step(net, x, m)
-    old = getattr(E, off)
+    old, old16 = getattr(E, off), E.YR_BF16
     try:
+        # (pre-BN tensors in fp32 on both sides: their bf16 storage is a precision choice of the plane path -- on this tiny net
+        # it moves the most sensitive gradient, first_conv.weight, by 30 % of its norm -- and not what this test is about)
+        E.YR_BF16 = False
+        lg1, g1 = _step(net, x, m)
         setattr(E, off, False)
         net.load_state_dict(sd)
         lg2, g2 = _step(net, x, m)
     finally:
         setattr(E, off, old)
+        E.YR_BF16 = old16
     assert float((lg1 - lg2).abs().max()) < 0.1
     for (k, _), a, b in zip(net.named_parameters(), g1, g2):
         ref = float(a.double().norm())
