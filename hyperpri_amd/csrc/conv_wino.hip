@@ -462,6 +462,7 @@ struct WinoWgradArgs {
   float* ws;                    // [splits][16][Cr][Nr]
   int N, H, W, Cr, Nr, cblk;
   int strips_x, strips_y, total, per_split;
+  int ntile, items, per_xcd;    // (c, n) tiles per split; work items; items per XCD band
 };
 
 #define WG_XROW 36               // staged halo pixels per row (34 used)
@@ -474,7 +475,14 @@ __global__ __launch_bounds__(512, 2) void conv_wino_wgrad_kernel(WinoWgradArgs a
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lh = lane >> 5;
   const int fa = wave >> 1, fb = wave & 1;
-  const int split = blockIdx.x, cb = blockIdx.y % a.cblk, nbk = blockIdx.y / a.cblk;
+  // XCD-aware order (round 3): workgroup id mod 8 labels the XCD (round-robin dispatch; speed only); XCD x owns the items
+  // [x * per_xcd, (x+1) * per_xcd), an item = (pixel split, (c, n) tile) with the TILE fastest: the cblk x nblk tiles that read the
+  // same pixel strips run back to back on ONE XCD and share its L2.  (Before: grid (splits, tiles) -- the tiles of a split were
+  // `splits` workgroups apart in dispatch order and re-read x and dy from beyond L2: 515 MB read per launch against ~300 MB.)
+  const int item = (int)(blockIdx.x & 7) * a.per_xcd + (int)(blockIdx.x >> 3);
+  if (item >= a.items) return;
+  const int split = item / a.ntile, tile = item - split * a.ntile;
+  const int cb = tile % a.cblk, nbk = tile / a.cblk;
   const int c_blk = cb * 64, n_blk = nbk * 64;
   const int u0 = split * a.per_split, u1 = min(a.total, u0 + a.per_split);
 
@@ -730,7 +738,9 @@ extern "C" int hpri_conv_wino_wgrad(const float* x, int x_cs, int x_coff, int x_
   a.cblk = a.Cr / 64;
   a.strips_x = hpri_cdiv(W, 32); a.strips_y = hpri_cdiv(H, 2); a.total = N * a.strips_x * a.strips_y;
   a.per_split = hpri_cdiv(a.total, splits);
-  dim3 grid((unsigned)splits, (unsigned)(a.cblk * (a.Nr / 64)), 1u);
+  a.ntile = a.cblk * (a.Nr / 64);
+  a.items = splits * a.ntile; a.per_xcd = hpri_cdiv(a.items, 8);
+  dim3 grid((unsigned)(a.per_xcd * 8), 1u, 1u);
   hipLaunchKernelGGL(conv_wino_wgrad_kernel, grid, dim3(512), 0, stream, a);
   HPRI_CHECK_LAUNCH();
   return HPRI_OK;

