@@ -43,7 +43,7 @@ struct ConvV3Args {
   int y16;                                   // the output view is bf16 (y points at __bf16, y_cs / y_coff in elements): the pre-BN tensor of
                                              // the bf16 mode at 2 bytes per element (statistics still from the fp32 sums)
   int ksplit; float* ws;
-  int nseg, tiles_img, ntiles, nb_count, per_xcd;
+  int nseg, tiles_img, ntiles, nb_count, per_xcd, nb_major;
   int seg_twl[V3_MAXSEG], seg_xbeg[V3_MAXSEG], seg_ntx[V3_MAXSEG], seg_first[V3_MAXSEG];
   int ncu, stagger_cycles;                   // compute units of the device; one-off delay of each CU's second occupant
 #ifdef HPRI_STAMPS
@@ -96,9 +96,19 @@ __global__ __launch_bounds__(256, 2) void conv_bf16v3_kernel(ConvV3Args a) {
   const int xcd = blockIdx.x & 7, nloc = (int)(gridDim.x >> 3);
   const int items_all = a.ntiles * a.nb_count;
   auto tile_of = [&](int k, V3Tile& t) -> bool {
-    const int item = xcd * a.per_xcd + k;
-    if (k >= a.per_xcd || item >= items_all) return false;
-    t.bx = item / a.nb_count; t.nb = item - t.bx * a.nb_count;
+    if (k >= a.per_xcd) return false;
+    if (a.nb_major) {
+      // wide layers (Cout_pad >= 512): XCD x owns the channel blocks nb = x (mod 8) of EVERY pixel tile, so the one or two packed
+      // weight slices it needs (Cin_pad x 1152 B each) stay in its L2 and the small input is what gets re-read; banded (below)
+      // such a layer streams all of its weights through every XCD once per tile (conv_wino4.hip measured 2-6 x the traffic)
+      const int nbx = a.nb_count >> 3;
+      t.bx = k / nbx; t.nb = (k - t.bx * nbx) * 8 + xcd;
+      if (t.bx >= a.ntiles) return false;
+    } else {
+      const int item = xcd * a.per_xcd + k;
+      if (item >= items_all) return false;
+      t.bx = item / a.nb_count; t.nb = item - t.bx * a.nb_count;
+    }
     t.img = t.bx / a.tiles_img;
     const int tin = t.bx - t.img * a.tiles_img;
     int seg = 0;
@@ -632,7 +642,8 @@ extern "C" int hpri_conv_bf16v3_dbg(const void* xp, long long x_plane, int x_cs,
   for (int k = 0; k < V3_MAXSEG; ++k) { a.seg_twl[k] = sg.twl[k]; a.seg_xbeg[k] = sg.xbeg[k]; a.seg_ntx[k] = sg.ntx[k]; a.seg_first[k] = sg.first[k]; }
   const long long items = (long long)a.ntiles * a.nb_count;
   HPRI_REQUIRE(items < (1ll << 28), "conv_bf16v3: too many work items");
-  a.per_xcd = (int)((items + 7) / 8);
+  a.nb_major = (a.nb_count % 8 == 0) ? 1 : 0;
+  a.per_xcd = a.nb_major ? a.ntiles * (a.nb_count / 8) : (int)((items + 7) / 8);
   a.ncu = hpri_cu_count(); a.stagger_cycles = stagger_cycles;
 #ifdef HPRI_STAMPS
   a.stamps = stamps;

@@ -27,7 +27,7 @@ struct Wino4Args {
   float4* stats;                // [N*tiles_img][Cout_pad] (mean, M2, count, 0) or nullptr
   int N, H, W, Cin_pad, Cout, Cout_pad, y_cw, accumulate, relu;
   int tiles_x, tiles_y;
-  int items, per_xcd;           // work items (pixel tiles x channel blocks) and items per XCD band
+  int items, per_xcd, banded;   // work items (pixel tiles x channel blocks), items per XCD band, item order (below)
   int ncu, stagger_cycles;      // compute units of the device (host: hipDeviceProp_t.multiProcessorCount) and the one-off delay of
                                 // each CU's second occupant (below); 0 cycles = no stagger
 #ifdef HPRI_STAMPS
@@ -69,13 +69,16 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(Wino4Args a) {
   const int fa = wave;                              // frequency row
   const int tiles_img = a.tiles_x * a.tiles_y;
   const int nbc = a.Cout_pad >> 6;
-  // XCD-aware order (round 3): workgroup id mod 8 labels the XCD (round-robin dispatch; speed only), and XCD x owns the items
-  // [x * per_xcd, (x+1) * per_xcd) -- the channel blocks of one pixel tile back to back, pixel tiles in raster order.  With the
-  // plain order (item = workgroup id) the nbc channel blocks of a tile landed on nbc DIFFERENT XCDs and every one of them
-  // fetched the tile's halo into its own L2: measured read traffic 1.41 x nbc x the input (profiles/
-  // r03_wino4_layer_traffic_before_xcd.json: 2.8 x at 2 blocks, 5.0 x at 4, 6.6 x at 8); the halo columns / rows shared by
-  // neighbouring tiles (the 1.41) never met in one L2 either.
-  const int item = (int)(blockIdx.x & 7) * a.per_xcd + (int)(blockIdx.x >> 3);
+  // Item order (round 3; workgroup id mod 8 labels the XCD under round-robin dispatch -- speed only, never correctness).  Two
+  // things are re-read through an XCD's 4 MB L2: the input halos (by the nbc channel blocks of a tile, and by neighbouring
+  // tiles) and the packed U slice of a channel block (Cin_pad x 4 KB, by every tile).  Measured per layer with the plain
+  // order item = workgroup id (profiles/r03_wino4_layer_traffic_before_xcd.json) and with XCD bands (..._all_banded.json):
+  //   nbc <= 4  BANDED: XCD x owns the items [x * per_xcd, (x+1) * per_xcd), channel blocks of a tile back to back, tiles in
+  //             raster order: the halos meet in ONE L2 (read traffic 1.41 x nbc x input -> 1.1-1.3 x at 608x968 / 304x484,
+  //             5.0 -> 3.8 x at 152x242) and all of U (<= 8 MB) still fits next to them;
+  //   nbc >= 8  PLAIN: block nb of every tile lands on XCD nb mod 8, so an XCD keeps ITS one or two U slices (2-4 MB each) in
+  //             L2 and re-reads the (small) input instead: 6.6 x against 12.9 x banded at 76x121, 3.4 x against 19 x at 38x60.
+  const int item = a.banded ? (int)(blockIdx.x & 7) * a.per_xcd + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
   if (item >= a.items) return;
   const int bx = item / nbc, nb = item - bx * nbc;
   const int img = bx / tiles_img, tin = bx - img * tiles_img;
@@ -443,7 +446,8 @@ extern "C" int hpri_conv_wino4(const float* x, int x_cs, int x_coff, const float
   const long long items = (long long)N * a.tiles_x * a.tiles_y * (Cout_pad / 64);
   HPRI_REQUIRE(items < (1ll << 28), "conv_wino4: too many work items");
   a.items = (int)items; a.per_xcd = (int)((items + 7) / 8);
-  dim3 grid((unsigned)(a.per_xcd * 8), 1u, 1u);
+  a.banded = (Cout_pad / 64) <= 4;
+  dim3 grid((unsigned)(a.banded ? a.per_xcd * 8 : a.items), 1u, 1u);
   hipLaunchKernelGGL(conv_wino4_kernel, grid, dim3(256), 0, stream, a);
   HPRI_CHECK_LAUNCH();
   return HPRI_OK;
