@@ -550,7 +550,7 @@ static V3Segs v3_segments(int H, int W) {
   V3Segs best{};
   long long best_cost = -1;
   // candidates: n32 columns of 32-wide tiles, the rest in 16-wide tiles
-  const int max32 = hpri_cdiv(W, 32);
+  const int max32 = hpri_option(3) == 16 ? 0 : hpri_cdiv(W, 32);
   for (int n32 = 0; n32 <= max32; ++n32) {
     const int rem = W - n32 * 32;
     const int n16 = rem > 0 ? hpri_cdiv(rem, 16) : 0;
