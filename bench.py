@@ -528,8 +528,13 @@ def main():
         out = {
             "metric": "HSI cubes/sec (608x968x238) fwd+bwd", "value": round(value, 4), "unit": "cubes/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "CubeNET-64 n_channels=238 HSI 608x968 fp32, per-GPU batch 2, train mode, "
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            # the arithmetic type of `value`: fp32 MFMA unless the caller switched the package default (HPRI_PRECISION), which
+            # the line then says instead of claiming f32
+            "dtype": {"fp32": "f32", "bf16": "bf16 (f32 accumulate)", "bf16x3": "bf16x3 (2 bf16 planes per operand, f32 accumulate)",
+                      "bf16x6": "bf16x6 (3 bf16 planes per operand: f32 emulation)"}[engine.DEFAULT_PRECISION],
+            "data": "synthetic",
+            "config": {"workload": "CubeNET-64 n_channels=238 HSI 608x968 " + engine.DEFAULT_PRECISION + ", per-GPU batch 2, train mode, "
                                    "BCEWithLogits, fwd+bwd" + (" + RCCL grad all-reduce" if world > 1 else ""),
                        "global_batch": world * BATCH, "parallelism": f"dp{world}"},
             "loss": round(loss_val, 6),

@@ -722,7 +722,17 @@ __global__ __launch_bounds__(256) void colsum_from_stats_kernel(const float4* __
   const int c = blockIdx.x * 4 + cl;
   double a = 0.0;
   if (c < C) {
-    for (int t = sl; t < tiles; t += 64) {
+    // eight records in flight per thread: with one, the loop was a chain of dependent L2 / HBM round trips (184 us per call
+    // beside a weight gradient on the second stream; profiles/r03_bf16_mode_bench_kernel_stats.csv)
+    int t = sl;
+    for (; t + 7 * 64 < tiles; t += 8 * 64) {
+      float4 r[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) r[u] = stats[(size_t)(t + u * 64) * Cpad + c0 + c];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a += (double)r[u].x * (double)r[u].z;
+    }
+    for (; t < tiles; t += 64) {
       const float4 r = stats[(size_t)t * Cpad + c0 + c];
       a += (double)r.x * (double)r.z;
     }
