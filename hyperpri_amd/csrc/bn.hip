@@ -582,7 +582,8 @@ extern "C" int hpri_bn_relu_bwd(const float* dy, int dy_cs, int dy_coff, const f
 }
 
 // the same, with dx also written as bf16 planes for the data-gradient / weight-gradient kernels of the bf16 modes
-static int bn_relu_bwd_impl(const float* dy, int dy_cs, int dy_coff, const float* x, bool x16, int x_cs, int x_coff,
+static int bn_relu_bwd_impl(const float* ext_part, int ext_nblk, int ext_cpart,
+                            const float* dy, int dy_cs, int dy_coff, const float* x, bool x16, int x_cs, int x_coff,
                             float* dx, int dx_cs, int dx_coff, const float* mean, const float* invstd,
                             const float* scale, const float* shift, float* dgamma, float* dbeta,
                             int accumulate_param_grads, float* dbias, int accumulate_dbias, float* workspace,
@@ -607,13 +608,20 @@ static int bn_relu_bwd_impl(const float* dy, int dy_cs, int dy_coff, const float
   float* dxpart = workspace + half;
   float* dxsums = dxpart + (size_t)G * nblk * 2 * Cpart;
   const int c4 = hpri_cdiv(C, 4), cq = pick_cq(c4), ycols = hpri_cdiv(c4, cq);
-  if (x16)
-    hipLaunchKernelGGL((col_reduce_kernel<0, true>), dim3(nblk, ycols, G), dim3(256), 0, stream, dy, dy_cs, dy_coff, x,
-                       x_cs, x_coff, mean, invstd, scale, shift, pix_per_group, C, cq, relu, part, Cpart);
-  else
-    hipLaunchKernelGGL((col_reduce_kernel<0, false>), dim3(nblk, ycols, G), dim3(256), 0, stream, dy, dy_cs, dy_coff, x,
-                       x_cs, x_coff, mean, invstd, scale, shift, pix_per_group, C, cq, relu, part, Cpart);
-  HPRI_CHECK_LAUNCH();
+  // the two reduction sweeps, unless the kernel that produced dy left the partial sums itself (hpri_conv_wino4_bnred)
+  const float* fin_part = part; int fin_nblk = nblk, fin_cpart = Cpart;
+  if (ext_part != nullptr) {
+    HPRI_REQUIRE(G == 1 && ext_nblk > 0 && ext_cpart >= C, "bn_relu_bwd_fused: partial sums need one group and cover the channels");
+    fin_part = ext_part; fin_nblk = ext_nblk; fin_cpart = ext_cpart;
+  } else {
+    if (x16)
+      hipLaunchKernelGGL((col_reduce_kernel<0, true>), dim3(nblk, ycols, G), dim3(256), 0, stream, dy, dy_cs, dy_coff, x,
+                         x_cs, x_coff, mean, invstd, scale, shift, pix_per_group, C, cq, relu, part, Cpart);
+    else
+      hipLaunchKernelGGL((col_reduce_kernel<0, false>), dim3(nblk, ycols, G), dim3(256), 0, stream, dy, dy_cs, dy_coff, x,
+                         x_cs, x_coff, mean, invstd, scale, shift, pix_per_group, C, cq, relu, part, Cpart);
+    HPRI_CHECK_LAUNCH();
+  }
   const bool pg = dgamma != nullptr && dbeta != nullptr;
   // The bias of the convolution in front of a TRAINING-mode BatchNorm has an exactly zero gradient: sum_p dx = scale * (sum g -
   // Np * mean(g) - mean(g xhat) * sum xhat) and sum xhat = 0.  The reference holds rounding noise there (~1e-9 of the other
@@ -622,7 +630,7 @@ static int bn_relu_bwd_impl(const float* dy, int dy_cs, int dy_coff, const float
   // all when the caller accumulates).  Eval-mode statistics (use_batch_stats = 0) keep the computed sum: it is not zero there.
   const bool dbias_zero = dbias != nullptr && use_batch_stats;
   float* zero_out = (dbias_zero && !accumulate_dbias && G == 1) ? dbias : nullptr;
-  hipLaunchKernelGGL(col_finalize_kernel, dim3(hpri_cdiv(C, 32), G), dim3(1024), 0, stream, part, nblk, Cpart, C, sums,
+  hipLaunchKernelGGL(col_finalize_kernel, dim3(hpri_cdiv(C, 32), G), dim3(1024), 0, stream, fin_part, fin_nblk, fin_cpart, C, sums,
                      (pg && G == 1) ? dbeta : nullptr, (pg && G == 1) ? dgamma : nullptr, accumulate_param_grads, zero_out);
   HPRI_CHECK_LAUNCH();
   if (dbias_zero && !accumulate_dbias && G > 1) {
@@ -666,9 +674,24 @@ extern "C" int hpri_bn_relu_bwd_pl(const float* dy, int dy_cs, int dy_coff, cons
                                    size_t ws_floats, long long P, long long pix_per_group, int C, int Cw, int relu,
                                    int use_batch_stats, void* planes, long long plane_stride, int pl_cs, int pl_coff,
                                    int pl_cw, int npl, hipStream_t stream) {
-  return bn_relu_bwd_impl(dy, dy_cs, dy_coff, x, false, x_cs, x_coff, dx, dx_cs, dx_coff, mean, invstd, scale, shift, dgamma, dbeta,
+  return bn_relu_bwd_impl(nullptr, 0, 0, dy, dy_cs, dy_coff, x, false, x_cs, x_coff, dx, dx_cs, dx_coff, mean, invstd, scale, shift, dgamma, dbeta,
                           accumulate_param_grads, dbias, accumulate_dbias, workspace, ws_floats, P, pix_per_group, C, Cw, relu,
                           use_batch_stats, planes, plane_stride, pl_cs, pl_coff, pl_cw, npl, stream);
+}
+
+// the same with the reduction already done: `partials`[part_blocks][2][part_cpart] = per-block sums of g*[y>0] and g*[y>0]*xhat
+// left by the data-gradient kernel that wrote dy (hpri_conv_wino4_bnred); one group only.  Workspace as hpri_bn_relu_bwd.
+extern "C" int hpri_bn_relu_bwd_fused(const float* partials, int part_blocks, int part_cpart, const float* dy, int dy_cs, int dy_coff,
+                                      const float* x, int x_cs, int x_coff, float* dx, int dx_cs, int dx_coff, const float* mean,
+                                      const float* invstd, const float* scale, const float* shift, float* dgamma, float* dbeta,
+                                      int accumulate_param_grads, float* dbias, int accumulate_dbias, float* workspace,
+                                      size_t ws_floats, long long P, long long pix_per_group, int C, int Cw, int relu,
+                                      int use_batch_stats, void* planes, long long plane_stride, int pl_cs, int pl_coff,
+                                      int pl_cw, int npl, hipStream_t stream) {
+  HPRI_REQUIRE(partials != nullptr, "bn_relu_bwd_fused: null partial sums");
+  return bn_relu_bwd_impl(partials, part_blocks, part_cpart, dy, dy_cs, dy_coff, x, false, x_cs, x_coff, dx, dx_cs, dx_coff, mean, invstd,
+                          scale, shift, dgamma, dbeta, accumulate_param_grads, dbias, accumulate_dbias, workspace, ws_floats, P,
+                          pix_per_group, C, Cw, relu, use_batch_stats, planes, plane_stride, pl_cs, pl_coff, pl_cw, npl, stream);
 }
 
 // the same with the pre-BN tensor stored as bf16 (see hpri_bn_apply_relu_x16)
@@ -680,7 +703,7 @@ extern "C" int hpri_bn_relu_bwd_x16(const float* dy, int dy_cs, int dy_coff, con
                                     int use_batch_stats, void* planes, long long plane_stride, int pl_cs, int pl_coff,
                                     int pl_cw, int npl, hipStream_t stream) {
   HPRI_REQUIRE(((uintptr_t)x16 & 7) == 0, "bn_relu_bwd_x16: the bf16 tensor must be 8-byte aligned");
-  return bn_relu_bwd_impl(dy, dy_cs, dy_coff, reinterpret_cast<const float*>(x16), true, x_cs, x_coff, dx, dx_cs, dx_coff, mean,
+  return bn_relu_bwd_impl(nullptr, 0, 0, dy, dy_cs, dy_coff, reinterpret_cast<const float*>(x16), true, x_cs, x_coff, dx, dx_cs, dx_coff, mean,
                           invstd, scale, shift, dgamma, dbeta, accumulate_param_grads, dbias, accumulate_dbias, workspace, ws_floats,
                           P, pix_per_group, C, Cw, relu, use_batch_stats, planes, plane_stride, pl_cs, pl_coff, pl_cw, npl, stream);
 }

@@ -25,6 +25,13 @@ struct Wino4Args {
   const float* bias;
   float* y; int y_cs, y_coff;
   float4* stats;                // [N*tiles_img][Cout_pad] (mean, M2, count, 0) or nullptr
+  // BatchNorm-backward reduction fused into a DATA-GRADIENT launch (round 3): this launch writes g = dL/dy of a conv -> BN -> ReLU
+  // stage whose only consumer it is; with bn_part != nullptr the epilogue also reads that stage's pre-BN tensor at its output
+  // positions and leaves the per-tile partial sums of g * [y > 0] and g * [y > 0] * xhat, which hpri_bn_relu_bwd_fused
+  // finalizes instead of sweeping g and the pre-BN tensor once more (bn.hip: col_reduce).
+  const float* bn_x; int bn_x_cs, bn_x_coff;        // the pre-BN tensor (fp32 NHWC view, same pixels and channels as y)
+  const float* bn_mean; const float* bn_invstd; const float* bn_scale; const float* bn_shift;
+  float* bn_part; int bn_cpart, bn_relu;            // [N*tiles_img][2][bn_cpart]
   int N, H, W, Cin_pad, Cout, Cout_pad, y_cw, accumulate, relu;
   int tiles_x, tiles_y;
   int items, per_xcd, banded;   // work items (pixel tiles x channel blocks), items per XCD band, item order (below)
@@ -169,6 +176,15 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(Wino4Args a) {
 
   const int nstages = a.Cin_pad >> 3;
   const int nchunks = (a.Cin_pad + 31) >> 5;
+  // the epilogue's bias quad, loaded here: four conditional loads in the epilogue were four serialized round trips
+  f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+  if (a.bias != nullptr) {
+    const int n0b = nb * 64 + (tid & 15) * 4;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) bias4[c] = a.bias[min(n0b + c, a.Cout - 1)];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) if (n0b + c >= a.Cout) bias4[c] = 0.f;
+  }
 #ifndef WINO4_NO_STAGGER
   // Two workgroups share a CU, and all workgroups of a launch take the same time: without help both run their output
   // transform (no MFMAs) at the same moment, for the whole launch.  The SECOND occupants of the first round (the dispatcher
@@ -273,10 +289,23 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(Wino4Args a) {
   const int n0 = nb * 64 + oq * 4;
   f32x4 outv[2][4];                                 // [item][pixel] x 4 channels
   const int vrows = min(8, a.H - Y0), vcols = min(16, a.W - X0);
-  f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
-  if (a.bias != nullptr) {
+  // accumulate (a skip gradient already holds the other producer's part): ALL old values are loaded before the first store
+  // -- a load behind a store waits for the store as well (vmcnt counts in order)
+  f32x4 oldv[2][4];
+  if (a.accumulate) {
 #pragma unroll
-    for (int c = 0; c < 4; ++c) if (n0 + c < a.Cout) bias4[c] = a.bias[n0 + c];
+    for (int it = 0; it < 2; ++it) {
+      const int ot = (tid >> 4) + 16 * it;
+      const int py = 2 * (ot >> 3), px = 2 * (ot & 7);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int yy = py + (k >> 1), xx = px + (k & 1);
+        const bool ok = yy < vrows && xx < vcols && n0 < a.y_cw;
+        const float* src = a.y + ((size_t)(img * a.H + Y0 + min(yy, vrows - 1)) * a.W + X0 + min(xx, vcols - 1)) * a.y_cs + a.y_coff + min(n0, a.y_cw - 4);
+        const f32x4 t = *reinterpret_cast<const f32x4*>(src);
+        oldv[it][k] = ok ? t : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
   }
 #pragma unroll
   for (int it = 0; it < 2; ++it) {
@@ -301,7 +330,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(Wino4Args a) {
       const bool ok = yy < vrows && xx < vcols;
       if (ok && n0 < a.y_cw) {
         float* dst = a.y + ((size_t)(img * a.H + Y0 + yy) * a.W + X0 + xx) * a.y_cs + a.y_coff + n0;
-        if (a.accumulate) v += *reinterpret_cast<const f32x4*>(dst);
+        if (a.accumulate) v += oldv[it][k];
         *reinterpret_cast<f32x4*>(dst) = v;
       }
       const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
@@ -341,6 +370,51 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(Wino4Args a) {
       __syncthreads();
       if (pass == 0) mean4 = *reinterpret_cast<const f32x4*>(red + 16 * 64 + oq * 4);
       __syncthreads();
+    }
+  }
+  if (a.bn_part != nullptr) {
+    // BatchNorm-backward partial sums of this tile (see Wino4Args): thread (tid>>4, oq) holds g at 8 pixels x 4 channels
+    f32x4 sc4, sh4, mu4, is4;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int n = min(n0 + c, a.Cout - 1);
+      sc4[c] = a.bn_scale[n]; sh4[c] = a.bn_shift[n]; mu4[c] = a.bn_mean[n]; is4[c] = a.bn_invstd[n];
+    }
+    f32x4 xv[2][4];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int ot = (tid >> 4) + 16 * it;
+      const int py = 2 * (ot >> 3), px = 2 * (ot & 7);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int yy = min(py + (k >> 1), vrows - 1), xx = min(px + (k & 1), vcols - 1);
+        xv[it][k] = *reinterpret_cast<const f32x4*>(a.bn_x + ((size_t)(img * a.H + Y0 + yy) * a.W + X0 + xx) * a.bn_x_cs + a.bn_x_coff +
+                                                    min(n0, a.Cout_pad - 4));
+      }
+    }
+    f32x4 t1 = {0.f, 0.f, 0.f, 0.f}, t2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          // outv is zero outside the image and beyond Cout, so those positions add nothing
+          const float gj = (!a.bn_relu || (xv[it][k][c] * sc4[c] + sh4[c] > 0.f)) ? outv[it][k][c] : 0.f;
+          t1[c] += gj;
+          t2[c] += gj * ((xv[it][k][c] - mu4[c]) * is4[c]);
+        }
+    __syncthreads();                                // everyone has read the exchange planes (and the statistics scratch)
+    float* red = reinterpret_cast<float*>(smem);    // [2][16][64 ch]
+    *reinterpret_cast<f32x4*>(red + (tid >> 4) * 64 + oq * 4) = t1;
+    *reinterpret_cast<f32x4*>(red + 1024 + (tid >> 4) * 64 + oq * 4) = t2;
+    __syncthreads();
+    if (tid < 128) {                                // (sum, channel) = (tid >> 6, tid & 63): fixed order over the 16 thread rows
+      const int which = tid >> 6, c = tid & 63;
+      float tsum = 0.f;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) tsum += red[which * 1024 + q * 64 + c];
+      if (nb * 64 + c < a.bn_cpart) a.bn_part[((size_t)bx * 2 + which) * a.bn_cpart + nb * 64 + c] = tsum;
     }
   }
   STAMP(3)
@@ -415,12 +489,19 @@ extern "C" int hpri_conv_wino4_plan(int N, int H, int W, int* stat_tiles) {
   return HPRI_OK;
 }
 
+extern "C" int hpri_conv_wino4_bnred(const float* x, int x_cs, int x_coff, const float* up, float* y, int y_cs, int y_coff, int N, int H,
+                                     int W, int Cin_pad, int Cout, int Cout_pad, int y_cw, const float* bn_x, int bn_x_cs, int bn_x_coff,
+                                     const float* bn_mean, const float* bn_invstd, const float* bn_scale, const float* bn_shift,
+                                     int bn_relu, float* bn_part, int bn_cpart, hipStream_t stream);
+
 // 3x3 / pad 1 / stride 1 convolution, Winograd F(2x2,3x3), fp32.  x: fp32 NHWC view with channels [Cin, Cin_pad) zero
 // (Cin_pad a multiple of 8); up from hpri_wino4_pack; accumulate bit 0: y += result, bit 1: ReLU epilogue; statistics:
 // one (mean, M2, count, 0) record per 16 x 8-pixel tile and channel (hpri_conv_wino4_plan).
-extern "C" int hpri_conv_wino4(const float* x, int x_cs, int x_coff, const float* up, const float* bias, float* y, int y_cs,
-                               int y_coff, float* stats, int N, int H, int W, int Cin_pad, int Cout, int Cout_pad, int y_cw,
-                               int accumulate, hipStream_t stream) {
+static int wino4_launch(const float* x, int x_cs, int x_coff, const float* up, const float* bias, float* y, int y_cs,
+                        int y_coff, float* stats, int N, int H, int W, int Cin_pad, int Cout, int Cout_pad, int y_cw,
+                        int accumulate, const float* bn_x, int bn_x_cs, int bn_x_coff, const float* bn_mean,
+                        const float* bn_invstd, const float* bn_scale, const float* bn_shift, int bn_relu, float* bn_part,
+                        int bn_cpart, hipStream_t stream) {
   HPRI_REQUIRE(x && up && y, "conv_wino4: null pointer");
   HPRI_REQUIRE(N > 0 && H > 0 && W > 0, "conv_wino4: empty image");
   HPRI_REQUIRE(Cin_pad > 0 && Cin_pad % 8 == 0, "conv_wino4: Cin_pad must be a positive multiple of 8");
@@ -439,6 +520,15 @@ extern "C" int hpri_conv_wino4(const float* x, int x_cs, int x_coff, const float
   HPRI_REQUIRE(y_cs % 4 == 0 && y_coff % 4 == 0 && a.y_cw % 4 == 0 && ((uintptr_t)y & 15) == 0,
                "conv_wino4: the output view must be float4-aligned (stride, offset and written width multiples of 4)");
   a.tiles_x = hpri_cdiv(W, 16); a.tiles_y = hpri_cdiv(H, 8);
+  a.bn_x = bn_x; a.bn_x_cs = bn_x_cs; a.bn_x_coff = bn_x_coff; a.bn_mean = bn_mean; a.bn_invstd = bn_invstd; a.bn_scale = bn_scale;
+  a.bn_shift = bn_shift; a.bn_part = bn_part; a.bn_cpart = bn_cpart; a.bn_relu = bn_relu;
+  if (bn_part != nullptr) {
+    HPRI_REQUIRE(bn_x && bn_mean && bn_invstd && bn_scale && bn_shift, "conv_wino4_bnred: null pointer");
+    HPRI_REQUIRE(!(accumulate & 1) && stats == nullptr, "conv_wino4_bnred: not together with accumulate or statistics");
+    HPRI_REQUIRE(bn_x_cs % 4 == 0 && bn_x_coff % 4 == 0 && bn_x_coff + Cout_pad <= bn_x_cs && ((uintptr_t)bn_x & 15) == 0,
+                 "conv_wino4_bnred: the pre-BN view must be float4-aligned and hold Cout_pad channels");
+    HPRI_REQUIRE(bn_cpart >= Cout && bn_cpart % 4 == 0, "conv_wino4_bnred: partial width must cover the channels");
+  }
   a.ncu = hpri_cu_count(); a.stagger_cycles = W4_STAGGER_CYCLES;
 #ifdef HPRI_STAMPS
   a.stamps = hpri_wino4_stamps;
@@ -451,4 +541,24 @@ extern "C" int hpri_conv_wino4(const float* x, int x_cs, int x_coff, const float
   hipLaunchKernelGGL(conv_wino4_kernel, grid, dim3(256), 0, stream, a);
   HPRI_CHECK_LAUNCH();
   return HPRI_OK;
+}
+
+extern "C" int hpri_conv_wino4(const float* x, int x_cs, int x_coff, const float* up, const float* bias, float* y, int y_cs,
+                               int y_coff, float* stats, int N, int H, int W, int Cin_pad, int Cout, int Cout_pad, int y_cw,
+                               int accumulate, hipStream_t stream) {
+  return wino4_launch(x, x_cs, x_coff, up, bias, y, y_cs, y_coff, stats, N, H, W, Cin_pad, Cout, Cout_pad, y_cw, accumulate, nullptr, 0,
+                      0, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0, stream);
+}
+
+// The same convolution as a DATA GRADIENT (mode-1 pack, no bias) that also leaves the BatchNorm-backward partial sums of the stage
+// whose output gradient it writes: bn_x = that stage's pre-BN tensor (same pixels / channels as y), per-channel mean / invstd /
+// scale / shift, bn_relu = the stage ends in a ReLU; bn_part[N * tiles][2][bn_cpart] (tiles: hpri_conv_wino4_plan) receives
+// sum g*[y>0] and sum g*[y>0]*xhat per 16 x 8-pixel tile; finish with hpri_bn_relu_bwd_fused.
+extern "C" int hpri_conv_wino4_bnred(const float* x, int x_cs, int x_coff, const float* up, float* y, int y_cs, int y_coff, int N, int H,
+                                     int W, int Cin_pad, int Cout, int Cout_pad, int y_cw, const float* bn_x, int bn_x_cs, int bn_x_coff,
+                                     const float* bn_mean, const float* bn_invstd, const float* bn_scale, const float* bn_shift,
+                                     int bn_relu, float* bn_part, int bn_cpart, hipStream_t stream) {
+  HPRI_REQUIRE(bn_part != nullptr, "conv_wino4_bnred: null partial buffer");
+  return wino4_launch(x, x_cs, x_coff, up, nullptr, y, y_cs, y_coff, nullptr, N, H, W, Cin_pad, Cout, Cout_pad, y_cw, 0, bn_x, bn_x_cs,
+                      bn_x_coff, bn_mean, bn_invstd, bn_scale, bn_shift, bn_relu, bn_part, bn_cpart, stream);
 }

@@ -62,7 +62,7 @@ class Act:
 
     Invariant: channels [C, cw) (cw = C rounded up to 8) exist inside the stride and hold zeros, so
     consumers may run their K loop over ``cw`` channels."""
-    __slots__ = ("buf", "N", "H", "W", "C", "cs", "coff", "pl", "parent", "f32_valid", "want_pl", "pl_part", "colsum_req", "b16")
+    __slots__ = ("buf", "N", "H", "W", "C", "cs", "coff", "pl", "parent", "f32_valid", "want_pl", "pl_part", "colsum_req", "b16", "bn_src")
 
     def __init__(self, buf: torch.Tensor, N: int, H: int, W: int, C: int, cs: int, coff: int = 0):
         self.buf, self.N, self.H, self.W, self.C, self.cs, self.coff = buf, N, H, W, C, cs, coff
@@ -73,6 +73,7 @@ class Act:
         self.want_pl = 0                        # plane mode marker: planes a 3x3 consumer of this tensor (or of its pooled map) would read
         self.colsum_req = None                  # (c0, C): somebody wants the column sums of channels [c0, c0+C) of this tensor's GRADIENT
         self.b16 = False                        # the buffer holds bf16 elements (a pre-BN tensor of the bf16 mode; read by the *_x16 BN passes only)
+        self.bn_src = None                      # (pre-BN Act, statistics, relu): this tensor is BN(+ReLU) of that one and has ONE consumer
 
     @property
     def cw(self) -> int:
@@ -315,6 +316,7 @@ class Tape:
         self.used_side = False
         self.sunk: Dict[int, torch.Tensor] = {}     # parameters whose gradient was written into the grad sink's storage
         self.colsum: Dict[int, tuple] = {}          # id(Act) -> (stats records, tiles, Cpad, c0) left by the data-gradient kernel that wrote its gradient
+        self.bnpart: Dict[int, tuple] = {}          # id(Act) -> (partial sums, blocks, Cpart) of its BatchNorm backward, left by the same kind of kernel
         self.uses: Dict[int, int] = {}              # id(parameter) -> ops recorded on this tape that will produce a gradient for it
         self._touched: List[int] = []               # parameters the running node asked a gradient slot for
 
@@ -392,6 +394,7 @@ class Tape:
         self.keep.clear()
         self.uses.clear()
         self.colsum.clear()
+        self.bnpart.clear()
 
 
 class BNRef:
@@ -846,6 +849,8 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
                   *(_pl_args(ypl) if cpl is None else (_p(cpl.buf), cpl.plane, cpl.cs, 0, y.C, 1)), _stream())
     if not tape.record:
         return y
+    if bn is not None and next_cout > 0 and groups == 1 and not yr16 and room == 0:
+        y.bn_src = (yr, st, relu)          # one consumer (the caller says so): its data-gradient kernel may do this stage's reduction
 
     def bwd(tp: Tape) -> None:
         g = tp.grads.pop(id(y), None)
@@ -867,7 +872,9 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
             f32_dead = (dpl is not None and ks == 3 and split == 0 and PLANE_CONV and PLANE_WGRAD and PLANES_ONLY_GRAD
                         and (need_dx or weight.requires_grad))
             dyr.f32_valid = not f32_dead
-            _lib.call("hpri_bn_relu_bwd_x16" if yr16 else "hpri_bn_relu_bwd_pl", g.ptr, g.cs, g.coff, yr.ptr, yr.cs, yr.coff,
+            bp = tp.bnpart.pop(id(y), None)
+            _lib.call(*(("hpri_bn_relu_bwd_fused", _p(bp[0]), bp[1], bp[2]) if bp is not None else
+                        ("hpri_bn_relu_bwd_x16" if yr16 else "hpri_bn_relu_bwd_pl",)), g.ptr, g.cs, g.coff, yr.ptr, yr.cs, yr.coff,
                       ctypes.c_void_p(0) if f32_dead else dyr.ptr, dyr.cs, dyr.coff,
                       _p(mean), _p(invstd), _p(scale), _p(shift), _p(dgam), _p(dbet), acc_g, _p(db), acc_b,
                       _p(ws), ws.numel(), x.P, x.P // G, cout, dyr.cw, int(relu), int(use_batch), *_pl_args(dpl), _stream())
@@ -911,7 +918,25 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
                               ctypes.byref(wsf_))
                 gtiles = tl.value
                 gstats = torch.empty(gtiles * _rup(cin, 64) * 4, dtype=torch.float32, device=dev)
-            if wino_d:
+            src = x.bn_src
+            if (wino_d and WINO4 and FUSE_BN_REDUCE and src is not None and not acc and gstats is None
+                    and src[0].cs - src[0].coff >= _rup(cin, 64)):
+                # this launch writes the ONLY contribution to dL/dx, and x = ReLU(BN(src[0])): its epilogue also leaves the
+                # per-tile partial sums of that BatchNorm's backward (the stage that produced x then skips its reduction sweeps)
+                upd, cin_cols_pad = _pack_wino(weight, 1, cout, cin, cin)
+                xr, xst, xrelu = src
+                tl = ctypes.c_int()
+                _lib.call("hpri_conv_wino4_plan", x.N, x.H, x.W, ctypes.byref(tl))
+                part = torch.empty(tl.value * 2 * cin_cols_pad, dtype=torch.float32, device=dev)
+                xm, xi, _xv, xsc, xsh = (xst[i * cin:(i + 1) * cin] for i in range(5))
+                wtiles = x.N * ((x.H + 1) // 2) * ((x.W + 1) // 2)
+                tag = "conv_winograd_f32<3,F(2x2)>" + (f" N{x.N} {x.H}x{x.W} K{dyr.cw} N{cin}" if SHAPE_TAGS else "")
+                with _timed(tag, 2.0 * x.N * x.H * x.W * cout * cin * 9, executed=2.0 * wtiles * 16 * cout * cin):
+                    _lib.call("hpri_conv_wino4_bnred", dyr.ptr, dyr.cs, dyr.coff, _p(upd), gx.ptr, gx.cs, gx.coff, x.N, x.H, x.W, dyr.cw,
+                              cin, cin_cols_pad, gx.cw, xr.ptr, xr.cs, xr.coff, _p(xm), _p(xi), _p(xsc), _p(xsh), int(xrelu),
+                              _p(part), cin_cols_pad, _stream())
+                tp.bnpart[id(x)] = (part, tl.value, cin_cols_pad)
+            elif wino_d:
                 upd, cin_cols_pad = _pack_wino(weight, 1, cout, cin, cin)
                 _conv_launch_wino(dyr, upd, None, gx, gstats, cout, cin, cin_cols_pad, gx.cw, accumulate=int(acc))
             elif v2:
@@ -933,6 +958,11 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
     return y
 
 
+# fp32 mode: the BatchNorm-backward reduction of a conv -> BN -> ReLU stage whose output has a single consumer (the inner tensor of a
+# DoubleConv, CubeNET's first layer) is taken in the epilogue of that consumer's Winograd data-gradient launch
+# (hpri_conv_wino4_bnred + hpri_bn_relu_bwd_fused) instead of two sweeps over the gradient and the pre-BN tensor.
+# HPRI_FUSE_BN_REDUCE: 1 (default) / 0.
+FUSE_BN_REDUCE = os.environ.get("HPRI_FUSE_BN_REDUCE", "1") != "0"
 # the ConvTranspose2d bias gradient from the epilogue records of the data-gradient kernel that wrote the concat's gradient
 # (hpri_colsum_from_stats) instead of a pass over that tensor (hpri_col_sum).  HPRI_COLSUM_FROM_STATS: 1 (default) / 0.
 COLSUM_FROM_STATS = os.environ.get("HPRI_COLSUM_FROM_STATS", "1") != "0"

@@ -111,6 +111,21 @@ int hpri_conv_wino4(const float* x, int x_cs, int x_coff, const float* up, const
                     hipStream_t stream);
 /* diagnostic builds (-DHPRI_STAMPS, tools/build_wino4_diag.sh) only; the product library returns HPRI_ERR_UNSUPPORTED */
 int hpri_wino4_set_stamps(unsigned long long* stamps);
+/* hpri_conv_wino4 as a DATA GRADIENT (mode-1 pack, no bias, no accumulate) that also leaves the BatchNorm-backward partial sums of the
+ * conv -> BN -> ReLU stage whose output gradient y it writes (model_parts.py:22-27's autograd): bn_x = that stage's pre-BN tensor
+ * (fp32 NHWC view, same pixels / channels as y, Cout_pad channels wide), its per-channel mean / invstd / scale / shift, bn_relu;
+ * bn_part[N * tiles][2][bn_cpart] (tiles: hpri_conv_wino4_plan) receives sum g*[y>0] and sum g*[y>0]*xhat per tile.  Finish with
+ * hpri_bn_relu_bwd_fused, which then skips its two reduction sweeps over g and the pre-BN tensor. */
+int hpri_conv_wino4_bnred(const float* x, int x_cs, int x_coff, const float* up, float* y, int y_cs, int y_coff, int N, int H,
+                          int W, int Cin_pad, int Cout, int Cout_pad, int y_cw, const float* bn_x, int bn_x_cs, int bn_x_coff,
+                          const float* bn_mean, const float* bn_invstd, const float* bn_scale, const float* bn_shift,
+                          int bn_relu, float* bn_part, int bn_cpart, hipStream_t stream);
+int hpri_bn_relu_bwd_fused(const float* partials, int part_blocks, int part_cpart, const float* dy, int dy_cs, int dy_coff,
+                           const float* x, int x_cs, int x_coff, float* dx, int dx_cs, int dx_coff, const float* mean,
+                           const float* invstd, const float* scale, const float* shift, float* dgamma, float* dbeta,
+                           int accumulate_param_grads, float* dbias, int accumulate_dbias, float* workspace, size_t ws_floats,
+                           long long P, long long pix_per_group, int C, int Cw, int relu, int use_batch_stats, void* planes,
+                           long long plane_stride, int pl_cs, int pl_coff, int pl_cw, int npl, hipStream_t stream);
 
 
 /* Winograd weight gradient (dU = sum over tiles of V * (A dY A^T), dg = G^T dU G): slabs ws[split][16][Cr][Nr] from
