@@ -96,30 +96,40 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_bf16v2_kernel(WgV2Args a) {
     yhx[q] = px;
   }
 
+// A unit's DMA pieces: ISSUE_PREP computes the unit's wave-uniform descriptors and origin, ISSUE_X(q) / ISSUE_Y(q) issue this
+// wave's piece q.  The first unit of a workgroup is issued in one go (ISSUE_UNIT); inside the loop the pieces of unit u+1 are
+// issued BETWEEN the MFMAs of unit u (round 3: issued as one burst behind the barrier, every wave of the CU -- all in lock-step --
+// stood in VMEM issue for 5-6 pieces while the matrix pipes idled).
+#define ISSUE_PREP(u_, buf_)                                                                                           \
+  int q_ = (u_);                                                                                                       \
+  const int sx_ = q_ % a.units_x; q_ /= a.units_x;                                                                     \
+  const int sy_ = q_ % a.units_y;                                                                                      \
+  const int img_ = q_ / a.units_y;                                                                                     \
+  const int y0_ = sy_ * 4, x0_ = sx_ * 32;                                                                             \
+  const hpri_rsrc_t rx_ = HPRI_MAKE_RSRC(a.xp + ((long long)(img_ * a.H + y0_ - 1) * a.W + x0_ - 1) * a.x_cs + a.x_coff + c_blk, 0x7FFFFF00); \
+  const hpri_rsrc_t ry_ = HPRI_MAKE_RSRC(a.dyp + ((long long)(img_ * a.H + y0_) * a.W + x0_) * a.dy_cs + a.dy_coff + n_blk, 0x7FFFFF00);     \
+  unsigned char* lx_ = smem + (buf_) * WG_UB;                                                                          \
+  (void)rx_; (void)ry_; (void)lx_;
+#define ISSUE_X(q)                                                                                                     \
+  {                                                                                                                    \
+    const int i_ = wave + 8 * (q);                                                                                     \
+    if (i_ < WG_XI) {                                                                                                  \
+      const int iy_ = y0_ - 1 + xhy[q], ix_ = x0_ - 1 + xhx[q];                                                        \
+      const bool in_ = (unsigned)iy_ < (unsigned)a.H && (unsigned)ix_ < (unsigned)a.W;                                 \
+      HPRI_LDS_DMA16(rx_, lx_ + i_ * 1024, in_ ? xoff[q] : HPRI_DMA_OOB, 0);                                           \
+    }                                                                                                                  \
+  }
+#define ISSUE_Y(q)                                                                                                     \
+  {                                                                                                                    \
+    const int i_ = wave + 8 * (q);                                                                                     \
+    const int iy_ = y0_ + yhy[q], ix_ = x0_ + yhx[q];                                                                  \
+    const bool in_ = iy_ < a.H && ix_ < a.W;                                                                           \
+    HPRI_LDS_DMA16(ry_, lx_ + WG_XB + i_ * 1024, in_ ? yoff[q] : HPRI_DMA_OOB, 0);                                     \
+  }
 #define ISSUE_UNIT(u_, buf_)                                                                                           \
   {                                                                                                                    \
-    int q_ = (u_);                                                                                                     \
-    const int sx_ = q_ % a.units_x; q_ /= a.units_x;                                                                   \
-    const int sy_ = q_ % a.units_y;                                                                                    \
-    const int img_ = q_ / a.units_y;                                                                                   \
-    const int y0_ = sy_ * 4, x0_ = sx_ * 32;                                                                           \
-    const hpri_rsrc_t rx_ = HPRI_MAKE_RSRC(a.xp + ((long long)(img_ * a.H + y0_ - 1) * a.W + x0_ - 1) * a.x_cs + a.x_coff + c_blk, 0x7FFFFF00); \
-    const hpri_rsrc_t ry_ = HPRI_MAKE_RSRC(a.dyp + ((long long)(img_ * a.H + y0_) * a.W + x0_) * a.dy_cs + a.dy_coff + n_blk, 0x7FFFFF00);     \
-    unsigned char* lx_ = smem + (buf_) * WG_UB;                                                                        \
-    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                                    \
-      const int i_ = wave + 8 * q;                                                                                     \
-      if (i_ < WG_XI) {                                                                                                \
-        const int iy_ = y0_ - 1 + xhy[q], ix_ = x0_ - 1 + xhx[q];                                                      \
-        const bool in_ = (unsigned)iy_ < (unsigned)a.H && (unsigned)ix_ < (unsigned)a.W;                               \
-        HPRI_LDS_DMA16(rx_, lx_ + i_ * 1024, in_ ? xoff[q] : HPRI_DMA_OOB, 0);                                         \
-      }                                                                                                                \
-    }                                                                                                                  \
-    _Pragma("unroll") for (int q = 0; q < 2; ++q) {                                                                    \
-      const int i_ = wave + 8 * q;                                                                                     \
-      const int iy_ = y0_ + yhy[q], ix_ = x0_ + yhx[q];                                                                \
-      const bool in_ = iy_ < a.H && ix_ < a.W;                                                                         \
-      HPRI_LDS_DMA16(ry_, lx_ + WG_XB + i_ * 1024, in_ ? yoff[q] : HPRI_DMA_OOB, 0);                                   \
-    }                                                                                                                  \
+    ISSUE_PREP(u_, buf_)                                                                                               \
+    ISSUE_X(0) ISSUE_X(1) ISSUE_X(2) ISSUE_X(3) ISSUE_Y(0) ISSUE_Y(1)                                                  \
   }
 
   // ---- transposed-read lane roles: 16-lane group = (k half lh, channel half lg); lane i of the group addresses pixel row
@@ -146,7 +156,8 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_bf16v2_kernel(WgV2Args a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();          // unit u has landed for everyone; everyone has finished reading unit u-1
     const int bo = ((u - u_begin) & 1) * WG_UB;
-    if (u + 1 < u_end) ISSUE_UNIT(u + 1, ((u + 1 - u_begin) & 1))
+    const bool more = u + 1 < u_end;
+    ISSUE_PREP(more ? u + 1 : u, ((u + 1 - u_begin) & 1))
     const unsigned char* sb = smem + bo;
 #pragma unroll
     for (int k4 = 0; k4 < 4; ++k4) {
@@ -164,10 +175,23 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_bf16v2_kernel(WgV2Args a) {
         const int base = (odd ? xO : xE) ^ (tbit << 6);
         const bf16x8 bfr = wg_tr_frag(sb + base + kg * (2 * WG_HW * 128) + T0 * 128);
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[t], 0, 0, 0);
+        // one DMA piece of the next unit behind MFMAs 2, 8, 14, 20 (X) and 26, 32 (dY) of the unit's 36
+        if (more) {
+          const int m = k4 * 9 + t;
+          if (m == 2) ISSUE_X(0)
+          if (m == 8) ISSUE_X(1)
+          if (m == 14) ISSUE_X(2)
+          if (m == 20) ISSUE_X(3)
+          if (m == 26) ISSUE_Y(0)
+          if (m == 32) ISSUE_Y(1)
+        }
       }
     }
   }
 #undef ISSUE_UNIT
+#undef ISSUE_PREP
+#undef ISSUE_X
+#undef ISSUE_Y
 
   // ---- the two pixel halves meet in LDS: kg 1 hands taps 0-4 to kg 0, kg 0 hands taps 5-8 to kg 1 ----
   float* ex = reinterpret_cast<float*>(smem);          // [tap_local*16 + r][256 threads]

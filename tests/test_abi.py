@@ -92,3 +92,42 @@ def test_split_k_is_priced_by_its_slab_traffic():
         assert k.value == 1 and ws.value == 0, (H, W, cin, cout, k.value)
     assert lib.hpri_conv_bf16v2_plan(1, 16, 24, 1024, 64, ctypes.byref(k), ctypes.byref(tl), ctypes.byref(ws)) == 0
     assert k.value > 1 and ws.value == k.value * 16 * 24 * 64       # a tiny problem: slices fill the chip
+
+
+def test_plane_conv_v3_plan_matches_a_python_restatement_of_its_tiling():
+    """hpri_conv_bf16v3_plan is host-only (no GPU needed): its statistics-tile count must equal the tiling the kernel documents --
+    column bands of 32 x 8 and 16 x 16 pixel tiles (256 pixels either way) chosen by padding cost, two workgroup slots per CU,
+    K slices only below half a round of slots, bf16 output unavailable for split problems."""
+    import ctypes
+    from hyperpri_amd import _lib
+    lib = _lib.load()
+
+    def cdiv(a, b):
+        return (a + b - 1) // b
+
+    def tiles_img(H, W):
+        best = None
+        for n32 in range(0, cdiv(W, 32) + 1):
+            rem = W - n32 * 32
+            if rem <= 0 and n32 * 32 - W >= 32:
+                continue
+            n16 = cdiv(rem, 16) if rem > 0 else 0
+            cost = cdiv(H, 8) * 8 * 32 * n32 + cdiv(H, 16) * 16 * 16 * n16
+            t = cdiv(H, 8) * n32 + cdiv(H, 16) * n16
+            if best is None or cost < best[0] or (cost == best[0] and n16 == 0):
+                best = (cost, t)
+        return best[1]
+    for (N, H, W, cin_pad, cout_pad) in [(2, 608, 968, 256, 64), (2, 304, 484, 128, 128), (2, 152, 242, 512, 256), (1, 76, 121, 1024, 512),
+                                         (2, 38, 60, 1024, 1024), (1, 17, 23, 32, 64), (3, 16, 16, 32, 320), (1, 1, 1, 32, 64)]:
+        k, tl, ws = ctypes.c_int(), ctypes.c_int(), ctypes.c_size_t()
+        assert lib.hpri_conv_bf16v3_plan(N, H, W, cin_pad, cout_pad, ctypes.byref(k), ctypes.byref(tl), ctypes.byref(ws)) == 0
+        assert 1 <= k.value <= 4
+        if k.value == 1:
+            assert tl.value == N * tiles_img(H, W), (N, H, W, tl.value)
+            assert ws.value == 0
+        else:
+            assert cin_pad // 32 // k.value >= 4                       # never fewer than four 32-channel chunks per slice
+            assert tl.value == N * cdiv(H * W, 64) and ws.value == k.value * N * H * W * cout_pad
+    # the Winograd plan: one record per 16 x 8-pixel tile
+    t = ctypes.c_int()
+    assert lib.hpri_conv_wino4_plan(2, 608, 968, ctypes.byref(t)) == 0 and t.value == 2 * 76 * 61
