@@ -281,11 +281,15 @@ def main():
         engine.synth_fill_(x[i], 1234 + n, mode=0)
         engine.synth_fill_(mask[i], 4321 + n, mode=1, thr=0.9)
     crit = HP.BCEWithLogitsLoss()        # nn.BCEWithLogitsLoss() semantics on the HIP path (csrc/step.hip)
+    fused_loss = os.environ.get("HPRI_BENCH_FUSED_LOSS", "1") != "0"
 
     def step():
         for p in net.parameters():
             p.grad = None
-        loss = crit(net(x), mask)
+        if fused_loss:
+            _, loss = HP.forward_loss(net, x, mask)     # same loss; computed inside the head's kernels
+        else:
+            loss = crit(net(x), mask)
         loss.backward()
         if sync is not None:
             sync.finish()
@@ -537,7 +541,7 @@ def main():
             "config": {"workload": "CubeNET-64 n_channels=238 HSI 608x968 " + engine.DEFAULT_PRECISION + ", per-GPU batch 2, train mode, "
                                    "BCEWithLogits, fwd+bwd" + (" + RCCL grad all-reduce" if world > 1 else ""),
                        "global_batch": world * BATCH, "parallelism": f"dp{world}"},
-            "loss": round(loss_val, 6),
+            "loss": round(loss_val, 6), "loss_in_head_kernels": fused_loss,
             "settle": settle,
             "rccl_ranks": world if use_pg else 0,
             "grad_sync": grad_sync,

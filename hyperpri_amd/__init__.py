@@ -6,7 +6,7 @@ Drop-in ``torch.nn.Module`` replacements for the reference's ``src/Experiments/m
 from .model_parts import DoubleConv, Down, OutConv, Up, set_precision  # noqa: F401
 from .models import (CubeNET, SpectralUNET, UNet, initialize_model, set_parameter_requires_grad,  # noqa: F401
                      translate_load_dir)
-from .trainer import (BCEWithLogitsLoss, FusedAdam, FusedSGD, PRCurve, SegCounts, SegmentationModel,  # noqa: F401
+from .trainer import (BCEWithLogitsLoss, forward_loss, FusedAdam, FusedSGD, PRCurve, SegCounts, SegmentationModel,  # noqa: F401
                       average_precision, load_checkpoint, network_state_dict)
 
 __version__ = "0.1.0"

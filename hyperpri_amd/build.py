@@ -28,6 +28,8 @@ def _hipcc() -> str:
 def _stamp() -> str:
     h = hashlib.sha256()
     for f in sorted(os.listdir(CSRC)):
+        if not os.path.isfile(os.path.join(CSRC, f)):
+            continue
         with open(os.path.join(CSRC, f), "rb") as fh:
             h.update(f.encode()); h.update(fh.read())
     h.update(" ".join(FLAGS).encode())

@@ -229,8 +229,23 @@ __global__ void fill_kernel(float* __restrict__ d, long long n, float v) {
 
 // ---------------------------------- 1x1 output conv ---------------------------------------------
 // logits[n][k][p] = sum_c x[n][p][c] * w[k][c] + b[k]   (NHWC in, NCHW out).  One 16-lane group per pixel.
+// BCE-with-logits pieces for the fused head (the loss inside the last layer's kernels; the stand-alone forms
+// live in step.hip and compute the same expressions)
+__device__ __forceinline__ float oc_bce_elem(float x, float y) { return fmaxf(x, 0.f) - x * y + log1pf(expf(-fabsf(x))); }
+__device__ __forceinline__ float oc_bce_grad(float xi, float yi) {           // (sigmoid(x) - y), as step.hip's bce_bwd_kernel
+  const float e = expf(-fabsf(xi)), r = 1.f / (1.f + e);
+  const float sp = xi >= 0.f ? r : e * r, sn = xi >= 0.f ? e * r : r;
+  return (1.f - yi) * sp - yi * sn;
+}
+
+// BCE = true: also the per-block fp64 partial sum of BCEWithLogits(y, target) (nn.BCEWithLogitsLoss of PLTrainer.py:86 on the
+// logits this kernel has just produced): one pass over the logits less, the loss finishes with step.hip's finalize kernel
+template <bool BCE>
 __global__ void outconv_fwd_kernel(const float* __restrict__ x, int x_cs, int x_coff, const float* __restrict__ w,
-                                   const float* __restrict__ b, float* __restrict__ y, int N, long long P, int C, int K) {
+                                   const float* __restrict__ b, float* __restrict__ y, int N, long long P, int C, int K,
+                                   const float* __restrict__ target, double* __restrict__ partial) {
+  __shared__ double bred[256];
+  double bsum = 0.0;
   const int gl = threadIdx.x & 15;
   const long long grp = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
   const long long ngrp = ((long long)gridDim.x * blockDim.x) >> 4;
@@ -250,15 +265,31 @@ __global__ void outconv_fwd_kernel(const float* __restrict__ x, int x_cs, int x_
       s += __shfl_xor(s, 8, 16); s += __shfl_xor(s, 4, 16); s += __shfl_xor(s, 2, 16); s += __shfl_xor(s, 1, 16);
       if (gl == 0) {
         const long long n = pg / P, p = pg - n * P;
-        y[(n * K + k) * P + p] = s + (b ? b[k] : 0.f);
+        const float v = s + (b ? b[k] : 0.f);
+        y[(n * K + k) * P + p] = v;
+        if (BCE) bsum += (double)oc_bce_elem(v, target[(n * K + k) * P + p]);
       }
     }
+  }
+  if (BCE) {
+    bred[threadIdx.x] = bsum;
+    __syncthreads();
+    for (int wd = 128; wd > 0; wd >>= 1) {
+      if (threadIdx.x < wd) bred[threadIdx.x] += bred[threadIdx.x + wd];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = bred[0];
   }
 }
 
 // dx[n][p][c] = sum_k dy[n][k][p] * w[k][c]  (written, or accumulated into dx)
+// BCE = true: dy is not a gradient tensor but the LOGITS; the gradient of the mean BCE-with-logits loss is formed on the fly,
+// g = (sigmoid(logit) - target) * gscale[0] / (N*K*P)
+template <bool BCE>
 __global__ void outconv_bwd_data_kernel(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx,
-                                        int dx_cs, int dx_coff, int N, long long P, int C, int Cw, int K, int accumulate) {
+                                        int dx_cs, int dx_coff, int N, long long P, int C, int Cw, int K, int accumulate,
+                                        const float* __restrict__ target, const float* __restrict__ gscale) {
+  const float gs = BCE ? (gscale ? gscale[0] : 1.f) / (float)((double)N * K * P) : 1.f;
   const int C4 = Cw >> 2;
   const long long total = (long long)N * P * C4;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -267,7 +298,8 @@ __global__ void outconv_bwd_data_kernel(const float* __restrict__ dy, const floa
     const long long n = pg / P, p = pg - n * P;
     float o[4] = {0.f, 0.f, 0.f, 0.f};
     for (int k = 0; k < K; ++k) {
-      const float g = dy[(n * K + k) * P + p];
+      float g = dy[(n * K + k) * P + p];
+      if (BCE) g = oc_bce_grad(g, target[(n * K + k) * P + p]) * gs;
 #pragma unroll
       for (int j = 0; j < 4; ++j)
         if (c + j < C) o[j] += g * w[(long long)k * C + c + j];
@@ -283,8 +315,11 @@ __global__ void outconv_bwd_data_kernel(const float* __restrict__ dy, const floa
 
 // partial[blk][k][c] = sum over the block's pixels of dy[k][p] * x[p][c]; partial_b[blk][k] = sum dy[k][p]
 // grid = (nblk, ceil(C4/CQ), K); block = 256 = ROWS x CQ
+template <bool BCE>
 __global__ void outconv_bwd_weight_kernel(const float* __restrict__ dy, const float* __restrict__ x, int x_cs, int x_coff,
-                                          int N, long long P, int C, int K, int CQ, float* __restrict__ part, int Cpart) {
+                                          int N, long long P, int C, int K, int CQ, float* __restrict__ part, int Cpart,
+                                          const float* __restrict__ target, const float* __restrict__ gscale) {
+  const float gs = BCE ? (gscale ? gscale[0] : 1.f) / (float)((double)N * K * P) : 1.f;
   __shared__ float4 red[256];
   __shared__ float redb[256];
   const int rows = 256 / CQ;
@@ -299,7 +334,8 @@ __global__ void outconv_bwd_weight_kernel(const float* __restrict__ dy, const fl
   float sb = 0.f;
   for (long long pg = p0 + pr; pg < p1; pg += rows) {
     const long long n = pg / P, p = pg - n * P;
-    const float g = dy[(n * K + k) * P + p];
+    float g = dy[(n * K + k) * P + p];
+    if (BCE) g = oc_bce_grad(g, target[(n * K + k) * P + p]) * gs;
     sb += g;
     if (c < C) {
       const float4 v = *reinterpret_cast<const float4*>(x + pg * x_cs + x_coff + c);
@@ -480,8 +516,23 @@ extern "C" int hpri_outconv_fwd(const float* x, int x_cs, int x_coff, const floa
   HPRI_REQUIRE(x && w && y && N > 0 && P > 0 && C > 0 && K > 0, "outconv_fwd: bad arguments");
   HPRI_REQ_V4(x_cs, x_coff);
   HPRI_REQUIRE(((C + 3) / 4) * 4 + x_coff <= x_cs, "outconv_fwd: channel stride too small for float4 reads");
-  hipLaunchKernelGGL(outconv_fwd_kernel, dim3(ew_blocks((long long)N * P * 16)), dim3(256), 0, stream, x, x_cs, x_coff, w, b,
-                     y, N, P, C, K);
+  hipLaunchKernelGGL(outconv_fwd_kernel<false>, dim3(ew_blocks((long long)N * P * 16)), dim3(256), 0, stream, x, x_cs, x_coff, w, b,
+                     y, N, P, C, K, (const float*)nullptr, (double*)nullptr);
+  HPRI_CHECK_LAUNCH();
+  return HPRI_OK;
+}
+
+// The same head with nn.BCEWithLogitsLoss() (mean) of its logits against `target` (N, K, P) computed on the way: `partial` receives
+// one fp64 partial sum per block (hpri_outconv_fwd_bce_blocks of them); hpri_bce_finish turns them into the loss.
+extern "C" size_t hpri_outconv_fwd_bce_blocks(int N, long long P) { return (size_t)ew_blocks((long long)N * P * 16); }
+extern "C" int hpri_outconv_fwd_bce(const float* x, int x_cs, int x_coff, const float* w, const float* b, float* y, const float* target,
+                                    double* partial, size_t partial_doubles, int N, long long P, int C, int K, hipStream_t stream) {
+  HPRI_REQUIRE(x && w && y && target && partial && N > 0 && P > 0 && C > 0 && K > 0, "outconv_fwd_bce: bad arguments");
+  HPRI_REQ_V4(x_cs, x_coff);
+  HPRI_REQUIRE(((C + 3) / 4) * 4 + x_coff <= x_cs, "outconv_fwd_bce: channel stride too small for float4 reads");
+  const int nb = ew_blocks((long long)N * P * 16);
+  if ((size_t)nb > partial_doubles) return hpri_set_error(HPRI_ERR_WORKSPACE, "outconv_fwd_bce: partial buffer too small");
+  hipLaunchKernelGGL(outconv_fwd_kernel<true>, dim3(nb), dim3(256), 0, stream, x, x_cs, x_coff, w, b, y, N, P, C, K, target, partial);
   HPRI_CHECK_LAUNCH();
   return HPRI_OK;
 }
@@ -499,30 +550,59 @@ extern "C" int hpri_outconv_bwd_plan(int N, long long P, int C, int K, int* nblk
 }
 
 // dx (optional), dw, db of the 1x1 output conv.  workspace: nblk*K*2*Cpart floats (hpri_outconv_bwd_plan)
-extern "C" int hpri_outconv_bwd(const float* dy, const float* x, int x_cs, int x_coff, const float* w, float* dx,
-                                int dx_cs, int dx_coff, int dx_cw, int dx_accumulate, float* dw, float* db,
-                                int accumulate_param_grads, float* workspace, size_t ws_floats, int N, long long P, int C,
-                                int K, hipStream_t stream) {
+static int outconv_bwd_impl(const float* dy, const float* target, const float* gscale, const float* x, int x_cs, int x_coff,
+                            const float* w, float* dx, int dx_cs, int dx_coff, int dx_cw, int dx_accumulate, float* dw, float* db,
+                            int accumulate_param_grads, float* workspace, size_t ws_floats, int N, long long P, int C,
+                            int K, hipStream_t stream) {
+  const bool bce = target != nullptr;
   HPRI_REQUIRE(dy && x && w && dw && workspace && N > 0 && P > 0 && C > 0 && K > 0, "outconv_bwd: bad arguments");
   HPRI_REQ_V4(x_cs, x_coff);
   if (dx != nullptr) {
     HPRI_REQ_V4(dx_cs, dx_coff);
     HPRI_REQUIRE(dx_cw % 4 == 0 && dx_cw >= C && dx_cw + dx_coff <= dx_cs, "outconv_bwd: dx channel layout");
-    hipLaunchKernelGGL(outconv_bwd_data_kernel, dim3(ew_blocks((long long)N * P * (dx_cw / 4))), dim3(256), 0, stream, dy, w,
-                       dx, dx_cs, dx_coff, N, P, C, dx_cw, K, dx_accumulate);
+    if (bce)
+      hipLaunchKernelGGL(outconv_bwd_data_kernel<true>, dim3(ew_blocks((long long)N * P * (dx_cw / 4))), dim3(256), 0, stream, dy, w,
+                         dx, dx_cs, dx_coff, N, P, C, dx_cw, K, dx_accumulate, target, gscale);
+    else
+      hipLaunchKernelGGL(outconv_bwd_data_kernel<false>, dim3(ew_blocks((long long)N * P * (dx_cw / 4))), dim3(256), 0, stream, dy, w,
+                         dx, dx_cs, dx_coff, N, P, C, dx_cw, K, dx_accumulate, (const float*)nullptr, (const float*)nullptr);
     HPRI_CHECK_LAUNCH();
   }
   int nblk, Cpart;
   hpri_outconv_bwd_plan(N, P, C, K, &nblk, &Cpart);
   if ((size_t)nblk * K * 2 * Cpart > ws_floats) return hpri_set_error(HPRI_ERR_WORKSPACE, "outconv_bwd: workspace too small");
   const int c4 = hpri_cdiv(C, 4), cq = pick_cq(c4);
-  hipLaunchKernelGGL(outconv_bwd_weight_kernel, dim3(nblk, hpri_cdiv(c4, cq), K), dim3(256), 0, stream, dy, x, x_cs, x_coff,
-                     N, P, C, K, cq, workspace, Cpart);
+  if (bce)
+    hipLaunchKernelGGL(outconv_bwd_weight_kernel<true>, dim3(nblk, hpri_cdiv(c4, cq), K), dim3(256), 0, stream, dy, x, x_cs, x_coff,
+                       N, P, C, K, cq, workspace, Cpart, target, gscale);
+  else
+    hipLaunchKernelGGL(outconv_bwd_weight_kernel<false>, dim3(nblk, hpri_cdiv(c4, cq), K), dim3(256), 0, stream, dy, x, x_cs, x_coff,
+                       N, P, C, K, cq, workspace, Cpart, (const float*)nullptr, (const float*)nullptr);
   HPRI_CHECK_LAUNCH();
   hipLaunchKernelGGL(outconv_bwd_weight_finalize_kernel, dim3(K * (C + 1)), dim3(256), 0, stream, workspace,
                      nblk, K, Cpart, C, dw, db, accumulate_param_grads);
   HPRI_CHECK_LAUNCH();
   return HPRI_OK;
+}
+
+extern "C" int hpri_outconv_bwd(const float* dy, const float* x, int x_cs, int x_coff, const float* w, float* dx,
+                                int dx_cs, int dx_coff, int dx_cw, int dx_accumulate, float* dw, float* db,
+                                int accumulate_param_grads, float* workspace, size_t ws_floats, int N, long long P, int C,
+                                int K, hipStream_t stream) {
+  return outconv_bwd_impl(dy, nullptr, nullptr, x, x_cs, x_coff, w, dx, dx_cs, dx_coff, dx_cw, dx_accumulate, dw, db,
+                          accumulate_param_grads, workspace, ws_floats, N, P, C, K, stream);
+}
+
+// Backward of the fused head + loss: the gradient of mean BCE-with-logits w.r.t. the logits, (sigmoid(logits) - target) *
+// gscale[0] / (N*K*P) (gscale: device scalar, the gradient arriving at the loss; nullptr = 1), is formed inside the two kernels
+// instead of being written out by a separate pass and read twice.
+extern "C" int hpri_outconv_bwd_bce(const float* logits, const float* target, const float* gscale, const float* x, int x_cs, int x_coff,
+                                    const float* w, float* dx, int dx_cs, int dx_coff, int dx_cw, int dx_accumulate, float* dw,
+                                    float* db, int accumulate_param_grads, float* workspace, size_t ws_floats, int N, long long P,
+                                    int C, int K, hipStream_t stream) {
+  HPRI_REQUIRE(target != nullptr, "outconv_bwd_bce: null target");
+  return outconv_bwd_impl(logits, target, gscale, x, x_cs, x_coff, w, dx, dx_cs, dx_coff, dx_cw, dx_accumulate, dw, db,
+                          accumulate_param_grads, workspace, ws_floats, N, P, C, K, stream);
 }
 
 extern "C" int hpri_synth_fill(float* dst, long long n, unsigned long long seed, int mode, float thr, float scale,

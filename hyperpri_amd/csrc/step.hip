@@ -85,6 +85,15 @@ extern "C" int hpri_bce_logits_fwd(const float* logits, const float* target, lon
   return HPRI_OK;
 }
 
+// loss = sum of `nblk` fp64 partial sums / n: the second half of hpri_bce_logits_fwd for partial sums another kernel produced
+// (hpri_outconv_fwd_bce: the loss computed inside the network's last layer)
+extern "C" int hpri_bce_finish(const double* partial, int nblk, long long n, float* loss, hipStream_t stream) {
+  HPRI_REQUIRE(partial && loss && nblk > 0 && n > 0, "bce_finish: bad arguments");
+  hipLaunchKernelGGL(bce_finalize_kernel, dim3(1), dim3(STEP_THREADS), 0, stream, partial, nblk, n, loss);
+  HPRI_CHECK_LAUNCH();
+  return HPRI_OK;
+}
+
 extern "C" int hpri_bce_logits_bwd(const float* logits, const float* target, long long n, const float* grad_out,
                                    float* dlogits, hipStream_t stream) {
   HPRI_REQUIRE(logits && target && dlogits && n > 0, "bce_logits_bwd: bad arguments");

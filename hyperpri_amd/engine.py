@@ -7,7 +7,9 @@ closure on the tape; ``model_parts.py`` / ``models.py`` compose them into the re
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes
+import threading
 import os
 from typing import Callable, Dict, List, Optional, Tuple
 
@@ -1359,24 +1361,70 @@ def concat_channels(tape: Tape, a: Act, b: Act) -> Act:
 # --------------------------------------------------------------------------------------------------
 # 1x1 output conv / final Linear
 # --------------------------------------------------------------------------------------------------
-def out_conv(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.Tensor], need_dx: bool = True):
+_PENDING = threading.local()
+
+
+class _BCESlot:
+    __slots__ = ("target", "used", "loss", "holder")
+
+    def __init__(self, target: torch.Tensor):
+        self.target, self.used, self.loss, self.holder = target, False, None, None
+
+
+@contextlib.contextmanager
+def pending_bce(target: torch.Tensor):
+    """While active, the next recorded ``out_conv`` whose logits have as many elements as ``target`` (fp32, contiguous)
+    also computes the mean BCE-with-logits against it; the slot says whether that happened (``used``) and holds the loss."""
+    prev = getattr(_PENDING, "bce", None)
+    slot = _PENDING.bce = _BCESlot(target)
+    try:
+        yield slot
+    finally:
+        _PENDING.bce = prev
+
+
+def out_conv(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.Tensor], need_dx: bool = True, fuse_loss: bool = True):
     """nn.Conv2d(C, n_classes, 1) (model_parts.py:96) / nn.Linear(2F, n_classes) (models.py:103,143).
     Returns (logits NCHW tensor, register_grad) -- the caller hands the incoming NCHW gradient to
-    ``register_grad`` before running the tape backwards."""
+    ``register_grad`` before running the tape backwards.  ``fuse_loss=False``: the caller re-orders the logits afterwards,
+    so a pending forward_loss() target does not line up with them element by element."""
     K = weight.shape[0]
     C = weight.numel() // K
     if C != x.C:
         raise RuntimeError(f"hyperpri_amd: out conv expects {C} channels, got {x.C}")
     dev = x.buf.device
     y = torch.empty((x.N, K, x.H, x.W), dtype=torch.float32, device=dev)
-    _lib.call("hpri_outconv_fwd", x.ptr, x.cs, x.coff, _p(weight), _p(bias), _p(y), x.N, x.H * x.W, C, K, _stream())
     holder: Dict[str, torch.Tensor] = {}
+    slot = getattr(_PENDING, "bce", None)
+    if fuse_loss and slot is not None and not slot.used and tape.record and slot.target.numel() == y.numel() and slot.target.device == dev:
+        # forward_loss(): the loss of PLTrainer.py:86 computed while the logits are produced (SURVEY.md 8f-2)
+        tgt = slot.target
+        nblk = _lib.load().hpri_outconv_fwd_bce_blocks(x.N, x.H * x.W)
+        part = torch.empty(nblk, dtype=torch.float64, device=dev)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        _lib.call("hpri_outconv_fwd_bce", x.ptr, x.cs, x.coff, _p(weight), _p(bias), _p(y), _p(tgt), _p(part), nblk,
+                  x.N, x.H * x.W, C, K, _stream())
+        _lib.call("hpri_bce_finish", _p(part), nblk, y.numel(), _p(loss), _stream())
+        holder["bce_y"], holder["bce_t"] = y, tgt
+        slot.used, slot.loss, slot.holder = True, loss, holder
+    else:
+        _lib.call("hpri_outconv_fwd", x.ptr, x.cs, x.coff, _p(weight), _p(bias), _p(y), x.N, x.H * x.W, C, K, _stream())
     if tape.record:
         def bwd(tp: Tape) -> None:
             gy = holder.pop("g", None)
             if gy is None:
                 return
-            gy = gy.contiguous()
+            gs = holder.pop("bce_g", None)              # the scalar gradient arriving at the fused loss (None: loss unused)
+            marker = holder.pop("bce_marker", None)
+            logits, tgt = holder.pop("bce_y", None), holder.pop("bce_t", None)
+            fused = gs is not None and marker is not None and gy.data_ptr() == marker.data_ptr() and not any(gy.stride())
+            if gs is not None and not fused:
+                # the logits had another consumer besides the fused loss: autograd has summed its gradient with the
+                # (all-zero) marker, so the loss's own share is added here by the stand-alone kernel
+                g2 = torch.empty_like(logits)
+                _lib.call("hpri_bce_logits_bwd", _p(logits), _p(tgt), logits.numel(), _p(gs), _p(g2), _stream())
+                gy = gy + g2
+            gy = logits if fused else gy.contiguous()
             dw, acc_w = tp.param_slot(weight)
             db = None
             if bias is not None:
@@ -1389,8 +1437,12 @@ def out_conv(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.Tens
                 gxp, gcs, gco, gcw = gx.ptr, gx.cs, gx.coff, gx.cw
             else:
                 gxp, gcs, gco, gcw, acc = ctypes.c_void_p(0), 0, 0, 0, False
-            _lib.call("hpri_outconv_bwd", _p(gy), x.ptr, x.cs, x.coff, _p(weight), gxp, gcs, gco, gcw, int(acc),
-                      _p(dw), _p(db), acc_w, _p(ws), ws.numel(), x.N, x.H * x.W, C, K, _stream())
+            if fused:
+                _lib.call("hpri_outconv_bwd_bce", _p(gy), _p(tgt), _p(gs), x.ptr, x.cs, x.coff, _p(weight), gxp, gcs, gco, gcw,
+                          int(acc), _p(dw), _p(db), acc_w, _p(ws), ws.numel(), x.N, x.H * x.W, C, K, _stream())
+            else:
+                _lib.call("hpri_outconv_bwd", _p(gy), x.ptr, x.cs, x.coff, _p(weight), gxp, gcs, gco, gcw, int(acc),
+                          _p(dw), _p(db), acc_w, _p(ws), ws.numel(), x.N, x.H * x.W, C, K, _stream())
         tape.note_params(weight, bias)
         tape.nodes.append(bwd)
     return y, holder

@@ -123,7 +123,7 @@ class SpectralUNET(torch.nn.Module):
             t = self._layer(tape, E.concat_channels(tape, x3, t), self.up2)
             t = self._layer(tape, E.concat_channels(tape, x2, t), self.up3)
             t = self._layer(tape, E.concat_channels(tape, x1, t), self.up4)
-            return E.out_conv(tape, E.concat_channels(tape, x0, t), self.outc.weight, self.outc.bias)
+            return E.out_conv(tape, E.concat_channels(tape, x0, t), self.outc.weight, self.outc.bias, fuse_loss=self.n_classes == 1)
         out = run(prog, [x], list(self.parameters()))
         if self.n_classes != 1:
             # models.py:144 stores each image's (R*C, n_classes) result with .reshape(n_classes, R, C): the FLAT order is

@@ -22,6 +22,7 @@ import torch
 from torch import nn
 
 from . import _lib
+from . import engine as _engine
 from .engine import _p, _require_cuda, _stream, bump_param_epoch
 
 
@@ -58,6 +59,45 @@ class _BCEFn(torch.autograd.Function):
             dx = torch.empty_like(x)
             _lib.call("hpri_bce_logits_bwd", _p(x), _p(y), x.numel(), _p(g), _p(dx), _stream())
         return dx.view(ctx.shape), None
+
+
+class _FusedLossFn(torch.autograd.Function):
+    """The autograd edge between the logits and a loss the head's kernel has already computed (engine.out_conv with a
+    pending target).  Backward hands the scalar gradient to the head's backward kernels through the tape's holder and
+    returns an all-zero stride-0 marker instead of a gradient tensor: no pass over the logits happens here."""
+
+    @staticmethod
+    def forward(ctx, logits: torch.Tensor, slot):
+        ctx.holder, ctx.shape = slot.holder, logits.shape
+        return slot.loss
+
+    @staticmethod
+    def backward(ctx, gout: torch.Tensor):
+        with torch.cuda.device(gout.device):
+            g = gout.contiguous().to(torch.float32)
+            marker = torch.zeros(1, dtype=torch.float32, device=g.device).expand(ctx.shape)
+        ctx.holder["bce_g"], ctx.holder["bce_marker"] = g, marker
+        return marker, None
+
+
+def forward_loss(network: nn.Module, image: torch.Tensor, target: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """``pred = network(image); loss = nn.BCEWithLogitsLoss()(pred, target)`` (PLTrainer.py:85-86) as one call, so that the
+    loss is computed inside the network's last layer (forward: the 1x1 head also leaves the BCE partial sums; backward:
+    the head's gradient kernels form (sigmoid(pred) - target)/n themselves).  Same values as the two-call form up to
+    fp32 summation order inside the head's weight gradient; falls back to the two-call form when the network's head does
+    not take the offer (hooks, ``fused_tape = False``, no gradient recording)."""
+    _require_cuda(image, "input tensor")
+    with torch.cuda.device(image.device):
+        tgt = _flat(target if target.dtype == torch.float32 else target.to(torch.float32), "BCEWithLogitsLoss target")
+    with _engine.pending_bce(tgt) as slot:
+        pred = network(image)
+    if isinstance(pred, tuple):                      # analyze=True networks return (pred, features)
+        pred = pred[0]
+    if slot.used and slot.holder is not None and pred.requires_grad and pred.numel() == tgt.numel():
+        return pred, _FusedLossFn.apply(pred, slot)
+    if pred.shape != target.shape:
+        raise ValueError(f"Target size ({tuple(target.shape)}) must be the same as input size ({tuple(pred.shape)})")
+    return pred, _BCEFn.apply(pred, target)
 
 
 class BCEWithLogitsLoss(nn.Module):
@@ -364,8 +404,11 @@ class SegmentationModel(nn.Module):
         return self.m_network(image)
 
     def _step(self, stage: str, batch, threshold: float) -> Tuple[torch.Tensor, torch.Tensor]:
-        pred = self._forward(batch["image"])
-        loss = self.f_criterion(pred, batch["mask"])
+        if type(self.f_criterion) is BCEWithLogitsLoss and torch.is_grad_enabled():
+            pred, loss = forward_loss(self.m_network, batch["image"], batch["mask"])      # loss inside the head's kernels
+        else:
+            pred = self._forward(batch["image"])
+            loss = self.f_criterion(pred, batch["mask"])
         c = self._counts.get(stage)
         if c is None or c.threshold != threshold:
             c = self._counts[stage] = _StepCounts(threshold, pred.device)

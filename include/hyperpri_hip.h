@@ -298,6 +298,18 @@ int hpri_outconv_bwd_plan(int N, long long P, int C, int K, int* nblk, int* Cpar
 int hpri_outconv_bwd(const float* dy, const float* x, int x_cs, int x_coff, const float* w, float* dx, int dx_cs,
                      int dx_coff, int dx_cw, int dx_accumulate, float* dw, float* db, int accumulate_param_grads,
                      float* workspace, size_t ws_floats, int N, long long P, int C, int K, hipStream_t stream);
+/* The head fused with the loss of PLTrainer.py:86: hpri_outconv_fwd_bce also leaves per-block fp64 partial sums of
+ * BCEWithLogits(logits, target) (hpri_outconv_fwd_bce_blocks doubles; finish: hpri_bce_finish -> mean loss); hpri_outconv_bwd_bce
+ * takes the LOGITS, the target and the device scalar arriving at the loss and forms (sigmoid(logits) - target) * g / n inside
+ * the data- and weight-gradient kernels.  Three launches and two passes over the logits less than loss and head apart. */
+size_t hpri_outconv_fwd_bce_blocks(int N, long long P);
+int hpri_outconv_fwd_bce(const float* x, int x_cs, int x_coff, const float* w, const float* b, float* y, const float* target,
+                         double* partial, size_t partial_doubles, int N, long long P, int C, int K, hipStream_t stream);
+int hpri_bce_finish(const double* partial, int nblk, long long n, float* loss, hipStream_t stream);
+int hpri_outconv_bwd_bce(const float* logits, const float* target, const float* gscale, const float* x, int x_cs, int x_coff,
+                         const float* w, float* dx, int dx_cs, int dx_coff, int dx_cw, int dx_accumulate, float* dw, float* db,
+                         int accumulate_param_grads, float* workspace, size_t ws_floats, int N, long long P, int C, int K,
+                         hipStream_t stream);
 /* nn.Upsample(scale_factor=2, 'bilinear', align_corners=True) (model_parts.py:57; models.py:195) writing at a pixel
  * offset of a padded destination, its gather-form gradient, and the element-wise "attention" product x2*x1
  * (model_parts.py:84-85). */

@@ -300,3 +300,76 @@ def test_packed_weight_cache_and_data_writes():
         E.bump_param_epoch()
         assert torch.equal(net(x), fresh)
         del ver
+
+
+@pytest.mark.parametrize("kind", ["unet", "cube64", "spectral"])
+def test_loss_inside_the_head_equals_loss_after_it(kind):
+    """forward_loss(): BCE-with-logits computed by the head's kernels (hpri_outconv_fwd_bce / _bwd_bce).  Same per-element
+    expressions and the same reduction order in the gradient kernels as the two-call form -> gradients bit-identical;
+    the loss differs only in how the fp64 partial sums are grouped."""
+    import hyperpri_amd as H
+    if kind == "spectral":
+        net, x = H.SpectralUNET(6, 1), _u(1237, (2, 1, 6, 36, 50))
+        shapes = OrderedDict((k, tuple(v.shape)) for k, v in net.state_dict().items())
+        net.load_state_dict(O.synth_state_dict(shapes))
+        net, x, m = net.to(DEV).train(), x.to(DEV), (_u(4321, (2, 1, 36, 50)) > 0.9).float().to(DEV)
+    else:
+        net, x, m = _net(kind)
+    crit = H.BCEWithLogitsLoss()
+    for p in net.parameters():
+        p.grad = None
+    pred_a = net(x)
+    loss_a = crit(pred_a, m)
+    loss_a.backward()
+    ga = [p.grad.clone() for p in net.parameters()]
+    for p in net.parameters():
+        p.grad = None
+    pred_b, loss_b = H.forward_loss(net, x, m)
+    assert type(loss_b.grad_fn).__name__.startswith("_FusedLossFn"), "the head did not take the loss"
+    loss_b.backward()
+    assert torch.equal(pred_a, pred_b)
+    assert abs(loss_a.item() - loss_b.item()) <= 2e-7 * abs(loss_a.item())
+    record_margin(f"fused_loss_{kind}", abs(loss_a.item() - loss_b.item()), 2e-7 * abs(loss_a.item()))
+    for (n, p), g in zip(net.named_parameters(), ga):
+        assert torch.equal(p.grad, g), n
+
+    # a second consumer of the logits and a scaled loss: the marker is summed by autograd -> stand-alone gradient path
+    for p in net.parameters():
+        p.grad = None
+    pred_c, loss_c = H.forward_loss(net, x, m)
+    (0.5 * loss_c + 1e-3 * pred_c.mean()).backward()
+    gc = [p.grad.clone() for p in net.parameters()]
+    for p in net.parameters():
+        p.grad = None
+    pred_d = net(x)
+    (0.5 * crit(pred_d, m) + 1e-3 * pred_d.mean()).backward()
+    for (n, p), g in zip(net.named_parameters(), gc):
+        ref = p.grad
+        assert torch.allclose(g, ref, rtol=1e-4, atol=1e-6 * float(ref.abs().max()) + 1e-12), n
+
+    # scaled loss alone stays on the fused path (the scalar reaches the kernels as a device pointer)
+    for p in net.parameters():
+        p.grad = None
+    _, loss_e = H.forward_loss(net, x, m)
+    (3.0 * loss_e).backward()
+    ge = [p.grad.clone() for p in net.parameters()]
+    for p in net.parameters():
+        p.grad = None
+    (3.0 * crit(net(x), m)).backward()
+    for (n, p), g in zip(net.named_parameters(), ge):
+        assert torch.equal(p.grad, g), n
+
+    # no gradient recording: the two-call form
+    with torch.no_grad():
+        pred_f, loss_f = H.forward_loss(net, x, m)
+    assert loss_f.grad_fn is None and abs(loss_f.item() - crit(pred_f, m).item()) < 1e-7
+
+
+def test_training_step_uses_the_fused_loss():
+    import hyperpri_amd as H
+    net, x, m = _net("unet")
+    model = H.SegmentationModel(net, optimizer="Adam", lr=1e-3)
+    loss = model.training_step({"image": x, "mask": m})
+    assert type(loss.grad_fn).__name__.startswith("_FusedLossFn")
+    loss.backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())
