@@ -70,6 +70,25 @@ int hpri_cu_count() {
   return n;
 }
 
+// A stream of the LOWEST priority the device offers, for work that should only fill what the caller's stream leaves free
+// (the engine's weight-gradient stream: its 256-workgroup launches otherwise hold every CU while the 2-64-workgroup finalize
+// kernels on the critical path wait for a slot).  *stream receives a hipStream_t the caller owns (hpri_stream_destroy).
+extern "C" int hpri_stream_create_low_priority(void** stream, int* priority) {
+  HPRI_REQUIRE(stream != nullptr, "stream_create_low_priority: null pointer");
+  int least = 0, greatest = 0;
+  if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return hpri_set_error(HPRI_ERR_LAUNCH, "stream priority range query failed");
+  hipStream_t s = nullptr;
+  if (hipStreamCreateWithPriority(&s, hipStreamNonBlocking, least) != hipSuccess) return hpri_set_error(HPRI_ERR_LAUNCH, "stream creation failed");
+  *stream = reinterpret_cast<void*>(s);
+  if (priority != nullptr) *priority = least;
+  return HPRI_OK;
+}
+extern "C" int hpri_stream_destroy(void* stream) {
+  if (stream != nullptr && hipStreamDestroy(reinterpret_cast<hipStream_t>(stream)) != hipSuccess)
+    return hpri_set_error(HPRI_ERR_LAUNCH, "stream destruction failed");
+  return HPRI_OK;
+}
+
 extern "C" int hpri_get_option(const char* name) {
   for (int i = 0; i < 4; ++i)
     if (name && strcmp(name, g_opt_name[i]) == 0) return hpri_option(i);

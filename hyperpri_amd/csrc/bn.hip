@@ -353,6 +353,38 @@ __global__ void col_finalize_kernel(const float* __restrict__ part, int nblk, in
   }
 }
 
+// Many partial rows (one per tile of a convolution launch that took the reduction in its epilogue: 4.6 k rows for a full-size
+// layer) are first folded to `S` rows by S x C/32 workgroups -- col_finalize_kernel alone walks them with C/32 workgroups.
+// folded[s][k][c] = sum over the rows of slice s (double accumulation, fixed order); grid (ceil(C/32), S), 1024 threads
+__global__ void col_fold_kernel(const float* __restrict__ part, int nblk, int Cpart, int C, float* __restrict__ folded) {
+  __shared__ double s[2][32][32];
+  const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  const int per = (nblk + gridDim.y - 1) / gridDim.y;
+  const int b0 = blockIdx.y * per, b1 = min(b0 + per, nblk);
+  double a1 = 0.0, a2 = 0.0;
+  if (c < C) {
+    const float* p = part + c;
+    int b = b0 + sl;
+    for (; b + 96 < b1; b += 128) {
+      float u1[4], u2[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { u1[u] = p[(size_t)(b + 32 * u) * 2 * Cpart]; u2[u] = p[(size_t)(b + 32 * u) * 2 * Cpart + Cpart]; }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { a1 += u1[u]; a2 += u2[u]; }
+    }
+    for (; b < b1; b += 32) { a1 += p[(size_t)b * 2 * Cpart]; a2 += p[(size_t)b * 2 * Cpart + Cpart]; }
+  }
+  s[0][sl][cl] = a1; s[1][sl][cl] = a2;
+  __syncthreads();
+  if (sl == 0 && c < C) {
+    double t1 = 0.0, t2 = 0.0;
+    for (int k = 0; k < 32; ++k) { t1 += s[0][k][cl]; t2 += s[1][k][cl]; }
+    folded[((size_t)blockIdx.y * 2) * Cpart + c] = (float)t1;
+    folded[((size_t)blockIdx.y * 2 + 1) * Cpart + c] = (float)t2;
+  }
+}
+
 // dgamma[c] (+)= sum_g s2[g][c], dbeta[c] (+)= sum_g s1[g][c]
 __global__ void bn_param_grad_kernel(const float* __restrict__ sums, int G, int C, float* __restrict__ dgamma,
                                      float* __restrict__ dbeta, int accumulate) {
@@ -613,6 +645,14 @@ static int bn_relu_bwd_impl(const float* ext_part, int ext_nblk, int ext_cpart,
   if (ext_part != nullptr) {
     HPRI_REQUIRE(G == 1 && ext_nblk > 0 && ext_cpart >= C, "bn_relu_bwd_fused: partial sums need one group and cover the channels");
     fin_part = ext_part; fin_nblk = ext_nblk; fin_cpart = ext_cpart;
+    // (the workspace's own partial rows are unused on this path: they hold the folded rows)
+    long long S = ((long long)nblk * 2 * Cpart) / (2ll * ext_cpart);
+    if (S > 64) S = 64;
+    if (S >= 4 && ext_nblk >= 16 * S) {
+      hipLaunchKernelGGL(col_fold_kernel, dim3(hpri_cdiv(C, 32), (unsigned)S), dim3(1024), 0, stream, ext_part, ext_nblk, ext_cpart, C, part);
+      HPRI_CHECK_LAUNCH();
+      fin_part = part; fin_nblk = (int)S;
+    }
   } else {
     if (x16)
       hipLaunchKernelGGL((col_reduce_kernel<0, true>), dim3(nblk, ycols, G), dim3(256), 0, stream, dy, dy_cs, dy_coff, x,
@@ -692,6 +732,22 @@ extern "C" int hpri_bn_relu_bwd_fused(const float* partials, int part_blocks, in
   return bn_relu_bwd_impl(partials, part_blocks, part_cpart, dy, dy_cs, dy_coff, x, false, x_cs, x_coff, dx, dx_cs, dx_coff, mean, invstd,
                           scale, shift, dgamma, dbeta, accumulate_param_grads, dbias, accumulate_dbias, workspace, ws_floats, P,
                           pix_per_group, C, Cw, relu, use_batch_stats, planes, plane_stride, pl_cs, pl_coff, pl_cw, npl, stream);
+}
+
+// hpri_bn_relu_bwd_fused with the pre-BN tensor stored as bf16 (partial sums from hpri_conv_bf16v3_bnred)
+extern "C" int hpri_bn_relu_bwd_fused_x16(const float* partials, int part_blocks, int part_cpart, const float* dy, int dy_cs, int dy_coff,
+                                          const void* x16, int x_cs, int x_coff, float* dx, int dx_cs, int dx_coff, const float* mean,
+                                          const float* invstd, const float* scale, const float* shift, float* dgamma, float* dbeta,
+                                          int accumulate_param_grads, float* dbias, int accumulate_dbias, float* workspace,
+                                          size_t ws_floats, long long P, long long pix_per_group, int C, int Cw, int relu,
+                                          int use_batch_stats, void* planes, long long plane_stride, int pl_cs, int pl_coff,
+                                          int pl_cw, int npl, hipStream_t stream) {
+  HPRI_REQUIRE(partials != nullptr, "bn_relu_bwd_fused_x16: null partial sums");
+  HPRI_REQUIRE(((uintptr_t)x16 & 7) == 0, "bn_relu_bwd_fused_x16: the bf16 tensor must be 8-byte aligned");
+  return bn_relu_bwd_impl(partials, part_blocks, part_cpart, dy, dy_cs, dy_coff, reinterpret_cast<const float*>(x16), true, x_cs, x_coff, dx,
+                          dx_cs, dx_coff, mean, invstd, scale, shift, dgamma, dbeta, accumulate_param_grads, dbias, accumulate_dbias,
+                          workspace, ws_floats, P, pix_per_group, C, Cw, relu, use_batch_stats, planes, plane_stride, pl_cs, pl_coff,
+                          pl_cw, npl, stream);
 }
 
 // the same with the pre-BN tensor stored as bf16 (see hpri_bn_apply_relu_x16)

@@ -46,6 +46,13 @@ struct ConvV3Args {
   int nseg, tiles_img, ntiles, nb_count, per_xcd, nb_major;
   int seg_twl[V3_MAXSEG], seg_xbeg[V3_MAXSEG], seg_ntx[V3_MAXSEG], seg_first[V3_MAXSEG];
   int ncu, stagger_cycles;                   // compute units of the device; one-off delay of each CU's second occupant
+  // conv_bf16v3_kernel<true> (a data-gradient launch that writes the ONLY contribution to dL/dx, x = ReLU(BN(bn_x))): the epilogue
+  // also reads the pre-BN tensor bn_x (bf16, elements per pixel bn_x_cs, first channel bn_x_coff, bn_cw readable channels) at its
+  // output positions and leaves per-tile partial sums of that BatchNorm's backward, bn_part[stat tile][2][bn_cpart] =
+  // (sum g*[y>0], sum g*[y>0]*xhat): the stage that produced x then skips its two reduction sweeps (hpri_bn_relu_bwd_fused)
+  const __bf16* bn_x; int bn_x_cs, bn_x_coff, bn_cw, bn_relu, bn_cpart;
+  const float *bn_mean, *bn_invstd, *bn_scale, *bn_shift;
+  float* bn_part;
 #ifdef HPRI_STAMPS
   unsigned long long* stamps;                // diagnostic builds only: [workgroup][16] stamps of wave 0 (tools/v3_stamps.py)
 #endif
@@ -80,6 +87,7 @@ __device__ __forceinline__ float v3_row_sum(float v) {
 // Geometry of one work item (256-pixel tile x 64-channel block); wave-uniform.
 struct V3Tile { int img, y0, x0, xlim, twl, nb, bx; };
 
+template <bool BNRED>
 __global__ __launch_bounds__(256, 2) void conv_bf16v3_kernel(ConvV3Args a) {
   __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * V3_A_BYTES + 2 * V3_B_BYTES + 512];
   unsigned char* a_lds = smem;
@@ -401,6 +409,25 @@ __global__ __launch_bounds__(256, 2) void conv_bf16v3_kernel(ConvV3Args a) {
     // inside the written width" (everywhere except the last block of a narrow tensor): the common path has no per-store
     // condition at all.
     const bool full = cur.nb * 64 + 64 <= dcw;
+    // BatchNorm-backward partial sums (see ConvV3Args): the pre-BN values at this lane's 4 pixels x 16 channels and the block's 64
+    // parameter quadruples are requested BEFORE the stores (vmcnt counts in order: a load behind a store waits for the store)
+    bf16x4_t xq[4][4];
+    f32x4 prm4 = {0.f, 0.f, 0.f, 0.f};
+    if (BNRED) {
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        const int p = (wave * 4 + mt) * 16 + li;
+        const int iy = min(cur.y0 + (p >> twl), a.H - 1), ix = min(cur.x0 + (p & (TW - 1)), a.W - 1);
+        const __bf16* xr = a.bn_x + ((size_t)(cur.img * a.H + iy) * a.W + ix) * a.bn_x_cs + a.bn_x_coff;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)      // channels beyond the readable width: any in-bounds quad (their g is an exact zero)
+          xq[mt][nt] = *reinterpret_cast<const bf16x4_t*>(xr + min(nlane + nt * 16, a.bn_cw - 4));
+      }
+      if (tid < 64) {
+        const int n = min(cur.nb * 64 + tid, a.Cout - 1);
+        prm4 = f32x4{a.bn_scale[n], a.bn_shift[n], a.bn_mean[n], a.bn_invstd[n]};
+      }
+    }
 #define V3_STORE_LOOP(ACC_, COND_)                                                                                    \
   if (ACC_) {               /* all loads first: a wait for a load behind a store would wait for the store as well */  \
     f32x4 old_[4][4];                                                                                                 \
@@ -417,7 +444,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16v3_kernel(ConvV3Args a) {
           if (COND_) *reinterpret_cast<f32x4*>(prow[mt] + nt * 16) = acc[mt][nt];                                     \
     }                                                                                                                 \
   }
-    if (!raw && a.y16) {
+    if (!BNRED && !raw && a.y16) {
       // bf16 output: a lane's four channels are one 8-byte store (round-to-nearest-even, v_cvt_pk_bf16_f32)
       __bf16* d16 = reinterpret_cast<__bf16*>(a.y);
 #pragma unroll
@@ -434,7 +461,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16v3_kernel(ConvV3Args a) {
             }
         }
       }
-    } else if (!raw && a.accumulate) {
+    } else if (!BNRED && !raw && a.accumulate) {
       if (full) { V3_STORE_LOOP(true, true) } else { V3_STORE_LOOP(true, nlane + nt * 16 < dcw) }
     } else {
       if (full) { V3_STORE_LOOP(false, true) } else { V3_STORE_LOOP(false, nlane + nt * 16 < dcw) }
@@ -443,7 +470,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16v3_kernel(ConvV3Args a) {
 #ifdef HPRI_STAMPS
     if (ntiles_done == 0) { V3_STAMP(2) }
 #endif
-    if (!raw && a.stats != nullptr) {
+    if (!BNRED && !raw && a.stats != nullptr) {
       // per-tile, per-channel (mean, M2, count): each wave makes an exact two-pass record of its own 64 pixels (sum, then
       // squared deviations from its own mean); the four wave records of a channel are merged with Chan's update after one
       // barrier.  (raw barriers: __syncthreads() would also wait for the output stores above.)
@@ -492,6 +519,45 @@ __global__ __launch_bounds__(256, 2) void conv_bf16v3_kernel(ConvV3Args a) {
         a.stats[(size_t)cur.bx * a.Cout_pad + cur.nb * 64 + tid] = make_float4(mean, m2, n, 0.f);
       }
       // (the scratch is rewritten only after the next item's main loop, i.e. behind many barriers)
+    }
+    if (BNRED) {
+      // scratch in halo buffer 1 behind the statistics': [64] parameter quads, then [4 waves][2 sums][64 channels]
+      float* prm = reinterpret_cast<float*>(smem + V3_A_BYTES + 4096);
+      float* red2 = prm + 256;
+      if (tid < 64) *reinterpret_cast<f32x4*>(prm + tid * 4) = prm4;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      V3_BARRIER();
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        f32x4 t1 = {0.f, 0.f, 0.f, 0.f}, t2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const f32x4 q = *reinterpret_cast<const f32x4*>(prm + (nt * 16 + 4 * lq + r) * 4);     // scale, shift, mean, invstd
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) {
+            const float xf = (float)xq[mt][nt][r];
+            const bool keep = ((vmask >> mt) & 1u) && (!a.bn_relu || (xf * q[0] + q[1] > 0.f));
+            const float gj = keep ? acc[mt][nt][r] : 0.f;
+            t1[r] += gj;
+            t2[r] += gj * ((xf - q[2]) * q[3]);
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { t1[r] = v3_row_sum(t1[r]); t2[r] = v3_row_sum(t2[r]); }
+        if (li == 0) {
+          *reinterpret_cast<f32x4*>(red2 + (wave * 2 + 0) * 64 + nt * 16 + 4 * lq) = t1;
+          *reinterpret_cast<f32x4*>(red2 + (wave * 2 + 1) * 64 + nt * 16 + 4 * lq) = t2;
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      V3_BARRIER();
+      if (tid < 128) {                           // (sum, channel) = (tid >> 6, tid & 63): the four wave records in a fixed order
+        const int which = tid >> 6, c = tid & 63;
+        float tsum = 0.f;
+#pragma unroll
+        for (int w2 = 0; w2 < 4; ++w2) tsum += red2[(w2 * 2 + which) * 64 + c];
+        if (cur.nb * 64 + c < a.bn_cpart) a.bn_part[((size_t)cur.bx * 2 + which) * a.bn_cpart + cur.nb * 64 + c] = tsum;
+      }
     }
 #ifdef HPRI_STAMPS
     if (ntiles_done == 0) { V3_STAMP(3) }
@@ -605,10 +671,14 @@ extern "C" int hpri_splitk_finish(const float* ws, int ksplit, int Cout_pad, con
 
 #define V3_STAGGER_CYCLES 6000      // about one store + statistics epilogue with a partner on the CU
 
-extern "C" int hpri_conv_bf16v3_dbg(const void* xp, long long x_plane, int x_cs, int x_coff, const void* wp, const float* bias,
-                                    float* y, int y_cs, int y_coff, float* stats, int N, int H, int W, int Cin_pad, int Cout,
-                                    int Cout_pad, int y_cw, int accumulate, int split, float* ws, size_t ws_floats,
-                                    unsigned long long* stamps, int stagger_cycles, hipStream_t stream) {
+struct V3BnRed {
+  const void* x16; int x_cs, x_coff; const float *mean, *invstd, *scale, *shift; int relu; float* part; int cpart;
+};
+
+static int v3_launch(const void* xp, long long x_plane, int x_cs, int x_coff, const void* wp, const float* bias,
+                     float* y, int y_cs, int y_coff, float* stats, int N, int H, int W, int Cin_pad, int Cout,
+                     int Cout_pad, int y_cw, int accumulate, int split, float* ws, size_t ws_floats,
+                     unsigned long long* stamps, int stagger_cycles, const V3BnRed* bn, hipStream_t stream) {
   HPRI_REQUIRE(xp && wp && y, "conv_bf16v3: null pointer");
   HPRI_REQUIRE(N > 0 && H > 0 && W > 0, "conv_bf16v3: empty image");
   HPRI_REQUIRE(Cin_pad > 0 && Cin_pad % 32 == 0, "conv_bf16v3: Cin_pad must be a positive multiple of 32");
@@ -655,10 +725,47 @@ extern "C" int hpri_conv_bf16v3_dbg(const void* xp, long long x_plane, int x_cs,
   if (nloc < 1) nloc = 1;
   if (nloc > a.per_xcd) nloc = a.per_xcd;
   dim3 grid((unsigned)(nloc * 8), 1u, (unsigned)a.ksplit);
-  hipLaunchKernelGGL(conv_bf16v3_kernel, grid, dim3(256), 0, stream, a);
+  a.bn_part = nullptr;
+  if (bn != nullptr) {
+    HPRI_REQUIRE(bn->x16 && bn->mean && bn->invstd && bn->scale && bn->shift && bn->part, "conv_bf16v3_bnred: null pointer");
+    HPRI_REQUIRE(a.ksplit == 1 && !a.accumulate && !a.y16 && stats == nullptr,
+                 "conv_bf16v3_bnred: not for split-K problems (hpri_conv_bf16v3_plan), accumulating launches, bf16 outputs or launches that record statistics");
+    HPRI_REQUIRE(bn->x_cs % 4 == 0 && bn->x_coff % 4 == 0 && ((uintptr_t)bn->x16 & 7) == 0 && bn->x_cs - bn->x_coff >= 4,
+                 "conv_bf16v3_bnred: the pre-BN view must be 8-byte aligned (stride and offset multiples of 4)");
+    HPRI_REQUIRE(bn->x_cs - bn->x_coff >= ((Cout + 3) & ~3) && bn->cpart >= Cout, "conv_bf16v3_bnred: pre-BN view / partial rows narrower than the channels");
+    a.bn_x = reinterpret_cast<const __bf16*>(bn->x16); a.bn_x_cs = bn->x_cs; a.bn_x_coff = bn->x_coff;
+    a.bn_cw = (bn->x_cs - bn->x_coff) & ~3;
+    a.bn_mean = bn->mean; a.bn_invstd = bn->invstd; a.bn_scale = bn->scale; a.bn_shift = bn->shift;
+    a.bn_relu = bn->relu; a.bn_part = bn->part; a.bn_cpart = bn->cpart;
+    hipLaunchKernelGGL(conv_bf16v3_kernel<true>, grid, dim3(256), 0, stream, a);
+  } else {
+    hipLaunchKernelGGL(conv_bf16v3_kernel<false>, grid, dim3(256), 0, stream, a);
+  }
   HPRI_CHECK_LAUNCH();
   if (a.ksplit == 1) return HPRI_OK;
   return hpri_splitk_finish(ws, a.ksplit, Cout_pad, bias, y, y_cs, y_coff, stats, N, H * W, Cout, a.y_cw, accumulate & 1, a.relu, stream);
+}
+
+extern "C" int hpri_conv_bf16v3_dbg(const void* xp, long long x_plane, int x_cs, int x_coff, const void* wp, const float* bias,
+                                    float* y, int y_cs, int y_coff, float* stats, int N, int H, int W, int Cin_pad, int Cout,
+                                    int Cout_pad, int y_cw, int accumulate, int split, float* ws, size_t ws_floats,
+                                    unsigned long long* stamps, int stagger_cycles, hipStream_t stream) {
+  return v3_launch(xp, x_plane, x_cs, x_coff, wp, bias, y, y_cs, y_coff, stats, N, H, W, Cin_pad, Cout, Cout_pad, y_cw, accumulate,
+                   split, ws, ws_floats, stamps, stagger_cycles, nullptr, stream);
+}
+
+// The data gradient of a 3x3 layer whose input x = ReLU(BN(bn_x16)) has no other consumer, with that BatchNorm's backward
+// reduction taken in the epilogue (the bf16-mode counterpart of hpri_conv_wino4_bnred): bn_x16 = the pre-BN tensor as bf16 (same
+// pixels as y; bn_x_cs / bn_x_coff in elements), its per-channel mean / invstd / scale / shift, bn_relu; bn_part[stat tiles][2][bn_cpart]
+// (stat tiles: hpri_conv_bf16v3_plan, which must report ksplit 1) receives sum g*[y>0] and sum g*[y>0]*xhat per tile.  Finish with
+// hpri_bn_relu_bwd_fused.
+extern "C" int hpri_conv_bf16v3_bnred(const void* xp, int x_cs, int x_coff, const void* wp, float* y, int y_cs, int y_coff, int N, int H,
+                                      int W, int Cin_pad, int Cout, int Cout_pad, int y_cw, const void* bn_x16, int bn_x_cs,
+                                      int bn_x_coff, const float* bn_mean, const float* bn_invstd, const float* bn_scale,
+                                      const float* bn_shift, int bn_relu, float* bn_part, int bn_cpart, hipStream_t stream) {
+  const V3BnRed bn{bn_x16, bn_x_cs, bn_x_coff, bn_mean, bn_invstd, bn_scale, bn_shift, bn_relu, bn_part, bn_cpart};
+  return v3_launch(xp, 0, x_cs, x_coff, wp, nullptr, y, y_cs, y_coff, nullptr, N, H, W, Cin_pad, Cout, Cout_pad, y_cw, 0, 0, nullptr, 0,
+                   nullptr, V3_STAGGER_CYCLES, &bn, stream);
 }
 
 // 3x3 pad-1 convolution (forward, or data gradient with the flipped pack) over bf16 activation planes: same argument

@@ -498,9 +498,20 @@ def _side(device) -> "torch.cuda.Stream":
     idx = device.index if device.index is not None else torch.cuda.current_device()
     st = _side_streams.get(idx)
     if st is None:
-        st = _side_streams[idx] = torch.cuda.Stream(device=device)
+        if SIDE_LOW_PRIORITY:
+            with torch.cuda.device(idx):
+                h = ctypes.c_void_p(); pr = ctypes.c_int()
+                _lib.call("hpri_stream_create_low_priority", ctypes.byref(h), ctypes.byref(pr))
+            st = torch.cuda.ExternalStream(h.value, device=torch.device("cuda", idx))
+        else:
+            st = torch.cuda.Stream(device=device)
+        _side_streams[idx] = st
     return st
 
+
+# HPRI_SIDE_LOW_PRIORITY=1: the weight-gradient stream is created at the device's lowest stream priority (see
+# hpri_stream_create_low_priority).
+SIDE_LOW_PRIORITY = os.environ.get("HPRI_SIDE_LOW_PRIORITY", "0") == "1"
 
 _issue_streams: Dict[int, "torch.cuda.Stream"] = {}
 
@@ -851,7 +862,7 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
                   *(_pl_args(ypl) if cpl is None else (_p(cpl.buf), cpl.plane, cpl.cs, 0, y.C, 1)), _stream())
     if not tape.record:
         return y
-    if bn is not None and next_cout > 0 and groups == 1 and not yr16 and room == 0:
+    if bn is not None and next_cout > 0 and groups == 1 and room == 0:
         y.bn_src = (yr, st, relu)          # one consumer (the caller says so): its data-gradient kernel may do this stage's reduction
 
     def bwd(tp: Tape) -> None:
@@ -875,7 +886,7 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
                         and (need_dx or weight.requires_grad))
             dyr.f32_valid = not f32_dead
             bp = tp.bnpart.pop(id(y), None)
-            _lib.call(*(("hpri_bn_relu_bwd_fused", _p(bp[0]), bp[1], bp[2]) if bp is not None else
+            _lib.call(*(("hpri_bn_relu_bwd_fused_x16" if yr16 else "hpri_bn_relu_bwd_fused", _p(bp[0]), bp[1], bp[2]) if bp is not None else
                         ("hpri_bn_relu_bwd_x16" if yr16 else "hpri_bn_relu_bwd_pl",)), g.ptr, g.cs, g.coff, yr.ptr, yr.cs, yr.coff,
                       ctypes.c_void_p(0) if f32_dead else dyr.ptr, dyr.cs, dyr.coff,
                       _p(mean), _p(invstd), _p(scale), _p(shift), _p(dgam), _p(dbet), acc_g, _p(db), acc_b,
@@ -921,7 +932,27 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
                 gtiles = tl.value
                 gstats = torch.empty(gtiles * _rup(cin, 64) * 4, dtype=torch.float32, device=dev)
             src = x.bn_src
-            if (wino_d and WINO4 and FUSE_BN_REDUCE and src is not None and not acc and gstats is None
+            v3_red = False
+            if v2 and BF16_V3 and FUSE_BN_REDUCE_BF16 and src is not None and src[0].b16 and not acc and gstats is None:
+                ksp = ctypes.c_int(); tl = ctypes.c_int(); wsf_ = ctypes.c_size_t()
+                _lib.call("hpri_conv_bf16v3_plan", x.N, x.H, x.W, _rup(cout, 32), _rup(cin, 64), ctypes.byref(ksp), ctypes.byref(tl),
+                          ctypes.byref(wsf_))
+                v3_red = ksp.value == 1
+            if v3_red:
+                # bf16 plane mode, same idea as the fp32 branch below: this launch writes the only contribution to dL/dx and
+                # x = ReLU(BN(src[0])), so its epilogue leaves the per-tile partial sums of that BatchNorm's backward
+                wpd, cin_cols_pad = _pack_bf16(weight, 1, cout, cin, T, cin, split=0)
+                xr, xst, xrelu = src
+                part = torch.empty(tl.value * 2 * cin_cols_pad, dtype=torch.float32, device=dev)
+                xm, xi, _xv, xsc, xsh = (xst[i * cin:(i + 1) * cin] for i in range(5))
+                pl = planes_of(dyr, 1)
+                tag = "conv_planes_bf16<3,v3 256x64>" + (f" N{x.N} {x.H}x{x.W} K{_rup(cout, 32)} N{cin}" if SHAPE_TAGS else "")
+                with _timed(tag, 2.0 * x.N * x.H * x.W * cout * cin * 9):
+                    _lib.call("hpri_conv_bf16v3_bnred", _p(pl.buf), pl.cs, pl.coff, _p(wpd), gx.ptr, gx.cs, gx.coff, x.N, x.H, x.W,
+                              _rup(cout, 32), cin, cin_cols_pad, gx.cw, xr.ptr, xr.cs, xr.coff, _p(xm), _p(xi), _p(xsc), _p(xsh),
+                              int(xrelu), _p(part), cin_cols_pad, _stream())
+                tp.bnpart[id(x)] = (part, tl.value, cin_cols_pad)
+            elif (wino_d and WINO4 and FUSE_BN_REDUCE and src is not None and not src[0].b16 and not acc and gstats is None
                     and src[0].cs - src[0].coff >= _rup(cin, 64)):
                 # this launch writes the ONLY contribution to dL/dx, and x = ReLU(BN(src[0])): its epilogue also leaves the
                 # per-tile partial sums of that BatchNorm's backward (the stage that produced x then skips its reduction sweeps)
@@ -965,6 +996,8 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
 # (hpri_conv_wino4_bnred + hpri_bn_relu_bwd_fused) instead of two sweeps over the gradient and the pre-BN tensor.
 # HPRI_FUSE_BN_REDUCE: 1 (default) / 0.
 FUSE_BN_REDUCE = os.environ.get("HPRI_FUSE_BN_REDUCE", "1") != "0"
+# The same in the bf16 plane mode (hpri_conv_bf16v3_bnred + hpri_bn_relu_bwd_fused_x16).  HPRI_FUSE_BN_REDUCE_BF16: 0 (default) / 1.
+FUSE_BN_REDUCE_BF16 = os.environ.get("HPRI_FUSE_BN_REDUCE_BF16", "0") == "1"
 # the ConvTranspose2d bias gradient from the epilogue records of the data-gradient kernel that wrote the concat's gradient
 # (hpri_colsum_from_stats) instead of a pass over that tensor (hpri_col_sum).  HPRI_COLSUM_FROM_STATS: 1 (default) / 0.
 COLSUM_FROM_STATS = os.environ.get("HPRI_COLSUM_FROM_STATS", "1") != "0"

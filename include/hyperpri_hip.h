@@ -46,6 +46,9 @@ int hpri_version(void);
  * from which the conv / weight-gradient kernels switch to their XCD-aware 1-D grids.  Results do not depend
  * on them, only block order and (for weight gradients) the number of partial slabs, i.e. the summation order. */
 int hpri_set_option(const char* name, int value);
+/* A non-blocking stream of the lowest priority the current device offers (*priority receives it); the caller owns it. */
+int hpri_stream_create_low_priority(void** stream, int* priority);
+int hpri_stream_destroy(void* stream);
 int hpri_get_option(const char* name);
 const char* hpri_last_error(void);
 
@@ -190,6 +193,16 @@ int hpri_conv_bf16v3_dbg(const void* xp, long long x_plane, int x_cs, int x_coff
                          int accumulate, int split, float* ws, size_t ws_floats, unsigned long long* stamps,
                          int stagger_cycles, hipStream_t stream);
 
+/* The data gradient of a 3x3 layer in the bf16 plane mode whose input x = ReLU(BN(bn_x16)) has no other consumer, with that
+ * BatchNorm's backward reduction taken in the epilogue (bf16 counterpart of hpri_conv_wino4_bnred): bn_x16 = the pre-BN tensor as
+ * bf16 (what hpri_conv_bf16v3 wrote with accumulate bit 2; same pixels as y, stride / offset in elements, multiples of 4);
+ * bn_part[stat_tiles][2][bn_cpart] (stat_tiles from hpri_conv_bf16v3_plan, which must report ksplit 1; bn_cpart >= Cout) receives
+ * sum g*[y>0] and sum g*[y>0]*xhat per tile.  Finish with hpri_bn_relu_bwd_fused. */
+int hpri_conv_bf16v3_bnred(const void* xp, int x_cs, int x_coff, const void* wp, float* y, int y_cs, int y_coff, int N, int H,
+                           int W, int Cin_pad, int Cout, int Cout_pad, int y_cw, const void* bn_x16, int bn_x_cs, int bn_x_coff,
+                           const float* bn_mean, const float* bn_invstd, const float* bn_scale, const float* bn_shift,
+                           int bn_relu, float* bn_part, int bn_cpart, hipStream_t stream);
+
 /* ---- weight gradients, fp32 MFMA, deterministic split-K (conv_wgrad.hip) --------------------------
  * Replaces the wgrad half of autograd for the same layers.  dst_mode 0 writes OIHW / (out,in),
  * dst_mode 1 writes ConvTranspose2d's (Cin,Cout,2,2).  Workspace: splits*KS*KS*Cr*Nr floats. */
@@ -262,6 +275,12 @@ int hpri_bn_relu_bwd_pl(const float* dy, int dy_cs, int dy_coff, const float* x,
 int hpri_bn_apply_relu_x16(const void* x16, int x_cs, int x_coff, float* y, int y_cs, int y_coff, const float* scale,
                            const float* shift, long long P, long long pix_per_group, int C, int Cw, int relu, void* planes,
                            long long plane_stride, int pl_cs, int pl_coff, int pl_cw, int npl, hipStream_t stream);
+int hpri_bn_relu_bwd_fused_x16(const float* partials, int part_blocks, int part_cpart, const float* dy, int dy_cs, int dy_coff,
+                               const void* x16, int x_cs, int x_coff, float* dx, int dx_cs, int dx_coff, const float* mean,
+                               const float* invstd, const float* scale, const float* shift, float* dgamma, float* dbeta,
+                               int accumulate_param_grads, float* dbias, int accumulate_dbias, float* workspace, size_t ws_floats,
+                               long long P, long long pix_per_group, int C, int Cw, int relu, int use_batch_stats, void* planes,
+                               long long plane_stride, int pl_cs, int pl_coff, int pl_cw, int npl, hipStream_t stream);
 int hpri_bn_relu_bwd_x16(const float* dy, int dy_cs, int dy_coff, const void* x16, int x_cs, int x_coff, float* dx,
                          int dx_cs, int dx_coff, const float* mean, const float* invstd, const float* scale,
                          const float* shift, float* dgamma, float* dbeta, int accumulate_param_grads, float* dbias,

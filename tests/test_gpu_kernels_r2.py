@@ -269,6 +269,85 @@ def test_bf16_plane_conv_v3_data_gradient_views_and_epilogues(lib, shape):
                                     P(None), 0, _st()) != 0
 
 
+@pytest.mark.parametrize("shape", [(2, 36, 50, 64, 6), (1, 19, 40, 128, 72), (2, 76, 121, 64, 64), (1, 152, 242, 32, 128)])
+@pytest.mark.parametrize("relu", [1, 0])
+def test_bf16_plane_conv_v3_bn_backward_partials_in_the_epilogue(lib, shape, relu):
+    """hpri_conv_bf16v3_bnred: the data gradient g of a 3x3 layer plus, per 256-pixel tile, sum g*[BN(x) > 0] and
+    sum g*[BN(x) > 0]*xhat of the BatchNorm(+ReLU) stage whose bf16 pre-BN tensor x sits at g's positions; then
+    hpri_bn_relu_bwd_fused_x16 on those partial rows against hpri_bn_relu_bwd_x16 doing its own two sweeps (the last shape
+    has enough tiles for the folding launch in front of the finalize)."""
+    N, H, W, K, Cols = shape
+    torch.manual_seed(11)
+    cs16, cols_pad, cw = rup(K, 32), rup(Cols, 64), rup(Cols, 8)
+    npx = N * H * W
+    dy = torch.randn(npx, K, device=DEV)
+    planes = torch.zeros(npx, cs16, dtype=torch.bfloat16, device=DEV)
+    planes[:, :K] = dy.to(torch.bfloat16)
+    w = torch.randn(K, Cols, 3, 3, device=DEV) * 0.05
+    wpd = torch.empty(((K + 31) // 32) * 9 * cols_pad * 32, dtype=torch.bfloat16, device=DEV)
+    assert lib.hpri_pack_weight_bf16(P(w), P(wpd), 1, K, Cols, cols_pad, 9, Cols, 0, 0, _st()) == 0
+    k, tl, wsf = ctypes.c_int(), ctypes.c_int(), ctypes.c_size_t()
+    lib.hpri_conv_bf16v3_plan(N, H, W, cs16, cols_pad, ctypes.byref(k), ctypes.byref(tl), ctypes.byref(wsf))
+    assert k.value == 1
+    xcs = rup(Cols, 8)
+    x16 = torch.zeros(npx, xcs, dtype=torch.bfloat16, device=DEV)
+    x16[:, :Cols] = (torch.randn(npx, Cols, device=DEV) * 1.5 + 0.3).to(torch.bfloat16)
+    mean = torch.randn(Cols, device=DEV) * 0.2
+    invstd = torch.rand(Cols, device=DEV) + 0.5
+    gamma = torch.randn(Cols, device=DEV)
+    scale = gamma * invstd
+    shift = torch.randn(Cols, device=DEV) * 0.3 - mean * scale
+    part = torch.full((tl.value * 2 * cols_pad,), float("nan"), device=DEV)
+    g = torch.full((npx, cw), float("nan"), device=DEV)
+    rc = lib.hpri_conv_bf16v3_bnred(P(planes), cs16, 0, P(wpd), P(g), cw, 0, N, H, W, cs16, Cols, cols_pad, cw, P(x16), xcs, 0,
+                                    P(mean), P(invstd), P(scale), P(shift), relu, P(part), cols_pad, _st())
+    assert rc == 0, lib.hpri_last_error()
+    g_plain = torch.empty_like(g)
+    assert lib.hpri_conv_bf16v3(P(planes), 0, cs16, 0, P(wpd), P(None), P(g_plain), cw, 0, P(None), N, H, W, cs16, Cols, cols_pad, cw, 0, 0,
+                                P(None), 0, _st()) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(g, g_plain)                                   # the gradient itself is the plain launch's, bit for bit
+    gd, xd = g[:, :Cols].double().cpu(), x16[:, :Cols].double().cpu()
+    keep = ((x16[:, :Cols].float() * scale + shift) > 0).cpu() if relu else torch.ones_like(gd, dtype=torch.bool)
+    gm = gd * keep
+    xhat = ((x16[:, :Cols].float() - mean) * invstd).double().cpu()
+    ref1, ref2 = gm.sum(0), (gm * xhat).sum(0)
+    pr = part.view(tl.value, 2, cols_pad).double().cpu()
+    assert torch.isfinite(pr[:, :, :Cols]).all()
+    s1, s2 = pr[:, 0, :Cols].sum(0), pr[:, 1, :Cols].sum(0)
+    tol1 = 2e-6 * float(gm.abs().sum(0).max()) + 1e-6
+    tol2 = 2e-6 * float((gm * xhat).abs().sum(0).max()) + 1e-6
+    record_margin(f"bf16v3/bnred/{N}x{H}x{W}x{K}x{Cols}/relu{relu}", max(float((s1 - ref1).abs().max()) / tol1, float((s2 - ref2).abs().max()) / tol2), 1.0)
+    assert float((s1 - ref1).abs().max()) < tol1 and float((s2 - ref2).abs().max()) < tol2
+    if cols_pad > Cols:
+        assert float(pr[:, :, Cols:cols_pad].abs().max()) == 0.0     # pad columns: exact zeros
+
+    # the consumer: BatchNorm backward from the partial rows == BatchNorm backward with its own sweeps (summation order only)
+    nblk, cpart = ctypes.c_int(), ctypes.c_int()
+    lib.hpri_col_reduce_plan(npx, 1, Cols, ctypes.byref(nblk), ctypes.byref(cpart))
+    outs = []
+    for fused in (True, False):
+        ws = torch.empty(2 * (nblk.value * 2 * cpart.value + 2 * Cols), device=DEV)
+        dx = torch.empty(npx, cw, device=DEV)
+        dgam, dbet, dbias = torch.empty(Cols, device=DEV), torch.empty(Cols, device=DEV), torch.empty(Cols, device=DEV)
+        tail = (P(g), cw, 0, P(x16), xcs, 0, P(dx), cw, 0, P(mean), P(invstd), P(scale), P(shift), P(dgam), P(dbet), 0, P(dbias), 0,
+                P(ws), ws.numel(), npx, npx, Cols, cw, relu, 1, P(None), 0, 0, 0, 0, 0, _st())
+        rc = lib.hpri_bn_relu_bwd_fused_x16(P(part), tl.value, cols_pad, *tail) if fused else lib.hpri_bn_relu_bwd_x16(*tail)
+        assert rc == 0, lib.hpri_last_error()
+        torch.cuda.synchronize()
+        outs.append((dx[:, :Cols].clone(), dgam.clone(), dbet.clone()))
+    for a, b, what in zip(outs[0], outs[1], ("dx", "dgamma", "dbeta")):
+        den = float(b.abs().max()) + 1e-12
+        assert float((a - b).abs().max()) <= 2e-5 * den, what
+    # boundary: accumulate-free only, statistics-free only, split-K problems refused, narrow pre-BN view refused
+    assert lib.hpri_conv_bf16v3_bnred(P(planes), cs16, 0, P(wpd), P(g), cw, 0, N, H, W, cs16, Cols, cols_pad, cw, P(x16), xcs - 4 if xcs - 4 < Cols else 2, 0,
+                                      P(mean), P(invstd), P(scale), P(shift), relu, P(part), cols_pad, _st()) != 0
+    assert lib.hpri_conv_bf16v3_bnred(P(planes), cs16, 0, P(wpd), P(g), cw, 0, N, H, W, cs16, Cols, cols_pad, cw, P(x16), xcs, 0,
+                                      P(mean), P(invstd), P(scale), P(shift), relu, P(None), cols_pad, _st()) != 0
+    assert lib.hpri_conv_bf16v3_bnred(P(planes), cs16, 0, P(wpd), P(g), cw, 0, N, H, W, cs16, Cols, cols_pad, cw, P(x16), xcs, 0,
+                                      P(mean), P(invstd), P(scale), P(shift), relu, P(part), Cols - 1, _st()) != 0
+
+
 @pytest.mark.parametrize("shape", [(1, 17, 23, 5, 7), (2, 36, 50, 64, 64), (1, 76, 121, 128, 192), (2, 38, 60, 40, 64), (1, 4, 32, 64, 64),
                                    (1, 3, 3, 8, 8), (1, 33, 31, 238, 64), (1, 1, 1, 3, 1)])
 def test_bf16_plane_weight_gradient_vs_fp64_of_rounded_operands(lib, shape):
