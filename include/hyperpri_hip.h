@@ -203,6 +203,26 @@ int hpri_conv_bf16v3_bnred(const void* xp, int x_cs, int x_coff, const void* wp,
                            const float* bn_mean, const float* bn_invstd, const float* bn_scale, const float* bn_shift,
                            int bn_relu, float* bn_part, int bn_cpart, hipStream_t stream);
 
+/* ---- plane-fed GEMM for the 1x1 forms of the bf16 mode (gemm_bf16v3.hip): nn.Linear / Conv2d(k=1) forward and data gradient
+ * (models.py:105-115,143; model_parts.py:96) and ConvTranspose2d(k=2,s=2) forward / data gradient (model_parts.py:63-64).
+ * hpri_gemm_bf16v3: y[p, n] (+)= sum_k x[p, k] w[n, k] + bias[n]; x = bf16 planes of N*HW rows (x_cs elements per row, K_pad read
+ * from x_coff on), w = hpri_pack_weight_bf16 with T = 1 (modes 0 / 1); outputs fp32 view y and / or bf16 view y16 (either may be
+ * NULL), y_cw columns written; accumulate bit 0: add to y, bit 1: ReLU; stats: one record row of stat_cp columns per 256-row tile
+ * (hpri_gemm_bf16v3_plan; tiles never straddle images) for hpri_bn_finalize.
+ * hpri_convt_fwd_bf16v3: column tap*Cup + co (pack mode 2) -> pixel (py0 + 2y + tap/2, px0 + 2x + tap%2), channel co of the
+ * [N, H2, W2] views; Cup % 16 == 0.  hpri_convt_dgrad_bf16v3: dx (+)= gather over the four parities of the dy planes (pack mode 3,
+ * K = 4*Cup); Cup % 32 == 0. */
+int hpri_gemm_bf16v3_plan(int N, long long HW, int* stat_tiles);
+int hpri_gemm_bf16v3(const void* xp, int x_cs, int x_coff, const void* wp, const float* bias, float* y, int y_cs, int y_coff,
+                     void* y16, int y16_cs, int y16_coff, float* stats, int stat_cp, int N, long long HW, int K_pad, int Ncols,
+                     int Ncols_pad, int y_cw, int accumulate, hipStream_t stream);
+int hpri_convt_fwd_bf16v3(const void* xp, int x_cs, int x_coff, const void* wp, const float* bias, float* y, int y_cs, int y_coff,
+                          void* y16, int y16_cs, int y16_coff, int N, int H, int W, int K_pad, int Cup, int Ncols_pad, int H2,
+                          int W2, int py0, int px0, hipStream_t stream);
+int hpri_convt_dgrad_bf16v3(const void* dyp, int dy_cs, int dy_coff, const void* wp, float* dx, int dx_cs, int dx_coff, int N,
+                            int H, int W, int Cup, int Cin, int Cin_pad, int dx_cw, int H2, int W2, int py0, int px0,
+                            int accumulate, hipStream_t stream);
+
 /* ---- weight gradients, fp32 MFMA, deterministic split-K (conv_wgrad.hip) --------------------------
  * Replaces the wgrad half of autograd for the same layers.  dst_mode 0 writes OIHW / (out,in),
  * dst_mode 1 writes ConvTranspose2d's (Cin,Cout,2,2).  Workspace: splits*KS*KS*Cr*Nr floats. */
