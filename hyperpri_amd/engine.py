@@ -234,6 +234,9 @@ PLANE_CONVERSIONS = 0        # generic fp32 -> planes passes launched (fused pro
 # straight from the accumulators) or conv_bf16v2.hip (one persistent 8-wave workgroup per CU).  Same packed weights, same
 # arguments; the statistics tiles differ (plan).  HPRI_BF16_V3: 1 (default) / 0.
 BF16_V3 = os.environ.get("HPRI_BF16_V3", "1") != "0"
+# bf16 mode: the 1x1 layers (nn.Linear of SpectralUNET) forward and data gradient by the plane-fed GEMM kernel
+# (gemm_bf16v3.hip); HPRI_PLANE_GEMM=0: the round-1 kernel that converts fp32 activations while staging.
+PLANE_GEMM = os.environ.get("HPRI_PLANE_GEMM", "1") != "0"
 
 
 # bf16 mode with the v3 plane convolution: the PRE-BatchNorm tensor of a conv -> BN -> ReLU stage (written by the convolution, read
@@ -303,6 +306,23 @@ def _conv_launch_v2(x: Act, wp: torch.Tensor, bias: Optional[torch.Tensor], y: A
     with _timed(tag, 2.0 * x.N * x.H * x.W * cin * cout * 9):
         _lib.call(_plane_conv(), _p(pl.buf), pl.plane, pl.cs, pl.coff, _p(wp), _p(bias), y.ptr, y.cs, y.coff, _p(stats),
                   x.N, x.H, x.W, cin_pad, cout, cout_pad, y_cw, accumulate, 0, _p(ws), wsf.value, _stream())
+
+
+def _gemm_launch(x: Act, wp: torch.Tensor, bias: Optional[torch.Tensor], y: Act, stats: Optional[torch.Tensor],
+                 K: int, ncols: int, ncols_pad: int, y_cw: int, accumulate: int = 0) -> None:
+    """1x1 convolution / Linear on bf16 planes (forward, or data gradient with the mode-1 pack): y may be an fp32 Act or a
+    bf16 one (``b16``: the pre-BN tensor of the bf16 mode)."""
+    pl = planes_of(x, 1)
+    kpad = _rup(K, 32)
+    null = ctypes.c_void_p(0)
+    f32 = (y.ptr, y.cs, y.coff) if not y.b16 else (null, 0, 0)
+    h16 = (y.ptr, y.cs, y.coff) if y.b16 else (null, 0, 0)
+    tag = "gemm_planes_bf16<1,v3 256x128>"
+    if SHAPE_TAGS:
+        tag += f" N{x.N} {x.H}x{x.W} K{kpad} N{ncols}"
+    with _timed(tag, 2.0 * x.P * K * ncols):
+        _lib.call("hpri_gemm_bf16v3", _p(pl.buf), pl.cs, pl.coff, _p(wp), _p(bias), *f32, *h16, _p(stats), ncols_pad,
+                  x.N, x.H * x.W, kpad, ncols, ncols_pad, y_cw, accumulate, _stream())
 
 
 class Tape:
@@ -766,6 +786,8 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
     split = _SPLIT.get(prec, 0)
     # operands by LDS-DMA from bf16 planes (conv_bf16v2.hip); its DMA offsets are 32-bit per image
     v2 = PLANE_CONV and prec == "bf16" and ks == 3 and _planes_fit(x, max(cin, cout))
+    # 1x1 layers of the bf16 mode on planes too (gemm_bf16v3.hip): forward and data gradient; the weight gradient still reads fp32
+    g3 = PLANE_GEMM and prec == "bf16" and ks == 1 and x.f32_valid and _rup(cin, 32) <= 8192
     if not x.f32_valid and not (v2 and x.pl is not None):
         raise RuntimeError("hyperpri_amd: internal error: a planes-only activation reached a kernel that reads fp32")
     wino = prec == "fp32" and ks == 3 and groups == 1 and _wino_ok(x, cout)
@@ -782,6 +804,8 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
         ksp_ = ctypes.c_int(); tl_ = ctypes.c_int(); wsf_ = ctypes.c_size_t()
         _lib.call("hpri_conv_bf16v3_plan", x.N, x.H, x.W, _rup(cin, 32), _rup(cout, 64), ctypes.byref(ksp_), ctypes.byref(tl_), ctypes.byref(wsf_))
         yr16 = ksp_.value == 1            # (split-K problems finish in fp32: hpri_splitk_finish)
+    if g3 and YR_BF16 and bn is not None:
+        yr16 = True
     if use_batch and (x.N * x.H * x.W) // max(groups, 1) <= 1:
         # torch.nn.functional.batch_norm's own check (_verify_batch_size): same error, same message
         raise ValueError("Expected more than 1 value per channel when training, got input size "
@@ -800,6 +824,8 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
         elif v2:
             _lib.call(_plane_conv() + "_plan", x.N, x.H, x.W, _rup(cin, 32), cout_pad, ctypes.byref(ksp), ctypes.byref(tl),
                       ctypes.byref(wsf))
+        elif g3:
+            _lib.call("hpri_gemm_bf16v3_plan", x.N, x.H * x.W, ctypes.byref(tl))
         elif lowp:
             _lib.call("hpri_conv_fwd_bf16_plan", x.N, x.H, x.W, cin_pad, cout_pad, ks, A_DIRECT, E_DIRECT, split,
                       ctypes.byref(ksp), ctypes.byref(tl), ctypes.byref(wsf))
@@ -812,6 +838,8 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
         _conv_launch_wino(x, wp, bias, yr, stats, cin, cout, cout_pad, yr.cw)
     elif v2:
         _conv_launch_v2(x, wp, bias, yr, stats, cin, cout, cout_pad, yr.cw, accumulate=4 if yr16 else 0)
+    elif g3:
+        _gemm_launch(x, wp, bias, yr, stats, cin, cout, cout_pad, yr.cw)
     elif lowp:
         _conv_launch_bf16(x, wp, bias, yr, stats, x.N, x.H, x.W, cin_pad, cout, cout_pad, yr.cw, ks, cin_true=cin, split=split)
     else:
@@ -840,8 +868,9 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
         # -- for the inner tensor of a DoubleConv (``next_cout`` > 0).  The OUTPUT of a DoubleConv is read by max-pooling, the
         # transposed convolution, the concat and the 1x1 output layer, all fp32 readers: no planes for it (573 MB of writes per
         # C2 step that nobody read); ``want_pl`` still tells the pooling pass to write ITS result as planes.
-        y.want_pl = 1 if (v2 and PLANE_PRODUCERS) else 0
-        ypl = new_planes(y, 1) if (y.want_pl and (next_cout > 0 or not PLANES_LAZY)) else None
+        y.want_pl = 1 if ((v2 or g3) and PLANE_PRODUCERS) else 0
+        # (a 1x1 layer's output is read by the next 1x1 layer or a concat in front of one: always planes)
+        ypl = new_planes(y, 1) if (y.want_pl and (next_cout > 0 or not PLANES_LAZY or g3)) else None
         cpl = None
         if ypl is None and y.want_pl and y.parent is not None and PLANES_CONCAT and y.C % 8 == 0:
             # a skip tensor: its planes go where the decoder's concat will want them -- channels [0, Cskip) of a plane buffer of the
@@ -880,7 +909,8 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
             db, acc_b = (tp.param_slot(bias) if bias is not None else (None, 0))
             mean, invstd, varu, scale, shift = (st[i * G * cout:(i + 1) * G * cout] for i in range(5))
             # read by the data gradient and by the weight gradient
-            dpl = new_planes(dyr, 1) if (v2 and (need_dx or (PLANE_WGRAD and weight.requires_grad)) and PLANE_PRODUCERS) else None
+            dpl = new_planes(dyr, 1) if ((v2 and (need_dx or (PLANE_WGRAD and weight.requires_grad)) or (g3 and need_dx))
+                                         and PLANE_PRODUCERS) else None
             # plane mode: when the weight gradient and the data gradient both read the bf16 planes, nobody reads the fp32 form
             f32_dead = (dpl is not None and ks == 3 and split == 0 and PLANE_CONV and PLANE_WGRAD and PLANES_ONLY_GRAD
                         and (need_dx or weight.requires_grad))
@@ -975,6 +1005,9 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
             elif v2:
                 wpd, cin_cols_pad = _pack_bf16(weight, 1, cout, cin, T, cin, split=0)
                 _conv_launch_v2(dyr, wpd, None, gx, gstats, cout, cin, cin_cols_pad, gx.cw, accumulate=int(acc))
+            elif g3:
+                wpd, cin_cols_pad = _pack_bf16(weight, 1, cout, cin, T, cin, split=0)
+                _gemm_launch(dyr, wpd, None, gx, None, cout, cin, cin_cols_pad, gx.cw, accumulate=int(acc))
             elif lowp:
                 wpd, cin_cols_pad = _pack_bf16(weight, 1, cout, cin, T, cin, split=split)
                 _conv_launch_bf16(dyr, wpd, None, gx, None, x.N, x.H, x.W, dyr.cw, cin, cin_cols_pad, gx.cw, ks,
