@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libhyperpri_hip.so")
-SOURCES = ["api.cpp", "conv_fwd.hip", "conv_bf16v2.hip", "conv_bf16v3.hip", "gemm_bf16v3.hip", "conv_wino.hip", "conv_wino4.hip", "conv_wgrad.hip", "conv_wgrad_bf16v2.hip", "pack.hip", "bn.hip", "elementwise.hip", "step.hip", "ingest.hip"]
+SOURCES = ["api.cpp", "conv_fwd.hip", "conv_bf16v2.hip", "conv_bf16v3.hip", "gemm_bf16v3.hip", "wgrad_bf16v3.hip", "conv_wino.hip", "conv_wino4.hip", "conv_wgrad.hip", "conv_wgrad_bf16v2.hip", "pack.hip", "bn.hip", "elementwise.hip", "step.hip", "ingest.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 
 

@@ -247,6 +247,14 @@ int hpri_conv_wgrad_bf16v2(const void* x_planes, int x_cs, int x_coff, int x_cva
                            int dy_coff, int dy_cvalid, float* ws, size_t ws_floats, int N, int H, int W, int Cin_pad,
                            int Cout_pad, hipStream_t stream);
 
+/* Weight gradient of the 1x1 layers (nn.Linear / Conv2d(k=1): models.py:105-115,143) from bf16 PLANES (wgrad_bf16v3.hip): plane 0
+ * of the layer input and of the output gradient, P pixel rows each (strides / offsets / valid widths multiples of 8 elements), both
+ * by LDS-DMA; slabs ws[splits][Nr][Cr] (sizes from the plan), finished by hpri_wgrad_reduce_ex(ws, dw, splits, Cr, Nr, Cin, Cout, 1,
+ * 0, 0, accumulate). */
+int hpri_wgrad1x1_bf16v3_plan(long long P, int Cin_pad, int Cout_pad, int* splits, int* Cr, int* Nr);
+int hpri_wgrad1x1_bf16v3(const void* x_planes, int x_cs, int x_coff, int x_cvalid, const void* dy_planes, int dy_cs, int dy_coff,
+                         int dy_cvalid, float* ws, size_t ws_floats, long long P, int Cin_pad, int Cout_pad, hipStream_t stream);
+
 /* ---- BatchNorm (+ReLU) (bn.hip): nn.BatchNorm2d/3d/1d + nn.ReLU, model_parts.py:23-27; models.py:113-114,
  * 172-173,178-179.  G groups = independent statistic sets (G = N for SpectralUNET's per-image loop,
  * models.py:132). */

@@ -172,3 +172,45 @@ def test_transposed_convolution_forward_and_data_gradient(lib, shape):
     errd = float((dx.double().cpu()[:, :Cin] - prior.double().cpu()[:, :Cin] - refd).abs().max())
     record_margin(f"gemm_bf16v3/convt_dgrad/{N}x{H}x{W}x{Cin}x{Cup}", errd, 2e-5 * scd)
     assert errd < 2e-5 * scd, (shape, errd)
+
+
+@pytest.mark.parametrize("shape", [(300, 40, 24), (5000, 238, 150), (70000, 330, 520), (33, 8, 8), (20000, 1650, 264)])
+@pytest.mark.parametrize("accumulate", [0, 1])
+def test_linear_weight_gradient_from_planes(lib, shape, accumulate):
+    """wgrad_bf16v3.hip: dW[n][c] = sum_p dY[p][n] X[p][c] from bf16 planes (channel-slice views of wider plane buffers, valid
+    widths below the tile widths, ragged pixel counts), slabs summed by hpri_wgrad_reduce_ex."""
+    Ppx, Cin, Cout = shape
+    torch.manual_seed(13)
+    xcs, ycs = rup(Cin, 32) + 32, rup(Cout, 32) + 8
+    xoff, yoff = 32, 8
+    x = torch.randn(Ppx, Cin, device=DEV)
+    dy = torch.randn(Ppx, Cout, device=DEV)
+    xp = torch.full((Ppx, xcs), 9.0, dtype=torch.bfloat16, device=DEV)          # channels outside the valid width hold junk on purpose
+    yp = torch.full((Ppx, ycs), 9.0, dtype=torch.bfloat16, device=DEV)
+    xv, yv = rup(Cin, 8), rup(Cout, 8)
+    xp[:, xoff:xoff + xv] = 0
+    yp[:, yoff:yoff + yv] = 0
+    xp[:, xoff:xoff + Cin] = x.to(torch.bfloat16)
+    yp[:, yoff:yoff + Cout] = dy.to(torch.bfloat16)
+    sp, cr, nr = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    assert lib.hpri_wgrad1x1_bf16v3_plan(Ppx, rup(Cin, 32), rup(Cout, 64), ctypes.byref(sp), ctypes.byref(cr), ctypes.byref(nr)) == 0
+    assert cr.value % 128 == 0 and nr.value % 256 == 0 and cr.value >= Cin and nr.value >= Cout and sp.value >= 1
+    ws = torch.full((sp.value * cr.value * nr.value,), float("nan"), device=DEV)
+    rc = lib.hpri_wgrad1x1_bf16v3(P(xp), xcs, xoff, xv, P(yp), ycs, yoff, yv, P(ws), ws.numel(), Ppx, rup(Cin, 32), rup(Cout, 64), _st())
+    assert rc == 0, lib.hpri_last_error()
+    prior = torch.randn(Cout, Cin, device=DEV)
+    dw = prior.clone()
+    rc = lib.hpri_wgrad_reduce_ex(P(ws), P(dw), sp.value, cr.value, nr.value, Cin, Cout, 1, 0, 0, accumulate, _st())
+    assert rc == 0, lib.hpri_last_error()
+    torch.cuda.synchronize()
+    assert torch.isfinite(ws).all()
+    ref = yp[:, yoff:yoff + Cout].double().cpu().T @ xp[:, xoff:xoff + Cin].double().cpu()
+    if accumulate:
+        ref = ref + prior.double().cpu()
+    sc = max(1.0, float(ref.abs().max()))
+    err = float((dw.double().cpu() - ref).abs().max())
+    record_margin(f"wgrad1x1_bf16v3/{Ppx}x{Cin}x{Cout}/acc{accumulate}", err, 3e-5 * sc)
+    assert err < 3e-5 * sc, (shape, err, sp.value)
+    # boundary: unaligned valid width, workspace too small
+    assert lib.hpri_wgrad1x1_bf16v3(P(xp), xcs, xoff, xv + 4, P(yp), ycs, yoff, yv, P(ws), ws.numel(), Ppx, rup(Cin, 32), rup(Cout, 64), _st()) != 0
+    assert lib.hpri_wgrad1x1_bf16v3(P(xp), xcs, xoff, xv, P(yp), ycs, yoff, yv, P(ws), ws.numel() - 1, Ppx, rup(Cin, 32), rup(Cout, 64), _st()) != 0

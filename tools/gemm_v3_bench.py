@@ -71,6 +71,32 @@ def convt(N, H, W, Cin, Cup, planes_only=False):
     return res
 
 
+def wgrad(Ppx, Cin, Cout):
+    kx, ky = rup(Cin, 32), rup(Cout, 32)
+    xp = (torch.rand(Ppx, kx, device=DEV) - 0.5).to(torch.bfloat16)
+    yp = (torch.rand(Ppx, ky, device=DEV) - 0.5).to(torch.bfloat16)
+    sp, cr, nr = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    lib.hpri_wgrad1x1_bf16v3_plan(Ppx, kx, rup(Cout, 64), ctypes.byref(sp), ctypes.byref(cr), ctypes.byref(nr))
+    ws = torch.empty(sp.value * cr.value * nr.value, device=DEV)
+    dw = torch.empty(Cout, Cin, device=DEV)
+
+    def fn():
+        rc = lib.hpri_wgrad1x1_bf16v3(P(xp), kx, 0, rup(Cin, 8), P(yp), ky, 0, rup(Cout, 8), P(ws), ws.numel(), Ppx, kx, rup(Cout, 64), st())
+        assert rc == 0, lib.hpri_last_error()
+
+    def fr():
+        rc = lib.hpri_wgrad_reduce_ex(P(ws), P(dw), sp.value, cr.value, nr.value, Cin, Cout, 1, 0, 0, 0, st())
+        assert rc == 0, lib.hpri_last_error()
+    ms, msr = timeit(fn), timeit(fr)
+    fl = 2.0 * Ppx * Cin * Cout
+    return {"op": "wgrad1x1", "P": Ppx, "Cin": Cin, "Cout": Cout, "splits": sp.value, "ms": round(ms, 4), "TF": round(fl / ms / 1e9, 1), "reduce_ms": round(msr, 4)}
+
+
+if os.environ.get("ONLY") == "wgrad":
+    for r in [wgrad(608 * 700, 1650, 1650), wgrad(608 * 700, 3300, 1650), wgrad(608 * 700, 238, 1650), wgrad(2 * 608 * 968, 64, 64)]:
+        print(json.dumps(r), flush=True)
+    sys.exit(0)
+
 for r in [linear(1, 608 * 700, 238, 1650), linear(1, 608 * 700, 1650, 1650), linear(1, 608 * 700, 1650, 1650, y16=True), linear(1, 608 * 700, 3300, 1650),
           linear(1, 608 * 700, 1650, 1650, stats=False), linear(2, 608 * 968, 64, 64),
           convt(2, 304, 484, 128, 64), convt(2, 152, 242, 256, 128), convt(2, 76, 121, 512, 256), convt(2, 38, 60, 1024, 512),
