@@ -421,31 +421,44 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restr
 // run of 1024 / S channels; its 256 threads are (256 / S channel quads) x (S slab slices): every thread streams float4s of its
 // slices for all nine taps (all loads independent), the slices meet in LDS in slice order (fixed: deterministic), and the
 // block writes its [channel][tap] run of dW contiguously.  S = 16 / 4 / 1 by the number of slabs.
-template <int S>
+template <int S, int T = 9>
 __global__ __launch_bounds__(256) void wgrad_reduce9_wide_kernel(const float* __restrict__ ws, float* __restrict__ dw, int splits,
                                                                  int Cr, int Nr, int Cin, int Cout, int accumulate) {
   constexpr int CQ = 256 / S, CR = CQ * 4;               // channel quads / channels per block
-  __shared__ float red[S][9][CR];
+  __shared__ float red[S][T][CR];
   const int cq = threadIdx.x % CQ, sl = threadIdx.x / CQ;
   const int n = blockIdx.y, c0 = blockIdx.x * CR, c = c0 + cq * 4;
-  f32x4 acc[9];
+  f32x4 acc[T];
 #pragma unroll
-  for (int t = 0; t < 9; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < T; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
   if (c < Cr) {
-    const size_t slab = (size_t)9 * Cr * Nr, row = (size_t)Nr * Cr;
+    const size_t slab = (size_t)T * Cr * Nr, row = (size_t)Nr * Cr;
     const float* p = ws + (size_t)n * Cr + c;
-    for (int k = sl; k < splits; k += S) {
+    if (T == 1) {
+      // one tap (the 1x1 layers: wgrad_bf16v3.hip): four slabs of a slice in flight instead of nine taps of one
+      int k = sl;
+      for (; k + 3 * S < splits; k += 4 * S) {
+        f32x4 v[4];
 #pragma unroll
-      for (int t = 0; t < 9; ++t) acc[t] += *reinterpret_cast<const f32x4*>(p + (size_t)k * slab + (size_t)t * row);
+        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4*>(p + (size_t)(k + u * S) * slab);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[0] += v[u];
+      }
+      for (; k < splits; k += S) acc[0] += *reinterpret_cast<const f32x4*>(p + (size_t)k * slab);
+    } else {
+      for (int k = sl; k < splits; k += S) {
+#pragma unroll
+        for (int t = 0; t < T; ++t) acc[t] += *reinterpret_cast<const f32x4*>(p + (size_t)k * slab + (size_t)t * row);
+      }
     }
   }
 #pragma unroll
-  for (int t = 0; t < 9; ++t) *reinterpret_cast<f32x4*>(&red[sl][t][cq * 4]) = acc[t];
+  for (int t = 0; t < T; ++t) *reinterpret_cast<f32x4*>(&red[sl][t][cq * 4]) = acc[t];
   __syncthreads();
-  const int nout = min(CR, Cin - c0) * 9;                // this block's run of dW: [channel][tap], contiguous
-  float* o = dw + ((size_t)n * Cin + c0) * 9;
+  const int nout = min(CR, Cin - c0) * T;                // this block's run of dW: [channel][tap], contiguous
+  float* o = dw + ((size_t)n * Cin + c0) * T;
   for (int i = threadIdx.x; i < nout; i += 256) {
-    const int cl = i / 9, t = i - cl * 9;
+    const int cl = i / T, t = i - cl * T;
     float v = red[0][t][cl];
 #pragma unroll
     for (int q = 1; q < S; ++q) v += red[q][t][cl];
@@ -453,17 +466,22 @@ __global__ __launch_bounds__(256) void wgrad_reduce9_wide_kernel(const float* __
   }
 }
 
-static void launch_wgrad_reduce9_wide(const float* ws, float* dw, int splits, int Cr, int Nr, int Cin, int Cout, int accumulate,
-                                      hipStream_t stream) {
+template <int T>
+static void launch_wgrad_reduce_wide(const float* ws, float* dw, int splits, int Cr, int Nr, int Cin, int Cout, int accumulate,
+                                     hipStream_t stream) {
   if (splits >= 16)
-    hipLaunchKernelGGL((wgrad_reduce9_wide_kernel<16>), dim3((unsigned)hpri_cdiv(Cin, 64), (unsigned)Cout), dim3(256), 0, stream, ws, dw,
+    hipLaunchKernelGGL((wgrad_reduce9_wide_kernel<16, T>), dim3((unsigned)hpri_cdiv(Cin, 64), (unsigned)Cout), dim3(256), 0, stream, ws, dw,
                        splits, Cr, Nr, Cin, Cout, accumulate);
   else if (splits >= 3)
-    hipLaunchKernelGGL((wgrad_reduce9_wide_kernel<4>), dim3((unsigned)hpri_cdiv(Cin, 256), (unsigned)Cout), dim3(256), 0, stream, ws, dw,
+    hipLaunchKernelGGL((wgrad_reduce9_wide_kernel<4, T>), dim3((unsigned)hpri_cdiv(Cin, 256), (unsigned)Cout), dim3(256), 0, stream, ws, dw,
                        splits, Cr, Nr, Cin, Cout, accumulate);
   else
-    hipLaunchKernelGGL((wgrad_reduce9_wide_kernel<1>), dim3((unsigned)hpri_cdiv(Cin, 1024), (unsigned)Cout), dim3(256), 0, stream, ws, dw,
+    hipLaunchKernelGGL((wgrad_reduce9_wide_kernel<1, T>), dim3((unsigned)hpri_cdiv(Cin, 1024), (unsigned)Cout), dim3(256), 0, stream, ws, dw,
                        splits, Cr, Nr, Cin, Cout, accumulate);
+}
+static void launch_wgrad_reduce9_wide(const float* ws, float* dw, int splits, int Cr, int Nr, int Cin, int Cout, int accumulate,
+                                      hipStream_t stream) {
+  launch_wgrad_reduce_wide<9>(ws, dw, splits, Cr, Nr, Cin, Cout, accumulate, stream);
 }
 
 
@@ -663,6 +681,7 @@ extern "C" int hpri_wgrad_reduce(const float* ws, float* dw, int N, int H, int W
                        splits, Cr, Nr, Cin, Cup, accumulate);
   else if (KS == 3 && dst_mode == 0 && Cr % 4 == 0) launch_wgrad_reduce9_wide(ws, dw, splits, Cr, Nr, Cin, Cout, accumulate, stream);
   else if (KS == 3) hipLaunchKernelGGL((wgrad_reduce_kernel<9>), grid, dim3(1024), 0, stream, ws, dw, splits, Cr, Nr, Cin, Cout, dst_mode, Cup, accumulate);
+  else if (KS == 1 && dst_mode == 0 && Cr % 4 == 0) launch_wgrad_reduce_wide<1>(ws, dw, splits, Cr, Nr, Cin, Cout, accumulate, stream);
   else hipLaunchKernelGGL((wgrad_reduce_kernel<1>), grid, dim3(1024), 0, stream, ws, dw, splits, Cr, Nr, Cin, Cout, dst_mode, Cup, accumulate);
   HPRI_CHECK_LAUNCH();
   return HPRI_OK;
@@ -679,6 +698,7 @@ extern "C" int hpri_wgrad_reduce_ex(const float* ws, float* dw, int splits, int 
   dim3 grid((unsigned)hpri_cdiv(Cin, 32), (unsigned)Cout);
   if (KS == 3 && dst_mode == 0 && Cr % 4 == 0) launch_wgrad_reduce9_wide(ws, dw, splits, Cr, Nr, Cin, Cout, accumulate, stream);
   else if (KS == 3) hipLaunchKernelGGL((wgrad_reduce_kernel<9>), grid, dim3(1024), 0, stream, ws, dw, splits, Cr, Nr, Cin, Cout, dst_mode, Cup, accumulate);
+  else if (KS == 1 && dst_mode == 0 && Cr % 4 == 0) launch_wgrad_reduce_wide<1>(ws, dw, splits, Cr, Nr, Cin, Cout, accumulate, stream);
   else hipLaunchKernelGGL((wgrad_reduce_kernel<1>), grid, dim3(1024), 0, stream, ws, dw, splits, Cr, Nr, Cin, Cout, dst_mode, Cup, accumulate);
   HPRI_CHECK_LAUNCH();
   return HPRI_OK;

@@ -71,19 +71,29 @@ extern "C" int hpri_pack_weight_scaled(const float* w, float* wp, const float* c
 // MFMA B operand wants); same four modes as the fp32 pack; round-to-nearest-even.
 // split = 1 (mode "bf16x3"): two planes per tap, [chunk][tap][plane][Ncols_pad][32]: hi = bf16(w), lo = bf16(w - hi);
 // split = 2 (mode "bf16x6"): three planes hi, mid, lo (24 mantissa bits: the fp32 value exactly)
+// gap_len > 0 (modes 0 and 1): the INPUT-channel axis of the layer carries gap_len structural-zero channels from gap_at on (the
+// padded concat of the bf16 plane mode: [a | zeros to the next multiple of 32 | b]); K (mode 0) resp. Ncols (mode 1) count the
+// padded axis, the weight tensor has the reference's unpadded width.
 __global__ void pack_weight_bf16_kernel(const float* __restrict__ w, __bf16* __restrict__ wp, int mode, int K, int Ncols,
                                         int Ncols_pad, int T, int chunks, int src_d1, int Cup, int split,
-                                        const float* __restrict__ colscale) {
+                                        const float* __restrict__ colscale, int gap_at = 0, int gap_len = 0) {
   const size_t total = (size_t)chunks * T * Ncols_pad * 32;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
     const int kk = (int)(idx & 31);
     size_t r = idx >> 5;
-    const int col = (int)(r % Ncols_pad); r /= Ncols_pad;
+    int col = (int)(r % Ncols_pad); r /= Ncols_pad;
     const int t = (int)(r % T);
     const int chunk = (int)(r / T);
-    const int k = chunk * 32 + kk;
+    int k = chunk * 32 + kk;
     float v = 0.f;
-    if (k < K && col < Ncols) {
+    bool in_gap = false;
+    const bool live = k < K && col < Ncols;
+    if (gap_len > 0) {
+      int& ax = mode == 0 ? k : col;             // the input-channel axis
+      in_gap = ax >= gap_at && ax < gap_at + gap_len;
+      if (ax >= gap_at + gap_len) ax -= gap_len;
+    }
+    if (live && !in_gap) {
       if (mode == 0) v = w[((size_t)col * src_d1 + k) * T + t];
       else if (mode == 1) v = w[((size_t)k * src_d1 + col) * T + (T - 1 - t)];
       else if (mode == 2) { const int tap = col / Cup, co = col - tap * Cup; v = w[((size_t)k * Cup + co) * 4 + tap]; }
@@ -118,6 +128,24 @@ extern "C" int hpri_pack_weight_bf16(const float* w, void* wp, int mode, int K, 
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(pack_weight_bf16_kernel, dim3(blocks), dim3(256), 0, stream, w, reinterpret_cast<__bf16*>(wp), mode, K,
                      Ncols, Ncols_pad, T, chunks, src_d1, Cup, split, (const float*)nullptr);
+  HPRI_CHECK_LAUNCH();
+  return HPRI_OK;
+}
+
+// hpri_pack_weight_bf16 for a layer whose input-channel axis is padded with gap_len zero channels at gap_at (modes 0 / 1 only):
+// K (mode 0) resp. Ncols (mode 1) is the PADDED channel count, src_d1 the weight tensor's own (unpadded) input width.
+extern "C" int hpri_pack_weight_bf16_gap(const float* w, void* wp, int mode, int K, int Ncols, int Ncols_pad, int T, int src_d1,
+                                         int gap_at, int gap_len, hipStream_t stream) {
+  HPRI_REQUIRE(w && wp, "pack_weight_bf16_gap: null pointer");
+  HPRI_REQUIRE((mode == 0 || mode == 1) && K > 0 && Ncols > 0 && Ncols_pad >= Ncols && Ncols_pad % 64 == 0, "pack_weight_bf16_gap: bad arguments");
+  HPRI_REQUIRE(gap_at >= 0 && gap_len >= 0 && gap_at + gap_len <= (mode == 0 ? K : Ncols) && (mode == 0 ? K : Ncols) - gap_len == src_d1,
+               "pack_weight_bf16_gap: the padded axis minus the gap must be the weight's input width");
+  const int chunks = hpri_cdiv(K, 32);
+  const size_t total = (size_t)chunks * T * Ncols_pad * 32;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(pack_weight_bf16_kernel, dim3(blocks), dim3(256), 0, stream, w, reinterpret_cast<__bf16*>(wp), mode, K, Ncols, Ncols_pad,
+                     T, chunks, src_d1, 0, 0, (const float*)nullptr, gap_at, gap_len);
   HPRI_CHECK_LAUNCH();
   return HPRI_OK;
 }

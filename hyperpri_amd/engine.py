@@ -64,7 +64,7 @@ class Act:
 
     Invariant: channels [C, cw) (cw = C rounded up to 8) exist inside the stride and hold zeros, so
     consumers may run their K loop over ``cw`` channels."""
-    __slots__ = ("buf", "N", "H", "W", "C", "cs", "coff", "pl", "parent", "f32_valid", "want_pl", "pl_part", "colsum_req", "b16", "bn_src")
+    __slots__ = ("buf", "N", "H", "W", "C", "cs", "coff", "pl", "parent", "f32_valid", "want_pl", "pl_part", "colsum_req", "b16", "bn_src", "cat_pl")
 
     def __init__(self, buf: torch.Tensor, N: int, H: int, W: int, C: int, cs: int, coff: int = 0):
         self.buf, self.N, self.H, self.W, self.C, self.cs, self.coff = buf, N, H, W, C, cs, coff
@@ -75,6 +75,7 @@ class Act:
         self.want_pl = 0                        # plane mode marker: planes a 3x3 consumer of this tensor (or of its pooled map) would read
         self.colsum_req = None                  # (c0, C): somebody wants the column sums of channels [c0, c0+C) of this tensor's GRADIENT
         self.b16 = False                        # the buffer holds bf16 elements (a pre-BN tensor of the bf16 mode; read by the *_x16 BN passes only)
+        self.cat_pl = None                      # (plane buffer, cs, offset of the second half, its channels): this tensor's planes are the first half of a padded concat
         self.bn_src = None                      # (pre-BN Act, statistics, relu): this tensor is BN(+ReLU) of that one and has ONE consumer
 
     @property
@@ -159,10 +160,11 @@ class Planes:
     """bf16 NHWC planes of an activation: plane p (0 = bf16(x), 1 = bf16(x - hi), ...) starts ``plane`` elements after
     the previous one, ``cs`` elements per pixel (a multiple of 32), channels [C, cs) are zero.  In the bf16 precision
     modes the 3x3 convolutions bring their operands into LDS by DMA straight from these planes (csrc/conv_bf16v2.hip)."""
-    __slots__ = ("buf", "plane", "cs", "coff", "npl")
+    __slots__ = ("buf", "plane", "cs", "coff", "npl", "cw")
 
-    def __init__(self, buf: torch.Tensor, plane: int, cs: int, coff: int, npl: int):
+    def __init__(self, buf: torch.Tensor, plane: int, cs: int, coff: int, npl: int, cw: int = 0):
         self.buf, self.plane, self.cs, self.coff, self.npl = buf, plane, cs, coff, npl
+        self.cw = cw or (cs - coff)          # channels of this view (a multiple of 32): narrower than cs - coff inside a padded concat
 
 
 # fp32 mode: 3x3 convolutions (forward and data gradient) by Winograd F(2x2,3x3) on the fp32 MFMA (csrc/conv_wino.hip):
@@ -267,7 +269,7 @@ def _pl_args(pl: Optional[Planes]):
     """(planes, plane_stride, cs, coff, cw, npl) arguments of the *_pl entry points; all zero = fp32 only."""
     if pl is None:
         return ctypes.c_void_p(0), 0, 0, 0, 0, 0
-    return _p(pl.buf), pl.plane, pl.cs, pl.coff, pl.cs - pl.coff, pl.npl
+    return _p(pl.buf), pl.plane, pl.cs, pl.coff, pl.cw, pl.npl
 
 
 def input_planes_for(module) -> int:
@@ -713,17 +715,22 @@ def _pack(w: torch.Tensor, mode: int, K: int, ncols: int, T: int, cup: int, d1: 
 
 
 def _pack_bf16(w: torch.Tensor, mode: int, K: int, ncols: int, T: int, d1: int, cup: int = 0,
-               split: int = 0) -> Tuple[torch.Tensor, int]:
+               split: int = 0, gap: Optional[Tuple[int, int]] = None) -> Tuple[torch.Tensor, int]:
+    """``gap`` = (first channel, length) of structural-zero channels on the layer's input-channel axis (modes 0 / 1, one plane):
+    K resp. ncols then count the padded axis (hpri_pack_weight_bf16_gap)."""
     ncols_pad = _rup(ncols, 64)
 
     def build():
         global PACK_LAUNCHES
         chunks = (K + 31) // 32
         wp = torch.empty(chunks * T * ncols_pad * 32 * (split + 1), dtype=torch.bfloat16, device=w.device)
-        _lib.call("hpri_pack_weight_bf16", _p(w), _p(wp), mode, K, ncols, ncols_pad, T, d1, cup, split, _stream())
+        if gap is not None:
+            _lib.call("hpri_pack_weight_bf16_gap", _p(w), _p(wp), mode, K, ncols, ncols_pad, T, d1, gap[0], gap[1], _stream())
+        else:
+            _lib.call("hpri_pack_weight_bf16", _p(w), _p(wp), mode, K, ncols, ncols_pad, T, d1, cup, split, _stream())
         PACK_LAUNCHES += 1
         return wp
-    return _cached_pack(w, ("bf16", mode, K, ncols, T, d1, cup, split), build), ncols_pad
+    return _cached_pack(w, ("bf16", mode, K, ncols, T, d1, cup, split, gap), build), ncols_pad
 
 
 def _conv_launch_bf16(x: Act, wp: torch.Tensor, bias: Optional[torch.Tensor], y: Act, stats: Optional[torch.Tensor],
@@ -766,15 +773,22 @@ def _conv_launch(x: Act, wp: torch.Tensor, bias: Optional[torch.Tensor], y: Act,
 # --------------------------------------------------------------------------------------------------
 def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.Tensor], bn: Optional[BNRef],
                  train: bool, ks: int, groups: int = 1, relu: bool = True, need_dx: bool = True,
-                 precision: Optional[str] = None, room: int = 0, next_cout: int = 0) -> Act:
+                 precision: Optional[str] = None, room: int = 0, next_cout: int = 0, cat_room: int = 0,
+                 cat_into: Optional[Act] = None, k_gap: Optional[Tuple[int, int]] = None, planes_only: bool = False) -> Act:
     """Conv2d(k=ks, pad=ks//2) -> BatchNorm -> ReLU  (model_parts.py:22-27; models.py:169-180 with the
     Conv3d weight (F,1,D,3,3) read as (F,D,3,3); models.py:108-114 for Linear -> BatchNorm1d -> ReLU with
-    ks = 1 and ``groups`` = images, each image being its own BN batch, models.py:132)."""
+    ks = 1 and ``groups`` = images, each image being its own BN batch, models.py:132).
+
+    The last four arguments belong to the plane form of SpectralUNET's skips (``plane_gemm_mode``; 1x1 layers, bf16 mode, BN
+    present): ``cat_room`` = C2 > 0: the result's planes are the first half of a padded concat [this | zeros to a multiple of
+    32 | C2 channels]; ``cat_into`` = a: the result's planes are the second half of ``a``'s concat (``concat_planes`` then has
+    nothing to copy); ``k_gap``: ``x`` is such a concat -- (first, length) of its structural-zero channels, which the weight does
+    not have; ``planes_only``: every consumer of the result reads planes (no fp32 copy is written)."""
     dev = x.buf.device
     T = ks * ks
     cout = weight.shape[0]
     cin = weight.numel() // (cout * T)
-    if cin != x.C:
+    if cin + (k_gap[1] if k_gap else 0) != x.C:
         raise RuntimeError(f"hyperpri_amd: conv expects {cin} input channels, got {x.C}")
     cin_pad = x.cw
     prec = precision or DEFAULT_PRECISION
@@ -787,15 +801,17 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
     # operands by LDS-DMA from bf16 planes (conv_bf16v2.hip); its DMA offsets are 32-bit per image
     v2 = PLANE_CONV and prec == "bf16" and ks == 3 and _planes_fit(x, max(cin, cout))
     # 1x1 layers of the bf16 mode on planes too (gemm_bf16v3.hip): forward and data gradient; the weight gradient still reads fp32
-    g3 = PLANE_GEMM and prec == "bf16" and ks == 1 and x.f32_valid and _rup(cin, 32) <= 8192
-    if not x.f32_valid and not (v2 and x.pl is not None):
+    g3 = PLANE_GEMM and prec == "bf16" and ks == 1 and (x.f32_valid or x.pl is not None) and _rup(x.C, 32) <= 8192
+    if (cat_room or cat_into is not None or k_gap or planes_only) and not (g3 and bn is not None and PLANE_WGRAD and PLANE_PRODUCERS):
+        raise RuntimeError("hyperpri_amd: internal error: the plane form of a skip concat needs the plane GEMM path (see plane_gemm_mode)")
+    if not x.f32_valid and not ((v2 or g3) and x.pl is not None):
         raise RuntimeError("hyperpri_amd: internal error: a planes-only activation reached a kernel that reads fp32")
     wino = prec == "fp32" and ks == 3 and groups == 1 and _wino_ok(x, cout)
     wino_d = prec == "fp32" and ks == 3 and groups == 1 and _wino_ok(x, cin)     # the data gradient has Cin columns
     if wino:
         wp, cout_pad = _pack_wino(weight, 0, cin, cout, cin)
     elif lowp:
-        wp, cout_pad = _pack_bf16(weight, 0, cin, cout, T, cin, split=split)
+        wp, cout_pad = _pack_bf16(weight, 0, x.C if k_gap else cin, cout, T, cin, split=split, gap=k_gap)
     else:
         wp, cout_pad = _pack(weight, 0, cin, cout, T, 0, cin)
     use_batch = bn is not None and train
@@ -839,7 +855,7 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
     elif v2:
         _conv_launch_v2(x, wp, bias, yr, stats, cin, cout, cout_pad, yr.cw, accumulate=4 if yr16 else 0)
     elif g3:
-        _gemm_launch(x, wp, bias, yr, stats, cin, cout, cout_pad, yr.cw)
+        _gemm_launch(x, wp, bias, yr, stats, x.C, cout, cout_pad, yr.cw)
     elif lowp:
         _conv_launch_bf16(x, wp, bias, yr, stats, x.N, x.H, x.W, cin_pad, cout, cout_pad, yr.cw, ks, cin_true=cin, split=split)
     else:
@@ -871,6 +887,20 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
         y.want_pl = 1 if ((v2 or g3) and PLANE_PRODUCERS) else 0
         # (a 1x1 layer's output is read by the next 1x1 layer or a concat in front of one: always planes)
         ypl = new_planes(y, 1) if (y.want_pl and (next_cout > 0 or not PLANES_LAZY or g3)) else None
+        if cat_room > 0:
+            # first half of a padded concat: [cout | zeros to the next multiple of 32 | cat_room channels], one plane buffer
+            ob = _rup(cout, 32)
+            ccs = _rup(ob + cat_room, 32)
+            cbuf = torch.empty(y.P * ccs, dtype=torch.bfloat16, device=dev)
+            ypl = y.pl = Planes(cbuf, y.P * ccs, ccs, 0, 1, cw=ob)
+            y.cat_pl = (cbuf, ccs, ob, cat_room)
+        elif cat_into is not None:
+            cbuf, ccs, ob, c2 = cat_into.cat_pl
+            if c2 != cout or cat_into.P != y.P:
+                raise RuntimeError("hyperpri_amd: internal error: concat halves do not match")
+            ypl = y.pl = Planes(cbuf, y.P * ccs, ccs, ob, 1, cw=ccs - ob)
+        if planes_only:
+            y.f32_valid = False
         cpl = None
         if ypl is None and y.want_pl and y.parent is not None and PLANES_CONCAT and y.C % 8 == 0:
             # a skip tensor: its planes go where the decoder's concat will want them -- channels [0, Cskip) of a plane buffer of the
@@ -909,11 +939,12 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
             db, acc_b = (tp.param_slot(bias) if bias is not None else (None, 0))
             mean, invstd, varu, scale, shift = (st[i * G * cout:(i + 1) * G * cout] for i in range(5))
             # read by the data gradient and by the weight gradient
-            dpl = new_planes(dyr, 1) if ((v2 and (need_dx or (PLANE_WGRAD and weight.requires_grad)) or (g3 and need_dx))
+            dpl = new_planes(dyr, 1) if ((v2 or g3) and (need_dx or (PLANE_WGRAD and weight.requires_grad))
                                          and PLANE_PRODUCERS) else None
             # plane mode: when the weight gradient and the data gradient both read the bf16 planes, nobody reads the fp32 form
-            f32_dead = (dpl is not None and ks == 3 and split == 0 and PLANE_CONV and PLANE_WGRAD and PLANES_ONLY_GRAD
-                        and (need_dx or weight.requires_grad))
+            # (1x1 layers: the plane GEMM and the plane weight gradient, gemm_bf16v3.hip / wgrad_bf16v3.hip)
+            f32_dead = (dpl is not None and split == 0 and PLANE_WGRAD and PLANES_ONLY_GRAD and (need_dx or weight.requires_grad)
+                        and ((ks == 3 and PLANE_CONV) or (g3 and _rup(cout, 32) <= 16384)))
             dyr.f32_valid = not f32_dead
             bp = tp.bnpart.pop(id(y), None)
             _lib.call(*(("hpri_bn_relu_bwd_fused_x16" if yr16 else "hpri_bn_relu_bwd_fused", _p(bp[0]), bp[1], bp[2]) if bp is not None else
@@ -936,7 +967,7 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
             main, side = torch.cuda.current_stream(dev), _side(dev)
             side.wait_stream(main)                      # dyr (and everything before it) is ready
             with torch.cuda.stream(side):
-                _wgrad(x, dyr, dw, acc_w, cin, cout, ks, bf16=lowp, split=split)
+                _wgrad(x, dyr, dw, acc_w, cin, cout, ks, bf16=lowp, split=split, gap=k_gap)
             for a_ in (x, dyr):                          # keep the caching allocator from recycling them early
                 a_.buf.record_stream(side)
                 if a_.pl is not None:
@@ -945,7 +976,7 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
             tp.used_side = True
         else:
             dw, acc_w = tp.param_slot(weight)
-            _wgrad(x, dyr, dw, acc_w, cin, cout, ks, bf16=lowp, split=split)
+            _wgrad(x, dyr, dw, acc_w, cin, cout, ks, bf16=lowp, split=split, gap=k_gap)
         if need_dx:
             gx, acc = tp.grad_slot(x)
             # the column sums of (a channel range of) this gradient are wanted -- the bias gradient of the ConvTranspose2d that
@@ -1006,8 +1037,8 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
                 wpd, cin_cols_pad = _pack_bf16(weight, 1, cout, cin, T, cin, split=0)
                 _conv_launch_v2(dyr, wpd, None, gx, gstats, cout, cin, cin_cols_pad, gx.cw, accumulate=int(acc))
             elif g3:
-                wpd, cin_cols_pad = _pack_bf16(weight, 1, cout, cin, T, cin, split=0)
-                _gemm_launch(dyr, wpd, None, gx, None, cout, cin, cin_cols_pad, gx.cw, accumulate=int(acc))
+                wpd, cin_cols_pad = _pack_bf16(weight, 1, cout, x.C if k_gap else cin, T, cin, split=0, gap=k_gap)
+                _gemm_launch(dyr, wpd, None, gx, None, cout, x.C, cin_cols_pad, gx.cw, accumulate=int(acc))
             elif lowp:
                 wpd, cin_cols_pad = _pack_bf16(weight, 1, cout, cin, T, cin, split=split)
                 _conv_launch_bf16(dyr, wpd, None, gx, None, x.N, x.H, x.W, dyr.cw, cin, cin_cols_pad, gx.cw, ks,
@@ -1099,11 +1130,39 @@ def _conv_folded_eval(x: Act, weight: torch.Tensor, bias: Optional[torch.Tensor]
 def _wgrad(x: Act, dy: Act, dw: torch.Tensor, accumulate: int, cin: int, cout: int, ks: int,
            bmode: int = A_DIRECT, dst_mode: int = 0, N: int = 0, H: int = 0, W: int = 0,
            H2: int = 0, W2: int = 0, py0: int = 0, px0: int = 0, cup: int = 0, bf16: bool = False,
-           split: int = 0) -> None:
+           split: int = 0, gap: Optional[Tuple[int, int]] = None) -> None:
     N, H, W = (N or x.N), (H or x.H), (W or x.W)
     cin_pad = x.cw
     cout_pad = _rup(cout, 64)
     plane_route = bf16 and split == 0 and ks == 3 and bmode == A_DIRECT and dst_mode == 0 and PLANE_CONV and PLANE_WGRAD
+    # 1x1 layers of the bf16 mode: both operands as planes too (wgrad_bf16v3.hip)
+    plane1 = (bf16 and split == 0 and ks == 1 and bmode == A_DIRECT and dst_mode == 0 and PLANE_GEMM and PLANE_WGRAD
+              and _rup(x.C, 32) <= 16384 and _rup(cout, 32) <= 16384)
+    if gap is not None and not plane1:
+        raise RuntimeError("hyperpri_amd: internal error: a padded concat reached a weight-gradient kernel that does not know its gap")
+    if plane1:
+        xpl, dpl = planes_of(x, 1), planes_of(dy, 1)
+        sp = ctypes.c_int(); pcr = ctypes.c_int(); pnr = ctypes.c_int()
+        npx = N * H * W
+        xcw = min(xpl.cw, _rup(x.C, 32))
+        _lib.call("hpri_wgrad1x1_bf16v3_plan", npx, xcw, cout_pad, ctypes.byref(sp), ctypes.byref(pcr), ctypes.byref(pnr))
+        pws = _ws(sp.value * pcr.value * pnr.value, x.buf.device)
+        ptag = "wgrad_planes_bf16<1,v3 256x128>"
+        if SHAPE_TAGS:
+            ptag += f" N{N} {H}x{W} C{xcw} N{cout}"
+        with _timed(ptag, 2.0 * npx * cin * cout):
+            _lib.call("hpri_wgrad1x1_bf16v3", _p(xpl.buf), xpl.cs, xpl.coff, xcw, _p(dpl.buf), dpl.cs, dpl.coff,
+                      min(dpl.cw, _rup(cout, 32)), _p(pws), pws.numel(), npx, xcw, cout_pad, _stream())
+        if gap is None:
+            _lib.call("hpri_wgrad_reduce_ex", _p(pws), _p(dw), sp.value, pcr.value, pnr.value, cin, cout, 1, 0, 0, accumulate, _stream())
+        else:
+            # the slabs' columns follow the padded concat: reduce at that width, then drop the gap columns on the way into dW
+            g0, gl = gap
+            tmp = torch.empty((cout, x.C), dtype=torch.float32, device=x.buf.device)
+            _lib.call("hpri_wgrad_reduce_ex", _p(pws), _p(tmp), sp.value, pcr.value, pnr.value, x.C, cout, 1, 0, 0, 0, _stream())
+            _lib.call("hpri_copy_slice_any", _p(tmp), x.C, 0, _p(dw), cin, 0, cout, g0, 0, int(accumulate), _stream())
+            _lib.call("hpri_copy_slice_any", _p(tmp), x.C, g0 + gl, _p(dw), cin, g0, cout, cin - g0, 0, int(accumulate), _stream())
+        return
     if not plane_route and not (x.f32_valid and dy.f32_valid):
         # every kernel below reads fp32: a planes-only operand (bf16 plane mode) would be read as uninitialised memory
         raise RuntimeError("hyperpri_amd: internal error: a planes-only activation reached a weight-gradient kernel that reads fp32")
@@ -1422,6 +1481,41 @@ def concat_channels(tape: Tape, a: Act, b: Act) -> Act:
                           0 if acc else gb.cw, int(acc), _stream())
         tape.nodes.append(bwd)
     return cat
+
+
+def plane_gemm_mode(module, bnorm: bool = True) -> bool:
+    """SpectralUNET in the bf16 mode with every switch of the plane path on: its skips are concatenated on planes (the two
+    halves' producers write into one padded plane buffer) and the inner tensors exist as planes only."""
+    prec = getattr(module, "hpri_precision", None) or DEFAULT_PRECISION
+    return bool(bnorm and prec == "bf16" and PLANE_GEMM and PLANE_WGRAD and PLANE_PRODUCERS and PLANES_ONLY_ACT and PLANES_CAT1)
+
+
+# HPRI_PLANES_CAT1=0: SpectralUNET's skips are concatenated in fp32 by copies (and converted to planes afterwards), as before.
+PLANES_CAT1 = os.environ.get("HPRI_PLANES_CAT1", "1") != "0"
+
+
+def concat_planes(tape: Tape, a: Act, b: Act) -> Tuple[Act, Tuple[int, int]]:
+    """torch.cat((a, b), -1) (models.py:139-143) when both halves already sit in one padded plane buffer (``conv_bn_relu`` with
+    ``cat_room`` / ``cat_into``): nothing is copied.  Returns the concat as a planes-only Act of the PADDED width and the
+    (first, length) of its structural-zero channels, which the consumer hands to ``conv_bn_relu(k_gap=...)``."""
+    if a.cat_pl is None or b.pl is None or b.pl.buf is not a.cat_pl[0]:
+        raise RuntimeError("hyperpri_amd: internal error: concat_planes needs halves produced with cat_room / cat_into")
+    cbuf, ccs, ob, c2 = a.cat_pl
+    C = ob + c2
+    cat = Act(torch.empty(8, dtype=torch.float32, device=a.buf.device), a.N, a.H, a.W, C, _rup(C, 8), 0)
+    cat.f32_valid = False
+    cat.pl = Planes(cbuf, a.P * ccs, ccs, 0, 1)
+    if tape.record:
+        def bwd(tp: Tape) -> None:
+            g = tp.grads.pop(id(cat), None)
+            if g is None:
+                return
+            # both halves start at multiples of 32 channels of the consumer's input gradient: views (the gap columns hold exact
+            # zeros: their weights are zero in the data-gradient pack)
+            tp.set_grad_view(a, Act(g.buf, g.N, g.H, g.W, a.C, g.cs, g.coff))
+            tp.set_grad_view(b, g.slice(ob, b.C))
+        tape.nodes.append(bwd)
+    return cat, (a.C, ob - a.C)
 
 
 # --------------------------------------------------------------------------------------------------

@@ -106,23 +106,42 @@ class SpectralUNET(torch.nn.Module):
         return torch.nn.Sequential(torch.nn.Linear(in_feats, out_feats), torch.nn.BatchNorm1d(out_feats),
                                    torch.nn.ReLU())
 
-    def _layer(self, tape, x, seq, need_dx=True):
+    def _layer(self, tape, x, seq, need_dx=True, **kw):
         bn = E.BNRef(seq[1]) if self._bnorm else None
         return E.conv_bn_relu(tape, x, seq[0].weight, seq[0].bias, bn, self.training, 1, groups=x.N, need_dx=need_dx,
-                              precision=getattr(self, "hpri_precision", None))
+                              precision=getattr(self, "hpri_precision", None), **kw)
 
     def forward(self, x):
         E.throttle(x.device)
         def prog(tape, a, need):
-            x0 = self._layer(tape, a[0], self.tail, need[0])
-            x1 = self._layer(tape, x0, self.down1)
-            x2 = self._layer(tape, x1, self.down2)
-            x3 = self._layer(tape, x2, self.down3)
-            x4 = self._layer(tape, x3, self.down4)
-            t = self._layer(tape, x4, self.up1)
-            t = self._layer(tape, E.concat_channels(tape, x3, t), self.up2)
-            t = self._layer(tape, E.concat_channels(tape, x2, t), self.up3)
-            t = self._layer(tape, E.concat_channels(tape, x1, t), self.up4)
+            L = self._layer
+            if E.plane_gemm_mode(self, self._bnorm) and (tape.record or self.training or not E.FOLD_EVAL_BN):    # (the folded predict path keeps the copying form)
+                # bf16 mode: the three inner skips are concatenated on bf16 planes -- the producers of both halves write into one
+                # padded plane buffer ([skip | zeros to a multiple of 32 | up]), the consumer's weight packs carry the gap -- and the
+                # tensors between the layers exist as planes only (torch.cat of models.py:139-143 without a byte moved)
+                f = self.layer_feats[0]
+                x0 = L(tape, a[0], self.tail, need[0])
+                x1 = L(tape, x0, self.down1, cat_room=f, planes_only=True)
+                x2 = L(tape, x1, self.down2, cat_room=f, planes_only=True)
+                x3 = L(tape, x2, self.down3, cat_room=f, planes_only=True)
+                x4 = L(tape, x3, self.down4, planes_only=True)
+                t = L(tape, x4, self.up1, cat_into=x3, planes_only=True)
+                c, gap = E.concat_planes(tape, x3, t)
+                t = L(tape, c, self.up2, k_gap=gap, cat_into=x2, planes_only=True)
+                c, gap = E.concat_planes(tape, x2, t)
+                t = L(tape, c, self.up3, k_gap=gap, cat_into=x1, planes_only=True)
+                c, gap = E.concat_planes(tape, x1, t)
+                t = L(tape, c, self.up4, k_gap=gap)
+                return E.out_conv(tape, E.concat_channels(tape, x0, t), self.outc.weight, self.outc.bias, fuse_loss=self.n_classes == 1)
+            x0 = L(tape, a[0], self.tail, need[0])
+            x1 = L(tape, x0, self.down1)
+            x2 = L(tape, x1, self.down2)
+            x3 = L(tape, x2, self.down3)
+            x4 = L(tape, x3, self.down4)
+            t = L(tape, x4, self.up1)
+            t = L(tape, E.concat_channels(tape, x3, t), self.up2)
+            t = L(tape, E.concat_channels(tape, x2, t), self.up3)
+            t = L(tape, E.concat_channels(tape, x1, t), self.up4)
             return E.out_conv(tape, E.concat_channels(tape, x0, t), self.outc.weight, self.outc.bias, fuse_loss=self.n_classes == 1)
         out = run(prog, [x], list(self.parameters()))
         if self.n_classes != 1:

@@ -151,6 +151,11 @@ int hpri_conv_fwd_bf16_plan(int N, int H, int W, int Cin_pad, int Cout_pad, int 
                             int* ksplit, int* stat_tiles, size_t* ws_floats);
 int hpri_pack_weight_bf16(const float* w, void* wp, int mode, int K, int Ncols, int Ncols_pad, int T, int src_d1,
                           int Cup, int split, hipStream_t stream);
+/* The same for a layer whose INPUT-channel axis carries gap_len structural-zero channels from gap_at on (the padded concat of the
+ * bf16 plane mode: [a | zeros up to a multiple of 32 | b]); modes 0 / 1; K (mode 0) resp. Ncols (mode 1) is the padded width, src_d1
+ * the weight's own. */
+int hpri_pack_weight_bf16_gap(const float* w, void* wp, int mode, int K, int Ncols, int Ncols_pad, int T, int src_d1, int gap_at,
+                              int gap_len, hipStream_t stream);
 int hpri_conv_fwd_bf16(const float* x, int x_cs, int x_coff, const void* wp, const float* bias, float* y, int y_cs,
                        int y_coff, float* stats, int N, int H, int W, int Cin_pad, int Cout, int Cout_pad, int y_cw,
                        int KS, int amode, int epi, int accumulate, int H2, int W2, int py0, int px0, int Cup, int split,

@@ -287,6 +287,44 @@ def test_full_size_cubenet128_bf16_vs_reference_fixture():
         assert abs(g - ref) <= 0.1 * ref + 1e-6, (k, g, ref)
 
 
+def test_full_size_spectral1650_bf16_vs_reference_fixture():
+    """BASELINE config C3 (SpectralUNET-1650 @608x700) in the bf16 mode against the REFERENCE fixture: the whole Linear stack on the
+    plane-fed GEMM / weight-gradient kernels (gemm_bf16v3.hip, wgrad_bf16v3.hip), skips concatenated on planes.  The gates of
+    tools/c3_modes.py: loss, sign agreement and Dice/IoU level, gradient norms."""
+    from hyperpri_amd import engine as E
+    z = _load("net_spectral1650_full")
+    seen = []
+    real = E._lib.call
+
+    def spy(name, *a):
+        seen.append(name)
+        return real(name, *a)
+    E._lib.call = spy
+    try:
+        net, xd, mask, lg, loss = _full_size_step("c3", "bf16")
+    finally:
+        E._lib.call = real
+    assert "hpri_gemm_bf16v3" in seen and "hpri_wgrad1x1_bf16v3" in seen and "hpri_conv_fwd_bf16" not in seen and "hpri_conv_wgrad_bf16" not in seen
+    stride = int(z["stride"])
+    sub = lg.reshape(-1)[::stride].numpy()
+    d = np.abs(sub - z["logits_sub"])
+    record_margin("full/c3_bf16/logits", d.max(), 0.05)
+    assert d.max() < 0.05 and abs(loss - float(z["loss"])) < 1e-4
+    assert float(((sub > 0) != (z["logits_sub"] > 0)).mean()) < 0.01
+    acc, dice, iou = O.seg_metrics(lg, mask)
+    assert abs(dice - float(z["dice"])) < 5e-4 and abs(iou - float(z["iou"])) < 5e-4
+    grads = OrderedDict((k, p.grad) for k, p in net.named_parameters())
+    worst = 0.0
+    for i, k in enumerate(list(z["grad_names"])):
+        if grads[k].dim() <= 1:
+            continue
+        g = float(grads[k].detach().double().norm())
+        ref = float(z["grad_l2"][i])
+        worst = max(worst, abs(g - ref) / (ref + 1e-12))
+        assert abs(g - ref) <= 0.1 * ref + 1e-6, (k, g, ref)
+    record_margin("full/c3_bf16/grad_norms", worst, 0.1)
+
+
 X3_CASES = [c for c in CASES if c[0] in ("net_unet3_tiny", "net_cubenet64_tiny", "net_cubenet128_tiny", "net_spectral_f50")]
 
 

@@ -57,11 +57,19 @@ def main():
             tot += v["total_ms"]
             print(f"{k:90s} n={v['launches']:3d} {v['total_ms']:9.3f} ms {v['tflops']:7.1f} TF")
         print("sum of timed kernels", round(tot, 2), "ms")
+    for _ in range(int(os.environ.get("WARM", "1")) - 1):      # further untimed steps (the allocator settles after two or three)
+        step()
+    torch.cuda.synchronize()
+    ms0 = torch.cuda.memory_stats()
     t0 = time.perf_counter()
     for _ in range(steps):
         loss = step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
+    ms1 = torch.cuda.memory_stats()
+    print("allocator in the timed steps: device mallocs", ms1.get("num_device_alloc", 0) - ms0.get("num_device_alloc", 0), "frees",
+          ms1.get("num_device_free", 0) - ms0.get("num_device_free", 0), "retries", ms1.get("num_alloc_retries", 0) - ms0.get("num_alloc_retries", 0),
+          "reserved GiB", round(torch.cuda.memory_reserved() / 2**30, 1), flush=True)
     print(f"{name} batch {batch}: {dt * 1e3:.1f} ms/step, {batch / dt:.3f} units/s, {batch * gflop / dt / 1e3:.1f} model TFLOP/s, "
           f"loss {float(loss.detach()):.6f}, peak mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB", flush=True)
 
