@@ -46,11 +46,25 @@ struct WgV2Args {
 #define WG_YB (WG_YI * 1024)
 #define WG_UB (WG_XB + WG_YB)
 
+#ifdef WG_BUILTIN_TR      /* the form of rounds 2-3 (A/B): hipcc puts "s_waitcnt vmcnt(0)" in front of every group of these reads */
 __device__ __forceinline__ bf16x8 wg_tr_frag(const unsigned char* p) {
   const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(p));
   const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(p + 512));     // pixel rows +4
   return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
+#endif
+// One fragment = two transposed reads (pixel rows L and L + 4) as inline assembly.  Through the builtin hipcc sees an LDS read it cannot
+// tell apart from the LDS-DMA writes in flight and waits vmcnt(0) before every group of reads: each DMA piece issued between the MFMAs
+// was waited for at once (wgrad_bf16v3.hip has the story).  The unit's counted vmcnt + barrier orders DMA writes and reads; the reads'
+// own completion is waited for by WG_WAIT_* below, whose operands tie the wait to the registers it guards.
+struct WgFrag { bf16x4 lo, hi; };
+__device__ __forceinline__ void wg_tr_issue(WgFrag& f, unsigned lds_addr) {
+  asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:512" : "=&v"(f.lo), "=&v"(f.hi) : "v"(lds_addr));
+}
+__device__ __forceinline__ bf16x8 wg_frag(const WgFrag& f) { return __builtin_shufflevector(f.lo, f.hi, 0, 1, 2, 3, 4, 5, 6, 7); }
+#define WG_WAIT5(a_, b0_, b1_, b2_, b3_)                                                                                  \
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a_.lo), "+v"(a_.hi), "+v"(b0_.lo), "+v"(b0_.hi), "+v"(b1_.lo), "+v"(b1_.hi), \
+               "+v"(b2_.lo), "+v"(b2_.hi), "+v"(b3_.lo), "+v"(b3_.hi))
 
 __global__ __launch_bounds__(512, 2) void conv_wgrad_bf16v2_kernel(WgV2Args a) {
   __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * WG_UB];
@@ -151,6 +165,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_bf16v2_kernel(WgV2Args a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
   if (u_begin < u_end) ISSUE_UNIT(u_begin, 0)
   for (int u = u_begin; u < u_end; ++u) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -158,24 +173,21 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_bf16v2_kernel(WgV2Args a) {
     const int bo = ((u - u_begin) & 1) * WG_UB;
     const bool more = u + 1 < u_end;
     ISSUE_PREP(more ? u + 1 : u, ((u + 1 - u_begin) & 1))
+#ifdef WG_BUILTIN_TR
     const unsigned char* sb = smem + bo;
 #pragma unroll
     for (int k4 = 0; k4 < 4; ++k4) {
-      // k16-step 4 kg + k4 of the unit; kg is a run-time (wave-uniform) value: its offsets go into the base, not the immediates
-      const int py_l = k4 >> 1, pxo = 16 * (k4 & 1);                 // row inside this group's two rows
+      const int py_l = k4 >> 1, pxo = 16 * (k4 & 1);
       const unsigned char* yrow = sb + yB + kg * (64 * 128) + (py_l * 32 + pxo) * 128;
       const bf16x8 af = wg_tr_frag(yrow);
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
         const int dy = t / 3, dx = t - dy * 3;
-        // window start T = (2 kg + py_l + dy) * 34 + pxo + dx: 2*kg*34 = 68 kg is a multiple of 4 -> parity and bit 1 of T
-        // are those of T0 = (py_l + dy) * 34 + pxo + dx
         const int T0 = (py_l + dy) * WG_HW + pxo + dx;
         const int odd = T0 & 1, tbit = ((T0 - odd) >> 1) & 1;
         const int base = (odd ? xO : xE) ^ (tbit << 6);
         const bf16x8 bfr = wg_tr_frag(sb + base + kg * (2 * WG_HW * 128) + T0 * 128);
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[t], 0, 0, 0);
-        // one DMA piece of the next unit behind MFMAs 2, 8, 14, 20 (X) and 26, 32 (dY) of the unit's 36
         if (more) {
           const int m = k4 * 9 + t;
           if (m == 2) ISSUE_X(0)
@@ -187,6 +199,60 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_bf16v2_kernel(WgV2Args a) {
         }
       }
     }
+#else
+    // k16-step 4 kg + k4 of the unit; kg is a run-time (wave-uniform) value: its offsets go into the bases, not the constants.
+    // X window start T = (2 kg + py_l + dy) * 34 + pxo + dx: 68 kg is a multiple of 4 -> parity and bit 1 of T are those of
+    // T0 = (py_l + dy) * 34 + pxo + dx; the half swap (^ 64) commutes with the additions (all multiples of 128).
+    const unsigned ya = lds0 + bo + yB + kg * (64 * 128);
+    const unsigned xe = lds0 + bo + xE + kg * (2 * WG_HW * 128), xo = lds0 + bo + xO + kg * (2 * WG_HW * 128);
+#define WG_XADDR(K4_, T_)                                                                                              \
+  ((((((K4_) >> 1) + (T_) / 3) * WG_HW + 16 * ((K4_) & 1) + (T_) % 3) & 1 ? xo : xe) ^                                  \
+   (((((((K4_) >> 1) + (T_) / 3) * WG_HW + 16 * ((K4_) & 1) + (T_) % 3) >> 1) & 1) << 6)) +                             \
+      ((((K4_) >> 1) + (T_) / 3) * WG_HW + 16 * ((K4_) & 1) + (T_) % 3) * 128
+#define WG_YADDR(K4_) (ya + ((((K4_) >> 1) * 32 + 16 * ((K4_) & 1)) * 128))
+    // Two read groups per k16-step, each waited for as a whole (lgkmcnt(0): scalar loads share the counter, so no counted waits):
+    // group A = the dY fragment + taps 0-3, group B = taps 4-8.  B arrives under the MFMAs of taps 0-3, the next step's A under 4-8.
+    WgFrag af[2], ba[4], bb[5];
+    wg_tr_issue(af[0], WG_YADDR(0));
+#pragma unroll
+    for (int t = 0; t < 4; ++t) wg_tr_issue(ba[t], WG_XADDR(0, t));
+    WG_WAIT5(af[0], ba[0], ba[1], ba[2], ba[3]);
+#pragma unroll
+    for (int k4 = 0; k4 < 4; ++k4) {
+#pragma unroll
+      for (int t = 4; t < 9; ++t) wg_tr_issue(bb[t - 4], WG_XADDR(k4, t));
+      const bf16x8 a8 = wg_frag(af[k4 & 1]);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, wg_frag(ba[t]), acc[t], 0, 0, 0);
+        if (more) {
+          const int m = k4 * 9 + t;
+          if (m == 2) ISSUE_X(0)
+          if (m == 20) ISSUE_X(3)
+        }
+      }
+      WG_WAIT5(bb[0], bb[1], bb[2], bb[3], bb[4]);
+      if (k4 < 3) {
+        wg_tr_issue(af[(k4 + 1) & 1], WG_YADDR(k4 + 1));
+#pragma unroll
+        for (int t = 0; t < 4; ++t) wg_tr_issue(ba[t], WG_XADDR(k4 + 1, t));
+      }
+#pragma unroll
+      for (int t = 4; t < 9; ++t) {
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, wg_frag(bb[t - 4]), acc[t], 0, 0, 0);
+        if (more) {
+          const int m = k4 * 9 + t;
+          if (m == 8) ISSUE_X(1)
+          if (m == 14) ISSUE_X(2)
+          if (m == 26) ISSUE_Y(0)
+          if (m == 32) ISSUE_Y(1)
+        }
+      }
+      if (k4 < 3) WG_WAIT5(af[(k4 + 1) & 1], ba[0], ba[1], ba[2], ba[3]);
+    }
+#undef WG_XADDR
+#undef WG_YADDR
+#endif
   }
 #undef ISSUE_UNIT
 #undef ISSUE_PREP
