@@ -50,6 +50,10 @@ struct ConvV3Args {
   // also reads the pre-BN tensor bn_x (bf16, elements per pixel bn_x_cs, first channel bn_x_coff, bn_cw readable channels) at its
   // output positions and leaves per-tile partial sums of that BatchNorm's backward, bn_part[stat tile][2][bn_cpart] =
   // (sum g*[y>0], sum g*[y>0]*xhat): the stage that produced x then skips its two reduction sweeps (hpri_bn_relu_bwd_fused)
+  // second output: channels [y2_c0, y2_c0 + y2_cw) (whole 64-channel blocks) of the result ALSO (y2_only: ONLY) as bf16 rows of
+  // y2_cs elements from y2_coff on -- the gradient of the upsampled half of a decoder concat, which its readers (the transposed
+  // convolution's data and weight gradient: gemm_bf16v3.hip, wgrad_bf16v3.hip) stage as planes
+  __bf16* y2; int y2_cs, y2_coff, y2_c0, y2_cw, y2_only;
   const __bf16* bn_x; int bn_x_cs, bn_x_coff, bn_cw, bn_relu, bn_cpart;
   const float *bn_mean, *bn_invstd, *bn_scale, *bn_shift;
   float* bn_part;
@@ -444,7 +448,27 @@ __global__ __launch_bounds__(256, 2) void conv_bf16v3_kernel(ConvV3Args a) {
           if (COND_) *reinterpret_cast<f32x4*>(prow[mt] + nt * 16) = acc[mt][nt];                                     \
     }                                                                                                                 \
   }
-    if (!BNRED && !raw && a.y16) {
+    const bool to_y2 = !BNRED && !raw && a.y2 != nullptr && cur.nb * 64 >= a.y2_c0 && cur.nb * 64 < a.y2_c0 + a.y2_cw;
+    if (to_y2) {
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        if ((vmask >> mt) & 1u) {
+          const int p = (wave * 4 + mt) * 16 + li;
+          const int iy = cur.y0 + (p >> twl), ix = cur.x0 + (p & (TW - 1));
+          __bf16* q = a.y2 + ((size_t)(cur.img * a.H + iy) * a.W + ix) * a.y2_cs + a.y2_coff + (cur.nb * 64 - a.y2_c0) + 4 * lq;
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) {
+            bf16x4_t h;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h[r] = (__bf16)acc[mt][nt][r];
+            *reinterpret_cast<bf16x4_t*>(q + nt * 16) = h;
+          }
+        }
+      }
+    }
+    if (to_y2 && a.y2_only) {
+      // (this block of the result exists as bf16 rows only)
+    } else if (!BNRED && !raw && a.y16) {
       // bf16 output: a lane's four channels are one 8-byte store (round-to-nearest-even, v_cvt_pk_bf16_f32)
       __bf16* d16 = reinterpret_cast<__bf16*>(a.y);
 #pragma unroll
@@ -671,6 +695,7 @@ extern "C" int hpri_splitk_finish(const float* ws, int ksplit, int Cout_pad, con
 
 #define V3_STAGGER_CYCLES 6000      // about one store + statistics epilogue with a partner on the CU
 
+struct V3Out2 { void* y2; int cs, coff, c0, cw, only; };
 struct V3BnRed {
   const void* x16; int x_cs, x_coff; const float *mean, *invstd, *scale, *shift; int relu; float* part; int cpart;
 };
@@ -678,7 +703,8 @@ struct V3BnRed {
 static int v3_launch(const void* xp, long long x_plane, int x_cs, int x_coff, const void* wp, const float* bias,
                      float* y, int y_cs, int y_coff, float* stats, int N, int H, int W, int Cin_pad, int Cout,
                      int Cout_pad, int y_cw, int accumulate, int split, float* ws, size_t ws_floats,
-                     unsigned long long* stamps, int stagger_cycles, const V3BnRed* bn, hipStream_t stream) {
+                     unsigned long long* stamps, int stagger_cycles, const V3BnRed* bn, hipStream_t stream,
+                     const V3Out2* o2 = nullptr) {
   HPRI_REQUIRE(xp && wp && y, "conv_bf16v3: null pointer");
   HPRI_REQUIRE(N > 0 && H > 0 && W > 0, "conv_bf16v3: empty image");
   HPRI_REQUIRE(Cin_pad > 0 && Cin_pad % 32 == 0, "conv_bf16v3: Cin_pad must be a positive multiple of 32");
@@ -725,6 +751,15 @@ static int v3_launch(const void* xp, long long x_plane, int x_cs, int x_coff, co
   if (nloc < 1) nloc = 1;
   if (nloc > a.per_xcd) nloc = a.per_xcd;
   dim3 grid((unsigned)(nloc * 8), 1u, (unsigned)a.ksplit);
+  a.y2 = nullptr; a.y2_cs = a.y2_coff = a.y2_c0 = a.y2_cw = a.y2_only = 0;
+  if (o2 != nullptr) {
+    HPRI_REQUIRE(o2->y2 != nullptr && bn == nullptr && a.ksplit == 1 && !a.accumulate && !a.y16,
+                 "conv_bf16v3_y2: the second output is not for split-K problems (hpri_conv_bf16v3_plan), accumulating launches or bf16 results");
+    HPRI_REQUIRE(o2->c0 % 64 == 0 && o2->cw % 64 == 0 && o2->cw > 0 && o2->c0 + o2->cw <= Cout_pad, "conv_bf16v3_y2: the channel range must be whole 64-channel blocks");
+    HPRI_REQUIRE(o2->cs % 4 == 0 && o2->coff % 4 == 0 && o2->coff + o2->cw <= o2->cs && ((uintptr_t)o2->y2 & 7) == 0,
+                 "conv_bf16v3_y2: the bf16 view must be 8-byte aligned and hold the channel range");
+    a.y2 = reinterpret_cast<__bf16*>(o2->y2); a.y2_cs = o2->cs; a.y2_coff = o2->coff; a.y2_c0 = o2->c0; a.y2_cw = o2->cw; a.y2_only = o2->only;
+  }
   a.bn_part = nullptr;
   if (bn != nullptr) {
     HPRI_REQUIRE(bn->x16 && bn->mean && bn->invstd && bn->scale && bn->shift && bn->part, "conv_bf16v3_bnred: null pointer");
@@ -766,6 +801,18 @@ extern "C" int hpri_conv_bf16v3_bnred(const void* xp, int x_cs, int x_coff, cons
   const V3BnRed bn{bn_x16, bn_x_cs, bn_x_coff, bn_mean, bn_invstd, bn_scale, bn_shift, bn_relu, bn_part, bn_cpart};
   return v3_launch(xp, 0, x_cs, x_coff, wp, nullptr, y, y_cs, y_coff, nullptr, N, H, W, Cin_pad, Cout, Cout_pad, y_cw, 0, 0, nullptr, 0,
                    nullptr, V3_STAGGER_CYCLES, &bn, stream);
+}
+
+// hpri_conv_bf16v3 (no accumulate, no split-K) whose result channels [c0, c0 + cw) -- whole 64-channel blocks -- are also
+// (y2_only != 0: only) written as bf16 rows: y2 + pixel * y2_cs + y2_coff + (channel - c0).  The data gradient of the first
+// convolution of a decoder stage leaves the gradient of the upsampled half of its concat input this way, for the plane-fed
+// transposed-convolution kernels (hpri_convt_dgrad_bf16v3, hpri_wgrad_convt_bf16v3).
+extern "C" int hpri_conv_bf16v3_y2(const void* xp, int x_cs, int x_coff, const void* wp, const float* bias, float* y, int y_cs, int y_coff,
+                                   float* stats, int N, int H, int W, int Cin_pad, int Cout, int Cout_pad, int y_cw, void* y2, int y2_cs,
+                                   int y2_coff, int y2_c0, int y2_cw, int y2_only, hipStream_t stream) {
+  const V3Out2 o2{y2, y2_cs, y2_coff, y2_c0, y2_cw, y2_only};
+  return v3_launch(xp, 0, x_cs, x_coff, wp, bias, y, y_cs, y_coff, stats, N, H, W, Cin_pad, Cout, Cout_pad, y_cw, 0, 0, nullptr, 0, nullptr,
+                   V3_STAGGER_CYCLES, nullptr, stream, &o2);
 }
 
 // 3x3 pad-1 convolution (forward, or data gradient with the flipped pack) over bf16 activation planes: same argument

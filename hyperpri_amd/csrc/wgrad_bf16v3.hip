@@ -31,6 +31,9 @@ struct Wg1Args {
   float* ws;                                          // [splits][Nr][Cr]
   long long P;                                        // pixels (all images)
   int Cr, Nr, splits, tiles_c, tiles, stages_per_split, total_stages;
+  // MODE 1 (ConvTranspose2d(2,2): dW[ci][co][tap] = sum_p X[p][ci] * dY[up(p, tap)][co]): X rows are the N*H*W low-resolution pixels,
+  // row n = tap * cup + co of the slab gathers dY at pixel (py0 + 2y + tap/2, px0 + 2x + tap%2) of the [N, H2, W2] gradient planes
+  int HW, W, H2, W2, py0, px0, cup;
 };
 
 // One fragment = two transposed reads (pixel rows L and L + 4).  Written as inline assembly: through the builtin
@@ -49,6 +52,7 @@ __device__ __forceinline__ bf16x8 w1_tr_frag(unsigned lds_addr) {
 #define W1_WAIT_FRAGS(a_, b_)                                                                                         \
   asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a_[0]), "+v"(a_[1]), "+v"(a_[2]), "+v"(a_[3]), "+v"(b_[0]), "+v"(b_[1]))
 
+template <int MODE>
 __global__ __launch_bounds__(256, 2) void wgrad1x1_bf16v3_kernel(Wg1Args a) {
   __shared__ __attribute__((aligned(1024))) unsigned char smem[3 * W1_STAGE_BYTES];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -76,28 +80,48 @@ __global__ __launch_bounds__(256, 2) void wgrad1x1_bf16v3_kernel(Wg1Args a) {
     const int ls = (lane & 7) ^ (((r >> 1) & 1) << 2);
     const int ch = arr * 64 + ls * 8;
     const bool ok = isx ? (c_blk + ch < a.x_cvalid) : (n_blk + ch < a.dy_cvalid);
-    off[q] = (unsigned)((isx ? r * a.x_cs : r * a.dy_cs) + ch) * 2u;
+    off[q] = (MODE == 1 && !isx) ? (unsigned)((ch - arr * 64) * 2)         // channel inside the array; the row comes per stage
+                                 : (unsigned)((isx ? r * a.x_cs : r * a.dy_cs) + ch) * 2u;
     okbits |= ok ? (1u << q) : 0u;                   // channels beyond the valid width: zero-filled (out-of-range offset)
   }
   const __bf16* xbase = a.xp + a.x_coff + c_blk;
-  const __bf16* ybase = a.dyp + a.dy_coff + n_blk;
+  const __bf16* ybase = MODE == 1 ? a.dyp + a.dy_coff : a.dyp + a.dy_coff + n_blk;
+  // MODE 1: the four dY arrays of a workgroup are 64-channel runs of (possibly different) taps; a wave's four dY pieces (q = 0..3)
+  // are the SAME 8 pixel rows of the four arrays, so the gather position is computed once per stage and lane
+  int tapoff[4] = {0, 0, 0, 0};                      // elements to add to the gathered row's offset for array q
+  if (MODE == 1) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int n0 = min(n_blk + q * 64, 4 * a.cup - 64);      // (arrays beyond the valid rows are masked by okbits)
+      const int tap = n0 / a.cup, co0 = n0 - tap * a.cup;
+      tapoff[q] = ((tap >> 1) * a.W2 + (tap & 1)) * a.dy_cs + co0;
+    }
+  }
   // (descriptors rebuilt per stage from the stage's first pixel row: wave-uniform, 64-bit, whatever the tensor size)
 #define W1_ISSUE_PREP(s_)                                                                                              \
   const long long p0_ = (long long)(s_) * 32;                                                                          \
   const unsigned long long px_ = (unsigned long long)(uintptr_t)(xbase + p0_ * a.x_cs);                                \
-  const unsigned long long py_ = (unsigned long long)(uintptr_t)(ybase + p0_ * a.dy_cs);                               \
+  const unsigned long long py_ = (unsigned long long)(uintptr_t)(MODE == 1 ? ybase : ybase + p0_ * a.dy_cs);           \
   /* (readfirstlane returns a SIGNED int: without the casts the low word is sign-extended over the high one) */       \
   const unsigned pxl_ = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)px_), pxh_ = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(px_ >> 32)); \
   const unsigned pyl_ = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)py_), pyh_ = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(py_ >> 32)); \
   const hpri_rsrc_t rx_ = HPRI_MAKE_RSRC((((unsigned long long)pxh_ << 32) | pxl_), 0x7FFFFF00);                       \
   const hpri_rsrc_t ry_ = HPRI_MAKE_RSRC((((unsigned long long)pyh_ << 32) | pyl_), 0x7FFFFF00);                       \
   const long long left_ = a.P - p0_;                 /* pixel rows of this stage that exist */                         \
-  (void)rx_; (void)ry_; (void)left_; (void)pxl_; (void)pxh_; (void)pyl_; (void)pyh_;
+  unsigned grow_ = 0u;                               /* MODE 1: byte offset of this lane's gathered dY row (parity 0) */ \
+  if (MODE == 1) {                                                                                                     \
+    const long long pp_ = p0_ + 8 * wave + (lane >> 3);                                                                \
+    const int pc_ = (int)(pp_ < a.P ? pp_ : a.P - 1);                                                                  \
+    const int img_ = pc_ / a.HW, rem_ = pc_ - img_ * a.HW, yy_ = rem_ / a.W, xx_ = rem_ - yy_ * a.W;                   \
+    grow_ = (unsigned)(((img_ * a.H2 + a.py0 + 2 * yy_) * a.W2 + a.px0 + 2 * xx_) * a.dy_cs) * 2u;                     \
+  }                                                                                                                    \
+  (void)rx_; (void)ry_; (void)left_; (void)pxl_; (void)pxh_; (void)pyl_; (void)pyh_; (void)grow_;
 #define W1_ISSUE(q, bo_)                                                                                               \
   {                                                                                                                    \
     const int i_ = wave + 4 * (q);                                                                                     \
     const bool in_ = ((okbits >> (q)) & 1u) && (long long)(8 * (i_ & 3) + (lane >> 3)) < left_;                        \
     if (i_ >= 16) { HPRI_LDS_DMA16(rx_, smem + (bo_) + i_ * 1024, in_ ? off[q] : HPRI_DMA_OOB, 0); }                   \
+    else if (MODE == 1) { HPRI_LDS_DMA16(ry_, smem + (bo_) + i_ * 1024, in_ ? grow_ + off[q] + (unsigned)(tapoff[(q) & 3] * 2) : HPRI_DMA_OOB, 0); } \
     else          { HPRI_LDS_DMA16(ry_, smem + (bo_) + i_ * 1024, in_ ? off[q] : HPRI_DMA_OOB, 0); }                   \
   }
 
@@ -231,10 +255,41 @@ extern "C" int hpri_wgrad1x1_bf16v3(const void* x_planes, int x_cs, int x_coff, 
   a.xp = reinterpret_cast<const __bf16*>(x_planes); a.x_cs = x_cs; a.x_coff = x_coff; a.x_cvalid = x_cvalid;
   a.dyp = reinterpret_cast<const __bf16*>(dy_planes); a.dy_cs = dy_cs; a.dy_coff = dy_coff; a.dy_cvalid = dy_cvalid;
   a.ws = ws; a.P = P;
+  a.HW = a.W = a.H2 = a.W2 = a.py0 = a.px0 = a.cup = 0;
   const long long items = (long long)a.splits * a.tiles;
   HPRI_REQUIRE(items < (1ll << 24), "wgrad1x1_bf16v3: too many work items");
   dim3 grid((unsigned)(hpri_cdiv((int)items, 8) * 8), 1u, 1u);
-  hipLaunchKernelGGL(wgrad1x1_bf16v3_kernel, grid, dim3(256), 0, stream, a);
+  hipLaunchKernelGGL(wgrad1x1_bf16v3_kernel<0>, grid, dim3(256), 0, stream, a);
+  HPRI_CHECK_LAUNCH();
+  return HPRI_OK;
+}
+
+// ConvTranspose2d(k = 2, s = 2) weight gradient from bf16 planes: x planes [N, H, W] (Cin channels), dy planes [N, H2, W2] (Cup channels
+// from dy_coff on; Cup a multiple of 64); slab rows n = tap * Cup + co, columns ci; sizes from hpri_wgrad1x1_bf16v3_plan(N*H*W, Cin_pad,
+// 4*Cup); finish with hpri_wgrad_reduce_ex(ws, dw, splits, Cr, Nr, Cin, 4*Cup, 1, 1, Cup, accumulate).
+extern "C" int hpri_wgrad_convt_bf16v3(const void* x_planes, int x_cs, int x_coff, int x_cvalid, const void* dy_planes, int dy_cs, int dy_coff,
+                                       float* ws, size_t ws_floats, int N, int H, int W, int Cin_pad, int Cup, int H2, int W2, int py0,
+                                       int px0, hipStream_t stream) {
+  HPRI_REQUIRE(x_planes && dy_planes && ws, "wgrad_convt_bf16v3: null pointer");
+  HPRI_REQUIRE(N > 0 && H > 0 && W > 0 && Cin_pad > 0 && Cup > 0 && Cup % 64 == 0, "wgrad_convt_bf16v3: Cup must be a positive multiple of 64");
+  HPRI_REQUIRE(x_cs % 8 == 0 && x_coff % 8 == 0 && x_cvalid % 8 == 0 && dy_cs % 8 == 0 && dy_coff % 8 == 0,
+               "wgrad_convt_bf16v3: channel strides / offsets / valid widths must be multiples of 8 (16-byte DMA granules)");
+  HPRI_REQUIRE(x_coff + x_cvalid <= x_cs && dy_coff + Cup <= dy_cs && x_cs <= 16384, "wgrad_convt_bf16v3: valid channels exceed the channel stride");
+  HPRI_REQUIRE(((uintptr_t)x_planes & 15) == 0 && ((uintptr_t)dy_planes & 15) == 0, "wgrad_convt_bf16v3: planes must be 16-byte aligned");
+  HPRI_REQUIRE(py0 >= 0 && px0 >= 0 && py0 + 2 * H <= H2 && px0 + 2 * W <= W2, "wgrad_convt_bf16v3: geometry out of range");
+  HPRI_REQUIRE((long long)N * H2 * W2 * dy_cs * 2 < 0x7FFFFF00ll && (long long)N * H * W < (1ll << 31), "wgrad_convt_bf16v3: gradient planes exceed 2 GiB (32-bit DMA offsets)");
+  Wg1Args a;
+  const long long P = (long long)N * H * W;
+  wg1_geometry(P, Cin_pad, 4 * Cup, &a);
+  if ((size_t)a.splits * a.Cr * a.Nr > ws_floats) return hpri_set_error(HPRI_ERR_WORKSPACE, "wgrad_convt_bf16v3: workspace too small");
+  a.xp = reinterpret_cast<const __bf16*>(x_planes); a.x_cs = x_cs; a.x_coff = x_coff; a.x_cvalid = x_cvalid;
+  a.dyp = reinterpret_cast<const __bf16*>(dy_planes); a.dy_cs = dy_cs; a.dy_coff = dy_coff; a.dy_cvalid = 4 * Cup;
+  a.ws = ws; a.P = P;
+  a.HW = H * W; a.W = W; a.H2 = H2; a.W2 = W2; a.py0 = py0; a.px0 = px0; a.cup = Cup;
+  const long long items = (long long)a.splits * a.tiles;
+  HPRI_REQUIRE(items < (1ll << 24), "wgrad_convt_bf16v3: too many work items");
+  dim3 grid((unsigned)(hpri_cdiv((int)items, 8) * 8), 1u, 1u);
+  hipLaunchKernelGGL(wgrad1x1_bf16v3_kernel<1>, grid, dim3(256), 0, stream, a);
   HPRI_CHECK_LAUNCH();
   return HPRI_OK;
 }

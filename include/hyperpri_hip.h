@@ -198,6 +198,12 @@ int hpri_conv_bf16v3_dbg(const void* xp, long long x_plane, int x_cs, int x_coff
                          int accumulate, int split, float* ws, size_t ws_floats, unsigned long long* stamps,
                          int stagger_cycles, hipStream_t stream);
 
+/* hpri_conv_bf16v3 (no accumulate; hpri_conv_bf16v3_plan must report ksplit 1) whose result channels [y2_c0, y2_c0 + y2_cw) -- whole
+ * 64-channel blocks -- are also (y2_only != 0: only) written as bf16 rows, y2 + pixel * y2_cs + y2_coff + (channel - y2_c0): the
+ * gradient of the upsampled half of a decoder concat for the plane-fed transposed-convolution kernels. */
+int hpri_conv_bf16v3_y2(const void* xp, int x_cs, int x_coff, const void* wp, const float* bias, float* y, int y_cs, int y_coff,
+                        float* stats, int N, int H, int W, int Cin_pad, int Cout, int Cout_pad, int y_cw, void* y2, int y2_cs,
+                        int y2_coff, int y2_c0, int y2_cw, int y2_only, hipStream_t stream);
 /* The data gradient of a 3x3 layer in the bf16 plane mode whose input x = ReLU(BN(bn_x16)) has no other consumer, with that
  * BatchNorm's backward reduction taken in the epilogue (bf16 counterpart of hpri_conv_wino4_bnred): bn_x16 = the pre-BN tensor as
  * bf16 (what hpri_conv_bf16v3 wrote with accumulate bit 2; same pixels as y, stride / offset in elements, multiples of 4);
@@ -259,6 +265,13 @@ int hpri_conv_wgrad_bf16v2(const void* x_planes, int x_cs, int x_coff, int x_cva
 int hpri_wgrad1x1_bf16v3_plan(long long P, int Cin_pad, int Cout_pad, int* splits, int* Cr, int* Nr);
 int hpri_wgrad1x1_bf16v3(const void* x_planes, int x_cs, int x_coff, int x_cvalid, const void* dy_planes, int dy_cs, int dy_coff,
                          int dy_cvalid, float* ws, size_t ws_floats, long long P, int Cin_pad, int Cout_pad, hipStream_t stream);
+
+/* ConvTranspose2d(k=2,s=2) weight gradient (model_parts.py:63-64) from bf16 planes: x [N,H,W] (Cin channels) and the gradient of the
+ * upsampled tensor dy [N,H2,W2] (Cup channels from dy_coff on, Cup % 64 == 0), gathered by parity; slab rows n = tap*Cup + co; plan:
+ * hpri_wgrad1x1_bf16v3_plan(N*H*W, Cin_pad, 4*Cup); finish: hpri_wgrad_reduce_ex(ws, dw, splits, Cr, Nr, Cin, 4*Cup, 1, 1, Cup, acc). */
+int hpri_wgrad_convt_bf16v3(const void* x_planes, int x_cs, int x_coff, int x_cvalid, const void* dy_planes, int dy_cs, int dy_coff,
+                            float* ws, size_t ws_floats, int N, int H, int W, int Cin_pad, int Cup, int H2, int W2, int py0, int px0,
+                            hipStream_t stream);
 
 /* ---- BatchNorm (+ReLU) (bn.hip): nn.BatchNorm2d/3d/1d + nn.ReLU, model_parts.py:23-27; models.py:113-114,
  * 172-173,178-179.  G groups = independent statistic sets (G = N for SpectralUNET's per-image loop,

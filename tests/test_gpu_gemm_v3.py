@@ -214,3 +214,82 @@ def test_linear_weight_gradient_from_planes(lib, shape, accumulate):
     # boundary: unaligned valid width, workspace too small
     assert lib.hpri_wgrad1x1_bf16v3(P(xp), xcs, xoff, xv + 4, P(yp), ycs, yoff, yv, P(ws), ws.numel(), Ppx, rup(Cin, 32), rup(Cout, 64), _st()) != 0
     assert lib.hpri_wgrad1x1_bf16v3(P(xp), xcs, xoff, xv, P(yp), ycs, yoff, yv, P(ws), ws.numel() - 1, Ppx, rup(Cin, 32), rup(Cout, 64), _st()) != 0
+
+
+@pytest.mark.parametrize("shape", [(2, 9, 15, 128, 64, 0, 0), (1, 19, 30, 96, 64, 1, 1), (2, 38, 60, 256, 128, 0, 0), (1, 76, 121, 200, 64, 0, 1)])
+def test_transposed_convolution_weight_gradient_from_planes(lib, shape):
+    """hpri_wgrad_convt_bf16v3: dW[ci][co][tap] = sum_p x[p][ci] * dy[up(p, tap)][co], x planes at low resolution, dy planes at
+    high resolution (a channel-slice view, pad ring present in two cases), gathered by parity inside the DMA offsets."""
+    N, H, W, Cin, Cup, dY, dX = shape
+    torch.manual_seed(17)
+    H2, W2 = 2 * H + dY, 2 * W + dX
+    py0, px0 = dY // 2, dX // 2
+    xcs = rup(Cin, 32)
+    x = torch.randn(N * H * W, Cin, device=DEV)
+    xp = _planes(x, xcs)
+    dcs = Cup + 64
+    dy = torch.randn(N, H2, W2, Cup, device=DEV)
+    dyp = torch.full((N * H2 * W2, dcs), 7.0, dtype=torch.bfloat16, device=DEV)
+    dyp[:, 64:64 + Cup] = dy.view(-1, Cup).to(torch.bfloat16)
+    sp, cr, nr = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    assert lib.hpri_wgrad1x1_bf16v3_plan(N * H * W, xcs, 4 * Cup, ctypes.byref(sp), ctypes.byref(cr), ctypes.byref(nr)) == 0
+    ws = torch.full((sp.value * cr.value * nr.value,), float("nan"), device=DEV)
+    rc = lib.hpri_wgrad_convt_bf16v3(P(xp), xcs, 0, rup(Cin, 8), P(dyp), dcs, 64, P(ws), ws.numel(), N, H, W, xcs, Cup, H2, W2, py0, px0, _st())
+    assert rc == 0, lib.hpri_last_error()
+    dw = torch.zeros(Cin, Cup, 2, 2, device=DEV)
+    rc = lib.hpri_wgrad_reduce_ex(P(ws), P(dw), sp.value, cr.value, nr.value, Cin, 4 * Cup, 1, 1, Cup, 0, _st())
+    assert rc == 0, lib.hpri_last_error()
+    torch.cuda.synchronize()
+    xr = xp[:, :Cin].double().cpu().view(N, H, W, Cin)
+    dyr = dyp[:, 64:64 + Cup].double().cpu().view(N, H2, W2, Cup)[:, py0:py0 + 2 * H, px0:px0 + 2 * W]
+    ref = torch.empty(Cin, Cup, 2, 2, dtype=torch.float64)
+    for a in range(2):
+        for b in range(2):
+            ref[:, :, a, b] = torch.einsum("nhwc,nhwk->ck", xr, dyr[:, a::2, b::2])
+    sc = max(1.0, float(ref.abs().max()))
+    err = float((dw.double().cpu() - ref).abs().max())
+    record_margin(f"wgrad_convt_bf16v3/{N}x{H}x{W}x{Cin}x{Cup}", err, 3e-5 * sc)
+    assert err < 3e-5 * sc, (shape, err, sp.value)
+    assert lib.hpri_wgrad_convt_bf16v3(P(xp), xcs, 0, rup(Cin, 8), P(dyp), dcs, 64, P(ws), ws.numel(), N, H, W, xcs, Cup + 32, H2, W2, py0, px0, _st()) != 0
+
+
+@pytest.mark.parametrize("shape", [(2, 36, 50, 64, 128, 64, 64), (1, 76, 121, 128, 256, 128, 128), (2, 19, 30, 32, 192, 128, 64)])
+@pytest.mark.parametrize("only", [0, 1])
+def test_bf16_plane_conv_v3_second_output(lib, shape, only):
+    """hpri_conv_bf16v3_y2: the data gradient of the first convolution of a decoder stage also (only = 1: only) leaves the channel
+    blocks of the upsampled half as bf16 rows; everything else is the plain launch bit for bit, statistics included."""
+    N, H, W, K, Cols, c0, cw2 = shape
+    torch.manual_seed(19)
+    cs16, cols_pad, cw = rup(K, 32), rup(Cols, 64), rup(Cols, 8)
+    npx = N * H * W
+    dy = torch.randn(npx, K, device=DEV)
+    planes = torch.zeros(npx, cs16, dtype=torch.bfloat16, device=DEV)
+    planes[:, :K] = dy.to(torch.bfloat16)
+    w = torch.randn(K, Cols, 3, 3, device=DEV) * 0.05
+    wpd = torch.empty(((K + 31) // 32) * 9 * cols_pad * 32, dtype=torch.bfloat16, device=DEV)
+    assert lib.hpri_pack_weight_bf16(P(w), P(wpd), 1, K, Cols, cols_pad, 9, Cols, 0, 0, _st()) == 0
+    k, tl, wsf = ctypes.c_int(), ctypes.c_int(), ctypes.c_size_t()
+    lib.hpri_conv_bf16v3_plan(N, H, W, cs16, cols_pad, ctypes.byref(k), ctypes.byref(tl), ctypes.byref(wsf))
+    assert k.value == 1
+    st1 = torch.empty(tl.value * cols_pad * 4, device=DEV)
+    st2 = torch.empty_like(st1)
+    g_plain = torch.empty(npx, cw, device=DEV)
+    assert lib.hpri_conv_bf16v3(P(planes), 0, cs16, 0, P(wpd), P(None), P(g_plain), cw, 0, P(st1), N, H, W, cs16, Cols, cols_pad, cw, 0, 0,
+                                P(None), 0, _st()) == 0
+    g = torch.full((npx, cw), -77.0, device=DEV)
+    y2cs = cw2 + 8
+    y2 = torch.full((npx, y2cs), 5.0, dtype=torch.bfloat16, device=DEV)
+    rc = lib.hpri_conv_bf16v3_y2(P(planes), cs16, 0, P(wpd), P(None), P(g), cw, 0, P(st2), N, H, W, cs16, Cols, cols_pad, cw, P(y2), y2cs, 4, c0,
+                                 cw2, only, _st())
+    assert rc == 0, lib.hpri_last_error()
+    torch.cuda.synchronize()
+    assert torch.equal(st1, st2)
+    assert torch.equal(y2[:, 4:4 + cw2], g_plain[:, c0:c0 + cw2].to(torch.bfloat16))
+    assert float(y2[:, :4].float().sub(5.0).abs().max()) == 0.0 and float(y2[:, 4 + cw2:].float().sub(5.0).abs().max()) == 0.0
+    assert torch.equal(g[:, :c0], g_plain[:, :c0]) and torch.equal(g[:, c0 + cw2:], g_plain[:, c0 + cw2:])
+    if only:
+        assert float(g[:, c0:c0 + cw2].sub(-77.0).abs().max()) == 0.0          # untouched
+    else:
+        assert torch.equal(g[:, c0:c0 + cw2], g_plain[:, c0:c0 + cw2])
+    assert lib.hpri_conv_bf16v3_y2(P(planes), cs16, 0, P(wpd), P(None), P(g), cw, 0, P(st2), N, H, W, cs16, Cols, cols_pad, cw, P(y2), y2cs, 4, c0 + 32,
+                                   cw2, only, _st()) != 0
