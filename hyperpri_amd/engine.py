@@ -64,7 +64,7 @@ class Act:
 
     Invariant: channels [C, cw) (cw = C rounded up to 8) exist inside the stride and hold zeros, so
     consumers may run their K loop over ``cw`` channels."""
-    __slots__ = ("buf", "N", "H", "W", "C", "cs", "coff", "pl", "parent", "f32_valid", "want_pl", "pl_part", "colsum_req", "b16", "bn_src", "cat_pl")
+    __slots__ = ("buf", "N", "H", "W", "C", "cs", "coff", "pl", "parent", "f32_valid", "want_pl", "pl_part", "colsum_req", "b16", "bn_src", "cat_pl", "up_slice")
 
     def __init__(self, buf: torch.Tensor, N: int, H: int, W: int, C: int, cs: int, coff: int = 0):
         self.buf, self.N, self.H, self.W, self.C, self.cs, self.coff = buf, N, H, W, C, cs, coff
@@ -75,6 +75,7 @@ class Act:
         self.want_pl = 0                        # plane mode marker: planes a 3x3 consumer of this tensor (or of its pooled map) would read
         self.colsum_req = None                  # (c0, C): somebody wants the column sums of channels [c0, c0+C) of this tensor's GRADIENT
         self.b16 = False                        # the buffer holds bf16 elements (a pre-BN tensor of the bf16 mode; read by the *_x16 BN passes only)
+        self.up_slice = None                    # (first channel, channels): the upsampled half of a decoder concat whose gradient its ConvTranspose2d wants as bf16 rows
         self.cat_pl = None                      # (plane buffer, cs, offset of the second half, its channels): this tensor's planes are the first half of a padded concat
         self.bn_src = None                      # (pre-BN Act, statistics, relu): this tensor is BN(+ReLU) of that one and has ONE consumer
 
@@ -340,6 +341,7 @@ class Tape:
         self.used_side = False
         self.sunk: Dict[int, torch.Tensor] = {}     # parameters whose gradient was written into the grad sink's storage
         self.colsum: Dict[int, tuple] = {}          # id(Act) -> (stats records, tiles, Cpad, c0) left by the data-gradient kernel that wrote its gradient
+        self.gupl: Dict[int, tuple] = {}            # id(Act) -> (Planes of the gradient of a concat's upsampled half, fp32 form absent?)
         self.bnpart: Dict[int, tuple] = {}          # id(Act) -> (partial sums, blocks, Cpart) of its BatchNorm backward, left by the same kind of kernel
         self.uses: Dict[int, int] = {}              # id(parameter) -> ops recorded on this tape that will produce a gradient for it
         self._touched: List[int] = []               # parameters the running node asked a gradient slot for
@@ -419,6 +421,7 @@ class Tape:
         self.uses.clear()
         self.colsum.clear()
         self.bnpart.clear()
+        self.gupl.clear()
 
 
 class BNRef:
@@ -774,7 +777,8 @@ def _conv_launch(x: Act, wp: torch.Tensor, bias: Optional[torch.Tensor], y: Act,
 def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.Tensor], bn: Optional[BNRef],
                  train: bool, ks: int, groups: int = 1, relu: bool = True, need_dx: bool = True,
                  precision: Optional[str] = None, room: int = 0, next_cout: int = 0, cat_room: int = 0,
-                 cat_into: Optional[Act] = None, k_gap: Optional[Tuple[int, int]] = None, planes_only: bool = False) -> Act:
+                 cat_into: Optional[Act] = None, k_gap: Optional[Tuple[int, int]] = None, planes_only: bool = False,
+                 out_planes: bool = False) -> Act:
     """Conv2d(k=ks, pad=ks//2) -> BatchNorm -> ReLU  (model_parts.py:22-27; models.py:169-180 with the
     Conv3d weight (F,1,D,3,3) read as (F,D,3,3); models.py:108-114 for Linear -> BatchNorm1d -> ReLU with
     ks = 1 and ``groups`` = images, each image being its own BN batch, models.py:132).
@@ -886,7 +890,8 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
         # C2 step that nobody read); ``want_pl`` still tells the pooling pass to write ITS result as planes.
         y.want_pl = 1 if ((v2 or g3) and PLANE_PRODUCERS) else 0
         # (a 1x1 layer's output is read by the next 1x1 layer or a concat in front of one: always planes)
-        ypl = new_planes(y, 1) if (y.want_pl and (next_cout > 0 or not PLANES_LAZY or g3)) else None
+        # (``out_planes``: the caller knows a plane reader for this output -- the next decoder stage's transposed convolution)
+        ypl = new_planes(y, 1) if (y.want_pl and (next_cout > 0 or not PLANES_LAZY or g3 or out_planes)) else None
         if cat_room > 0:
             # first half of a padded concat: [cout | zeros to the next multiple of 32 | cat_room channels], one plane buffer
             ob = _rup(cout, 32)
@@ -1035,7 +1040,28 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
                 _conv_launch_wino(dyr, upd, None, gx, gstats, cout, cin, cin_cols_pad, gx.cw, accumulate=int(acc))
             elif v2:
                 wpd, cin_cols_pad = _pack_bf16(weight, 1, cout, cin, T, cin, split=0)
-                _conv_launch_v2(dyr, wpd, None, gx, gstats, cout, cin, cin_cols_pad, gx.cw, accumulate=int(acc))
+                us = x.up_slice
+                y2 = None
+                if us is not None and BF16_V3 and CONVT_PLANES and not acc and us[0] % 64 == 0 and us[1] % 64 == 0:
+                    ksp = ctypes.c_int(); tl = ctypes.c_int(); wsf_ = ctypes.c_size_t()
+                    _lib.call("hpri_conv_bf16v3_plan", x.N, x.H, x.W, _rup(cout, 32), cin_cols_pad, ctypes.byref(ksp), ctypes.byref(tl),
+                              ctypes.byref(wsf_))
+                    if ksp.value == 1:
+                        y2 = torch.empty(x.P * us[1], dtype=torch.bfloat16, device=dev)
+                if y2 is not None:
+                    # the gradient of the upsampled half of this concat also leaves as bf16 rows (its readers, the transposed
+                    # convolution's data and weight gradient, stage planes); with the bias gradient coming from the statistics
+                    # records nobody reads that half in fp32, so it is not written
+                    only = gstats is not None
+                    pl = planes_of(dyr, 1)
+                    with _timed("conv_planes_bf16<3,v3 256x64>" + (f" N{x.N} {x.H}x{x.W} K{_rup(cout, 32)} N{cin}" if SHAPE_TAGS else ""),
+                                2.0 * x.N * x.H * x.W * cout * cin * 9):
+                        _lib.call("hpri_conv_bf16v3_y2", _p(pl.buf), pl.cs, pl.coff, _p(wpd), ctypes.c_void_p(0), gx.ptr, gx.cs, gx.coff,
+                                  _p(gstats), x.N, x.H, x.W, _rup(cout, 32), cin, cin_cols_pad, gx.cw, _p(y2), us[1], 0, us[0], us[1],
+                                  int(only), _stream())
+                    tp.gupl[id(x)] = (Planes(y2, x.P * us[1], us[1], 0, 1), only)
+                else:
+                    _conv_launch_v2(dyr, wpd, None, gx, gstats, cout, cin, cin_cols_pad, gx.cw, accumulate=int(acc))
             elif g3:
                 wpd, cin_cols_pad = _pack_bf16(weight, 1, cout, x.C if k_gap else cin, T, cin, split=0, gap=k_gap)
                 _gemm_launch(dyr, wpd, None, gx, None, cout, x.C, cin_cols_pad, gx.cw, accumulate=int(acc))
@@ -1288,9 +1314,16 @@ def _upsample_into(tape: Tape, x1: Act, dst: Act, weight: Optional[torch.Tensor]
             # fp32 form of the upsampled half has no reader (the next convolution and its weight gradient read planes)
             wp, ncols_pad = _pack_bf16(weight, 2, cin, 4 * cup, 1, cup, cup, split=0)
             pl, pc0 = dst_planes
-            with _timed("conv_fwd_bf16<1,4x1,direct,d2s+planes>", 2.0 * x1.N * x1.H * x1.W * cin * 4 * cup):
-                _lib.call("hpri_convt_fwd_bf16_pl", x1.ptr, x1.cs, x1.coff, _p(wp), _p(bias), ctypes.c_void_p(0), dst.cs, dst.coff,
-                          x1.N, x1.H, x1.W, x1.cw, 4 * cup, ncols_pad, H2, W2, py0, px0, cup, _p(pl.buf), pl.cs, pc0, _stream())
+            if CONVT_PLANES and x1.pl is not None and cup % 16 == 0 and _rup(cin, 32) <= min(x1.pl.cw, 8192):
+                # the input's planes were written by its producer (``out_planes``): both operands by LDS-DMA (gemm_bf16v3.hip)
+                xp_ = x1.pl
+                with _timed("gemm_planes_bf16<convT,d2s+planes>", 2.0 * x1.N * x1.H * x1.W * cin * 4 * cup):
+                    _lib.call("hpri_convt_fwd_bf16v3", _p(xp_.buf), xp_.cs, xp_.coff, _p(wp), _p(bias), ctypes.c_void_p(0), 0, 0,
+                              _p(pl.buf), pl.cs, pc0, x1.N, x1.H, x1.W, _rup(cin, 32), cup, ncols_pad, H2, W2, py0, px0, _stream())
+            else:
+                with _timed("conv_fwd_bf16<1,4x1,direct,d2s+planes>", 2.0 * x1.N * x1.H * x1.W * cin * 4 * cup):
+                    _lib.call("hpri_convt_fwd_bf16_pl", x1.ptr, x1.cs, x1.coff, _p(wp), _p(bias), ctypes.c_void_p(0), dst.cs, dst.coff,
+                              x1.N, x1.H, x1.W, x1.cw, 4 * cup, ncols_pad, H2, W2, py0, px0, cup, _p(pl.buf), pl.cs, pc0, _stream())
             planes_written = True
         elif bf16:
             wp, ncols_pad = _pack_bf16(weight, 2, cin, 4 * cup, 1, cup, cup, split=usplit)
@@ -1334,7 +1367,38 @@ def _upsample_into(tape: Tape, x1: Act, dst: Act, weight: Optional[torch.Tensor]
                 ws = _ws(nblk.value * 2 * cpart.value + 2 * cup, dev)
                 _lib.call("hpri_col_sum", gu.ptr, gu.cs, gu.coff, _p(db), acc_b, _p(ws), ws.numel(), gu.P, cup, _stream())
         bprec = precision or DEFAULT_PRECISION
-        if weight.requires_grad:
+        gp = tp.gupl.pop(id(dst), None)
+        gpl = gp[0] if gp is not None else None
+        if gpl is None and not gu.f32_valid:
+            raise RuntimeError("hyperpri_amd: internal error: the gradient of an upsampled tensor exists as planes only, but the planes are gone")
+        pw = gpl is not None and cup % 64 == 0 and _rup(cin, 32) <= 16384          # weight gradient on planes (wgrad_bf16v3.hip)
+        pd = gpl is not None and cup % 32 == 0                                   # data gradient on planes (gemm_bf16v3.hip)
+        if gpl is not None and not gu.f32_valid and not ((pw or not weight.requires_grad) and (pd or not need_dx1)):
+            raise RuntimeError("hyperpri_amd: internal error: a planes-only gradient reached a transposed convolution that reads fp32")
+
+        def wgrad_planes():
+            xp_ = planes_of(x1, 1)
+            sp = ctypes.c_int(); pcr = ctypes.c_int(); pnr = ctypes.c_int()
+            xcw = min(xp_.cw, _rup(cin, 32))
+            _lib.call("hpri_wgrad1x1_bf16v3_plan", x1.P, xcw, 4 * cup, ctypes.byref(sp), ctypes.byref(pcr), ctypes.byref(pnr))
+            pws = _ws(sp.value * pcr.value * pnr.value, dev)
+            with _timed("wgrad_planes_bf16<convT>", 2.0 * x1.P * cin * 4 * cup):
+                _lib.call("hpri_wgrad_convt_bf16v3", _p(xp_.buf), xp_.cs, xp_.coff, xcw, _p(gpl.buf), gpl.cs, gpl.coff, _p(pws), pws.numel(),
+                          x1.N, x1.H, x1.W, xcw, cup, H2, W2, py0, px0, _stream())
+            _lib.call("hpri_wgrad_reduce_ex", _p(pws), _p(dw), sp.value, pcr.value, pnr.value, cin, 4 * cup, 1, 1, cup, acc_w, _stream())
+        if weight.requires_grad and pw:
+            dw, acc_w = tp.param_slot(weight)
+            if SIDE_STREAM and need_dx1 and _EVENT_LOG is None and (_GRAD_SINK is None or SIDE_STREAM_WITH_SINK):
+                main, side = torch.cuda.current_stream(dev), _side(dev)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    wgrad_planes()
+                for t in (x1.buf, gpl.buf, dw) + ((x1.pl.buf,) if x1.pl is not None else ()):
+                    t.record_stream(side)
+                tp.used_side = True
+            else:
+                wgrad_planes()
+        elif weight.requires_grad:
             dw, acc_w = tp.param_slot(weight)
             if SIDE_STREAM and need_dx1 and _EVENT_LOG is None and (_GRAD_SINK is None or SIDE_STREAM_WITH_SINK):
                 # the weight gradient and the data gradient of the transposed convolution only share inputs: second stream
@@ -1349,7 +1413,13 @@ def _upsample_into(tape: Tape, x1: Act, dst: Act, weight: Optional[torch.Tensor]
             else:
                 _wgrad(x1, gu, dw, acc_w, cin, 4 * cup, 1, bmode=A_S2D, dst_mode=1, H2=H2, W2=W2, py0=py0, px0=px0, cup=cup,
                        bf16=bprec in LOWP, split=_SPLIT.get(bprec, 0))
-        if need_dx1:
+        if need_dx1 and pd:
+            gx, acc = tp.grad_slot(x1)
+            wpd, cols_pad = _pack_bf16(weight, 3, 4 * cup, cin, 1, cup, cup, split=0)
+            with _timed("gemm_planes_bf16<convT,s2d>", 2.0 * x1.N * x1.H * x1.W * cin * 4 * cup):
+                _lib.call("hpri_convt_dgrad_bf16v3", _p(gpl.buf), gpl.cs, gpl.coff, _p(wpd), gx.ptr, gx.cs, gx.coff, x1.N, x1.H, x1.W, cup, cin,
+                          cols_pad, gx.cw, H2, W2, py0, px0, int(acc), _stream())
+        elif need_dx1:
             gx, acc = tp.grad_slot(x1)
             if bprec in LOWP:
                 wpd, cols_pad = _pack_bf16(weight, 3, 4 * cup, cin, 1, cup, cup, split=_SPLIT.get(bprec, 0))
@@ -1408,13 +1478,21 @@ def up_concat(tape: Tape, x1: Act, skip: Act, weight: Optional[torch.Tensor], bi
     if tape.record:
         if weight is not None and bias is not None and bias.requires_grad and cat.H == 2 * x1.H and cat.W == 2 * x1.W:
             cat.colsum_req = (skip.C, cup)     # (no pad ring: F.pad's backward would have to drop ring pixels from the sums)
+        if weight is not None and wrote and CONVT_PLANES and cat.H == 2 * x1.H and cat.W == 2 * x1.W:
+            cat.up_slice = (skip.C, cup)       # plane mode: the consumer's data-gradient launch leaves this half's gradient as bf16 rows
 
         def bwd(tp: Tape) -> None:
             g = tp.grads.pop(id(cat), None)
             if g is None:
                 return
             tp.set_grad_view(skip, g.slice(0, skip.C))
-            tp.grads[id(ups)] = g.slice(skip.C, cup)
+            gu = g.slice(skip.C, cup)
+            gp = tp.gupl.pop(id(cat), None)
+            if gp is not None:
+                tp.gupl[id(ups)] = gp
+                gu.pl = gp[0]
+                gu.f32_valid = not gp[1]
+            tp.grads[id(ups)] = gu
             cs = tp.colsum.pop(id(cat), None)
             if cs is not None:
                 tp.colsum[id(ups)] = cs + (skip.C,)
@@ -1488,6 +1566,17 @@ def plane_gemm_mode(module, bnorm: bool = True) -> bool:
     halves' producers write into one padded plane buffer) and the inner tensors exist as planes only."""
     prec = getattr(module, "hpri_precision", None) or DEFAULT_PRECISION
     return bool(bnorm and prec == "bf16" and PLANE_GEMM and PLANE_WGRAD and PLANE_PRODUCERS and PLANES_ONLY_ACT and PLANES_CAT1)
+
+
+# bf16 mode, decoder stages: ConvTranspose2d forward, data gradient and weight gradient on the plane-fed kernels (gemm_bf16v3.hip,
+# wgrad_bf16v3.hip); the gradient of the upsampled half of the concat arrives as bf16 rows from the data-gradient launch that
+# produces it (hpri_conv_bf16v3_y2).  HPRI_CONVT_PLANES=0: the round-1 kernels that convert fp32 while staging.
+CONVT_PLANES = os.environ.get("HPRI_CONVT_PLANES", "1") != "0"
+
+
+def convt_planes_mode(module) -> bool:
+    prec = getattr(module, "hpri_precision", None) or DEFAULT_PRECISION
+    return bool(prec == "bf16" and CONVT_PLANES and PLANE_CONV and PLANE_WGRAD and PLANE_PRODUCERS and BF16_V3 and PLANES_CONVT and PLANES_CONCAT)
 
 
 # HPRI_PLANES_CAT1=0: SpectralUNET's skips are concatenated in fp32 by copies (and converted to planes afterwards), as before.

@@ -55,10 +55,12 @@ class UNet(nn.Module):
                 x2 = self.down1._ops(tape, x1, room=skip_room(self.up3))
                 x3 = self.down2._ops(tape, x2, room=skip_room(self.up2))
                 x4 = self.down3._ops(tape, x3, room=skip_room(self.up1))
-                x5 = self.down4._ops(tape, x4)
-                y = self.up1._ops(tape, x5, x4)
-                y = self.up2._ops(tape, y, x3)
-                y = self.up3._ops(tape, y, x2)
+                # (bf16 mode: what feeds a transposed convolution is also written as planes by its producer)
+                cp = E.convt_planes_mode(self) and not self.bilinear and not self.use_attention
+                x5 = self.down4._ops(tape, x4, out_planes=cp)
+                y = self.up1._ops(tape, x5, x4, out_planes=cp)
+                y = self.up2._ops(tape, y, x3, out_planes=cp)
+                y = self.up3._ops(tape, y, x2, out_planes=cp)
                 y = self.up4._ops(tape, y, x1)
                 return self.outc._ops(tape, y)
             logits = run(prog, [x], list(self.parameters()), input_planes=E.input_planes_for(self))
@@ -218,10 +220,11 @@ class CubeNET(torch.nn.Module):
                 x2 = self.down1._ops(tape, x1, room=skip_room(self.up3))
                 x3 = self.down2._ops(tape, x2, room=skip_room(self.up2))
                 x4 = self.down3._ops(tape, x3, room=skip_room(self.up1))
-                x5 = self.down4._ops(tape, x4)
-                y = self.up1._ops(tape, x5, x4)
-                y = self.up2._ops(tape, y, x3)
-                y = self.up3._ops(tape, y, x2)
+                cp = E.convt_planes_mode(self) and not self.bilinear and not self.use_attention     # see UNet.forward
+                x5 = self.down4._ops(tape, x4, out_planes=cp)
+                y = self.up1._ops(tape, x5, x4, out_planes=cp)
+                y = self.up2._ops(tape, y, x3, out_planes=cp)
+                y = self.up3._ops(tape, y, x2, out_planes=cp)
                 y = self._up4_ops(tape, y, x1)
                 return self.outc._ops(tape, y)
             logits = run(prog, [x], list(self.parameters()), input_planes=E.input_planes_for(self))

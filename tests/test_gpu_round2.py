@@ -218,15 +218,20 @@ def test_plane_mode_traffic_savings_do_not_change_results(kind):
     sd = {k: v.clone() for k, v in net.state_dict().items()}
     names = ["PLANES_ONLY_GRAD", "PLANES_ONLY_ACT", "PLANES_LAZY", "PLANES_CONCAT", "PLANES_CONVT"]
     assert all(getattr(E, n) for n in names)          # the defaults under test
-    lg1, g1 = _step(net, x, m)
-    bufs1 = {k: v.clone() for k, v in net.named_buffers()}
+    # (the transposed convolutions stay on ONE kernel family in both runs: their plane-fed kernels -- CONVT_PLANES, which needs
+    # PLANES_CONCAT / PLANES_CONVT -- sum in another order; that switch has its own test below)
+    convt = E.CONVT_PLANES
+    E.CONVT_PLANES = False
     saved = {n: getattr(E, n) for n in names}
     try:
+        lg1, g1 = _step(net, x, m)
+        bufs1 = {k: v.clone() for k, v in net.named_buffers()}
         for n in names:
             setattr(E, n, False)
         net.load_state_dict(sd)
         lg2, g2 = _step(net, x, m)
     finally:
+        E.CONVT_PLANES = convt
         for n, v in saved.items():
             setattr(E, n, v)
     assert torch.equal(lg1, lg2)
@@ -415,3 +420,45 @@ def test_bf16_mode_bn_backward_reduction_in_the_data_gradient_epilogue(kind):
         worst = max(worst, float((a.double() - b.double()).norm()) / ref)
     record_margin(f"bf16_bnred_switch_{kind}", worst, 2e-2)
     assert worst <= 2e-2, worst
+
+
+@pytest.mark.parametrize("kind", ["unet", "cube64", "cube128"])
+def test_bf16_mode_transposed_convolutions_on_planes(kind):
+    """HPRI_CONVT_PLANES (default on): ConvTranspose2d forward, data gradient and weight gradient on the plane-fed kernels, the gradient
+    of the upsampled half arriving as bf16 rows from hpri_conv_bf16v3_y2.  Same bf16 operand values as the round-1 kernels (which
+    round fp32 while staging), another summation order: a few last-place flips of bf16 roundings downstream."""
+    import hyperpri_amd as H
+    from hyperpri_amd import engine as E
+    net, x, m = _net(kind)
+    H.set_precision(net, "bf16")
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    assert E.CONVT_PLANES
+    seen = []
+    real = E._lib.call
+
+    def spy(name, *a):
+        seen.append(name)
+        return real(name, *a)
+    E._lib.call = spy
+    try:
+        lg1, g1 = _step(net, x, m)
+    finally:
+        E._lib.call = real
+    for fn in ("hpri_convt_fwd_bf16v3", "hpri_conv_bf16v3_y2", "hpri_convt_dgrad_bf16v3", "hpri_wgrad_convt_bf16v3"):
+        assert fn in seen, fn
+    try:
+        E.CONVT_PLANES = False
+        net.load_state_dict(sd)
+        lg2, g2 = _step(net, x, m)
+    finally:
+        E.CONVT_PLANES = True
+    assert float((lg1 - lg2).abs().max()) <= 2e-2 * max(1.0, float(lg2.abs().max()))
+    worst = 0.0
+    for (k, _), a, b in zip(net.named_parameters(), g1, g2):
+        assert torch.isfinite(a).all(), k
+        ref = float(b.double().norm())
+        if ref < 1e-6:
+            continue
+        worst = max(worst, float((a.double() - b.double()).norm()) / ref)
+    record_margin(f"bf16_convt_planes_switch_{kind}", worst, 0.35)
+    assert worst <= 0.35, worst          # two correct bf16 paths on this tiny, ill-conditioned net: see the round-1-kernel test above (0.15 typical)
