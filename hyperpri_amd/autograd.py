@@ -79,6 +79,7 @@ class _HipFn(torch.autograd.Function):
         tape.backward()
         if tape.used_side:
             join_side(gout.device)          # weight gradients issued on the side stream
+        tape.side_keep.clear()              # (what that stream read may be recycled now: the main stream is ordered behind it)
         need = ctx.needs_input_grad[4:]
         res = []
         for i, a in enumerate(ctx.acts):

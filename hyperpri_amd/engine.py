@@ -338,6 +338,7 @@ class Tape:
         self.grads: Dict[int, Act] = {}
         self.param_grads: Dict[int, torch.Tensor] = {}
         self.keep: List[object] = []
+        self.side_keep: List[object] = []          # tensors the weight-gradient stream reads: alive until the caller has joined that stream (autograd.py)
         self.used_side = False
         self.sunk: Dict[int, torch.Tensor] = {}     # parameters whose gradient was written into the grad sink's storage
         self.colsum: Dict[int, tuple] = {}          # id(Act) -> (stats records, tiles, Cpad, c0) left by the data-gradient kernel that wrote its gradient
@@ -934,7 +935,13 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
         if g is None:
             return
         if bn is not None:
-            dyr = Act.new(x.N, x.H, x.W, cout, dev)
+            # plane mode: when the weight gradient and the data gradient both read the bf16 planes, nobody reads the fp32 form
+            # (1x1 layers: the plane GEMM and the plane weight gradient, gemm_bf16v3.hip / wgrad_bf16v3.hip) -- and it gets no storage
+            want_dpl = (v2 or g3) and (need_dx or (PLANE_WGRAD and weight.requires_grad)) and PLANE_PRODUCERS
+            f32_dead = bool(want_dpl and split == 0 and PLANE_WGRAD and PLANES_ONLY_GRAD and (need_dx or weight.requires_grad)
+                            and ((ks == 3 and PLANE_CONV) or (g3 and _rup(cout, 32) <= 16384)))
+            dyr = (Act(torch.empty(8, dtype=torch.float32, device=dev), x.N, x.H, x.W, cout, _rup(cout, 8), 0) if f32_dead
+                   else Act.new(x.N, x.H, x.W, cout, dev))
             G = groups if use_batch else 1
             nblk = ctypes.c_int(); cpart = ctypes.c_int()
             _lib.call("hpri_col_reduce_plan", x.P // G, G, cout, ctypes.byref(nblk), ctypes.byref(cpart))
@@ -944,12 +951,7 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
             db, acc_b = (tp.param_slot(bias) if bias is not None else (None, 0))
             mean, invstd, varu, scale, shift = (st[i * G * cout:(i + 1) * G * cout] for i in range(5))
             # read by the data gradient and by the weight gradient
-            dpl = new_planes(dyr, 1) if ((v2 or g3) and (need_dx or (PLANE_WGRAD and weight.requires_grad))
-                                         and PLANE_PRODUCERS) else None
-            # plane mode: when the weight gradient and the data gradient both read the bf16 planes, nobody reads the fp32 form
-            # (1x1 layers: the plane GEMM and the plane weight gradient, gemm_bf16v3.hip / wgrad_bf16v3.hip)
-            f32_dead = (dpl is not None and split == 0 and PLANE_WGRAD and PLANES_ONLY_GRAD and (need_dx or weight.requires_grad)
-                        and ((ks == 3 and PLANE_CONV) or (g3 and _rup(cout, 32) <= 16384)))
+            dpl = new_planes(dyr, 1) if want_dpl else None
             dyr.f32_valid = not f32_dead
             bp = tp.bnpart.pop(id(y), None)
             _lib.call(*(("hpri_bn_relu_bwd_fused_x16" if yr16 else "hpri_bn_relu_bwd_fused", _p(bp[0]), bp[1], bp[2]) if bp is not None else
@@ -973,11 +975,10 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
             side.wait_stream(main)                      # dyr (and everything before it) is ready
             with torch.cuda.stream(side):
                 _wgrad(x, dyr, dw, acc_w, cin, cout, ks, bf16=lowp, split=split, gap=k_gap)
-            for a_ in (x, dyr):                          # keep the caching allocator from recycling them early
-                a_.buf.record_stream(side)
-                if a_.pl is not None:
-                    a_.pl.buf.record_stream(side)
-            dw.record_stream(side)
+            # what the second stream reads stays alive until the main stream has joined it at the end of backward (then it is
+            # reusable at once; record_stream() instead left the blocks pending at the allocator while the host ran ahead into
+            # the next step: four device allocations per bf16 step, for ever)
+            tp.side_keep.extend((x, dyr, dw))
             tp.used_side = True
         else:
             dw, acc_w = tp.param_slot(weight)
@@ -1393,8 +1394,7 @@ def _upsample_into(tape: Tape, x1: Act, dst: Act, weight: Optional[torch.Tensor]
                 side.wait_stream(main)
                 with torch.cuda.stream(side):
                     wgrad_planes()
-                for t in (x1.buf, gpl.buf, dw) + ((x1.pl.buf,) if x1.pl is not None else ()):
-                    t.record_stream(side)
+                tp.side_keep.extend((x1, gpl, dw))
                 tp.used_side = True
             else:
                 wgrad_planes()
@@ -1407,8 +1407,7 @@ def _upsample_into(tape: Tape, x1: Act, dst: Act, weight: Optional[torch.Tensor]
                 with torch.cuda.stream(side):
                     _wgrad(x1, gu, dw, acc_w, cin, 4 * cup, 1, bmode=A_S2D, dst_mode=1, H2=H2, W2=W2, py0=py0, px0=px0, cup=cup,
                            bf16=bprec in LOWP, split=_SPLIT.get(bprec, 0))
-                for t in (x1.buf, gu.buf, dw):
-                    t.record_stream(side)
+                tp.side_keep.extend((x1, gu, dw))
                 tp.used_side = True
             else:
                 _wgrad(x1, gu, dw, acc_w, cin, 4 * cup, 1, bmode=A_S2D, dst_mode=1, H2=H2, W2=W2, py0=py0, px0=px0, cup=cup,
