@@ -1301,7 +1301,11 @@ def _upsample_into(tape: Tape, x1: Act, dst: Act, weight: Optional[torch.Tensor]
             tape.nodes.append(bwd_crop)
         return False
     planes_written = False
-    if dY or dX:
+    # the plane-fed transposed-convolution kernel (gemm_bf16v3.hip) also handles a pad ring: the ring is zeroed in the planes
+    use_pl = (weight is not None and dst_planes is not None and CONVT_PLANES and x1.pl is not None and cup % 16 == 0
+              and (precision or DEFAULT_PRECISION) == "bf16" and PLANES_CONVT and PLANE_CONV and PLANE_WGRAD
+              and _rup(weight.shape[0], 32) <= min(x1.pl.cw, 8192))
+    if (dY or dX) and not use_pl:
         _lib.call("hpri_fill_pad", dst.ptr, dst.cs, dst.coff, dst.N, H2, W2, cup, py0, py0 + 2 * x1.H, px0, px0 + 2 * x1.W, _stream())
     if weight is not None:
         cin = weight.shape[0]
@@ -1310,14 +1314,18 @@ def _upsample_into(tape: Tape, x1: Act, dst: Act, weight: Optional[torch.Tensor]
         uprec = precision or DEFAULT_PRECISION
         bf16 = uprec in LOWP
         usplit = _SPLIT.get(uprec, 0)
-        if bf16 and usplit == 0 and dst_planes is not None and not (dY or dX) and PLANES_CONVT and PLANE_CONV and PLANE_WGRAD:
+        if bf16 and usplit == 0 and dst_planes is not None and (use_pl or not (dY or dX)) and PLANES_CONVT and PLANE_CONV and PLANE_WGRAD:
             # plane mode: the 2x2 patches go straight into the concat's bf16 planes (``dst_planes`` = (Planes, first channel)); the
             # fp32 form of the upsampled half has no reader (the next convolution and its weight gradient read planes)
             wp, ncols_pad = _pack_bf16(weight, 2, cin, 4 * cup, 1, cup, cup, split=0)
             pl, pc0 = dst_planes
-            if CONVT_PLANES and x1.pl is not None and cup % 16 == 0 and _rup(cin, 32) <= min(x1.pl.cw, 8192):
+            if use_pl:
                 # the input's planes were written by its producer (``out_planes``): both operands by LDS-DMA (gemm_bf16v3.hip)
                 xp_ = x1.pl
+                if dY or dX:
+                    # pad ring of the upsampled half inside the concat's planes: pairs of bf16 zeroed as floats (all offsets even)
+                    _lib.call("hpri_fill_pad", _p(pl.buf), pl.cs // 2, pc0 // 2, dst.N, H2, W2, cup // 2, py0, py0 + 2 * x1.H, px0,
+                              px0 + 2 * x1.W, _stream())
                 with _timed("gemm_planes_bf16<convT,d2s+planes>", 2.0 * x1.N * x1.H * x1.W * cin * 4 * cup):
                     _lib.call("hpri_convt_fwd_bf16v3", _p(xp_.buf), xp_.cs, xp_.coff, _p(wp), _p(bias), ctypes.c_void_p(0), 0, 0,
                               _p(pl.buf), pl.cs, pc0, x1.N, x1.H, x1.W, _rup(cin, 32), cup, ncols_pad, H2, W2, py0, px0, _stream())
@@ -1477,7 +1485,7 @@ def up_concat(tape: Tape, x1: Act, skip: Act, weight: Optional[torch.Tensor], bi
     if tape.record:
         if weight is not None and bias is not None and bias.requires_grad and cat.H == 2 * x1.H and cat.W == 2 * x1.W:
             cat.colsum_req = (skip.C, cup)     # (no pad ring: F.pad's backward would have to drop ring pixels from the sums)
-        if weight is not None and wrote and CONVT_PLANES and cat.H == 2 * x1.H and cat.W == 2 * x1.W:
+        if weight is not None and wrote and CONVT_PLANES:
             cat.up_slice = (skip.C, cup)       # plane mode: the consumer's data-gradient launch leaves this half's gradient as bf16 rows
 
         def bwd(tp: Tape) -> None:
