@@ -477,7 +477,16 @@ extern "C" int hpri_bn_relu_bwd_pl(const float* dy, int dy_cs, int dy_coff, cons
                                    size_t ws_floats, long long P, long long pix_per_group, int C, int Cw, int relu,
                                    int use_batch_stats, void* planes, long long plane_stride, int pl_cs, int pl_coff,
                                    int pl_cw, int npl, hipStream_t stream);
-static inline int pick_cq(int c4) { int q = 1; while (q < c4 && q < 64) q <<= 1; return q; }
+// channel quads per workgroup row (a power of two).  Up to 64 (256 channels) a workgroup holds 4+ pixel rows; tensors wider than
+// 1024 channels (SpectralUNET-1650) take a whole 1024-channel run of ONE pixel: 4-KB contiguous pieces instead of 1-KB pieces 6.6 KB
+// apart (option "bn_wide_cq", api.cpp; measured: its three BatchNorm kernels 2-4 % faster, a C3 step 135.9 -> 133.6 ms; the 512 / 1024
+// channel layers of the U-Nets measured neutral and keep the narrow form)
+static inline int pick_cq(int c4) {
+  const int cap = (c4 > 256 && hpri_option(4) != 0) ? 256 : 64;
+  int q = 1;
+  while (q < c4 && q < cap) q <<= 1;
+  return q;
+}
 static inline int ew_blocks(long long total) {
   long long b = (total + 255) / 256;
   if (b > 8192) b = 8192;

@@ -42,7 +42,7 @@ extern "C" {
 #define HPRI_E_D2S 1    /* 2x2 stride-2 pixel-shuffle store (convT forward)          */
 
 int hpri_version(void);
-/* Launch-plan options (process-wide): "conv_nbx_min", "wgrad_xcd_min_tiles", "wgrad_xcd_min_strips", "bf16v3_tile_width" -- the problem sizes
+/* Launch-plan options (process-wide): "conv_nbx_min", "wgrad_xcd_min_tiles", "wgrad_xcd_min_strips", "bf16v3_tile_width", "bn_wide_cq" -- the problem sizes
  * from which the conv / weight-gradient kernels switch to their XCD-aware 1-D grids.  Results do not depend
  * on them, only block order and (for weight gradients) the number of partial slabs, i.e. the summation order. */
 int hpri_set_option(const char* name, int value);
