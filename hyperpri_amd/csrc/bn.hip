@@ -230,7 +230,7 @@ __global__ void bn_apply_relu_kernel(const float* __restrict__ x, int x_cs, int 
 // backward, stage 1: per-channel partial sums of g = dy * [y > 0] and g * xhat over pixel ranges
 // -------------------------------------------------------------------------------------------------
 // grid = (nblk, ceil(C4/CQ), G); block = 256 = ROWS x CQ; partial layout [G][nblk][2][Cq4*4]
-template <int MODE, bool XB = false>  // 0: BN+ReLU backward sums (s1 = sum g, s2 = sum g*xhat); 1: plain column sum of dy
+template <int MODE, bool XB = false, bool DB = false>  // 0: BN+ReLU backward sums (s1 = sum g, s2 = sum g*xhat); 1: plain column sum of dy; DB: dy stored as bf16
 __global__ void col_reduce_kernel(const float* __restrict__ dy, int dy_cs, int dy_coff, const float* __restrict__ x,
                                   int x_cs, int x_coff, const float* __restrict__ mean,
                                   const float* __restrict__ invstd, const float* __restrict__ scale,
@@ -265,7 +265,7 @@ __global__ void col_reduce_kernel(const float* __restrict__ dy, int dy_cs, int d
       float4 dv[4], xv[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        dv[u] = *reinterpret_cast<const float4*>(dy + (p + u * rows) * dy_cs + dy_coff + c);
+        dv[u] = bn_load_x4<DB>(dy, (p + u * rows) * dy_cs + dy_coff + c);
         if (MODE == 0) xv[u] = bn_load_x4<XB>(x, (p + u * rows) * x_cs + x_coff + c);
       }
 #pragma unroll
@@ -286,7 +286,7 @@ __global__ void col_reduce_kernel(const float* __restrict__ dy, int dy_cs, int d
       }
     }
     for (; p < p1; p += rows) {
-      const float4 dv = *reinterpret_cast<const float4*>(dy + p * dy_cs + dy_coff + c);
+      const float4 dv = bn_load_x4<DB>(dy, p * dy_cs + dy_coff + c);
       const float d[4] = {dv.x, dv.y, dv.z, dv.w};
       if (MODE == 0) {
         const float4 xv = bn_load_x4<XB>(x, p * x_cs + x_coff + c);
@@ -398,7 +398,7 @@ __global__ void bn_param_grad_kernel(const float* __restrict__ sums, int G, int 
 
 // dx = scale * (g - s1/Np - xhat * s2/Np)   (training) ;  dx = scale * g  (eval: use_batch_stats = 0)
 // same 2-D mapping as bn_apply_relu_kernel; also emits per-block column sums of dx (the conv-bias gradient)
-template <bool XB>
+template <bool XB, bool DB = false>
 __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, int dy_cs, int dy_coff, const float* __restrict__ x,
                                     int x_cs, int x_coff, float* __restrict__ dx, int dx_cs, int dx_coff,
                                     const float* __restrict__ mean, const float* __restrict__ invstd,
@@ -437,7 +437,7 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, int dy_cs, int
     const size_t base = (size_t)g * pix_per_group;
     for (int q = q0 + pr; q < q1; q += rows) {
       const size_t p = base + q;
-      const float4 dv = *reinterpret_cast<const float4*>(dy + p * dy_cs + dy_coff + c);
+      const float4 dv = bn_load_x4<DB>(dy, p * dy_cs + dy_coff + c);
       const float4 xv = bn_load_x4<XB>(x, p * x_cs + x_coff + c);
       const float d[4] = {dv.x, dv.y, dv.z, dv.w}, xx[4] = {xv.x, xv.y, xv.z, xv.w};
       float o[4];
@@ -625,6 +625,7 @@ extern "C" int hpri_bn_relu_bwd(const float* dy, int dy_cs, int dy_coff, const f
 // the same, with dx also written as bf16 planes for the data-gradient / weight-gradient kernels of the bf16 modes
 static int bn_relu_bwd_impl(const float* ext_part, int ext_nblk, int ext_cpart,
                             const float* dy, int dy_cs, int dy_coff, const float* x, bool x16, int x_cs, int x_coff,
+                            bool dy16,
                             float* dx, int dx_cs, int dx_coff, const float* mean, const float* invstd,
                             const float* scale, const float* shift, float* dgamma, float* dbeta,
                             int accumulate_param_grads, float* dbias, int accumulate_dbias, float* workspace,
@@ -663,7 +664,10 @@ static int bn_relu_bwd_impl(const float* ext_part, int ext_nblk, int ext_cpart,
       fin_part = part; fin_nblk = (int)S;
     }
   } else {
-    if (x16)
+    if (x16 && dy16)
+      hipLaunchKernelGGL((col_reduce_kernel<0, true, true>), dim3(nblk, ycols, G), dim3(256), 0, stream, dy, dy_cs, dy_coff, x,
+                         x_cs, x_coff, mean, invstd, scale, shift, pix_per_group, C, cq, relu, part, Cpart);
+    else if (x16)
       hipLaunchKernelGGL((col_reduce_kernel<0, true>), dim3(nblk, ycols, G), dim3(256), 0, stream, dy, dy_cs, dy_coff, x,
                          x_cs, x_coff, mean, invstd, scale, shift, pix_per_group, C, cq, relu, part, Cpart);
     else
@@ -694,7 +698,11 @@ static int bn_relu_bwd_impl(const float* ext_part, int ext_nblk, int ext_cpart,
   // the apply kernel uses the same (pixel blocks x channel columns x groups) grid as the reduce, so its dx column
   // partials have the reduce's layout; Cw may add one more channel column than C (zero pads)
   const int ycols_w = hpri_cdiv((Cw > po.cw ? Cw : po.cw) >> 2, cq);
-  if (x16)
+  if (x16 && dy16)
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<true, true>), dim3(nblk, ycols_w, G), dim3(256), 0, stream, dy, dy_cs, dy_coff, x, x_cs,
+                       x_coff, dx, dx_cs, dx_coff, mean, invstd, scale, shift, sums, (int)pix_per_group, C, Cw, cq, relu,
+                       use_batch_stats, dbias != nullptr ? dxpart : nullptr, Cpart, po);
+  else if (x16)
     hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(nblk, ycols_w, G), dim3(256), 0, stream, dy, dy_cs, dy_coff, x, x_cs,
                        x_coff, dx, dx_cs, dx_coff, mean, invstd, scale, shift, sums, (int)pix_per_group, C, Cw, cq, relu,
                        use_batch_stats, dbias != nullptr ? dxpart : nullptr, Cpart, po);
@@ -723,7 +731,7 @@ extern "C" int hpri_bn_relu_bwd_pl(const float* dy, int dy_cs, int dy_coff, cons
                                    size_t ws_floats, long long P, long long pix_per_group, int C, int Cw, int relu,
                                    int use_batch_stats, void* planes, long long plane_stride, int pl_cs, int pl_coff,
                                    int pl_cw, int npl, hipStream_t stream) {
-  return bn_relu_bwd_impl(nullptr, 0, 0, dy, dy_cs, dy_coff, x, false, x_cs, x_coff, dx, dx_cs, dx_coff, mean, invstd, scale, shift, dgamma, dbeta,
+  return bn_relu_bwd_impl(nullptr, 0, 0, dy, dy_cs, dy_coff, x, false, x_cs, x_coff, false, dx, dx_cs, dx_coff, mean, invstd, scale, shift, dgamma, dbeta,
                           accumulate_param_grads, dbias, accumulate_dbias, workspace, ws_floats, P, pix_per_group, C, Cw, relu,
                           use_batch_stats, planes, plane_stride, pl_cs, pl_coff, pl_cw, npl, stream);
 }
@@ -738,7 +746,7 @@ extern "C" int hpri_bn_relu_bwd_fused(const float* partials, int part_blocks, in
                                       int use_batch_stats, void* planes, long long plane_stride, int pl_cs, int pl_coff,
                                       int pl_cw, int npl, hipStream_t stream) {
   HPRI_REQUIRE(partials != nullptr, "bn_relu_bwd_fused: null partial sums");
-  return bn_relu_bwd_impl(partials, part_blocks, part_cpart, dy, dy_cs, dy_coff, x, false, x_cs, x_coff, dx, dx_cs, dx_coff, mean, invstd,
+  return bn_relu_bwd_impl(partials, part_blocks, part_cpart, dy, dy_cs, dy_coff, x, false, x_cs, x_coff, false, dx, dx_cs, dx_coff, mean, invstd,
                           scale, shift, dgamma, dbeta, accumulate_param_grads, dbias, accumulate_dbias, workspace, ws_floats, P,
                           pix_per_group, C, Cw, relu, use_batch_stats, planes, plane_stride, pl_cs, pl_coff, pl_cw, npl, stream);
 }
@@ -753,7 +761,7 @@ extern "C" int hpri_bn_relu_bwd_fused_x16(const float* partials, int part_blocks
                                           int pl_cw, int npl, hipStream_t stream) {
   HPRI_REQUIRE(partials != nullptr, "bn_relu_bwd_fused_x16: null partial sums");
   HPRI_REQUIRE(((uintptr_t)x16 & 7) == 0, "bn_relu_bwd_fused_x16: the bf16 tensor must be 8-byte aligned");
-  return bn_relu_bwd_impl(partials, part_blocks, part_cpart, dy, dy_cs, dy_coff, reinterpret_cast<const float*>(x16), true, x_cs, x_coff, dx,
+  return bn_relu_bwd_impl(partials, part_blocks, part_cpart, dy, dy_cs, dy_coff, reinterpret_cast<const float*>(x16), true, x_cs, x_coff, false, dx,
                           dx_cs, dx_coff, mean, invstd, scale, shift, dgamma, dbeta, accumulate_param_grads, dbias, accumulate_dbias,
                           workspace, ws_floats, P, pix_per_group, C, Cw, relu, use_batch_stats, planes, plane_stride, pl_cs, pl_coff,
                           pl_cw, npl, stream);
@@ -768,9 +776,25 @@ extern "C" int hpri_bn_relu_bwd_x16(const float* dy, int dy_cs, int dy_coff, con
                                     int use_batch_stats, void* planes, long long plane_stride, int pl_cs, int pl_coff,
                                     int pl_cw, int npl, hipStream_t stream) {
   HPRI_REQUIRE(((uintptr_t)x16 & 7) == 0, "bn_relu_bwd_x16: the bf16 tensor must be 8-byte aligned");
-  return bn_relu_bwd_impl(nullptr, 0, 0, dy, dy_cs, dy_coff, reinterpret_cast<const float*>(x16), true, x_cs, x_coff, dx, dx_cs, dx_coff, mean,
+  return bn_relu_bwd_impl(nullptr, 0, 0, dy, dy_cs, dy_coff, reinterpret_cast<const float*>(x16), true, x_cs, x_coff, false, dx, dx_cs, dx_coff, mean,
                           invstd, scale, shift, dgamma, dbeta, accumulate_param_grads, dbias, accumulate_dbias, workspace, ws_floats,
                           P, pix_per_group, C, Cw, relu, use_batch_stats, planes, plane_stride, pl_cs, pl_coff, pl_cw, npl, stream);
+}
+
+// the same with the incoming gradient dy ALSO stored as bf16 (dy_cs / dy_coff in elements): the gradient of the inner tensor of a
+// DoubleConv in the bf16 mode, written by its only producer (hpri_conv_bf16v3 with the bf16 output bit) and read only here
+extern "C" int hpri_bn_relu_bwd_x16_dy16(const void* dy16, int dy_cs, int dy_coff, const void* x16, int x_cs, int x_coff,
+                                         float* dx, int dx_cs, int dx_coff, const float* mean, const float* invstd,
+                                         const float* scale, const float* shift, float* dgamma, float* dbeta,
+                                         int accumulate_param_grads, float* dbias, int accumulate_dbias, float* workspace,
+                                         size_t ws_floats, long long P, long long pix_per_group, int C, int Cw, int relu,
+                                         int use_batch_stats, void* planes, long long plane_stride, int pl_cs, int pl_coff,
+                                         int pl_cw, int npl, hipStream_t stream) {
+  HPRI_REQUIRE(((uintptr_t)x16 & 7) == 0 && ((uintptr_t)dy16 & 7) == 0, "bn_relu_bwd_x16_dy16: the bf16 tensors must be 8-byte aligned");
+  return bn_relu_bwd_impl(nullptr, 0, 0, reinterpret_cast<const float*>(dy16), dy_cs, dy_coff, reinterpret_cast<const float*>(x16), true, x_cs,
+                          x_coff, true, dx, dx_cs, dx_coff, mean, invstd, scale, shift, dgamma, dbeta, accumulate_param_grads, dbias,
+                          accumulate_dbias, workspace, ws_floats, P, pix_per_group, C, Cw, relu, use_batch_stats, planes, plane_stride,
+                          pl_cs, pl_coff, pl_cw, npl, stream);
 }
 
 // out[c] (+)= sum over all P pixels of src[p][coff + c]   (conv / linear bias gradients)

@@ -955,7 +955,8 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
             dyr.f32_valid = not f32_dead
             bp = tp.bnpart.pop(id(y), None)
             _lib.call(*(("hpri_bn_relu_bwd_fused_x16" if yr16 else "hpri_bn_relu_bwd_fused", _p(bp[0]), bp[1], bp[2]) if bp is not None else
-                        ("hpri_bn_relu_bwd_x16" if yr16 else "hpri_bn_relu_bwd_pl",)), g.ptr, g.cs, g.coff, yr.ptr, yr.cs, yr.coff,
+                        (("hpri_bn_relu_bwd_x16_dy16" if g.b16 else "hpri_bn_relu_bwd_x16") if yr16 else "hpri_bn_relu_bwd_pl",)),
+                      g.ptr, g.cs, g.coff, yr.ptr, yr.cs, yr.coff,
                       ctypes.c_void_p(0) if f32_dead else dyr.ptr, dyr.cs, dyr.coff,
                       _p(mean), _p(invstd), _p(scale), _p(shift), _p(dgam), _p(dbet), acc_g, _p(db), acc_b,
                       _p(ws), ws.numel(), x.P, x.P // G, cout, dyr.cw, int(relu), int(use_batch), *_pl_args(dpl), _stream())
@@ -984,7 +985,22 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
             dw, acc_w = tp.param_slot(weight)
             _wgrad(x, dyr, dw, acc_w, cin, cout, ks, bf16=lowp, split=split, gap=k_gap)
         if need_dx:
-            gx, acc = tp.grad_slot(x)
+            g16 = False
+            if (v2 and BF16_V3 and GRAD_BF16_INNER and x.bn_src is not None and x.bn_src[0].b16 and tp.grads.get(id(x)) is None
+                    and x.colsum_req is None and not FUSE_BN_REDUCE_BF16):
+                ksp = ctypes.c_int(); tl = ctypes.c_int(); wsf_ = ctypes.c_size_t()
+                _lib.call("hpri_conv_bf16v3_plan", x.N, x.H, x.W, _rup(cout, 32), _rup(cin, 64), ctypes.byref(ksp), ctypes.byref(tl),
+                          ctypes.byref(wsf_))
+                g16 = ksp.value == 1
+            if g16:
+                # x is the inner tensor of a DoubleConv: this launch is the only producer of dL/dx and the BatchNorm backward of
+                # the stage that made x its only reader -> bf16 storage (the reader rounds its own result to bf16 anyway)
+                gx = Act(torch.empty(x.P * _rup(cin, 8), dtype=torch.bfloat16, device=dev), x.N, x.H, x.W, cin, _rup(cin, 8), 0)
+                gx.b16, gx.f32_valid = True, False
+                tp.grads[id(x)] = gx
+                acc = False
+            else:
+                gx, acc = tp.grad_slot(x)
             # the column sums of (a channel range of) this gradient are wanted -- the bias gradient of the ConvTranspose2d that
             # produced half of a concat: the data-gradient kernel records them per tile in its epilogue (the BatchNorm statistics
             # machinery) instead of a dedicated pass over the tensor afterwards
@@ -1039,6 +1055,9 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
             elif wino_d:
                 upd, cin_cols_pad = _pack_wino(weight, 1, cout, cin, cin)
                 _conv_launch_wino(dyr, upd, None, gx, gstats, cout, cin, cin_cols_pad, gx.cw, accumulate=int(acc))
+            elif v2 and g16:
+                wpd, cin_cols_pad = _pack_bf16(weight, 1, cout, cin, T, cin, split=0)
+                _conv_launch_v2(dyr, wpd, None, gx, None, cout, cin, cin_cols_pad, gx.cw, accumulate=4)
             elif v2:
                 wpd, cin_cols_pad = _pack_bf16(weight, 1, cout, cin, T, cin, split=0)
                 us = x.up_slice
@@ -1579,6 +1598,9 @@ def plane_gemm_mode(module, bnorm: bool = True) -> bool:
 # wgrad_bf16v3.hip); the gradient of the upsampled half of the concat arrives as bf16 rows from the data-gradient launch that
 # produces it (hpri_conv_bf16v3_y2).  HPRI_CONVT_PLANES=0: the round-1 kernels that convert fp32 while staging.
 CONVT_PLANES = os.environ.get("HPRI_CONVT_PLANES", "1") != "0"
+# bf16 mode: the gradient of the INNER tensor of a DoubleConv (one producer: the second convolution's data-gradient launch; one
+# reader: the first stage's BatchNorm backward) is stored as bf16: 6 instead of 12 bytes of traffic per element.  HPRI_GRAD_BF16_INNER=0: fp32.
+GRAD_BF16_INNER = os.environ.get("HPRI_GRAD_BF16_INNER", "1") != "0"
 
 
 def convt_planes_mode(module) -> bool:

@@ -333,6 +333,14 @@ int hpri_bn_relu_bwd_x16(const float* dy, int dy_cs, int dy_coff, const void* x1
                          int accumulate_dbias, float* workspace, size_t ws_floats, long long P, long long pix_per_group,
                          int C, int Cw, int relu, int use_batch_stats, void* planes, long long plane_stride, int pl_cs,
                          int pl_coff, int pl_cw, int npl, hipStream_t stream);
+/* ... and with the incoming gradient stored as bf16 as well (the inner tensor of a DoubleConv in the bf16 mode: written by its only
+ * producer, hpri_conv_bf16v3 with the bf16-output bit, read only here; dy_cs / dy_coff in elements) */
+int hpri_bn_relu_bwd_x16_dy16(const void* dy16, int dy_cs, int dy_coff, const void* x16, int x_cs, int x_coff, float* dx,
+                              int dx_cs, int dx_coff, const float* mean, const float* invstd, const float* scale,
+                              const float* shift, float* dgamma, float* dbeta, int accumulate_param_grads, float* dbias,
+                              int accumulate_dbias, float* workspace, size_t ws_floats, long long P, long long pix_per_group,
+                              int C, int Cw, int relu, int use_batch_stats, void* planes, long long plane_stride, int pl_cs,
+                              int pl_coff, int pl_cw, int npl, hipStream_t stream);
 
 /* ---- bandwidth-bound ops (elementwise.hip) ---------------------------------------------------------
  * layout change at the module boundary (dataset.py:267-271 hands NC(D)HW), nn.MaxPool2d(2)
