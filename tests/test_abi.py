@@ -131,3 +131,45 @@ def test_plane_conv_v3_plan_matches_a_python_restatement_of_its_tiling():
     # the Winograd plan: one record per 16 x 8-pixel tile
     t = ctypes.c_int()
     assert lib.hpri_conv_wino4_plan(2, 608, 968, ctypes.byref(t)) == 0 and t.value == 2 * 76 * 61
+
+
+def test_plane_gemm_and_1x1_weight_gradient_plans_match_a_python_restatement():
+    """hpri_gemm_bf16v3_plan / hpri_wgrad1x1_bf16v3_plan are host-only: statistics tiles of the GEMM never straddle an image; the
+    weight gradient pads its slab to 256 n x 128 c tiles, takes a multiple of 8 pixel splits (one XCD owns whole splits) for about
+    three rounds of two workgroups per CU, never fewer than 64 stages of 32 pixels per split, and a single split for small problems;
+    the bad-argument paths of the new entry points return errors without a launch."""
+    import ctypes
+    from hyperpri_amd import _lib
+    lib = _lib.load()
+
+    def cdiv(a, b):
+        return (a + b - 1) // b
+    for N, HW in [(1, 425600), (2, 588544), (3, 257), (1, 5), (4, 256)]:
+        t = ctypes.c_int()
+        assert lib.hpri_gemm_bf16v3_plan(N, HW, ctypes.byref(t)) == 0 and t.value == N * cdiv(HW, 256)
+    assert lib.hpri_gemm_bf16v3_plan(0, 10, ctypes.byref(ctypes.c_int())) != 0
+    slots = 2 * 256                                             # (no device here: the compute-unit count falls back to 256)
+    for P, cin_pad, cout_pad in [(425600, 1664, 1664), (425600, 3328, 1664), (425600, 256, 1664), (1177088, 64, 64), (300, 64, 64), (5000, 256, 192),
+                                 (2 * 304 * 484, 128, 256)]:
+        sp, cr, nr = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        assert lib.hpri_wgrad1x1_bf16v3_plan(P, cin_pad, cout_pad, ctypes.byref(sp), ctypes.byref(cr), ctypes.byref(nr)) == 0
+        assert cr.value == cdiv(cin_pad, 128) * 128 and nr.value == cdiv(cout_pad, 256) * 256
+        tiles = (cr.value // 128) * (nr.value // 256)
+        stages = cdiv(P, 32)
+        s = cdiv(cdiv(3 * slots, tiles), 8) * 8
+        while s > 8 and stages // s < 64:
+            s -= 8
+        if s == 8 and stages // 8 < 16:
+            s = 1
+        per = cdiv(stages, s)
+        assert sp.value == cdiv(stages, per), (P, cin_pad, cout_pad, sp.value, s)
+        assert sp.value == 1 or sp.value % 8 == 0 or cdiv(stages, per) < s          # (rounding may drop empty trailing splits)
+    null = ctypes.c_void_p(0)
+    assert lib.hpri_gemm_bf16v3(null, 64, 0, null, null, null, 0, 0, null, 0, 0, null, 0, 1, 256, 64, 64, 64, 64, 0, null) != 0
+    assert lib.hpri_convt_fwd_bf16v3(null, 64, 0, null, null, null, 0, 0, null, 0, 0, 1, 4, 4, 64, 16, 64, 8, 8, 0, 0, null) != 0
+    assert lib.hpri_convt_dgrad_bf16v3(null, 64, 0, null, null, 64, 0, 1, 4, 4, 32, 64, 64, 64, 8, 8, 0, 0, 0, null) != 0
+    assert lib.hpri_wgrad1x1_bf16v3(null, 64, 0, 64, null, 64, 0, 64, null, 0, 100, 64, 64, null) != 0
+    assert lib.hpri_wgrad_convt_bf16v3(null, 64, 0, 64, null, 64, 0, null, 0, 1, 4, 4, 64, 64, 8, 8, 0, 0, null) != 0
+    assert lib.hpri_conv_bf16v3_y2(null, 64, 0, null, null, null, 64, 0, null, 1, 8, 8, 64, 64, 64, 64, null, 64, 0, 0, 64, 0, null) != 0
+    assert lib.hpri_pack_weight_bf16_gap(null, null, 0, 64, 64, 64, 1, 60, 30, 4, null) != 0
+    assert b"null" in lib.hpri_last_error() or len(lib.hpri_last_error()) > 0
