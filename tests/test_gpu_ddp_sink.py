@@ -35,11 +35,14 @@ def _oracle_grads(rank):
     return loss, grads
 
 
-def test_two_ranks_engine_sink_equals_mean_of_oracle_gradients(tmp_path):
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_two_ranks_engine_sink_equals_mean_of_oracle_gradients(tmp_path, prec):
+    """(bf16: BASELINE config 4's arithmetic under DDP -- the plane kernels write the weight gradients into the buckets from the
+    second stream; the same control flow and the same bit-equality between ranks, values in the bf16 band around the oracle mean.)"""
     world, port = 2, str(_free_port())
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4", GPU_MAX_HW_QUEUES="8")
     outs = [str(tmp_path / f"rank{r}.npz") for r in range(world)]
-    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_ddp_sink_rank.py"), str(r), str(world), port, outs[r]],
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_ddp_sink_rank.py"), str(r), str(world), port, outs[r], prec],
                               env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
     logs = []
     for p in procs:
@@ -63,8 +66,9 @@ def test_two_ranks_engine_sink_equals_mean_of_oracle_gradients(tmp_path):
         assert len(z[r]["issue_to_finish_ms"]) == nb          # overlap_ms(): one issue event per bucket
     # ---- values: identical on both ranks, and the mean of the per-rank oracle gradients ----
     ora = [_oracle_grads(r) for r in range(world)]
+    tol_loss, tol_g = (1e-5, 2e-2) if prec == "fp32" else (5e-3, 0.7)
     for r in range(world):
-        assert abs(float(z[r]["loss0"]) - ora[r][0]) < 1e-5
+        assert abs(float(z[r]["loss0"]) - ora[r][0]) < tol_loss
     worst = 0.0
     for k in ora[0][1]:
         a0, a1 = z[0]["g/" + k], z[1]["g/" + k]
@@ -72,6 +76,7 @@ def test_two_ranks_engine_sink_equals_mean_of_oracle_gradients(tmp_path):
         want = (ora[0][1][k].double() + ora[1][1][k].double()).numpy() / 2
         err = float(np.linalg.norm(a0.astype(np.float64) - want))
         ref = float(np.linalg.norm(want))
+        assert np.isfinite(a0).all(), k
         if ref < 1e-6:                                        # conv biases in front of a training-mode BN: zero up to rounding
             assert err < 1e-5, k
             continue
@@ -80,5 +85,6 @@ def test_two_ranks_engine_sink_equals_mean_of_oracle_gradients(tmp_path):
         # REFERENCE's own fp32 gradients sit up to 1.1e-2 (relative L2) from its fp64 gradients on this network
         # (tests/golden/grads_cubenet64_tiny.npz), so the oracle can pin the HIP average to that level, not below; the exact
         # statement of this test is the bit-equality of the two ranks above
-        assert err <= 2e-2 * ref, (k, err, ref)
-    record_margin("ddp_sink/world2/grad_rel_l2", worst, 2e-2)
+        # (bf16: two correct bf16 paths on this tiny net sit ~0.3 from fp32 in relative L2 -- tests/test_gpu_round2.py)
+        assert err <= tol_g * ref, (k, err, ref)
+    record_margin(f"ddp_sink/world2/{prec}/grad_rel_l2", worst, tol_g)
