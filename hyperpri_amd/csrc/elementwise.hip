@@ -250,6 +250,48 @@ __global__ void outconv_fwd_kernel(const float* __restrict__ x, int x_cs, int x_
   const long long grp = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
   const long long ngrp = ((long long)gridDim.x * blockDim.x) >> 4;
   const int C4 = (C + 3) >> 2;
+  if (K == 1 && (C & 3) == 0 && C4 <= 64) {
+    // one class, up to 256 channels (every head of the reference: model_parts.py:96 with n_classes = 1): the lane's weight quads live
+    // in registers, four pixels are in flight per 16-lane group, no per-pixel division.  Same products in the same order as the
+    // generic loop below (bit-identical logits): that loop paid four dependent scalar weight loads, each behind a condition, and a
+    // 64-bit division per pixel -- 2.0 TB/s on the 301 MB of a full-resolution 64-channel map.
+    float4 wq[4];
+    int qi[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int q = gl + 16 * j;
+      qi[j] = min(q, C4 - 1) * 4;                                    // (lanes beyond the channels read a valid quad and weigh it by zero)
+      wq[j] = q < C4 ? *reinterpret_cast<const float4*>(w + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const int nj = (C4 + 15) >> 4;                                     // quads per lane (uniform)
+    const float b0 = b ? b[0] : 0.f;
+    const long long NP = (long long)N * P;
+    for (long long pg0 = grp; pg0 < NP; pg0 += 4 * ngrp) {
+      float4 v[4][4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long long pg = min(pg0 + u * ngrp, NP - 1);
+        const float* xp = x + pg * x_cs + x_coff;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (j < nj) v[u][j] = *reinterpret_cast<const float4*>(xp + qi[j]);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long long pg = pg0 + u * ngrp;
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (j < nj) { s += v[u][j].x * wq[j].x; s += v[u][j].y * wq[j].y; s += v[u][j].z * wq[j].z; s += v[u][j].w * wq[j].w; }
+        s += __shfl_xor(s, 8, 16); s += __shfl_xor(s, 4, 16); s += __shfl_xor(s, 2, 16); s += __shfl_xor(s, 1, 16);
+        if (gl == 0 && pg < NP) {
+          const float o = s + b0;
+          y[pg] = o;
+          if (BCE) bsum += (double)oc_bce_elem(o, target[pg]);
+        }
+      }
+    }
+  } else
   for (long long pg = grp; pg < (long long)N * P; pg += ngrp) {
     const float* xp = x + pg * x_cs + x_coff;
     for (int k = 0; k < K; ++k) {
@@ -292,6 +334,36 @@ __global__ void outconv_bwd_data_kernel(const float* __restrict__ dy, const floa
   const float gs = BCE ? (gscale ? gscale[0] : 1.f) / (float)((double)N * K * P) : 1.f;
   const int C4 = Cw >> 2;
   const long long total = (long long)N * P * C4;
+  if (K == 1 && C4 <= 256 && (C4 & (C4 - 1)) == 0 && (C & 3) == 0) {
+    // one class, a power-of-two number of channel quads: a thread keeps ONE quad of the weight row and walks pixels, four in flight
+    // (the generic loop below: a 64-bit division and four conditional scalar weight loads per element)
+    const int qd = threadIdx.x & (C4 - 1), rows = blockDim.x / C4;
+    const int c = qd * 4;
+    const float4 wv = c < C ? *reinterpret_cast<const float4*>(w + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const long long NP = (long long)N * P, step = (long long)gridDim.x * rows;
+    for (long long pg0 = (long long)blockIdx.x * rows + threadIdx.x / C4; pg0 < NP; pg0 += 4 * step) {
+      float g[4];
+      float4 old[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long long pg = min(pg0 + u * step, NP - 1);
+        g[u] = dy[pg];
+        if (BCE) g[u] = oc_bce_grad(g[u], target[pg]) * gs;
+        old[u] = accumulate ? *reinterpret_cast<const float4*>(dx + pg * dx_cs + dx_coff + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long long pg = pg0 + u * step;
+        if (pg < NP) {
+          // (0 + g*w, then + old: the generic loop's order)
+          float o0 = 0.f + g[u] * wv.x, o1 = 0.f + g[u] * wv.y, o2 = 0.f + g[u] * wv.z, o3 = 0.f + g[u] * wv.w;
+          if (accumulate) { o0 += old[u].x; o1 += old[u].y; o2 += old[u].z; o3 += old[u].w; }
+          *reinterpret_cast<float4*>(dx + pg * dx_cs + dx_coff + c) = make_float4(o0, o1, o2, o3);
+        }
+      }
+    }
+    return;
+  }
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const long long pg = i / C4;
     const int c = (int)(i - pg * C4) * 4;
@@ -332,7 +404,27 @@ __global__ void outconv_bwd_weight_kernel(const float* __restrict__ dy, const fl
   const long long p1 = (p0 + per < NP) ? p0 + per : NP;
   float s[4] = {0.f, 0.f, 0.f, 0.f};
   float sb = 0.f;
-  for (long long pg = p0 + pr; pg < p1; pg += rows) {
+  long long pgs = p0 + pr;
+  if (K == 1) {
+    // one class: dy is indexed by the pixel itself; four pixels in flight, added in ascending order (the sums of the loop below)
+    for (; pgs + 3 * rows < p1; pgs += 4 * rows) {
+      float g[4];
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long long pg = pgs + u * rows;
+        g[u] = dy[pg];
+        if (BCE) g[u] = oc_bce_grad(g[u], target[pg]) * gs;
+        v[u] = c < C ? *reinterpret_cast<const float4*>(x + pg * x_cs + x_coff + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        sb += g[u];
+        if (c < C) { s[0] += g[u] * v[u].x; s[1] += g[u] * v[u].y; s[2] += g[u] * v[u].z; s[3] += g[u] * v[u].w; }
+      }
+    }
+  }
+  for (long long pg = pgs; pg < p1; pg += rows) {
     const long long n = pg / P, p = pg - n * P;
     float g = dy[(n * K + k) * P + p];
     if (BCE) g = oc_bce_grad(g, target[(n * K + k) * P + p]) * gs;
