@@ -134,37 +134,53 @@ __device__ __forceinline__ int first_argmax4(float a, float b, float c, float d)
   return k;
 }
 
+// One thread per 2x2 WINDOW and channel quad (round 1-3: one per input pixel, each reading all four values of its window -- four
+// times the load instructions, three 64-bit divisions per element): the window's four values and the pooled gradient are read once,
+// the four results written (or accumulated) from the same thread.  Windows of the last row / column of an odd-sized map have no
+// pooled value: their pixels get 0.  32-bit index arithmetic (host: N * ceil(H/2) * ceil(W/2) * C4 < 2^31).
 __global__ void maxpool2_bwd_kernel(const float* __restrict__ x, int x_cs, int x_coff, const float* __restrict__ dy,
                                     int dy_cs, int dy_coff, float* __restrict__ dx, int dx_cs, int dx_coff, int N, int H,
                                     int W, int OH, int OW, int C4, int accumulate) {
-  const long long total = (long long)N * H * W * C4;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int c = (int)(i % C4) * 4;
-    long long r = i / C4;
-    const int ix = (int)(r % W); r /= W;
-    const int iy = (int)(r % H);
-    const int n = (int)(r / H);
-    const int oy = iy >> 1, ox = ix >> 1;
-    float o[4] = {0.f, 0.f, 0.f, 0.f};
-    if (oy < OH && ox < OW) {
-      const float* b = x + (((long long)n * H + 2 * oy) * W + 2 * ox) * x_cs + x_coff + c;
+  const int WH = (H + 1) >> 1, WW = (W + 1) >> 1;
+  const unsigned total = (unsigned)N * WH * WW * C4;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const unsigned c = (i % (unsigned)C4) * 4u;
+    unsigned r = i / (unsigned)C4;
+    const int wx = (int)(r % (unsigned)WW); r /= (unsigned)WW;
+    const int wy = (int)(r % (unsigned)WH);
+    const int n = (int)(r / (unsigned)WH);
+    const int iy = 2 * wy, ix = 2 * wx;
+    const bool row1 = iy + 1 < H, col1 = ix + 1 < W, pooled = wy < OH && wx < OW;      // (pooled implies row1 && col1)
+    const long long pix = ((long long)n * H + iy) * W + ix;
+    float4 o[4] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f),
+                   make_float4(0.f, 0.f, 0.f, 0.f)};
+    if (pooled) {
+      const float* b = x + pix * x_cs + x_coff + c;
       const float4 v00 = *reinterpret_cast<const float4*>(b);
       const float4 v01 = *reinterpret_cast<const float4*>(b + x_cs);
       const float4 v10 = *reinterpret_cast<const float4*>(b + (long long)W * x_cs);
       const float4 v11 = *reinterpret_cast<const float4*>(b + (long long)W * x_cs + x_cs);
-      const float4 g = *reinterpret_cast<const float4*>(dy + (((long long)n * OH + oy) * OW + ox) * dy_cs + dy_coff + c);
-      const int me = (iy & 1) * 2 + (ix & 1);
-      if (first_argmax4(v00.x, v01.x, v10.x, v11.x) == me) o[0] = g.x;
-      if (first_argmax4(v00.y, v01.y, v10.y, v11.y) == me) o[1] = g.y;
-      if (first_argmax4(v00.z, v01.z, v10.z, v11.z) == me) o[2] = g.z;
-      if (first_argmax4(v00.w, v01.w, v10.w, v11.w) == me) o[3] = g.w;
+      const float4 g = *reinterpret_cast<const float4*>(dy + (((long long)n * OH + wy) * OW + wx) * dy_cs + dy_coff + c);
+      const int kx = first_argmax4(v00.x, v01.x, v10.x, v11.x), ky = first_argmax4(v00.y, v01.y, v10.y, v11.y);
+      const int kz = first_argmax4(v00.z, v01.z, v10.z, v11.z), kw = first_argmax4(v00.w, v01.w, v10.w, v11.w);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        o[m].x = kx == m ? g.x : 0.f; o[m].y = ky == m ? g.y : 0.f; o[m].z = kz == m ? g.z : 0.f; o[m].w = kw == m ? g.w : 0.f;
+      }
     }
-    float* p = dx + (((long long)n * H + iy) * W + ix) * dx_cs + dx_coff + c;
+    float* p = dx + pix * dx_cs + dx_coff + c;
+    float* pm[4] = {p, p + dx_cs, p + (long long)W * dx_cs, p + (long long)W * dx_cs + dx_cs};
+    const bool ok[4] = {true, col1, row1, row1 && col1};
     if (accumulate) {
-      const float4 old = *reinterpret_cast<const float4*>(p);
-      o[0] += old.x; o[1] += old.y; o[2] += old.z; o[3] += old.w;
+      float4 old[4];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) old[m] = ok[m] ? *reinterpret_cast<const float4*>(pm[m]) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) { o[m].x += old[m].x; o[m].y += old[m].y; o[m].z += old[m].z; o[m].w += old[m].w; }
     }
-    *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]);
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+      if (ok[m]) *reinterpret_cast<float4*>(pm[m]) = o[m];
   }
 }
 
@@ -560,7 +576,9 @@ extern "C" int hpri_maxpool2_bwd(const float* x, int x_cs, int x_coff, const flo
                                  int dx_cs, int dx_coff, int N, int H, int W, int C, int accumulate, hipStream_t stream) {
   HPRI_REQUIRE(x && dy && dx && N > 0 && H >= 2 && W >= 2 && C > 0 && C % 4 == 0, "maxpool2_bwd: bad arguments");
   HPRI_REQ_V4(x_cs, x_coff); HPRI_REQ_V4(dy_cs, dy_coff); HPRI_REQ_V4(dx_cs, dx_coff);
-  hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(ew_blocks((long long)N * H * W * (C / 4))), dim3(256), 0, stream, x, x_cs,
+  const long long windows = (long long)N * ((H + 1) / 2) * ((W + 1) / 2) * (C / 4);
+  HPRI_REQUIRE(windows < (1ll << 31), "maxpool2_bwd: more than 2^31 window quads");
+  hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(ew_blocks(windows)), dim3(256), 0, stream, x, x_cs,
                      x_coff, dy, dy_cs, dy_coff, dx, dx_cs, dx_coff, N, H, W, H / 2, W / 2, C / 4, accumulate);
   HPRI_CHECK_LAUNCH();
   return HPRI_OK;

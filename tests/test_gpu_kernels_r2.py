@@ -385,3 +385,32 @@ def test_bf16_plane_weight_gradient_vs_fp64_of_rounded_operands(lib, shape):
     assert lib.hpri_conv_wgrad_bf16v2(P(xp), cs16, 0, cs16, P(dp), cso16, 0, cso16, P(ws), ws.numel() - 1, N, H, W, cs16, rup(Cout, 64), _st()) != 0
     # misaligned channel stride is an error return
     assert lib.hpri_conv_wgrad_bf16v2(P(xp), cs16 + 4, 0, cs16, P(dp), cso16, 0, cso16, P(ws), ws.numel(), N, H, W, cs16, rup(Cout, 64), _st()) != 0
+
+
+@pytest.mark.parametrize("shape", [(2, 9, 11, 8), (1, 36, 50, 64), (3, 7, 8, 12), (1, 2, 2, 4), (2, 25, 12, 40)])
+@pytest.mark.parametrize("accumulate", [0, 1])
+def test_maxpool_backward_one_thread_per_window(lib, shape, accumulate):
+    """hpri_maxpool2_bwd (round 3: one thread per 2x2 window) against torch's max_pool2d autograd: odd heights / widths (the floor
+    drops the last row / column: zero gradient there), ties (the FIRST maximum in scan order takes the gradient, as ATen), a
+    channel-slice view of a wider gradient buffer, accumulate."""
+    N, H, W, C = shape
+    torch.manual_seed(23)
+    x = torch.randn(N, H, W, C, device=DEV)
+    x[:, ::2, ::2] = x[:, ::2, ::2].round()                   # ties inside windows
+    x[:, : H // 2 * 2 : 2, 1 : W // 2 * 2 : 2] = x[:, : H // 2 * 2 : 2, : W // 2 * 2 : 2]
+    OH, OW = H // 2, W // 2
+    dy = torch.randn(N, OH, OW, C, device=DEV)
+    cs, off = C + 8, 4
+    prior = torch.randn(N * H * W, cs, device=DEV)
+    dx = prior.clone()
+    rc = lib.hpri_maxpool2_bwd(P(x), C, 0, P(dy), C, 0, P(dx), cs, off, N, H, W, C, accumulate, _st())
+    assert rc == 0, lib.hpri_last_error()
+    torch.cuda.synchronize()
+    xr = x.permute(0, 3, 1, 2).detach().cpu().double().requires_grad_(True)
+    yr = torch.nn.functional.max_pool2d(xr, 2)
+    yr.backward(dy.permute(0, 3, 1, 2).cpu().double())
+    ref = xr.grad.permute(0, 2, 3, 1).reshape(-1, C)
+    got = dx.double().cpu()
+    want = ref + (prior.double().cpu()[:, off:off + C] if accumulate else 0)
+    assert torch.equal(got[:, off:off + C].float(), want.float())
+    assert torch.equal(got[:, :off], prior.double().cpu()[:, :off]) and torch.equal(got[:, off + C:], prior.double().cpu()[:, off + C:])
