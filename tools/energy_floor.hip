@@ -1,0 +1,233 @@
+// Energy floor of the bf16 plane kernels: what the chip sustains (wall TFLOP/s AND in-kernel clock) on a bare loop that issues
+// the same KIND and NUMBER of instructions per MFMA as a candidate kernel structure -- ds_read_b128 fragment reads per MFMA (the
+// wave tile P x Q sets them: (P + Q) / (P Q)), LDS-DMA pieces per stage (L2-resident "weights" and streamed "halo"), vector-ALU
+// instructions per MFMA (a Winograd-domain transform + 3-plane split) -- on RANDOM operands, every CU busy, after >= 2 s of
+// back-to-back launches (MI355X_MICROARCH.md, DVFS give-back 6; cdna_hip_programming.md rule 28).  No convolution is computed:
+// only the instruction mix and the data movement are real.  VERDICT r3 item 1 asks for exactly this before another scheduling A/B.
+//   hipcc --offload-arch=gfx950 -O3 tools/energy_floor.hip -o tools/bin/energy_floor && tools/bin/energy_floor [filter]
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstring>
+#include <cstdlib>
+#include <vector>
+#include <algorithm>
+#include <string>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+#define MAKE_RSRC(p_, n_) __builtin_amdgcn_make_buffer_rsrc((void*)(p_), 0, (int)(n_), 0x00020000)
+#define LDS_DMA16(rs_, lds_, v_, s_) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_, lds_, 16, v_, s_, 0, 0)
+#else      // (the host pass drops a kernel template that mentions the device-only descriptor type)
+typedef int rsrc_t;
+#define MAKE_RSRC(p_, n_) 0
+#define LDS_DMA16(rs_, lds_, v_, s_) ((void)(rs_))
+#endif
+
+#define LDS_FRAG_BYTES (64 * 1024)     // fragment image (random bf16), read lane-linear: conflict-free ds_read_b128
+#define LDS_DMA_BYTES (8 * 1024)       // where the DMA pieces land (never read: a model)
+
+struct Args {
+  const unsigned char* resident; unsigned resident_bytes;   // small: stays in L2 (the packed weights of a 64-channel block)
+  const unsigned char* stream; unsigned long long stream_bytes;   // large: every piece is read once per launch (the input planes)
+  unsigned long long* out;     // [wg][4]: d(memtime), d(memrealtime), -, -
+  int stages;                  // loop trips; one stage = 3 groups ("taps") of P*Q MFMAs
+  int zero;                    // 1: all operands zero (the data-independent part of the power)
+};
+
+// SHAPE 0: v_mfma_f32_16x16x32_bf16, wave tile 16P x 16Q;  SHAPE 1: v_mfma_f32_32x32x16_bf16, wave tile 32P x 32Q.
+// RG: in RG of the 3 groups of a stage the fragments are re-read from LDS (0: they stay in registers, the bare loop).  NVG vector-ALU instructions per group
+// (v_and / v_sub_f32 / v_perm round robin: the 3-plane split's mix).  NDR / NDS: LDS-DMA pieces per STAGE from the resident / the
+// streamed buffer.  MINW: waves per SIMD the launch is built for (2: two 4-wave workgroups per CU; 1: one, 512 registers).
+template <int SHAPE, int P, int Q, int RG, int NVG, int NDR, int NDS, int MINW>
+__global__ __launch_bounds__(256, MINW) void floor_kernel(Args a) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[LDS_FRAG_BYTES + LDS_DMA_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // random bf16 in (-1/8, 1/8), or zeros
+  for (int i = tid; i < LDS_FRAG_BYTES / 4; i += 256) {
+    unsigned x = (blockIdx.x * 16411u + i) * 0x9E3779B9u;
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    const unsigned lo = 0x3C00u | (x & 0x80FFu) | ((x >> 3) & 0x0100u), hi = 0x3C00u | ((x >> 16) & 0x80FFu) | ((x >> 9) & 0x0100u);
+    reinterpret_cast<unsigned*>(smem)[i] = a.zero ? 0u : (lo | (hi << 16));
+  }
+  __syncthreads();
+  constexpr int NACC = SHAPE == 0 ? 4 : 16;
+  typedef float accv __attribute__((ext_vector_type(NACC)));
+  accv acc[P][Q];
+#pragma unroll
+  for (int p = 0; p < P; ++p)
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+#pragma unroll
+      for (int r = 0; r < NACC; ++r) acc[p][q][r] = a.zero ? 0.f : (float)((tid * 7 + p * 3 + q * 5 + r) & 15) * 0.01f;
+  bf16x8 fa[P], fb[Q];
+  const unsigned char* fbase = smem + lane * 16;
+#pragma unroll
+  for (int p = 0; p < P; ++p) fa[p] = *reinterpret_cast<const bf16x8*>(fbase + p * 1024);
+#pragma unroll
+  for (int q = 0; q < Q; ++q) fb[q] = *reinterpret_cast<const bf16x8*>(fbase + (P + q) * 1024);
+  float vx[8]; int vi[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { vx[i] = 0.37f * (float)(lane + i); vi[i] = lane * 77 + i; }
+  const rsrc_t rs_r = MAKE_RSRC(a.resident, a.resident_bytes);
+  // streamed buffer: each workgroup owns a contiguous slice; the descriptor base is moved per workgroup (offsets stay 32-bit)
+  const unsigned long long slice = (a.stream_bytes / gridDim.x) & ~1023ull;
+  const unsigned long long sb = (unsigned long long)(uintptr_t)a.stream + slice * blockIdx.x;
+  const unsigned slo = __builtin_amdgcn_readfirstlane((unsigned)sb), shi = __builtin_amdgcn_readfirstlane((unsigned)(sb >> 32));
+  const rsrc_t rs_s = MAKE_RSRC((((unsigned long long)shi << 32) | slo), (slice > 0x7FFFFF00ull ? 0x7FFFFF00ull : slice));
+  const unsigned lane16 = lane * 16;
+  unsigned rpos = wave * 1024u, spos = wave * 1024u;
+  auto lds_dst = [&](int i) { return (__attribute__((address_space(3))) void*)(smem + LDS_FRAG_BYTES + ((wave * 2 + (i & 1)) << 10)); };
+
+  unsigned long long t0, t1, r0, r1;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r0)::"memory");
+  for (int s = 0; s < a.stages; ++s) {
+    if (NDR + NDS > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDR + NDS) : "memory");
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+      if (g < RG) {
+        const unsigned pi0 = (unsigned)(s * 3 + g) * (P + Q);
+#pragma unroll
+        for (int p = 0; p < P; ++p) fa[p] = *reinterpret_cast<const bf16x8*>(fbase + (((pi0 + p) & 63u) << 10));
+#pragma unroll
+        for (int q = 0; q < Q; ++q) fb[q] = *reinterpret_cast<const bf16x8*>(fbase + (((pi0 + P + q) & 63u) << 10));
+      }
+#pragma unroll
+      for (int p = 0; p < P; ++p)
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+          const int j = p * Q + q;
+          if constexpr (SHAPE == 0) acc[p][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[q], fa[p], acc[p][q], 0, 0, 0);
+          else acc[p][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[q], fa[p], acc[p][q], 0, 0, 0);
+          // vector-ALU filler, spread evenly over the group
+#pragma unroll
+          for (int v = (j * NVG) / (P * Q); v < ((j + 1) * NVG) / (P * Q); ++v) {
+            const int r = v & 7;
+            if (v % 3 == 0) asm volatile("v_and_b32 %0, 0xffff0000, %0" : "+v"(vi[r]));
+            else if (v % 3 == 1) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(vx[r]) : "v"(vx[(r + 1) & 7]));
+            else asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(vi[r]) : "v"(vi[(r + 3) & 7]), "v"(0x07060302));
+          }
+          // DMA pieces of the stage, spread over its 3 P Q MFMAs
+          const int jj = g * P * Q + j;
+          const int want = ((jj + 1) * (NDR + NDS)) / (3 * P * Q), dma_done = (jj * (NDR + NDS)) / (3 * P * Q);
+          if (want > dma_done) {
+            if (dma_done < NDR) {
+              LDS_DMA16(rs_r, lds_dst(dma_done), lane16, rpos);
+              rpos += 4096u; if (rpos + 1024u > a.resident_bytes) rpos = wave * 1024u;
+            } else {
+              LDS_DMA16(rs_s, lds_dst(dma_done), lane16, spos);
+              spos += 4096u; if ((unsigned long long)spos + 1024u > slice || spos > 0x7FFFF000u) spos = wave * 1024u;
+            }
+          }
+        }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r1)::"memory");
+  float sum = 0.f;
+#pragma unroll
+  for (int p = 0; p < P; ++p)
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+#pragma unroll
+      for (int r = 0; r < NACC; ++r) sum += acc[p][q][r];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) sum += vx[i] + (float)vi[i];
+  if (sum == 12345.678f) a.out[0] = 1;
+  if (tid == 0) { a.out[4 + blockIdx.x * 4 + 0] = t1 - t0; a.out[4 + blockIdx.x * 4 + 1] = r1 - r0; }
+}
+
+static unsigned char *g_res, *g_str; static unsigned long long g_str_bytes; static unsigned long long* g_out;
+static const char* g_filter = nullptr;
+
+template <int SHAPE, int P, int Q, int RG, int NVG, int NDR, int NDS, int MINW>
+void run(const char* name, int zero = 0) {
+  if (g_filter && !strstr(name, g_filter)) return;
+  int ncu = 256; hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, 0);
+  const int grid = ncu * MINW;
+  const double flop_per_mfma = 32768.0;     // both shapes: 2 * 16*16*32 = 2 * 32*32*16 / 2 ... (16x16x32: 16384; 32x32x16: 32768)
+  const double fpm = SHAPE == 0 ? 16384.0 : flop_per_mfma;
+  const double cyc = SHAPE == 0 ? 16.0 : 32.0;
+  const int mfma_stage = 3 * P * Q;
+  // ~4 ms per launch at a guessed 1 PF
+  const double flop_stage_chip = fpm * mfma_stage * 4.0 * grid;
+  int stages = (int)(4e-3 * 1.0e15 / flop_stage_chip);
+  if (stages < 8) stages = 8;
+  Args a{g_res, 256u * 1024u, g_str, g_str_bytes, g_out, stages, zero};
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  auto launch = [&]() { hipLaunchKernelGGL((floor_kernel<SHAPE, P, Q, RG, NVG, NDR, NDS, MINW>), dim3(grid), dim3(256), 0, 0, a); };
+  // settle: >= 2 s of back-to-back launches
+  hipEventRecord(e0); launch(); hipEventRecord(e1); hipDeviceSynchronize();
+  float ms1; hipEventElapsedTime(&ms1, e0, e1);
+  const double warm_s = getenv("FLOOR_WARM_S") ? atof(getenv("FLOOR_WARM_S")) : 2.2;      // settle time in front of the timed launches
+  int nwarm = (int)(warm_s * 1000.0 / (ms1 > 0.05f ? ms1 : 0.05f)); if (nwarm > 40000) nwarm = 40000;
+  for (int i = 0; i < nwarm; ++i) launch();
+  const int reps = 40;
+  hipEventRecord(e0);
+  for (int i = 0; i < reps; ++i) launch();
+  hipEventRecord(e1); hipDeviceSynchronize();
+  if (hipGetLastError() != hipSuccess) { printf("{\"name\": \"%s\", \"error\": \"launch\"}\n", name); return; }
+  float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
+  std::vector<unsigned long long> h(4 + (size_t)grid * 4);
+  hipMemcpy(h.data(), g_out, h.size() * 8, hipMemcpyDeviceToHost);
+  std::vector<double> clk, cy;
+  for (int b = 0; b < grid; ++b) { const double dt = (double)h[4 + b * 4], dr = (double)h[4 + b * 4 + 1]; if (dr > 0) { clk.push_back(dt / dr * 0.1); cy.push_back(dt); } }
+  std::sort(clk.begin(), clk.end()); std::sort(cy.begin(), cy.end());
+  const double tf = fpm * mfma_stage * (double)stages * 4.0 * grid / (ms * 1e-3) / 1e12;
+  const double cyc_per_mfma_simd = cy[cy.size() / 2] / ((double)stages * mfma_stage * MINW);
+  const double dma_bytes = (double)(NDR + NDS) * 1024.0 * 4.0 * grid * stages;
+  printf("{\"name\": \"%s\", \"mfma\": \"%s\", \"wave_tile\": \"%dx%d\", \"waves_per_simd\": %d, \"ds_read_b128_per_mfma\": %.3f, \"valu_per_mfma\": %.2f, "
+         "\"dma_pieces_per_stage_resident\": %d, \"dma_pieces_per_stage_streamed\": %d, \"data\": \"%s\", \"settle_s\": %.1f, \"ms\": %.3f, \"tflops\": %.1f, \"frac_of_2.5PF\": %.3f, "
+         "\"in_kernel_ghz_median\": %.3f, \"cycles_per_mfma_per_simd\": %.2f, \"ideal_cycles\": %.0f, \"dma_TBps\": %.2f, \"stream_TBps\": %.2f}\n",
+         name, SHAPE == 0 ? "16x16x32" : "32x32x16", (SHAPE == 0 ? 16 : 32) * P, (SHAPE == 0 ? 16 : 32) * Q, MINW,
+         (double)RG * (P + Q) / (3.0 * P * Q), (double)NVG / (P * Q), NDR, NDS, zero ? "zeros" : "random", warm_s, ms, tf, tf / 2500.0,
+         clk.empty() ? 0.0 : clk[clk.size() / 2], cyc_per_mfma_simd, cyc, dma_bytes / (ms * 1e-3) / 1e12,
+         (double)NDS * 1024.0 * 4.0 * grid * stages / (ms * 1e-3) / 1e12);
+  fflush(stdout);
+}
+
+int main(int argc, char** argv) {
+  if (argc > 1) g_filter = argv[1];
+  g_str_bytes = 4ull << 30;
+  hipMalloc(&g_res, 256 * 1024); hipMalloc(&g_str, g_str_bytes); hipMalloc(&g_out, (4 + 1024 * 4) * 8);
+  hipMemset(g_out, 0, (4 + 1024 * 4) * 8);
+  {   // random bf16-looking bytes (finite: exponent field forced small)
+    std::vector<unsigned> h((64u << 20) / 4);
+    unsigned x = 12345u;
+    for (auto& v : h) { x = x * 1664525u + 1013904223u; v = (x & 0x80FF80FFu) | 0x3C003C00u | ((x >> 5) & 0x01000100u); }
+    for (unsigned long long off = 0; off < g_str_bytes; off += (64u << 20)) hipMemcpy(g_str + off, h.data(), 64u << 20, hipMemcpyHostToDevice);
+    hipMemcpy(g_res, h.data(), 256 * 1024, hipMemcpyHostToDevice);
+  }
+  //      SHAPE P  Q  RG NVG NDR NDS MINW
+  run<0, 4, 4, 0, 0, 0, 0, 2>("bare16 regs 64x64 w2");
+  run<0, 4, 4, 0, 0, 0, 0, 2>("bare16 regs 64x64 w2 zeros", 1);
+  run<1, 2, 2, 0, 0, 0, 0, 2>("bare32 regs 64x64 w2");
+  run<0, 4, 4, 3, 0, 0, 0, 2>("reads16 64x64 w2");            // v3's wave tile: 0.5 reads per MFMA
+  run<0, 4, 4, 3, 0, 0, 0, 2>("reads16 64x64 w2 zeros", 1);
+  run<0, 8, 4, 3, 0, 0, 0, 2>("reads16 128x64 w2");           // 0.375
+  run<0, 6, 4, 3, 0, 0, 0, 2>("reads16 96x64 w2");            // 0.417
+  run<0, 8, 8, 3, 0, 0, 0, 1>("reads16 128x128 w1");          // 0.25, one wave per SIMD
+  run<0, 16, 4, 3, 0, 0, 0, 1>("reads16 256x64 w1");          // 0.3125, one wave per SIMD
+  run<1, 2, 2, 3, 0, 0, 0, 2>("reads32 64x64 w2");            // 32x32x16: 1 read per 32-cycle MFMA
+  run<1, 4, 2, 3, 0, 0, 0, 2>("reads32 128x64 w2");
+  // + the DMA of the 3x3 plane convolution (per wave and stage: 3 weight pieces, L2-resident; halo pieces streamed)
+  run<0, 4, 4, 3, 0, 3, 2, 2>("conv16 64x64 w2 dma3+2");      // conv_bf16v3 as built
+  run<0, 4, 4, 3, 0, 3, 0, 2>("conv16 64x64 w2 dma3+0");      // ... without the streamed part
+  run<0, 4, 4, 3, 0, 0, 2, 2>("conv16 64x64 w2 dma0+2");      // ... without the weight part (one weight stream per CU: half of it)
+  run<0, 8, 4, 3, 0, 3, 4, 2>("conv16 128x64 w2 dma3+4");     // 512-pixel workgroups: same halo bytes per MFMA, half the weight bytes
+  run<0, 4, 4, 3, 0, 3, 2, 2>("conv16 64x64 w2 dma3+2 zeros", 1);
+  // + vector-ALU per MFMA: the Winograd-domain 3-plane split (transform + split ~ 7 VALU per V value = 56 per 8-value fragment;
+  //   one V fragment triple feeds 6 Q MFMAs)
+  run<0, 4, 4, 3, 16, 0, 0, 2>("valu16 64x64 w2 1.0/mfma");
+  run<0, 4, 4, 3, 32, 0, 0, 2>("valu16 64x64 w2 2.0/mfma");
+  run<0, 4, 4, 3, 37, 3, 2, 2>("wino6 16x16x32 Q=4: 2.33 valu/mfma + dma");
+  run<0, 4, 8, 3, 37, 3, 2, 1>("wino6 16x16x32 Q=8: 1.17 valu/mfma + dma w1");
+  run<0, 4, 4, 1, 37, 3, 2, 2>("wino6 16x16x32 Q=4: 2.33 valu/mfma + dma, reads 1 group in 3");
+  run<1, 2, 2, 3, 19, 3, 2, 2>("wino6 32x32x16 Q=2x32: 4.67 valu/mfma32 + dma");
+  run<1, 2, 4, 3, 19, 3, 2, 1>("wino6 32x32x16 Q=4x32: 2.33 valu/mfma32 + dma w1");
+  return 0;
+}

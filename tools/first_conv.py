@@ -22,7 +22,39 @@ FLOPS = 2.0 * N * H * W * CIN * COUT * 9
 PEAK_BF16 = 2500.0      # TFLOP/s, MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 
 
-def measure(reps=20, modes=("bf16_planes", "fp32")):
+def _time(call, reps, settle_s, check):
+    """(burst ms, sustained ms): ``reps`` launches timed right after three warm-up launches on a chip that has just been idle
+    (what rounds 1-3 reported), and the same after ``settle_s`` seconds of back-to-back launches.  The two differ by ~20 % on
+    this layer: the chip raises its clock only over tens of milliseconds of load (profiles/r04_first_conv_ramp.txt: 800 TF over
+    the first 10 launches from idle, 847 over 50, 945-994 sustained for 20 s with no droop), and a step of the network keeps
+    it loaded, so the sustained figure is the one that describes the kernel inside a step."""
+    import time
+    for _ in range(3):
+        check(call())
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        call()
+    e1.record()
+    torch.cuda.synchronize()
+    burst = e0.elapsed_time(e1) / reps
+    if settle_s <= 0:
+        return burst, burst
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < settle_s:
+        for _ in range(100):
+            call()
+        torch.cuda.synchronize()
+    n = max(reps, 50)
+    e0.record()
+    for _ in range(n):
+        call()
+    e1.record()
+    torch.cuda.synchronize()
+    return burst, e0.elapsed_time(e1) / n
+
+
+def measure(reps=20, modes=("bf16_planes", "fp32"), settle_s=1.0):
     lib = _lib.load()
     dev = torch.device("cuda", 0)
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -60,6 +92,13 @@ def measure(reps=20, modes=("bf16_planes", "fp32")):
                                 cout_pad, COUT, 0, 0, P(ws), ws.numel(), st)
             out["bf16_kernel"] = kern
             alg_bytes = N * H * W * (cs16 * 2 + COUT * 4) + wp.numel() * 2
+            if kern == "hpri_conv_bf16v3":
+                # the form the bf16 STEP runs (engine.YR_BF16): the pre-BN tensor leaves as bf16 straight from the accumulators
+                # (statistics from the fp32 sums) -- SURVEY.md 7.3-2's fp16-in / fp16-out variant of the roofline claim
+                y16 = torch.empty(N * H * W * COUT, dtype=torch.bfloat16, device=dev)
+                call16 = lambda: conv(P(planes), 0, cs16, 0, P(wp), P(b), P(y16), COUT, 0, P(stats), N, H, W, cs16, COUT,
+                                      cout_pad, COUT, 4, 0, P(ws), ws.numel(), st)
+                alg16 = N * H * W * (cs16 * 2 + COUT * 2) + wp.numel() * 2
         else:
             wp = torch.empty(lib.hpri_packed_weight_floats(CIN, cout_pad, 9), device=dev)
             assert lib.hpri_pack_weight(P(w), P(wp), 0, CIN, COUT, cout_pad, 9, 0, 0, CIN, st) == 0
@@ -69,20 +108,21 @@ def measure(reps=20, modes=("bf16_planes", "fp32")):
             call = lambda: lib.hpri_conv_fwd(P(x), cs, 0, P(wp), P(b), P(y), COUT, 0, P(stats), N, H, W, cs, COUT, cout_pad, COUT, 3,
                                              0, 0, 0, 0, 0, 0, 0, 0, P(ws), ws.numel(), st)
             alg_bytes = N * H * W * (cs * 4 + COUT * 4) + wp.numel() * 4
-        for _ in range(3):
-            assert call() == 0, lib.hpri_last_error()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
-            call()
-        e1.record()
-        torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / reps
+        def check(rc):
+            assert rc == 0, lib.hpri_last_error()
+        burst, ms = _time(call, reps, settle_s, check)
         tf = FLOPS / ms / 1e9
         out[mode] = {"ms": round(ms, 4), "tflops": round(tf, 1), "algorithmic_hbm_mb": round(alg_bytes / 1e6, 1),
-                     "algorithmic_tb_s": round(alg_bytes / ms / 1e9, 2)}
+                     "algorithmic_tb_s": round(alg_bytes / ms / 1e9, 2), "settle_s": settle_s,
+                     "ms_burst_from_idle": round(burst, 4), "tflops_burst_from_idle": round(FLOPS / burst / 1e9, 1)}
         if mode == "bf16_planes":
             out[mode]["frac_of_2.5PF"] = round(tf / PEAK_BF16, 4)
+            if out.get("bf16_kernel") == "hpri_conv_bf16v3":
+                b16, ms16 = _time(call16, reps, settle_s, check)
+                out["bf16_planes_bf16_out"] = {"ms": round(ms16, 4), "tflops": round(FLOPS / ms16 / 1e9, 1),
+                                               "frac_of_2.5PF": round(FLOPS / ms16 / 1e9 / PEAK_BF16, 4),
+                                               "algorithmic_hbm_mb": round(alg16 / 1e6, 1), "algorithmic_tb_s": round(alg16 / ms16 / 1e9, 2),
+                                               "ms_burst_from_idle": round(b16, 4)}
         else:
             out[mode]["frac_of_157.3TF"] = round(tf / 157.3, 4)
     # ---- fp32 Winograd F(2x2,3x3) on the same layer (the headline path; conv_wino4.hip) ----
@@ -112,4 +152,4 @@ def measure(reps=20, modes=("bf16_planes", "fp32")):
 if __name__ == "__main__":
     reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
     modes = tuple(sys.argv[2].split(",")) if len(sys.argv) > 2 else ("bf16_planes", "fp32")
-    print(json.dumps(measure(reps, modes)))
+    print(json.dumps(measure(reps, modes, settle_s=float(os.environ.get("SETTLE", "1.0")))))
