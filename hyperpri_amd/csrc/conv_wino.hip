@@ -668,6 +668,9 @@ __global__ __launch_bounds__(64 * S) void wino_wgrad_reduce_wide_kernel(const fl
 #pragma unroll
   for (int xi = 0; xi < 16; ++xi) u[xi] = 0.f;
   const size_t slab = (size_t)16 * Cr * Nr;
+  // (one slab = 16 independent loads in flight per thread, 16 k per workgroup; unrolled by hipcc, the S = 16 form -- 1024
+  // threads, 128 registers -- spilled 50 of them)
+#pragma unroll 1
   for (int k = sl; k < splits; k += S) {
     const float* p = ws + (size_t)k * slab + (size_t)c * Nr + n;
 #pragma unroll
@@ -679,6 +682,7 @@ __global__ __launch_bounds__(64 * S) void wino_wgrad_reduce_wide_kernel(const fl
   }
   __syncthreads();
   if (sl > 0 || n >= Cout) return;
+#pragma unroll 2
   for (int q = 0; q < S - 1; ++q)
 #pragma unroll
     for (int xi = 0; xi < 16; ++xi) u[xi] += red[q][xi][ln];

@@ -257,7 +257,7 @@ __device__ __forceinline__ float oc_bce_grad(float xi, float yi) {           // 
 // BCE = true: also the per-block fp64 partial sum of BCEWithLogits(y, target) (nn.BCEWithLogitsLoss of PLTrainer.py:86 on the
 // logits this kernel has just produced): one pass over the logits less, the loss finishes with step.hip's finalize kernel
 template <bool BCE>
-__global__ void outconv_fwd_kernel(const float* __restrict__ x, int x_cs, int x_coff, const float* __restrict__ w,
+__global__ __launch_bounds__(256) void outconv_fwd_kernel(const float* __restrict__ x, int x_cs, int x_coff, const float* __restrict__ w,
                                    const float* __restrict__ b, float* __restrict__ y, int N, long long P, int C, int K,
                                    const float* __restrict__ target, double* __restrict__ partial) {
   __shared__ double bred[256];

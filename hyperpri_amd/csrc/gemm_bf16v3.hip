@@ -262,7 +262,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16v3_kernel(GemmV3Args a) {
         }
       }
       if (a.y != nullptr) {
-        if (a.accumulate) {
+        if (MODE != 1 && a.accumulate) {          // (the transposed convolution's forward never accumulates: hpri_convt_fwd_bf16v3; with the
+                                                  //  64 registers of old values compiled in, that form spilled 10)
           f32x4 old_[4][4];
 #pragma unroll
           for (int mt = 0; mt < 4; ++mt)
@@ -402,6 +403,7 @@ static int g3_launch(int mode, const void* xp, int x_cs, int x_coff, const void*
   if (y16 != nullptr)
     HPRI_REQUIRE(y16_cs % 4 == 0 && y16_coff % 4 == 0 && ((uintptr_t)y16 & 7) == 0, "gemm_bf16v3: the bf16 output view must be 8-byte aligned");
   HPRI_REQUIRE(!(a.accumulate && y == nullptr), "gemm_bf16v3: accumulate needs the fp32 output");
+  HPRI_REQUIRE(!(a.accumulate && mode == 1), "gemm_bf16v3: the depth-to-space form does not accumulate");
   if (mode == 0 || mode == 2) {
     HPRI_REQUIRE(y_cw % 4 == 0 && y_cw >= Ncols && y_cw <= ((Ncols_pad + G3_BN - 1) / G3_BN) * G3_BN, "gemm_bf16v3: written width must be a multiple of 4 in [Ncols, column blocks]");
     if (y != nullptr) HPRI_REQUIRE(y_cw + y_coff <= y_cs, "gemm_bf16v3: written width exceeds the fp32 row stride");
