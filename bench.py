@@ -149,6 +149,64 @@ def cpu_baseline():
                       f"{t:.2f} s/step"}
 
 
+# BASELINE.json's other configurations, per GPU: name -> (constructor, input shape for batch b, per-GPU batch,
+# algorithmic GFLOP per unit fwd+bwd from SURVEY.md 8d, what BASELINE.json calls it)
+OTHER_CONFIGS = {
+    "C1_unet3_rgb": (lambda HP: HP.UNet(3, 1, bilinear=False), lambda b: (b, 3, 608, 968), 2, 2591.51,
+                     "UNET n_channels=3 RGB 608x968 batch=2 (configs[0]; the reference runs it on CPU)"),
+    "C3_spectralunet_1650": (lambda HP: HP.SpectralUNET(238, 1, 1650), lambda b: (b, 238, 608, 700), 1, 77150.90,
+                             "SpectralUNET n_channels=238 spectral_bn_size=1650 patch 608x700, no model shard (configs[2]); per-GPU batch 1"),
+    "C5_cubenet128_300": (lambda HP: HP.CubeNET(300, 1, first_depth=128, bilinear=False), lambda b: (b, 1, 300, 608, 968), 2, 3986.84,
+                          "CubeNET-128 full-band 300-ch 968x608 (configs[4]; per-GPU share of the 8-GPU DDP job, batch 2)"),
+}
+
+
+def run_other_configs(dev, modes_for, steps=3, warmup=3):
+    """One GPU, forward + BCE loss + backward (the metric's step), ``warmup`` untimed + ``steps`` timed steps per (config, mode):
+    ms/step, units/s, model TFLOP/s (SURVEY.md 8d's algorithmic flops), peak memory, device allocations inside the timed steps."""
+    import gc
+    import hyperpri_amd as HP
+    from hyperpri_amd import engine
+    out = {}
+    for name, (mk, shp, batch, gflop, what) in OTHER_CONFIGS.items():
+        row = {"workload": what, "batch": batch}
+        for mode in modes_for(name):
+            net = mk(HP).to(dev).train()
+            synth_init_(net)
+            HP.set_precision(net, mode)
+            x = torch.empty(shp(batch), dtype=torch.float32, device=dev)
+            mask = torch.empty((batch, 1) + tuple(x.shape[-2:]), dtype=torch.float32, device=dev)
+            for i in range(batch):
+                engine.synth_fill_(x[i], 1234 + i, mode=0)
+                engine.synth_fill_(mask[i], 4321 + i, mode=1, thr=0.9)
+
+            def step():
+                for p in net.parameters():
+                    p.grad = None
+                _, loss = HP.forward_loss(net, x, mask)
+                loss.backward()
+                return loss
+            torch.cuda.reset_peak_memory_stats(dev)
+            for _ in range(warmup):
+                step()
+            torch.cuda.synchronize()
+            m0 = torch.cuda.memory_stats(dev).get("num_device_alloc", 0)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                loss = step()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / steps
+            row[mode] = {"ms_per_step": round(dt * 1e3, 2), "units_per_s": round(batch / dt, 3),
+                         "model_tflops": round(batch * gflop / dt / 1e3, 1), "loss": round(float(loss.detach()), 6),
+                         "peak_mem_gib": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1),
+                         "device_mallocs_in_timed_steps": int(torch.cuda.memory_stats(dev).get("num_device_alloc", 0) - m0)}
+            del net, x, mask, step, loss
+            gc.collect()
+            torch.cuda.empty_cache()
+        out[name] = row
+    return out
+
+
 def _free_port():
     import socket
     s = socket.socket()
@@ -200,7 +258,8 @@ def dry_launch_rank():
     dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     if rank == 0:
         print(json.dumps({"metric": "launcher rehearsal (no GPU work)", "value": None, "n_gpus": world,
-                          "allreduce_sum": float(t[0]), "seconds": float(dt)}), flush=True)
+                          "allreduce_sum": float(t[0]), "seconds": float(dt), "ranks": world, "global_batch": world * BATCH,
+                          "sample_seeds_last_rank": [1234 + (world - 1) * BATCH + i for i in range(BATCH)]}), flush=True)
     dist.destroy_process_group()
 
 
@@ -216,6 +275,8 @@ def main():
                          "profiling passes use this so that their kernel tables show the hot path alone)")
     ap.add_argument("--no-training-shaped", action="store_true",
                     help="skip the `value_training_shaped` leg (the same loop with FusedAdam.step() after every backward)")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="skip the `configs` leg (BASELINE.json's other configurations C1 / C3 / C5 per GPU, fp32 and bf16, 3 + 3 steps each)")
     ap.add_argument("--bf16-steps", type=int, default=5,
                     help="extra steps in each of the precision modes bf16x6, bf16x3 and bf16 (reported as 'bf16x6_mode' / 'bf16x3_mode' / "
                          "'bf16_mode', never as 'value'); 0 = skip")
@@ -534,6 +595,19 @@ def main():
                                       "no epilogue sustains 1297-1300 TF = 0.52 of 2.5 PF at 1.54-1.55 GHz in-kernel on random operands",
                       "fp32_kernel_same_layer": r["fp32"], "fp32_winograd_same_layer": r.get("fp32_winograd")}
 
+    # ---- BASELINE.json's other configurations on this GPU (N = 1 only: they are per-GPU figures; never part of `value`) ----
+    configs = None
+    if rank == 0 and world == 1 and not args.no_configs:
+        del x, mask
+        net = None
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+        configs = run_other_configs(dev, lambda name: ("fp32", "bf16x3", "bf16") if name.startswith("C3") else ("fp32", "bf16"))
+        configs["note"] = ("per-GPU step = forward + BCEWithLogits + backward on synthetic inputs, 3 warm-up + 3 timed steps; fp32 = exact "
+                           "fp32 MFMA (Winograd for 3x3), bf16x3 = 2 bf16 planes per operand (meets the fp32 contract: logits within 1e-3, "
+                           "Dice/IoU to 4 dp on the reference fixture), bf16 = Dice-level parity; model_tflops = SURVEY.md 8d flops / time")
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline()
@@ -563,7 +637,7 @@ def main():
             "model_tflops_note": "value x 2910.17 GFLOP/cube (direct-convolution flops of the reference graph, SURVEY.md 8d) per GPU; "
                                  "the fp32 path executes fewer multiplies than that (Winograd), so this can exceed the fp32 MFMA peak",
             "value_training_shaped": training_shaped,
-            "roofline": roofline, "roofline_238to64": first_conv, "cpu_baseline": cpu, "optimizer_step": optimizer_step, "bf16x6_mode": bf16x6_mode, "bf16x3_mode": bf16x3_mode, "bf16_mode": bf16_mode,
+            "roofline": roofline, "roofline_238to64": first_conv, "cpu_baseline": cpu, "optimizer_step": optimizer_step, "configs": configs, "bf16x6_mode": bf16x6_mode, "bf16x3_mode": bf16x3_mode, "bf16_mode": bf16_mode,
         }
         print(json.dumps(out), flush=True)
     if use_pg:

@@ -99,9 +99,15 @@ class GradSync:
         # every forward.  A pre-hook on the TOP-LEVEL module: the fused tape only steps aside for hooks on children.
         self._buf_hook = None
         if broadcast_buffers and self.world > 1:
-            # training-mode forwards only: an eval / validation forward that runs on a subset of the ranks (rank-0-only
-            # validation) must not enter a collective the other ranks never join
-            self._buf_hook = module.register_forward_pre_hook(lambda m, inp: self.sync_buffers() if m.training else None)
+            # broadcast_buffers=True  : every forward through the module, whatever its mode -- torch DDP's behaviour (a validation
+            #                           forward on ALL ranks then reads rank 0's running statistics, as under Lightning DDP);
+            # broadcast_buffers="train": training-mode forwards only -- for loops that validate on a subset of the ranks (rank-0-only
+            #                           validation), where an eval forward must not enter a collective the other ranks never
+            #                           join; call sync_buffers() on all ranks before such a validation to get DDP's values.
+            if broadcast_buffers == "train":
+                self._buf_hook = module.register_forward_pre_hook(lambda m, inp: self.sync_buffers() if m.training else None)
+            else:
+                self._buf_hook = module.register_forward_pre_hook(lambda m, inp: self.sync_buffers())
         if self.collective and engine.SIDE_STREAM and not engine.SIDE_STREAM_WITH_SINK and not GradSync._warned_queues:
             GradSync._warned_queues = True
             import sys

@@ -417,6 +417,22 @@ class Tape:
                         sink.ready(p)
                 else:
                     sink.ready(p)
+        if sink is not None:
+            # a parameter announced by several nodes (note_params) whose LAST announcing node never asked for its slot -- e.g. a
+            # module called twice inside one tape with one result unused (that node returns before param_slot) -- still holds a
+            # finished gradient in its bucket: hand it over now, or GradSync.finish() would zero it as "never landed"
+            for pid, left in self.uses.items():
+                p = self.sunk.get(pid)
+                if p is not None and left > 0 and pid in self.param_grads:
+                    if self.used_side:
+                        dev = p.device
+                        iss = _issue_stream(dev)
+                        iss.wait_stream(torch.cuda.current_stream(dev))
+                        iss.wait_stream(_side(dev))
+                        with torch.cuda.stream(iss):
+                            sink.ready(p)
+                    else:
+                        sink.ready(p)
         self.nodes.clear()
         self.keep.clear()
         self.uses.clear()
@@ -1504,7 +1520,9 @@ def up_concat(tape: Tape, x1: Act, skip: Act, weight: Optional[torch.Tensor], bi
     if tape.record:
         if weight is not None and bias is not None and bias.requires_grad and cat.H == 2 * x1.H and cat.W == 2 * x1.W:
             cat.colsum_req = (skip.C, cup)     # (no pad ring: F.pad's backward would have to drop ring pixels from the sums)
-        if weight is not None and wrote and CONVT_PLANES:
+        # (hpri_wgrad_convt_bf16v3 addresses the WHOLE gradient tensor with 32-bit DMA offsets and takes Cin <= 16384: beyond that --
+        #  per-GPU batches of ~29 and more at 608x968 with 64 upsampled channels -- the fp32 half stays and the round-1 kernels run)
+        if (weight is not None and wrote and CONVT_PLANES and cat.P * cup * 2 < 0x7FFFFF00 and _rup(weight.shape[0], 32) <= 16384):
             cat.up_slice = (skip.C, cup)       # plane mode: the consumer's data-gradient launch leaves this half's gradient as bf16 rows
 
         def bwd(tp: Tape) -> None:
@@ -1683,7 +1701,10 @@ def out_conv(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.Tens
         _lib.call("hpri_outconv_fwd_bce", x.ptr, x.cs, x.coff, _p(weight), _p(bias), _p(y), _p(tgt), _p(part), nblk,
                   x.N, x.H * x.W, C, K, _stream())
         _lib.call("hpri_bce_finish", _p(part), nblk, y.numel(), _p(loss), _stream())
-        holder["bce_y"], holder["bce_t"] = y, tgt
+        # a DETACHED alias of the logits (same storage, same version counter, no grad_fn): holding ``y`` itself would close the
+        # cycle ctx -> holder -> y -> grad_fn -> ctx and keep a never-backpropagated tape alive until the cyclic collector runs
+        holder["bce_y"], holder["bce_t"] = y.detach(), tgt
+        holder["bce_ver"] = (y._version, tgt._version)
         slot.used, slot.loss, slot.holder = True, loss, holder
     else:
         _lib.call("hpri_outconv_fwd", x.ptr, x.cs, x.coff, _p(weight), _p(bias), _p(y), x.N, x.H * x.W, C, K, _stream())
@@ -1695,6 +1716,11 @@ def out_conv(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.Tens
             gs = holder.pop("bce_g", None)              # the scalar gradient arriving at the fused loss (None: loss unused)
             marker = holder.pop("bce_marker", None)
             logits, tgt = holder.pop("bce_y", None), holder.pop("bce_t", None)
+            ver = holder.pop("bce_ver", None)
+            if gs is not None and ver is not None and (logits._version, tgt._version) != ver:
+                # what save_for_backward would have caught (nn.BCEWithLogitsLoss saves both): the kernels below re-read them
+                raise RuntimeError("hyperpri_amd: one of the variables needed for gradient computation has been modified by an inplace "
+                                   "operation: the logits or the target of forward_loss() changed between forward and backward")
             fused = gs is not None and marker is not None and gy.data_ptr() == marker.data_ptr() and not any(gy.stride())
             if gs is not None and not fused:
                 # the logits had another consumer besides the fused loss: autograd has summed its gradient with the

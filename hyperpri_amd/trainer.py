@@ -85,7 +85,14 @@ def forward_loss(network: nn.Module, image: torch.Tensor, target: torch.Tensor) 
     loss is computed inside the network's last layer (forward: the 1x1 head also leaves the BCE partial sums; backward:
     the head's gradient kernels form (sigmoid(pred) - target)/n themselves).  Same values as the two-call form up to
     fp32 summation order inside the head's weight gradient; falls back to the two-call form when the network's head does
-    not take the offer (hooks, ``fused_tape = False``, no gradient recording)."""
+    not take the offer (hooks, ``fused_tape = False``, no gradient recording).
+
+    What differs from the two-call form, by design: the autograd edge from the loss to ``pred`` carries an all-zero stride-0
+    marker, not ``(sigmoid(pred) - target) / n`` -- the head's backward kernels form that product themselves.  So
+    ``torch.autograd.grad(loss, pred)``, ``pred.retain_grad()`` and tensor hooks on ``pred`` see zeros for the loss's share
+    (parameter and input gradients are complete and bit-identical to the two-call form).  Code that inspects dLoss/dLogits should
+    call ``criterion(network(image), target)`` instead.  The logits and the target are re-read in backward: an in-place write to
+    either in between raises, as it would for tensors saved by ``nn.BCEWithLogitsLoss``."""
     _require_cuda(image, "input tensor")
     with torch.cuda.device(image.device):
         tgt = _flat(target if target.dtype == torch.float32 else target.to(torch.float32), "BCEWithLogitsLoss target")
@@ -93,6 +100,12 @@ def forward_loss(network: nn.Module, image: torch.Tensor, target: torch.Tensor) 
         pred = network(image)
     if isinstance(pred, tuple):                      # analyze=True networks return (pred, features)
         pred = pred[0]
+    if pred.shape != target.shape:
+        # nn.BCEWithLogitsLoss (and _BCEFn) refuse e.g. an (N,H,W) mask against (N,1,H,W) logits; so does the fused form, whose
+        # kernels only ever compared element counts
+        if slot.holder is not None:
+            slot.holder.clear()
+        raise ValueError(f"Target size ({tuple(target.shape)}) must be the same as input size ({tuple(pred.shape)})")
     if slot.used and slot.holder is not None and pred.requires_grad and pred.numel() == tgt.numel():
         return pred, _FusedLossFn.apply(pred, slot)
     if pred.shape != target.shape:

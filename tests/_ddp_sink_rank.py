@@ -40,10 +40,17 @@ def main():
     if prec != "fp32":
         H.set_precision(net, prec)
     assert net.fused_tape
-    sync = GradSync(net, bucket_mb=4.0, tail_mb=0.25)        # 31 M parameters -> a handful of buckets
     x = u(1235 + rank, (2, 1, 6, 36, 50)).to(dev)
     m = (u(4321 + rank, (2, 1, 36, 50)) > 0.9).float().to(dev)
     res = {}
+    # this rank's gradients from the PLAIN loop (no sink, no collective), same HIP kernels: the parent holds the synchronised
+    # gradients to the exact mean of the two ranks' plain gradients (the kernels are deterministic)
+    torch.nn.BCEWithLogitsLoss()(net(x), m).backward()
+    torch.cuda.synchronize()
+    for k, p in net.named_parameters():
+        res["plain/" + k] = p.grad.detach().cpu().numpy()
+        p.grad = None
+    sync = GradSync(net, bucket_mb=4.0, tail_mb=0.25)        # 31 M parameters -> a handful of buckets
     for step in range(2):                                    # the second step reuses the buckets the first one installed as .grad
         for p in net.parameters():
             p.grad = None

@@ -140,7 +140,7 @@ def _buf_worker(rank, world, port, out):
     net = torch.nn.Sequential(torch.nn.Linear(4, 4), torch.nn.BatchNorm1d(4))
     with torch.no_grad():
         net[1].running_mean.fill_(float(rank + 1))          # the ranks' statistics have drifted apart
-    sync = GradSync(net, broadcast_buffers=True)
+    sync = GradSync(net, broadcast_buffers="train")         # training-mode forwards only (True = every forward, as torch DDP)
     net.eval()
     if rank == 0:
         net(torch.randn(3, 4))                              # validation on rank 0 only: an eval forward enters no collective
@@ -156,9 +156,33 @@ def _buf_worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
+def _buf_worker_eval(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from hyperpri_amd.ddp import GradSync
+    net = torch.nn.Sequential(torch.nn.Linear(4, 4), torch.nn.BatchNorm1d(4))
+    with torch.no_grad():
+        net[1].running_mean.fill_(float(rank + 1))
+    sync = GradSync(net, broadcast_buffers=True)            # torch DDP's behaviour: EVERY forward, eval included
+    net.eval()
+    net(torch.randn(3, 4))                                  # validation on all ranks: rank 0's statistics are the ones in use
+    out[rank] = net[1].running_mean.clone()
+    sync.remove()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_broadcast_buffers_true_covers_eval_forwards():
+    """with broadcast_buffers=True torch DDP broadcasts on every forward through the wrapper, whatever the mode."""
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_buf_worker_eval, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert torch.equal(out[0], torch.full((4,), 1.0)) and torch.equal(out[1], out[0])
+
+
 def test_broadcast_buffers_like_torch_ddp():
-    """GradSync(broadcast_buffers=True): rank 0's BN buffers replace everyone's at the start of a training-mode forward (torch DDP's
-    default), as one coalesced broadcast per dtype; eval-mode forwards do not communicate."""
+    """GradSync(broadcast_buffers="train"): rank 0's BN buffers replace everyone's at the start of a training-mode forward, as one
+    coalesced broadcast per dtype; eval-mode forwards do not communicate (rank-0-only validation)."""
     mgr = mp.Manager()
     out = mgr.dict()
     mp.spawn(_buf_worker, args=(2, _free_port(), out), nprocs=2, join=True)

@@ -69,6 +69,16 @@ def test_two_ranks_engine_sink_equals_mean_of_oracle_gradients(tmp_path, prec):
     tol_loss, tol_g = (1e-5, 2e-2) if prec == "fp32" else (5e-3, 0.7)
     for r in range(world):
         assert abs(float(z[r]["loss0"]) - ora[r][0]) < tol_loss
+    # ---- the gate: every reduced gradient equals the mean of the two ranks' PLAIN-loop HIP gradients,
+    #      (a + b) / 2 in fp32 exactly as gloo's sum and finish()'s division form it -- a stale split-K slab, a bucket issued before
+    #      its last gradient landed or a missing stream join shows up here as a non-zero difference
+    worst_exact = 0.0
+    for k in ora[0][1]:
+        mean = ((z[0]["plain/" + k] + z[1]["plain/" + k]) / np.float32(world)).astype(np.float32)
+        d = float(np.abs(z[0]["g/" + k].astype(np.float64) - mean).max())
+        worst_exact = max(worst_exact, d / max(float(np.abs(mean).max()), 1e-30))
+        assert np.array_equal(z[0]["g/" + k], mean), (k, d)
+    record_margin(f"ddp_sink/world2/{prec}/max_rel_err_vs_plain_mean", worst_exact, 1e-12)
     worst = 0.0
     for k in ora[0][1]:
         a0, a1 = z[0]["g/" + k], z[1]["g/" + k]
@@ -88,3 +98,17 @@ def test_two_ranks_engine_sink_equals_mean_of_oracle_gradients(tmp_path, prec):
         # (bf16: two correct bf16 paths on this tiny net sit ~0.3 from fp32 in relative L2 -- tests/test_gpu_round2.py)
         assert err <= tol_g * ref, (k, err, ref)
     record_margin(f"ddp_sink/world2/{prec}/grad_rel_l2", worst, tol_g)
+
+
+
+def test_bucket_hand_over_is_ordered_behind_both_compute_streams():
+    """an ordering test that is sensitive with ONE rank (tests/_ddp_order_rank.py, a fresh child process so
+    that GPU_MAX_HW_QUEUES=8 holds and the weight-gradient stream is live under the sink).  The collective is replaced by an
+    in-place ``mul_(2)`` launched on a stream of its own that waits only for what a c10d collective waits for -- the stream that is
+    current when ``GradSync._issue`` calls it.  Every gradient must come out exactly 2x the plain-loop gradient: a weight-gradient
+    kernel still running on the second stream when its bucket is handed over (a missing join) lands after the doubling."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4", GPU_MAX_HW_QUEUES="8")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_ddp_order_rank.py"), str(_free_port())], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=420)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert "ORDER-OK" in r.stdout, r.stdout[-2000:]

@@ -215,3 +215,59 @@ def test_average_precision_matches_sklearn():
     want = O.average_precision(p, t)
     assert abs(got - want) < 1e-9, (got, want)
     assert average_precision(p.to(DEV), torch.zeros(n, device=DEV)) != average_precision(p.to(DEV), torch.zeros(n, device=DEV))  # nan
+
+
+def _tiny_head_net():
+    import hyperpri_amd as H
+    torch.manual_seed(3)
+    return H.UNet(3, 1, bilinear=False).to(DEV).train()
+
+
+def test_forward_loss_checks_what_bcewithlogits_checks():
+    """the fused head only compared element counts.  A (N,H,W) mask against (N,1,H,W) logits must raise
+    ValueError as nn.BCEWithLogitsLoss does; an in-place write to the logits or the target between forward and backward must raise
+    as tensors saved for backward would; a loss that is never back-propagated must not keep the tape alive through a reference
+    cycle (memory returns without the cyclic collector)."""
+    import gc
+    import hyperpri_amd as H
+    net = _tiny_head_net()
+    x = _u(41, (2, 3, 16, 24)).to(DEV)
+    mask = (_u(42, (2, 1, 16, 24)) > 0.5).float().to(DEV)
+    with pytest.raises(ValueError, match="must be the same as input size"):
+        H.forward_loss(net, x, mask[:, 0])
+    # target written in place after the forward
+    pred, loss = H.forward_loss(net, x, mask)
+    mask.mul_(0.5)
+    with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+        loss.backward()
+    mask = (_u(42, (2, 1, 16, 24)) > 0.5).float().to(DEV)
+    # logits written in place after the forward
+    pred, loss = H.forward_loss(net, x, mask)
+    pred.detach().add_(1.0)
+    with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+        loss.backward()
+    # untouched: same gradients as the two-call form
+    for p in net.parameters():
+        p.grad = None
+    pred, loss = H.forward_loss(net, x, mask)
+    loss.backward()
+    g1 = [p.grad.clone() for p in net.parameters()]
+    for p in net.parameters():
+        p.grad = None
+    H.BCEWithLogitsLoss()(net(x), mask).backward()
+    for a, b in zip(g1, [p.grad for p in net.parameters()]):
+        assert torch.equal(a, b)
+    # no cycle: a dropped (pred, loss) pair frees its activations without gc
+    del pred, loss, g1
+    gc.collect()
+    torch.cuda.synchronize()
+    gc.disable()
+    try:
+        base = torch.cuda.memory_allocated()
+        for _ in range(3):
+            pred, loss = H.forward_loss(net, x, mask)
+            del pred, loss
+        torch.cuda.synchronize()
+        assert torch.cuda.memory_allocated() <= base + 4096, (torch.cuda.memory_allocated(), base)
+    finally:
+        gc.enable()

@@ -67,3 +67,23 @@ def test_unannounced_parameter_counts_as_single_use():
 def test_throttle_is_a_no_op_on_cpu_and_parses_its_bound():
     engine.throttle(torch.device("cpu"))
     assert engine.STEPS_IN_FLIGHT >= 0
+
+
+def test_parameter_whose_last_announcing_node_returns_early_is_still_handed_over():
+    """a module called twice in one tape with one result unused -- that node leaves before it asks for the slot.  The
+    gradient the other call wrote into the bucket must reach ``ready()`` at the end of backward (GradSync.finish() zeroes slots
+    that never landed)."""
+    w = torch.nn.Parameter(torch.zeros(3))
+    sink = _Sink([w])
+    engine.set_grad_sink(sink)
+    try:
+        tape = engine.Tape(True)
+        tape.note_params(w)
+        tape.nodes.append(lambda tp: None)                               # first recorded use: its output got no gradient
+        tape.note_params(w)
+        tape.nodes.append(lambda tp: tp.param_slot(w)[0].fill_(4.0))     # second use (runs first in backward)
+        tape.backward()
+    finally:
+        engine.set_grad_sink(None)
+    assert sink.order == [id(w)]
+    assert torch.equal(sink.seen_at_ready[id(w)], torch.full((3,), 4.0))
