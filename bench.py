@@ -46,6 +46,29 @@ def synth_init_(net):
             synth_fill_(p.data, 1000 + k, mode=2, scale=1.0 / math.sqrt(fan_in))
 
 
+def _lib_stamp():
+    """Source stamp of the loaded HIP library (hyperpri_amd/build.py writes it next to the .so)."""
+    try:
+        from hyperpri_amd import build as _B
+        return open(_B.LIB + ".stamp").read().strip()
+    except Exception:
+        return None
+
+
+def _replayable(path):
+    """(kernels, note): the per-kernel figures of a committed PMC file, or (None, why not) when the file was recorded on another
+    build of the library (replayed counters must not outlive the kernels they were read from)."""
+    try:
+        doc = json.load(open(path))
+    except Exception:
+        return None, "unreadable"
+    have, want = doc.get("library_stamp"), _lib_stamp()
+    if have is None or want is None or have != want:
+        return None, (f"{os.path.relpath(path, ROOT)} was recorded on another build of the library (stamp {str(have)[:12]} vs loaded "
+                      f"{str(want)[:12]}): not replayed; re-run tools/measure.sh + tools/pmc_traffic.py")
+    return doc["kernels"], None
+
+
 def pmc_traffic(tag):
     """(HBM bytes per launch of the dominant kernel, source file) REPLAYED from the committed PMC passes
     (profiles/*_pmc_traffic.json, produced by tools/measure.sh + tools/pmc_traffic.py with the gfx950 FETCH_SIZE
@@ -55,10 +78,9 @@ def pmc_traffic(tag):
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic.json")))   # the fp32 bench passes only
     if not files:
         return None, None
-    try:
-        kern = json.load(open(files[-1]))["kernels"]
-    except Exception:
-        return None, None
+    kern, why = _replayable(files[-1])
+    if kern is None:
+        return None, "NOT REPLAYED: " + why
     src = os.path.relpath(files[-1], ROOT)
     if tag.startswith("conv_fwd<3,2x2"):
         key = "conv_fwd_kernel<3, 2, 2, 0, 0>"
@@ -86,10 +108,9 @@ def first_conv_traffic():
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_first_conv_pmc_traffic.json")))
     if not files:
         return None, None
-    try:
-        kern = json.load(open(files[-1]))["kernels"]
-    except Exception:
-        return None, None
+    kern, why = _replayable(files[-1])
+    if kern is None:
+        return None, "NOT REPLAYED: " + why
     src = os.path.relpath(files[-1], ROOT) + " (replayed: rocprofv3 --pmc passes of tools/first_conv.py, not measured in this run)"
     for k, v in kern.items():
         if "conv_bf16v3" in k or (("conv_bf16v2" in k) and not any("conv_bf16v3" in q for q in kern)):
@@ -334,7 +355,6 @@ def main():
 
     net = HP.CubeNET(BANDS, 1, first_depth=64, bilinear=False).to(dev).train()
     synth_init_(net)
-    sync = GradSync(net, force=args.force_sync) if use_pg else None
     x = torch.empty((BATCH, 1, BANDS, H, W), dtype=torch.float32, device=dev)
     mask = torch.empty((BATCH, 1, H, W), dtype=torch.float32, device=dev)
     for i in range(BATCH):
@@ -343,6 +363,18 @@ def main():
         engine.synth_fill_(mask[i], 4321 + n, mode=1, thr=0.9)
     crit = HP.BCEWithLogitsLoss()        # nn.BCEWithLogitsLoss() semantics on the HIP path (csrc/step.hip)
     fused_loss = os.environ.get("HPRI_BENCH_FUSED_LOSS", "1") != "0"
+    # N > 1: this rank's gradients from the PLAIN loop (no sink, no collective) before the gradient sink is installed: after the
+    # timed steps every reduced gradient is compared with the mean of the ranks' plain gradients (`grad_sync.max_rel_err`; the
+    # kernels are deterministic and the parameters frozen, so over gloo the two are bit-equal and over RCCL equal to its
+    # summation order) -- ranks that merely hold EQUAL gradients say nothing about a stale slab or an early hand-over
+    plain_flat = None
+    if use_pg and world > 1:
+        crit(net(x), mask).backward()
+        torch.cuda.synchronize()
+        plain_flat = torch.cat([p.grad.detach().reshape(-1) for p in net.parameters()])
+        for p in net.parameters():
+            p.grad = None
+    sync = GradSync(net, force=args.force_sync) if use_pg else None
 
     def step():
         for p in net.parameters():
@@ -412,6 +444,22 @@ def main():
     if sync is not None:
         ov = sync.overlap_ms()           # last timed step: per bucket, all-reduce issue -> finish() return (stream time)
         equal = None
+        max_rel_err = None
+        if plain_flat is not None:
+            ref = plain_flat.clone()
+            dist.all_reduce(ref, op=dist.ReduceOp.SUM)
+            ref.div_(world)
+            got = torch.cat([p.grad.detach().reshape(-1) for p in net.parameters()])
+            errs, off = [], 0
+            for p in net.parameters():
+                n = p.numel()
+                d = (got[off:off + n].double() - ref[off:off + n].double()).abs().max()
+                errs.append(d / ref[off:off + n].double().abs().max().clamp_min(1e-30))
+                off += n
+            mre = torch.stack(errs).max()
+            dist.all_reduce(mre, op=dist.ReduceOp.MAX)
+            max_rel_err = float(mre)
+            del ref, got
         if one_gpu and world > 1:
             # rehearsal check: after finish() every rank must hold the same (averaged) gradients
             cs = torch.stack([torch.stack([p.grad.double().abs().sum(), p.grad.double().sum()]) for p in net.parameters()]).sum(0)
@@ -419,6 +467,9 @@ def main():
             dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
             equal = bool(torch.equal(lo, hi))
         grad_sync = {"backend": "gloo on one GPU (REHEARSAL, not a measurement)" if one_gpu else "nccl (RCCL)",
+                     "max_rel_err": max_rel_err,
+                     "max_rel_err_is": "max over parameter tensors and ranks of max|reduced gradient - mean of the ranks' plain-loop HIP "
+                                       "gradients| / max|mean| (0.0 = bit-equal; null at N = 1)",
                      "ranks_hold_equal_gradients": equal, "grad_mb": round(sum(b.flat.numel() for b in sync.buckets) * 4 / 2 ** 20, 1),
                      "gradients_written_in_place": True, "overlap": ov, "buckets_issued_by": dict(sync.issued),
                      "note": "buckets are issued from inside the backward tape as their last gradient lands; "
@@ -557,8 +608,9 @@ def main():
                                    "and channel pair); `direct_equivalent_tflops` prices the same launches at SURVEY.md 8d's direct-"
                                    "convolution flops (36 per 2x2), which is what `value` x 2910.17 GFLOP/cube uses") if wino else
                                   "direct implicit GEMM: executed = algorithmic flops",
-                    "traffic": traffic, "traffic_source": (f"replayed from {traffic_src} (rocprofv3 --pmc passes of this "
-                                                           "workload, committed; not measured in this run)") if traffic_src else None,
+                    "traffic": traffic, "traffic_source": (traffic_src if (traffic_src or "").startswith("NOT REPLAYED") else
+                                                           f"replayed from {traffic_src} (rocprofv3 --pmc passes of this workload on the "
+                                                           "same build of the library, committed; not measured in this run)") if traffic_src else None,
                     "avg_launch_ms": round(dom[1]["avg_ms"], 4), "launches_per_step": dom[1]["launches"] // 2,
                     "algorithmic_gflop_per_launch": round(dom[1]["flops_per_launch"] / 1e9, 3),
                     "executed_gflop_per_launch": round(dom[1]["executed_flops_per_launch"] / 1e9, 3),

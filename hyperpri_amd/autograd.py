@@ -9,6 +9,9 @@ Backward runs the tape in reverse on the autograd worker thread with the thread'
 """
 from __future__ import annotations
 
+import itertools
+import os
+import threading
 from typing import Callable, List, Sequence
 
 import torch
@@ -101,10 +104,77 @@ class _HipFn(torch.autograd.Function):
         return (None, None, None, None, *res)
 
 
-def run(program: Callable, inputs: Sequence[torch.Tensor], params: Sequence[torch.Tensor], input_planes: int = 0) -> torch.Tensor:
+# ---- the same node as a PyTorch-ROCm custom operator (torch.library; BASELINE.json north_star: "registered as PyTorch-ROCm custom
+# ops through a thin C-ABI extension") ---------------------------------------------------------------------------------------------
+# One operator per reference module, all with the schema
+#     hyperpri::<name>(Tensor[] inputs, Tensor[] params, int program, bool grad_mode, int input_planes) -> Tensor
+# registered for the CUDA (= ROCm) dispatch key only -- there is no CPU kernel to fall back to -- with its backward registered
+# through ``register_autograd``.  ``program`` is a handle into the table of tape programs of the calling module (the op graph the
+# reference module stands for, closed over the module for its BatchNorm buffers, which a training-mode forward updates in place as
+# nn.BatchNorm does); the kernels behind it are reached through the C ABI (include/hyperpri_hip.h) exactly as from _HipFn.
+# HPRI_DISPATCHER=0 routes the modules through the plain autograd.Function instead (same tape, same kernels, same results).
+OP_NAMES = ("unet", "cubenet", "cubenet_stem", "cubenet_up4", "spectral_unet", "double_conv", "down", "up", "out_conv", "run_program")
+USE_DISPATCHER = os.environ.get("HPRI_DISPATCHER", "1") != "0"
+_PROGRAMS: dict = {}
+_HANDLES = itertools.count(1)
+_TLS = threading.local()
+
+
+class _Ctx:      # what _HipFn keeps on its ctx, for the operator path
+    pass
+
+
+def _op_forward(inputs: List[torch.Tensor], params: List[torch.Tensor], program: int, grad_mode: bool, input_planes: int) -> torch.Tensor:
+    prog = _PROGRAMS[program]
+    st = _Ctx()
+    st.needs_input_grad = (False, False, False, False, *[t.requires_grad for t in inputs], *[p.requires_grad for p in params])
+    with torch.cuda.device(inputs[0].device):
+        res = _HipFn._forward(st, prog, len(inputs), tuple(params), (grad_mode, int(input_planes)), *inputs, *params)
+    # picked up by _op_setup_context, which the autograd kernel calls right after this forward (nothing to keep when nothing was recorded)
+    _TLS.last = st if getattr(st, "tape", None) is not None else None
+    return res
+
+
+def _op_setup_context(ctx, inputs, output):
+    ctx.st = getattr(_TLS, "last", None)
+    _TLS.last = None
+
+
+def _op_backward(ctx, gout):
+    st = ctx.st
+    if st is None or getattr(st, "tape", None) is None:
+        raise RuntimeError("hyperpri_amd: backward called twice (retain_graph is not supported)")
+    n_in = st.n_in
+    with torch.cuda.device(gout.device):
+        res = _HipFn._backward(st, gout)[4:]
+    return list(res[:n_in]), list(res[n_in:]), None, None, None
+
+
+def _register_ops():
+    ops = {}
+    for name in OP_NAMES:
+        op = torch.library.custom_op(f"hyperpri::{name}", _op_forward_named(name), mutates_args=(), device_types="cuda")
+        op.register_autograd(_op_backward, setup_context=_op_setup_context)
+        ops[name] = op
+    return ops
+
+
+def _op_forward_named(name):
+    def fwd(inputs: List[torch.Tensor], params: List[torch.Tensor], program: int, grad_mode: bool, input_planes: int) -> torch.Tensor:
+        return _op_forward(inputs, params, program, grad_mode, input_planes)
+    fwd.__name__ = name
+    return fwd
+
+
+OPS = _register_ops()
+
+
+def run(program: Callable, inputs: Sequence[torch.Tensor], params: Sequence[torch.Tensor], input_planes: int = 0,
+        name: str = "run_program") -> torch.Tensor:
     """Run ``program`` as one autograd node.  ``params`` are the nn.Parameters the program reads (the
     program closes over the owning module; they are listed here so autograd routes their gradients).
-    ``input_planes`` > 0: the layout pass of an NCHW input also writes that many bf16 planes (bf16 plane mode)."""
+    ``input_planes`` > 0: the layout pass of an NCHW input also writes that many bf16 planes (bf16 plane mode).
+    ``name``: the custom operator the call goes through (``torch.ops.hyperpri.<name>``)."""
     dev = inputs[0].device
     for p in params:
         _require_cuda(p, "module parameter")
@@ -114,4 +184,11 @@ def run(program: Callable, inputs: Sequence[torch.Tensor], params: Sequence[torc
             raise RuntimeError("hyperpri_amd: parameters must be contiguous")
     for t in inputs:
         _require_cuda(t, "input tensor")
+    if USE_DISPATCHER:
+        h = next(_HANDLES)
+        _PROGRAMS[h] = program
+        try:
+            return getattr(torch.ops.hyperpri, name)(list(inputs), list(params), h, torch.is_grad_enabled(), int(input_planes))
+        finally:
+            _PROGRAMS.pop(h, None)
     return _HipFn.apply(program, len(inputs), tuple(params), (torch.is_grad_enabled(), int(input_planes)), *inputs, *params)

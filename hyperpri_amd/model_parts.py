@@ -72,7 +72,7 @@ class DoubleConv(nn.Module):
                                 out_planes)
 
     def forward(self, x):
-        return run(lambda tape, a, need: self._ops(tape, a[0], need[0]), [x], list(self.parameters()))
+        return run(lambda tape, a, need: self._ops(tape, a[0], need[0]), [x], list(self.parameters()), name="double_conv")
 
 
 class Down(nn.Module):
@@ -86,7 +86,7 @@ class Down(nn.Module):
         return self.maxpool_conv[1]._ops(tape, E.maxpool2(tape, x), room=room, out_planes=out_planes)
 
     def forward(self, x):
-        return run(lambda tape, a, need: self._ops(tape, a[0]), [x], list(self.parameters()))
+        return run(lambda tape, a, need: self._ops(tape, a[0]), [x], list(self.parameters()), name="down")
 
 
 class Up(nn.Module):
@@ -116,7 +116,7 @@ class Up(nn.Module):
                                          precision=getattr(self, "hpri_precision", None)), out_planes=out_planes)
 
     def forward(self, x1, x2):
-        return run(lambda tape, a, need: self._ops(tape, a[0], a[1], need[0]), [x1, x2], list(self.parameters()))
+        return run(lambda tape, a, need: self._ops(tape, a[0], a[1], need[0]), [x1, x2], list(self.parameters()), name="up")
 
 
 class OutConv(nn.Module):
@@ -130,4 +130,4 @@ class OutConv(nn.Module):
         return E.out_conv(tape, x, self.conv.weight, self.conv.bias, need_dx)
 
     def forward(self, x):
-        return run(lambda tape, a, need: self._ops(tape, a[0], need[0]), [x], list(self.parameters()))
+        return run(lambda tape, a, need: self._ops(tape, a[0], need[0]), [x], list(self.parameters()), name="out_conv")

@@ -63,7 +63,7 @@ class UNet(nn.Module):
                 y = self.up3._ops(tape, y, x2, out_planes=cp)
                 y = self.up4._ops(tape, y, x1)
                 return self.outc._ops(tape, y)
-            logits = run(prog, [x], list(self.parameters()), input_planes=E.input_planes_for(self))
+            logits = run(prog, [x], list(self.parameters()), input_planes=E.input_planes_for(self), name="unet")
         else:
             x1 = self.inc(x)
             x2 = self.down1(x1)
@@ -145,7 +145,7 @@ class SpectralUNET(torch.nn.Module):
             t = L(tape, E.concat_channels(tape, x2, t), self.up3)
             t = L(tape, E.concat_channels(tape, x1, t), self.up4)
             return E.out_conv(tape, E.concat_channels(tape, x0, t), self.outc.weight, self.outc.bias, fuse_loss=self.n_classes == 1)
-        out = run(prog, [x], list(self.parameters()))
+        out = run(prog, [x], list(self.parameters()), name="spectral_unet")
         if self.n_classes != 1:
             # models.py:144 stores each image's (R*C, n_classes) result with .reshape(n_classes, R, C): the FLAT order is
             # pixel-major, class-minor.  `out` holds true class planes (N, K, R, C); re-order to the reference's element order
@@ -196,7 +196,7 @@ class CubeNET(torch.nn.Module):
 
     def _stem(self, x):
         params = list(self.inc.parameters()) + list(self.inc2.parameters())
-        return run(lambda tape, a, need: self._stem_ops(tape, a[0], need[0]), [x], params)
+        return run(lambda tape, a, need: self._stem_ops(tape, a[0], need[0]), [x], params, name="cubenet_stem")
 
     def _up4_ops(self, tape, y, x1, need_dx1=True):
         """Last decoder stage: ``up4`` (first_depth 64) or the inline upsample4 -> pad -> cat -> upconv4 (models.py:229-240)."""
@@ -227,7 +227,7 @@ class CubeNET(torch.nn.Module):
                 y = self.up3._ops(tape, y, x2, out_planes=cp)
                 y = self._up4_ops(tape, y, x1)
                 return self.outc._ops(tape, y)
-            logits = run(prog, [x], list(self.parameters()), input_planes=E.input_planes_for(self))
+            logits = run(prog, [x], list(self.parameters()), input_planes=E.input_planes_for(self), name="cubenet")
         else:
             x1 = self._stem(x)
             x2 = self.down1(x1)
@@ -241,7 +241,7 @@ class CubeNET(torch.nn.Module):
                 y = self.up4(y, x1)
             else:
                 params4 = list(self.upsample4.parameters()) + list(self.upconv4.parameters())
-                y = run(lambda tape, a, need: self._up4_ops(tape, a[0], a[1], need[0]), [y, x1], params4)
+                y = run(lambda tape, a, need: self._up4_ops(tape, a[0], a[1], need[0]), [y, x1], params4, name="cubenet_up4")
             logits = self.outc(y)
         if self.analyze:
             return (logits, logits, torch.sigmoid(logits))

@@ -1,0 +1,178 @@
+"""The drop-in boundary end to end (VERDICT r3 item 9 ii): the two shim files of INTEGRATION.md section 2 -- taken from
+the document itself -- are written into a checkout-shaped temporary tree (``src/`` a namespace package without ``__init__.py``, as
+in the reference), and reached the way the reference reaches its hot path:
+
+    src/Experiments/params_shaped.py   ``from .models import *`` + a get_network()-shaped constructor call
+                                       (restated from params_HyperPRI.py:12, 283-301 -- not a copy of it)
+    src/trainer_shaped.py              ``from .Experiments.models import *`` + training_step / configure_optimizers shaped
+                                       methods (restated from PLTrainer.py:26, 79-98, 163-180)
+
+The CPU test imports through that chain and checks names, constructor signatures and state_dict keys; the GPU test runs a
+training_step-shaped loop through it and compares with the same loop on ``hyperpri_amd`` imported directly."""
+import os
+import re
+import subprocess
+import sys
+import textwrap
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+PARAMS_SHAPED = '''
+    import torch
+    from .models import *                      # the star-import the reference's experiment parameters use
+
+
+    class ExpShaped:
+        def __init__(self, model_name, hsi_lo=0, hsi_hi=6, num_classes=1, cube_featmaps=64, spectral_bn_size=4,
+                     bilinear=False, use_attention=False, channels=3):
+            self.model_name, self.hsi_lo, self.hsi_hi, self.num_classes = model_name, hsi_lo, hsi_hi, num_classes
+            self.cube_featmaps, self.spectral_bn_size = cube_featmaps, spectral_bn_size
+            self.bilinear, self.use_attention, self.channels = bilinear, use_attention, channels
+
+        def get_network(self):
+            name = self.model_name.lower()
+            if name == "spectralunet":
+                return SpectralUNET(self.hsi_hi - self.hsi_lo, self.num_classes, bn_feats=self.spectral_bn_size)
+            if name == "cubenet":
+                return CubeNET(self.hsi_hi - self.hsi_lo, self.num_classes, first_depth=self.cube_featmaps,
+                               bilinear=self.bilinear, use_attention=self.use_attention)
+            if name == "unet":
+                return UNet(self.channels, self.num_classes, bilinear=self.bilinear, feature_extraction=False,
+                            use_attention=self.use_attention)
+            raise RuntimeError("invalid model")
+'''
+
+TRAINER_SHAPED = '''
+    import torch
+    from torch import nn, optim
+    from .Experiments.models import *           # as the reference's trainer module does
+
+
+    class ModelShaped:
+        def __init__(self, network, criterion, optimizer="Adam", learn_rate=1e-3, decay=0.0, threshold=0.5):
+            self.m_network, self.f_criterion = network, criterion
+            self.p_optimizer, self.p_learn_rate, self.p_decay, self.threshold = optimizer, learn_rate, decay, threshold
+
+        def training_step(self, batch, batch_idx):
+            mask = batch["mask"].to(torch.int32)
+            if hasattr(self.m_network, "analyze") and self.m_network.analyze:
+                pred, _ = self.m_network(batch["image"])
+            else:
+                pred = self.m_network(batch["image"])
+            loss = self.f_criterion(pred, batch["mask"])
+            seg = torch.sigmoid(pred.detach()) > self.threshold
+            self.last = {"acc": float((seg.to(torch.int32) == mask).float().mean()), "pred": pred}
+            return loss
+
+        def configure_optimizers(self):
+            params = self.m_network.parameters()
+            if self.p_optimizer.upper() == "ADAM":
+                return optim.Adam(params, lr=self.p_learn_rate, weight_decay=self.p_decay)
+            return optim.SGD(params, lr=self.p_learn_rate, weight_decay=self.p_decay)
+'''
+
+DRIVER = '''
+    import importlib, json, sys
+    import torch
+    mode = sys.argv[1]
+    P = importlib.import_module("src.Experiments.params_shaped")
+    T = importlib.import_module("src.trainer_shaped")
+    M = importlib.import_module("src.Experiments.models")
+    MP = importlib.import_module("src.Experiments.model_parts")
+    import hyperpri_amd
+    out = {"models_file": M.__file__, "names_ok": True}
+    for n in ("UNet", "SpectralUNET", "CubeNET", "initialize_model", "translate_load_dir", "set_parameter_requires_grad",
+              "DoubleConv", "Down", "Up", "OutConv", "torch", "nn", "F"):
+        # every public name of the reference's models.py / model_parts.py is visible to the star-importing callers
+        if not (hasattr(P, n) and hasattr(T, n)):
+            out["names_ok"] = False
+            out.setdefault("missing", []).append(n)
+    out["same_classes"] = (P.CubeNET is hyperpri_amd.CubeNET) and (T.UNet is hyperpri_amd.UNet) and (MP.DoubleConv is hyperpri_amd.DoubleConv)
+    nets = {k: P.ExpShaped(k).get_network() for k in ("unet", "cubenet", "spectralunet")}
+    out["keys"] = {k: len(v.state_dict()) for k, v in nets.items()}
+    out["first_conv_alias"] = "first_conv.weight" in nets["cubenet"].state_dict() and "inc.0.weight" in nets["cubenet"].state_dict()
+    out["analyze_attr"] = hasattr(nets["unet"], "analyze") and hasattr(nets["cubenet"], "analyze")      # (models.py:26,151; PLTrainer.py:82 reads it)
+    if mode == "gpu":
+        dev = torch.device("cuda", 0)
+        torch.manual_seed(11)
+        net = P.ExpShaped("cubenet").get_network().to(dev)
+        torch.manual_seed(11)
+        ref = hyperpri_amd.CubeNET(6, 1, first_depth=64, bilinear=False, use_attention=False).to(dev)
+        g = torch.Generator().manual_seed(3)
+        batches = [{"image": torch.rand(2, 1, 6, 16, 24, generator=g).to(dev), "mask": (torch.rand(2, 1, 16, 24, generator=g) > 0.8).float().to(dev)}
+                   for _ in range(3)]
+        losses = {}
+        for tag, n in (("shim", net), ("direct", ref)):
+            model = T.ModelShaped(n, nn.BCEWithLogitsLoss(), optimizer="Adam", learn_rate=1e-3)
+            opt = model.configure_optimizers()
+            n.train()
+            ls = []
+            for i, b in enumerate(batches):
+                opt.zero_grad()
+                loss = model.training_step(b, i)
+                loss.backward()
+                opt.step()
+                ls.append(float(loss))
+            losses[tag] = ls
+            out[tag + "_pred_shape"] = list(model.last["pred"].shape)
+            out[tag + "_pred_contiguous"] = bool(model.last["pred"].is_contiguous())
+        out["losses"] = losses
+        out["params_equal"] = all(torch.equal(a, b) for a, b in zip(net.state_dict().values(), ref.state_dict().values()))
+        from hyperpri_amd import _lib
+        out["native_lib"] = _lib.load()._name
+    print("RESULT " + json.dumps(out))
+'''
+
+
+def _shims_from_integration_md():
+    """The two code blocks of INTEGRATION.md section 2, verbatim: the document is what gets tested."""
+    txt = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    sec = txt[txt.index("## 2. Reference-side binding"):txt.index("with `hyperpri_amd`'s parent directory on `PYTHONPATH`")]
+    blocks = re.findall(r"```python\n(.*?)```", sec, flags=re.S)
+    assert len(blocks) == 2, "INTEGRATION.md section 2 must hold exactly the two shim files"
+    return blocks[0], blocks[1]
+
+
+def _tree(tmp_path):
+    mp, mo = _shims_from_integration_md()
+    exp = tmp_path / "checkout" / "src" / "Experiments"
+    os.makedirs(exp)
+    (exp / "model_parts.py").write_text(mp)
+    (exp / "models.py").write_text(mo)
+    (exp / "params_shaped.py").write_text(textwrap.dedent(PARAMS_SHAPED))
+    (tmp_path / "checkout" / "src" / "trainer_shaped.py").write_text(textwrap.dedent(TRAINER_SHAPED))
+    (tmp_path / "checkout" / "driver.py").write_text(textwrap.dedent(DRIVER))
+    return tmp_path / "checkout"
+
+
+def _run(tmp_path, mode):
+    import json
+    co = _tree(tmp_path)
+    env = dict(os.environ, PYTHONPATH=f"{co}{os.pathsep}{ROOT}", PYTHONDONTWRITEBYTECODE="1")
+    r = subprocess.run([sys.executable, str(co / "driver.py"), mode], cwd=str(co), env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1]
+    return json.loads(line[7:]), co
+
+
+def test_shim_files_bind_the_package_through_the_reference_import_chain(tmp_path):
+    out, co = _run(tmp_path, "cpu")
+    assert out["models_file"].startswith(str(co)), out["models_file"]          # the checkout's own models.py was the entry point
+    assert out["names_ok"], out.get("missing")
+    assert out["same_classes"]
+    assert out["keys"] == {"unet": 136, "cubenet": 138, "spectralunet": 65}      # state_dict keys of the reference modules (SURVEY.md 8c iv)
+    assert out["first_conv_alias"] and out["analyze_attr"]
+
+
+@pytest.mark.gpu
+def test_training_step_shaped_loop_through_the_shims(tmp_path):
+    out, _ = _run(tmp_path, "gpu")
+    assert out["names_ok"] and out["same_classes"]
+    assert out["shim_pred_shape"] == [2, 1, 16, 24] and out["shim_pred_contiguous"]
+    ls = out["losses"]
+    assert ls["shim"] == ls["direct"]              # the same kernels behind both import paths: bit-equal losses over three Adam steps
+    assert all(0.0 < v < 5.0 for v in ls["shim"]) and out["params_equal"]
+    assert out["native_lib"].endswith("libhyperpri_hip.so")

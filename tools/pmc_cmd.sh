@@ -5,6 +5,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 TAG=$1; shift
 OUT=$R/gpurun_out/$TAG
 rm -rf $OUT; mkdir -p $OUT
+cp $R/hyperpri_amd/lib/libhyperpri_hip.so.stamp $OUT/lib_stamp.txt    # which build the counters belong to
 cd /tmp && export TMPDIR=/tmp
 ARGS=()
 for a in "$@"; do if [ -e "$R/$a" ]; then ARGS+=("$R/$a"); else ARGS+=("$a"); fi; done

@@ -44,8 +44,15 @@ def main():
     if not out:
         raise SystemExit(f"no FETCH_SIZE / WRITE_SIZE rows under {src}: nothing written (bench.py replays profiles/{tag}_pmc_traffic.json)")
     os.makedirs(os.path.join(root, "profiles"), exist_ok=True)
+    # the source stamp of the library the passes ran (tools/measure.sh copies it next to the counters; fallback: the local build):
+    # bench.py replays these figures only while the loaded library carries the same stamp
+    stamp = None
+    for cand in (os.path.join(src, "lib_stamp.txt"), os.path.join(root, "hyperpri_amd", "lib", "libhyperpri_hip.so.stamp")):
+        if os.path.exists(cand):
+            stamp = open(cand).read().strip()
+            break
     with open(os.path.join(root, "profiles", f"{tag}_pmc_traffic.json"), "w") as fh:
-        json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on bench.py --steps 2 --warmup 1; "
+        json.dump({"library_stamp": stamp, "note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on bench.py --steps 2 --warmup 1; "
                            "bytes = counter*1024, FETCH_SIZE doubled (gfx950 correction, MI355X_MICROARCH.md HBM section)",
                    "kernels": out}, fh, indent=1)
     for f in glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True):
