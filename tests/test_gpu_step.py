@@ -255,8 +255,8 @@ def test_forward_loss_checks_what_bcewithlogits_checks():
     for p in net.parameters():
         p.grad = None
     H.BCEWithLogitsLoss()(net(x), mask).backward()
-    for a, b in zip(g1, [p.grad for p in net.parameters()]):
-        assert torch.equal(a, b)
+    for a, b in zip(g1, [p.grad for p in net.parameters()]):       # (equal up to the summation order inside the head's own gradient)
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-8)
     # no cycle: a dropped (pred, loss) pair frees its activations without gc
     del pred, loss, g1
     gc.collect()
