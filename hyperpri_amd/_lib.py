@@ -12,8 +12,10 @@ import re
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libhyperpri_hip.so")
+DIAG = os.environ.get("HPRI_DIAG", "0") == "1"      # the diagnostics build (hyperpri_amd/build.py, include/hyperpri_hip_diag.h)
+LIB_PATH = os.path.join(_HERE, "lib", "libhyperpri_hip_diag.so" if DIAG else "libhyperpri_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "hyperpri_hip.h")
+DIAG_HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "hyperpri_hip_diag.h")
 
 _lock = threading.Lock()
 _lib = None
@@ -70,6 +72,8 @@ def load():
                 "There is no CPU/PyTorch fallback for the hot path.")
         lib = ctypes.CDLL(LIB_PATH)
         _decls = parse_header()
+        if DIAG:
+            _decls.update(parse_header(DIAG_HEADER_PATH))
         for name, (restype, argtypes) in _decls.items():
             fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
             fn.restype = restype

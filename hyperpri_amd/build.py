@@ -13,9 +13,13 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
-LIB = os.path.join(LIBDIR, "libhyperpri_hip.so")
-SOURCES = ["api.cpp", "conv_fwd.hip", "conv_bf16v2.hip", "conv_bf16v3.hip", "gemm_bf16v3.hip", "wgrad_bf16v3.hip", "conv_wino.hip", "conv_wino4.hip", "conv_wgrad.hip", "conv_wgrad_bf16v2.hip", "pack.hip", "bn.hip", "elementwise.hip", "step.hip", "ingest.hip"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
+# HPRI_DIAG=1: the diagnostics build -- superseded kernel generations and neutral / negative variants kept for A/B measurements
+# (include/hyperpri_hip_diag.h) compiled in with -DHPRI_DIAG_KERNELS, as a SEPARATE library; the product library has one kernel
+# family per precision mode and form.
+DIAG = os.environ.get("HPRI_DIAG", "0") == "1"
+LIB = os.path.join(LIBDIR, "libhyperpri_hip_diag.so" if DIAG else "libhyperpri_hip.so")
+SOURCES = ["api.cpp", "conv_fwd.hip", *(["conv_bf16v2.hip"] if DIAG else []), "conv_bf16v3.hip", "gemm_bf16v3.hip", "wgrad_bf16v3.hip", "conv_wino.hip", "conv_wino4.hip", "conv_wgrad.hip", "conv_wgrad_bf16v2.hip", "pack.hip", "bn.hip", "elementwise.hip", "step.hip", "ingest.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", *(["-DHPRI_DIAG_KERNELS"] if DIAG else [])]
 
 
 def _hipcc() -> str:
@@ -46,7 +50,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     objs = []
     procs = []
     for s in SOURCES:
-        o = os.path.join(LIBDIR, s.rsplit(".", 1)[0] + ".o")
+        o = os.path.join(LIBDIR, s.rsplit(".", 1)[0] + ("_diag.o" if DIAG else ".o"))
         objs.append(o)
         cmd = [hipcc, *FLAGS, "-x", "hip", "-c", os.path.join(CSRC, s), "-o", o, "-I", CSRC]
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

@@ -72,6 +72,7 @@ int hpri_cu_count() {
   return n;
 }
 
+#ifdef HPRI_DIAG_KERNELS   // measured neutral (round 3): diagnostics build only
 // A stream of the LOWEST priority the device offers, for work that should only fill what the caller's stream leaves free
 // (the engine's weight-gradient stream: its 256-workgroup launches otherwise hold every CU while the 2-64-workgroup finalize
 // kernels on the critical path wait for a slot).  *stream receives a hipStream_t the caller owns (hpri_stream_destroy).
@@ -90,6 +91,8 @@ extern "C" int hpri_stream_destroy(void* stream) {
     return hpri_set_error(HPRI_ERR_LAUNCH, "stream destruction failed");
   return HPRI_OK;
 }
+
+#endif   // HPRI_DIAG_KERNELS
 
 extern "C" int hpri_get_option(const char* name) {
   for (int i = 0; i < 5; ++i)

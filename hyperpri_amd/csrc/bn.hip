@@ -751,6 +751,7 @@ extern "C" int hpri_bn_relu_bwd_fused(const float* partials, int part_blocks, in
                           pix_per_group, C, Cw, relu, use_batch_stats, planes, plane_stride, pl_cs, pl_coff, pl_cw, npl, stream);
 }
 
+#ifdef HPRI_DIAG_KERNELS   // counterpart of hpri_conv_bf16v3_bnred (diagnostics build only)
 // hpri_bn_relu_bwd_fused with the pre-BN tensor stored as bf16 (partial sums from hpri_conv_bf16v3_bnred)
 extern "C" int hpri_bn_relu_bwd_fused_x16(const float* partials, int part_blocks, int part_cpart, const float* dy, int dy_cs, int dy_coff,
                                           const void* x16, int x_cs, int x_coff, float* dx, int dx_cs, int dx_coff, const float* mean,
@@ -766,6 +767,7 @@ extern "C" int hpri_bn_relu_bwd_fused_x16(const float* partials, int part_blocks
                           workspace, ws_floats, P, pix_per_group, C, Cw, relu, use_batch_stats, planes, plane_stride, pl_cs, pl_coff,
                           pl_cw, npl, stream);
 }
+#endif   // HPRI_DIAG_KERNELS
 
 // the same with the pre-BN tensor stored as bf16 (see hpri_bn_apply_relu_x16)
 extern "C" int hpri_bn_relu_bwd_x16(const float* dy, int dy_cs, int dy_coff, const void* x16, int x_cs, int x_coff,

@@ -305,18 +305,11 @@ __global__ __launch_bounds__(256, 2) void conv_bf16v3_kernel(ConvV3Args a) {
 #define V3_I3(par_, dy_) if (more_a) { V3_DMA_A((par_) ^ 1, c + 1, ((dy_) & 1) * 3 + 0); }
 #define V3_I4(par_, dy_) if (more_a) { V3_DMA_A((par_) ^ 1, c + 1, ((dy_) & 1) * 3 + 1); }
 #define V3_I5(par_, dy_) if (more_a) { V3_DMA_A((par_) ^ 1, c + 1, ((dy_) & 1) * 3 + 2); }
-#ifdef V3_DMA_FIRST      /* A/B switch: all six right behind the barrier instead of between the MFMAs */
-#define V3_ISSUE_FIRST(x_) x_
-#define V3_ISSUE_MID(x_)
-#else
+// (measured and dropped in round 3, each neutral on one box: all six DMA pieces right behind the barrier instead of between the
+// MFMAs, no s_setprio at all, the epilogue at raised priority: DESIGN.md 4)
 #define V3_ISSUE_FIRST(x_)
 #define V3_ISSUE_MID(x_) x_
-#endif
-#ifdef V3_NO_SETPRIO
-#define V3_SETPRIO(p_)
-#else
 #define V3_SETPRIO(p_) __builtin_amdgcn_s_setprio(p_)
-#endif
 #ifdef HPRI_STAMPS
 #define V3_TOP_BEGIN() long long tb_; { __builtin_amdgcn_sched_barrier(0); tb_ = (long long)__builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
 #define V3_TOP_END() { __builtin_amdgcn_sched_barrier(0); wait_cycles += (long long)__builtin_amdgcn_s_memtime() - tb_; __builtin_amdgcn_sched_barrier(0); }
@@ -359,12 +352,6 @@ __global__ __launch_bounds__(256, 2) void conv_bf16v3_kernel(ConvV3Args a) {
     //      every wave has left the main loop (barrier), so halo buffer 0 and weight buffer 0 are free whatever the chunk parity;
     //      the statistics scratch below lives in halo buffer 1 ----
     V3_BARRIER();
-#ifdef V3_EPI_PRIO
-    // the epilogue is ~600 vector instructions and 16 stores per wave: at the main loop's priority or below it only gets the
-    // issue slots the partner workgroup's MFMA stream leaves over and takes 3-5 x as long, during which this workgroup's
-    // share of the matrix pipe is idle -- so it runs ABOVE the partner's main loop
-    __builtin_amdgcn_s_setprio(V3_EPI_PRIO);
-#endif
     k += nloc;
     have = tile_of(k, nxt);
     if (have) {
@@ -587,9 +574,6 @@ __global__ __launch_bounds__(256, 2) void conv_bf16v3_kernel(ConvV3Args a) {
     if (ntiles_done == 0) { V3_STAMP(3) }
     ++ntiles_done;
 #endif
-#ifdef V3_EPI_PRIO
-    __builtin_amdgcn_s_setprio(0);
-#endif
     if (have && nxt.twl != cur.twl) build_aofs(nxt.twl);
     cur = nxt;
     slot ^= 1;
@@ -772,7 +756,11 @@ static int v3_launch(const void* xp, long long x_plane, int x_cs, int x_coff, co
     a.bn_cw = (bn->x_cs - bn->x_coff) & ~3;
     a.bn_mean = bn->mean; a.bn_invstd = bn->invstd; a.bn_scale = bn->scale; a.bn_shift = bn->shift;
     a.bn_relu = bn->relu; a.bn_part = bn->part; a.bn_cpart = bn->cpart;
+#ifdef HPRI_DIAG_KERNELS
     hipLaunchKernelGGL(conv_bf16v3_kernel<true>, grid, dim3(256), 0, stream, a);
+#else
+    return hpri_set_error(HPRI_ERR_UNSUPPORTED, "conv_bf16v3_bnred: diagnostics build only (HPRI_DIAG=1 python -m hyperpri_amd.build)");
+#endif
   } else {
     hipLaunchKernelGGL(conv_bf16v3_kernel<false>, grid, dim3(256), 0, stream, a);
   }
@@ -781,6 +769,7 @@ static int v3_launch(const void* xp, long long x_plane, int x_cs, int x_coff, co
   return hpri_splitk_finish(ws, a.ksplit, Cout_pad, bias, y, y_cs, y_coff, stats, N, H * W, Cout, a.y_cw, accumulate & 1, a.relu, stream);
 }
 
+#ifdef HPRI_DIAG_KERNELS   // (stagger and stamp buffer given by the caller: tools/v3_bench.py, tools/v3_stamps.py)
 extern "C" int hpri_conv_bf16v3_dbg(const void* xp, long long x_plane, int x_cs, int x_coff, const void* wp, const float* bias,
                                     float* y, int y_cs, int y_coff, float* stats, int N, int H, int W, int Cin_pad, int Cout,
                                     int Cout_pad, int y_cw, int accumulate, int split, float* ws, size_t ws_floats,
@@ -788,7 +777,9 @@ extern "C" int hpri_conv_bf16v3_dbg(const void* xp, long long x_plane, int x_cs,
   return v3_launch(xp, x_plane, x_cs, x_coff, wp, bias, y, y_cs, y_coff, stats, N, H, W, Cin_pad, Cout, Cout_pad, y_cw, accumulate,
                    split, ws, ws_floats, stamps, stagger_cycles, nullptr, stream);
 }
+#endif   // HPRI_DIAG_KERNELS
 
+#ifdef HPRI_DIAG_KERNELS   // measured neutral to -3 % in round 3: kept for A/B in the diagnostics build only
 // The data gradient of a 3x3 layer whose input x = ReLU(BN(bn_x16)) has no other consumer, with that BatchNorm's backward
 // reduction taken in the epilogue (the bf16-mode counterpart of hpri_conv_wino4_bnred): bn_x16 = the pre-BN tensor as bf16 (same
 // pixels as y; bn_x_cs / bn_x_coff in elements), its per-channel mean / invstd / scale / shift, bn_relu; bn_part[stat tiles][2][bn_cpart]
@@ -802,6 +793,8 @@ extern "C" int hpri_conv_bf16v3_bnred(const void* xp, int x_cs, int x_coff, cons
   return v3_launch(xp, 0, x_cs, x_coff, wp, nullptr, y, y_cs, y_coff, nullptr, N, H, W, Cin_pad, Cout, Cout_pad, y_cw, 0, 0, nullptr, 0,
                    nullptr, V3_STAGGER_CYCLES, &bn, stream);
 }
+
+#endif   // HPRI_DIAG_KERNELS
 
 // hpri_conv_bf16v3 (no accumulate, no split-K) whose result channels [c0, c0 + cw) -- whole 64-channel blocks -- are also
 // (y2_only != 0: only) written as bf16 rows: y2 + pixel * y2_cs + y2_coff + (channel - c0).  The data gradient of the first
@@ -821,6 +814,6 @@ extern "C" int hpri_conv_bf16v3(const void* xp, long long x_plane, int x_cs, int
                                 float* y, int y_cs, int y_coff, float* stats, int N, int H, int W, int Cin_pad, int Cout,
                                 int Cout_pad, int y_cw, int accumulate, int split, float* ws, size_t ws_floats,
                                 hipStream_t stream) {
-  return hpri_conv_bf16v3_dbg(xp, x_plane, x_cs, x_coff, wp, bias, y, y_cs, y_coff, stats, N, H, W, Cin_pad, Cout, Cout_pad,
-                              y_cw, accumulate, split, ws, ws_floats, nullptr, V3_STAGGER_CYCLES, stream);
+  return v3_launch(xp, x_plane, x_cs, x_coff, wp, bias, y, y_cs, y_coff, stats, N, H, W, Cin_pad, Cout, Cout_pad, y_cw, accumulate,
+                   split, ws, ws_floats, nullptr, V3_STAGGER_CYCLES, nullptr, stream);
 }

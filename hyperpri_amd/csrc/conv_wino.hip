@@ -24,6 +24,10 @@
 //              keeps its 32 outputs for the two-pass BatchNorm partial statistics of the tile.
 #include "common.h"
 
+// The first form of the fused forward kernel (8 waves, 16 x 16 pixels, one workgroup per CU; superseded by conv_wino4.hip in round 2)
+// is compiled into the DIAGNOSTICS build only (HPRI_DIAG=1 python -m hyperpri_amd.build: -DHPRI_DIAG_KERNELS; include/hyperpri_hip_diag.h);
+// the weight-gradient kernels below are the product's.
+#ifdef HPRI_DIAG_KERNELS
 __device__ __attribute__((aligned(64))) float hpri_wino_zero[16];
 
 struct WinoArgs {
@@ -386,8 +390,11 @@ __global__ void wino_pack_kernel(const float* __restrict__ w, float* __restrict_
   }
 }
 
+#endif   // HPRI_DIAG_KERNELS
+
 extern "C" size_t hpri_wino_packed_floats(int K, int Ncols_pad) { return (size_t)hpri_cdiv(K, 8) * 16 * 8 * Ncols_pad; }
 
+#ifdef HPRI_DIAG_KERNELS
 extern "C" int hpri_wino_pack(const float* w, float* up, const float* colscale, int mode, int K, int Ncols, int Ncols_pad,
                               int src_d1, hipStream_t stream) {
   HPRI_REQUIRE(w && up, "wino_pack: null pointer");
@@ -442,6 +449,8 @@ extern "C" int hpri_conv_wino(const float* x, int x_cs, int x_coff, const float*
   HPRI_CHECK_LAUNCH();
   return HPRI_OK;
 }
+
+#endif   // HPRI_DIAG_KERNELS
 
 // =====================================================================================================================
 // Winograd weight gradient.  With M = U (.) V and Y = A^T M A, the gradient of the transformed filter is

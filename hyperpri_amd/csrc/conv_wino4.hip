@@ -472,12 +472,12 @@ extern "C" int hpri_wino4_pack(const float* w, float* up, const float* colscale,
   return HPRI_OK;
 }
 
-// Stamp buffer of the diagnostic build (-DHPRI_STAMPS, tools/build_wino4_diag.sh).  The product library keeps no state: the
-// entry point exists (the header declares it) and refuses.
+// Stamp buffer of the diagnostic builds (-DHPRI_STAMPS, tools/build_wino4_diag.sh; declared in include/hyperpri_hip_diag.h).  The
+// product library keeps no state and has no such entry point.
 #ifdef HPRI_STAMPS
 static unsigned long long* hpri_wino4_stamps = nullptr;
 extern "C" int hpri_wino4_set_stamps(unsigned long long* p) { hpri_wino4_stamps = p; return HPRI_OK; }
-#else
+#elif defined(HPRI_DIAG_KERNELS)
 extern "C" int hpri_wino4_set_stamps(unsigned long long*) {
   return hpri_set_error(HPRI_ERR_UNSUPPORTED, "wino4_set_stamps: this library was built without -DHPRI_STAMPS");
 }

@@ -882,3 +882,49 @@ extern "C" int hpri_copy_slice_any(const float* src, int s_cs, int s_coff, float
   HPRI_CHECK_LAUNCH();
   return HPRI_OK;
 }
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+// ---- fp32 NHWC view -> bf16 planes (generic producer; fused producers write planes themselves) ---------------------------
+// planes[p][pixel][cs16]: plane 0 = bf16(x), plane 1 = bf16(x - hi), plane 2 = bf16(x - hi - mid); channels [C, cw16) = 0
+__global__ void to_planes_kernel(const float* __restrict__ x, int cs, int coff, __bf16* __restrict__ pl, long long plane,
+                                 int cs16, int coff16, long long P, int C, int cw16, int npl) {
+  const int q8 = cw16 >> 3;
+  const long long total = P * q8;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const long long p = idx / q8;
+    const int c = (int)(idx - p * q8) * 8;
+    float v[8];
+    const float* src = x + p * cs + coff + c;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      if (c + h * 4 + 3 < C) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(src + h * 4);
+        v[h * 4 + 0] = t[0]; v[h * 4 + 1] = t[1]; v[h * 4 + 2] = t[2]; v[h * 4 + 3] = t[3];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[h * 4 + e] = (c + h * 4 + e < C) ? src[h * 4 + e] : 0.f;
+      }
+    }
+    for (int k = 0; k < npl; ++k) {
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const __bf16 hv = (__bf16)v[e]; o[e] = hv; v[e] -= (float)hv; }
+      *reinterpret_cast<bf16x8*>(pl + (size_t)k * plane + p * cs16 + coff16 + c) = o;
+    }
+  }
+}
+
+extern "C" int hpri_to_planes(const float* x, int cs, int coff, void* planes, long long plane_stride, int cs16, int coff16,
+                              long long P, int C, int cw16, int npl, hipStream_t stream) {
+  HPRI_REQUIRE(x && planes, "to_planes: null pointer");
+  HPRI_REQUIRE(P > 0 && C > 0 && cw16 >= C && cw16 % 8 == 0 && coff16 % 8 == 0 && coff16 + cw16 <= cs16 && cs16 % 8 == 0,
+               "to_planes: bad plane geometry");
+  HPRI_REQUIRE(cs % 4 == 0 && coff % 4 == 0 && npl >= 1 && npl <= 3 && plane_stride % 8 == 0, "to_planes: bad arguments");
+  const long long total = P * (cw16 >> 3);
+  long long blocks = (total + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(to_planes_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, cs, coff,
+                     reinterpret_cast<__bf16*>(planes), plane_stride, cs16, coff16, P, C, cw16, npl);
+  HPRI_CHECK_LAUNCH();
+  return HPRI_OK;
+}

@@ -54,9 +54,9 @@ class GradSync:
     def __init__(self, module: torch.nn.Module, bucket_mb: Optional[float] = None, process_group=None,
                  broadcast_buffers: bool = False, force: bool = False, tail_mb: Optional[float] = None):
         if bucket_mb is None:
-            bucket_mb = float(os.environ.get("HPRI_BUCKET_MB", "24"))
+            bucket_mb = 24.0           # few large messages: xGMI is point-to-point (7 links x ~153 GB/s), a ring is per-link bound
         if tail_mb is None:
-            tail_mb = float(os.environ.get("HPRI_TAIL_MB", "2"))
+            tail_mb = 2.0              # the last bucket's all-reduce is the only one that cannot overlap with backward
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.collective = self.world > 1 or (force and dist.is_initialized())   # force: rehearse with one rank

@@ -11,6 +11,7 @@ import contextlib
 import ctypes
 import threading
 import os
+import types
 from typing import Callable, Dict, List, Optional, Tuple
 
 import torch
@@ -171,38 +172,27 @@ class Planes:
 # fp32 mode: 3x3 convolutions (forward and data gradient) by Winograd F(2x2,3x3) on the fp32 MFMA (csrc/conv_wino.hip):
 # 2.25x fewer multiplies in the same arithmetic type; 0 = direct implicit GEMM everywhere
 WINOGRAD = os.environ.get("HPRI_WINOGRAD", "1") != "0"
-WINO_WGRAD = os.environ.get("HPRI_WINO_WGRAD", "1") != "0"     # ... and the weight gradients
+WINO_WGRAD = WINOGRAD     # ... and the weight gradients (same switch)
 WINO_MIN_BLOCKS = 256        # workgroups (16x16-pixel tiles x 64-channel blocks) below which the direct split-K kernel is used
 
 
 def _wino_ok(x: "Act", ncols: int) -> bool:
-    th = 8 if WINO4 else 16                  # tile height of the kernel in use (conv_wino4.hip: 16 x 8 pixels)
+    th = 8                                   # tile height of conv_wino4.hip (16 x 8 pixels)
     if x.H * x.W * x.cs * 4 >= (1 << 32) - 65536:      # 32-bit DMA offsets per image (conv_wino4 / wgrad): direct kernels beyond that
         return False
     return WINOGRAD and x.N * ((x.H + th - 1) // th) * ((x.W + 15) // 16) * (_rup(ncols, 64) // 64) >= WINO_MIN_BLOCKS
 
 
-# Which of the two fused Winograd kernels: conv_wino4.hip (4-wave workgroups of 16 x 8 pixels, two per CU: the output
-# transform of one runs under the MFMAs of the other) or conv_wino.hip (8 waves, 16 x 16 pixels, one per CU).  Their packed
-# weights differ in layout, so the choice is part of the pack-cache key.  HPRI_WINO4: 1 (default) / 0.
-WINO4 = os.environ.get("HPRI_WINO4", "1") != "0"
-
-
-def _wino_sfx() -> str:
-    return "wino4" if WINO4 else "wino"
-
-
 def _pack_wino(w: torch.Tensor, mode: int, K: int, ncols: int, d1: int) -> Tuple[torch.Tensor, int]:
     ncols_pad = _rup(ncols, 64)
-    kind = _wino_sfx()
 
     def build():
         global PACK_LAUNCHES
         up = torch.empty(_lib.load().hpri_wino_packed_floats(K, ncols_pad), dtype=torch.float32, device=w.device)
-        _lib.call(f"hpri_{kind}_pack", _p(w), _p(up), ctypes.c_void_p(0), mode, K, ncols, ncols_pad, d1, _stream())
+        _lib.call("hpri_wino4_pack", _p(w), _p(up), ctypes.c_void_p(0), mode, K, ncols, ncols_pad, d1, _stream())
         PACK_LAUNCHES += 1
         return up
-    return _cached_pack(w, (kind, mode, K, ncols, d1), build), ncols_pad
+    return _cached_pack(w, ("wino4", mode, K, ncols, d1), build), ncols_pad
 
 
 def _conv_launch_wino(x: Act, up: torch.Tensor, bias: Optional[torch.Tensor], y: Act, stats: Optional[torch.Tensor],
@@ -212,31 +202,36 @@ def _conv_launch_wino(x: Act, up: torch.Tensor, bias: Optional[torch.Tensor], y:
         tag += f" N{x.N} {x.H}x{x.W} K{x.cw} N{cout}"
     wtiles = x.N * ((x.H + 1) // 2) * ((x.W + 1) // 2)
     with _timed(tag, 2.0 * x.N * x.H * x.W * cin * cout * 9, executed=2.0 * wtiles * 16 * cin * cout):
-        _lib.call(f"hpri_conv_{_wino_sfx()}", x.ptr, x.cs, x.coff, _p(up), _p(bias), y.ptr, y.cs, y.coff, _p(stats), x.N, x.H, x.W, x.cw,
+        _lib.call("hpri_conv_wino4", x.ptr, x.cs, x.coff, _p(up), _p(bias), y.ptr, y.cs, y.coff, _p(stats), x.N, x.H, x.W, x.cw,
                   cout, cout_pad, y_cw, accumulate, _stream())
 
 
+# ---- switches ----------------------------------------------------------------------------------------------------------------------
+# Twelve environment switches are documented: HPRI_PRECISION, HPRI_WINOGRAD, HPRI_SIDE_STREAM,
+# HPRI_SIDE_STREAM_SINK, HPRI_PLANE_CONV, HPRI_PLANE_WGRAD, HPRI_PLANE_GEMM, HPRI_FUSIONS, HPRI_PACK_CACHE, HPRI_PACK_VERIFY,
+# HPRI_STEPS_IN_FLIGHT, HPRI_DISPATCHER.  HPRI_FUSIONS=0 turns off, together, every traffic-saving fusion of rounds 2-3 (tensors
+# kept as bf16 planes only, bf16 pre-BN tensors and inner gradients, plane concats, plane-fed transposed convolutions, BatchNorm /
+# bias sums from a neighbour's epilogue): the results stay inside the same parity gates (most of the fusions are bit-neutral), the
+# step reads and writes more.  The individual module attributes below exist so that tests can show each fusion's (non-)effect on
+# the values one at a time; they have no environment variables of their own.
+FUSIONS = os.environ.get("HPRI_FUSIONS", "1") != "0"
 PLANE_CONV = os.environ.get("HPRI_PLANE_CONV", "1") != "0"   # bf16 mode: 3x3 convs on bf16 planes (0: round-1 kernel)
 PLANE_WGRAD = os.environ.get("HPRI_PLANE_WGRAD", "1") != "0"  # ... and their weight gradients (0: round-1 kernel)
 # the BatchNorm backward of a plane-mode layer writes its result as bf16 planes ONLY when both consumers read planes (one fp32
-# tensor write less per layer and step).  HPRI_PLANES_ONLY_GRAD: 1 (default) / 0.
-PLANES_ONLY_GRAD = os.environ.get("HPRI_PLANES_ONLY_GRAD", "1") != "0"
-# ... and the inner tensor of a DoubleConv (conv -> BN -> ReLU -> [here] -> conv) likewise.  HPRI_PLANES_ONLY_ACT: 1 (default) / 0.
-PLANES_ONLY_ACT = os.environ.get("HPRI_PLANES_ONLY_ACT", "1") != "0"
-# no planes for tensors whose readers inside these networks are all fp32 (the output of a DoubleConv).  HPRI_PLANES_LAZY: 1 / 0.
-PLANES_LAZY = os.environ.get("HPRI_PLANES_LAZY", "1") != "0"
-# a skip tensor's planes are written straight into the plane buffer of the decoder's concat.  HPRI_PLANES_CONCAT: 1 / 0.
-PLANES_CONCAT = os.environ.get("HPRI_PLANES_CONCAT", "1") != "0"
-# ... and the transposed convolution writes its half of those planes itself (no fp32 form, no conversion).  HPRI_PLANES_CONVT: 1 / 0.
-PLANES_CONVT = os.environ.get("HPRI_PLANES_CONVT", "1") != "0"
+# tensor write less per layer and step).  (HPRI_FUSIONS.)
+PLANES_ONLY_GRAD = FUSIONS
+# ... and the inner tensor of a DoubleConv (conv -> BN -> ReLU -> [here] -> conv) likewise.  (HPRI_FUSIONS.)
+PLANES_ONLY_ACT = FUSIONS
+# no planes for tensors whose readers inside these networks are all fp32 (the output of a DoubleConv).  (HPRI_FUSIONS.)
+PLANES_LAZY = FUSIONS
+# a skip tensor's planes are written straight into the plane buffer of the decoder's concat.  (HPRI_FUSIONS.)
+PLANES_CONCAT = FUSIONS
+# ... and the transposed convolution writes its half of those planes itself (no fp32 form, no conversion).  (HPRI_FUSIONS.)
+PLANES_CONVT = FUSIONS
 PLANE_PRODUCERS = True       # producers (BN-apply, BN-backward, ...) write the planes themselves; False: generic pass only
 PLANE_CONVERSIONS = 0        # generic fp32 -> planes passes launched (fused producers do not count)
 
 
-# Which plane convolution: conv_bf16v3.hip (4-wave workgroups of 256 px x 64 ch, two per CU, v_mfma_f32_16x16x32_bf16, stores
-# straight from the accumulators) or conv_bf16v2.hip (one persistent 8-wave workgroup per CU).  Same packed weights, same
-# arguments; the statistics tiles differ (plan).  HPRI_BF16_V3: 1 (default) / 0.
-BF16_V3 = os.environ.get("HPRI_BF16_V3", "1") != "0"
 # bf16 mode: the 1x1 layers (nn.Linear of SpectralUNET) forward and data gradient by the plane-fed GEMM kernel
 # (gemm_bf16v3.hip); HPRI_PLANE_GEMM=0: the round-1 kernel that converts fp32 activations while staging.
 PLANE_GEMM = os.environ.get("HPRI_PLANE_GEMM", "1") != "0"
@@ -245,12 +240,8 @@ PLANE_GEMM = os.environ.get("HPRI_PLANE_GEMM", "1") != "0"
 # bf16 mode with the v3 plane convolution: the PRE-BatchNorm tensor of a conv -> BN -> ReLU stage (written by the convolution, read
 # by the normalise pass and twice by the BatchNorm backward, by nobody else) is stored as bf16: 2 instead of 4 bytes per element on
 # four tensor sweeps per layer and step.  The statistics still come from the fp32 accumulators.  Dice-level parity re-run:
-# profiles/r03_bf16_dice_parity.json.  HPRI_YR_BF16: 1 (default) / 0.
-YR_BF16 = os.environ.get("HPRI_YR_BF16", "1") != "0"
-
-
-def _plane_conv() -> str:
-    return "hpri_conv_bf16v3" if BF16_V3 else "hpri_conv_bf16v2"
+# profiles/r03_bf16_dice_parity.json.  (HPRI_FUSIONS.)
+YR_BF16 = FUSIONS
 
 
 def _planes_fit(x: Act, channels: int) -> bool:
@@ -301,13 +292,13 @@ def _conv_launch_v2(x: Act, wp: torch.Tensor, bias: Optional[torch.Tensor], y: A
     pl = planes_of(x, 1)
     cin_pad = _rup(cin, 32)
     ksplit = ctypes.c_int(); tiles = ctypes.c_int(); wsf = ctypes.c_size_t()
-    _lib.call(_plane_conv() + "_plan", x.N, x.H, x.W, cin_pad, cout_pad, ctypes.byref(ksplit), ctypes.byref(tiles), ctypes.byref(wsf))
+    _lib.call("hpri_conv_bf16v3_plan", x.N, x.H, x.W, cin_pad, cout_pad, ctypes.byref(ksplit), ctypes.byref(tiles), ctypes.byref(wsf))
     ws = _ws(wsf.value, x.buf.device) if wsf.value else None
-    tag = "conv_planes_bf16<3,v3 256x64>" if BF16_V3 else f"conv_planes_bf16<3,{'4x2' if cout_pad % 128 == 0 else '8x1'}>"
+    tag = "conv_planes_bf16<3,v3 256x64>"
     if SHAPE_TAGS:
         tag += f" N{x.N} {x.H}x{x.W} K{cin_pad} N{cout}"
     with _timed(tag, 2.0 * x.N * x.H * x.W * cin * cout * 9):
-        _lib.call(_plane_conv(), _p(pl.buf), pl.plane, pl.cs, pl.coff, _p(wp), _p(bias), y.ptr, y.cs, y.coff, _p(stats),
+        _lib.call("hpri_conv_bf16v3", _p(pl.buf), pl.plane, pl.cs, pl.coff, _p(wp), _p(bias), y.ptr, y.cs, y.coff, _p(stats),
                   x.N, x.H, x.W, cin_pad, cout, cout_pad, y_cw, accumulate, 0, _p(ws), wsf.value, _stream())
 
 
@@ -540,20 +531,9 @@ def _side(device) -> "torch.cuda.Stream":
     idx = device.index if device.index is not None else torch.cuda.current_device()
     st = _side_streams.get(idx)
     if st is None:
-        if SIDE_LOW_PRIORITY:
-            with torch.cuda.device(idx):
-                h = ctypes.c_void_p(); pr = ctypes.c_int()
-                _lib.call("hpri_stream_create_low_priority", ctypes.byref(h), ctypes.byref(pr))
-            st = torch.cuda.ExternalStream(h.value, device=torch.device("cuda", idx))
-        else:
-            st = torch.cuda.Stream(device=device)
-        _side_streams[idx] = st
+        st = _side_streams[idx] = torch.cuda.Stream(device=device)
     return st
 
-
-# HPRI_SIDE_LOW_PRIORITY=1: the weight-gradient stream is created at the device's lowest stream priority (see
-# hpri_stream_create_low_priority).
-SIDE_LOW_PRIORITY = os.environ.get("HPRI_SIDE_LOW_PRIORITY", "0") == "1"
 
 _issue_streams: Dict[int, "torch.cuda.Stream"] = {}
 
@@ -791,6 +771,9 @@ def _conv_launch(x: Act, wp: torch.Tensor, bias: Optional[torch.Tensor], y: Act,
 # --------------------------------------------------------------------------------------------------
 # conv (3x3 pad 1 | 1x1 | Linear) [+ BatchNorm + ReLU]
 # --------------------------------------------------------------------------------------------------
+# One stage = planning (which kernel family serves this layer in this precision mode), the forward launch, the BatchNorm
+# finalize + apply pass, and a backward node made of three parts (BatchNorm backward, weight gradient, data gradient).  Each
+# part is its own function over the stage's context ``c`` (a SimpleNamespace: what the closures of rounds 1-3 captured).
 def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.Tensor], bn: Optional[BNRef],
                  train: bool, ks: int, groups: int = 1, relu: bool = True, need_dx: bool = True,
                  precision: Optional[str] = None, room: int = 0, next_cout: int = 0, cat_room: int = 0,
@@ -805,328 +788,350 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
     32 | C2 channels]; ``cat_into`` = a: the result's planes are the second half of ``a``'s concat (``concat_planes`` then has
     nothing to copy); ``k_gap``: ``x`` is such a concat -- (first, length) of its structural-zero channels, which the weight does
     not have; ``planes_only``: every consumer of the result reads planes (no fp32 copy is written)."""
-    dev = x.buf.device
     T = ks * ks
     cout = weight.shape[0]
     cin = weight.numel() // (cout * T)
     if cin + (k_gap[1] if k_gap else 0) != x.C:
         raise RuntimeError(f"hyperpri_amd: conv expects {cin} input channels, got {x.C}")
-    cin_pad = x.cw
     prec = precision or DEFAULT_PRECISION
     if prec not in PRECISIONS:
         raise RuntimeError(f"hyperpri_amd: unknown precision {prec!r}; choose from {PRECISIONS}")
     if bn is not None and not train and not tape.record and FOLD_EVAL_BN:
         return _conv_folded_eval(x, weight, bias, bn, ks, cin, cout, relu, prec, room)
-    lowp = prec in LOWP
-    split = _SPLIT.get(prec, 0)
-    # operands by LDS-DMA from bf16 planes (conv_bf16v2.hip); its DMA offsets are 32-bit per image
-    v2 = PLANE_CONV and prec == "bf16" and ks == 3 and _planes_fit(x, max(cin, cout))
-    # 1x1 layers of the bf16 mode on planes too (gemm_bf16v3.hip): forward and data gradient; the weight gradient still reads fp32
-    g3 = PLANE_GEMM and prec == "bf16" and ks == 1 and (x.f32_valid or x.pl is not None) and _rup(x.C, 32) <= 8192
-    if (cat_room or cat_into is not None or k_gap or planes_only) and not (g3 and bn is not None and PLANE_WGRAD and PLANE_PRODUCERS):
-        raise RuntimeError("hyperpri_amd: internal error: the plane form of a skip concat needs the plane GEMM path (see plane_gemm_mode)")
-    if not x.f32_valid and not ((v2 or g3) and x.pl is not None):
-        raise RuntimeError("hyperpri_amd: internal error: a planes-only activation reached a kernel that reads fp32")
-    wino = prec == "fp32" and ks == 3 and groups == 1 and _wino_ok(x, cout)
-    wino_d = prec == "fp32" and ks == 3 and groups == 1 and _wino_ok(x, cin)     # the data gradient has Cin columns
-    if wino:
-        wp, cout_pad = _pack_wino(weight, 0, cin, cout, cin)
-    elif lowp:
-        wp, cout_pad = _pack_bf16(weight, 0, x.C if k_gap else cin, cout, T, cin, split=split, gap=k_gap)
-    else:
-        wp, cout_pad = _pack(weight, 0, cin, cout, T, 0, cin)
-    use_batch = bn is not None and train
-    yr16 = False
-    if v2 and BF16_V3 and YR_BF16 and bn is not None and groups == 1:
-        ksp_ = ctypes.c_int(); tl_ = ctypes.c_int(); wsf_ = ctypes.c_size_t()
-        _lib.call("hpri_conv_bf16v3_plan", x.N, x.H, x.W, _rup(cin, 32), _rup(cout, 64), ctypes.byref(ksp_), ctypes.byref(tl_), ctypes.byref(wsf_))
-        yr16 = ksp_.value == 1            # (split-K problems finish in fp32: hpri_splitk_finish)
-    if g3 and YR_BF16 and bn is not None:
-        yr16 = True
-    if use_batch and (x.N * x.H * x.W) // max(groups, 1) <= 1:
-        # torch.nn.functional.batch_norm's own check (_verify_batch_size): same error, same message
-        raise ValueError("Expected more than 1 value per channel when training, got input size "
-                         f"torch.Size([{x.N // max(groups, 1)}, {cout}, {x.H}, {x.W}])")
-    if yr16:
-        yr = Act(torch.empty(x.P * _rup(cout, 8), dtype=torch.bfloat16, device=dev), x.N, x.H, x.W, cout, _rup(cout, 8), 0)
-        yr.b16, yr.f32_valid = True, False
-    else:
-        yr = Act.new(x.N, x.H, x.W, cout, dev)
-    stats = None
-    tiles = 0
-    if use_batch:
-        ksp = ctypes.c_int(); tl = ctypes.c_int(); wsf = ctypes.c_size_t()
-        if wino:
-            _lib.call(f"hpri_conv_{_wino_sfx()}_plan", x.N, x.H, x.W, ctypes.byref(tl))
-        elif v2:
-            _lib.call(_plane_conv() + "_plan", x.N, x.H, x.W, _rup(cin, 32), cout_pad, ctypes.byref(ksp), ctypes.byref(tl),
-                      ctypes.byref(wsf))
-        elif g3:
-            _lib.call("hpri_gemm_bf16v3_plan", x.N, x.H * x.W, ctypes.byref(tl))
-        elif lowp:
-            _lib.call("hpri_conv_fwd_bf16_plan", x.N, x.H, x.W, cin_pad, cout_pad, ks, A_DIRECT, E_DIRECT, split,
-                      ctypes.byref(ksp), ctypes.byref(tl), ctypes.byref(wsf))
-        else:
-            _lib.call("hpri_conv_fwd_plan", x.N, x.H, x.W, cin_pad, cout_pad, ks, A_DIRECT, E_DIRECT, ctypes.byref(ksp),
-                      ctypes.byref(tl), ctypes.byref(wsf))
-        tiles = tl.value
-        stats = torch.empty(tiles * cout_pad * 4, dtype=torch.float32, device=dev)
-    if wino:
-        _conv_launch_wino(x, wp, bias, yr, stats, cin, cout, cout_pad, yr.cw)
-    elif v2:
-        _conv_launch_v2(x, wp, bias, yr, stats, cin, cout, cout_pad, yr.cw, accumulate=4 if yr16 else 0)
-    elif g3:
-        _gemm_launch(x, wp, bias, yr, stats, x.C, cout, cout_pad, yr.cw)
-    elif lowp:
-        _conv_launch_bf16(x, wp, bias, yr, stats, x.N, x.H, x.W, cin_pad, cout, cout_pad, yr.cw, ks, cin_true=cin, split=split)
-    else:
-        _conv_launch(x, wp, bias, yr, stats, x.N, x.H, x.W, cin_pad, cout, cout_pad, yr.cw, ks, cin_true=cin)
-    del wp
+    c = types.SimpleNamespace(x=x, weight=weight, bias=bias, bn=bn, ks=ks, T=T, groups=groups, relu=relu, need_dx=need_dx, prec=prec,
+                              cin=cin, cout=cout, cin_pad=x.cw, k_gap=k_gap, dev=x.buf.device, lowp=prec in LOWP,
+                              split=_SPLIT.get(prec, 0), use_batch=bn is not None and train)
+    _conv_pick_kernels(c, cat_room, cat_into, planes_only)
+    _conv_forward(c)
     if bn is None:
-        y = yr
-        st = None
+        c.y, c.st = c.yr, None
     else:
-        G = groups if use_batch else 1
-        st = torch.empty(5 * G * cout, dtype=torch.float32, device=dev)   # mean, invstd, var_unbiased, scale, shift
-        mean, invstd, varu, scale, shift = (st[i * G * cout:(i + 1) * G * cout] for i in range(5))
-        if use_batch:
-            global _BN_EPOCH
-            _BN_EPOCH += 1
-            _lib.call("hpri_bn_finalize", _p(stats), tiles // G, G, cout_pad, cout, _p(bn.weight), _p(bn.bias),
-                      bn.eps, bn.momentum, _p(mean), _p(invstd), _p(varu), _p(scale), _p(shift),
-                      _p(bn.running_mean), _p(bn.running_var), _p(bn.num_batches_tracked), _stream())
-        else:
-            _lib.call("hpri_bn_eval_prepare", _p(bn.running_mean), _p(bn.running_var), _p(bn.weight), _p(bn.bias),
-                      bn.eps, cout, _p(mean), _p(invstd), _p(scale), _p(shift), _stream())
-        y = Act.new_with_room(x.N, x.H, x.W, cout, room, dev)    # room > 0: a skip tensor, written where its concat needs it
-        ppg = (x.P // G)
-        # bf16 plane mode: the normalise pass also writes y as bf16 planes -- what the next 3x3 convolution (and the
-        # weight gradient) stage by DMA -- so no conversion pass has to read y again
-        # -- for the inner tensor of a DoubleConv (``next_cout`` > 0).  The OUTPUT of a DoubleConv is read by max-pooling, the
-        # transposed convolution, the concat and the 1x1 output layer, all fp32 readers: no planes for it (573 MB of writes per
-        # C2 step that nobody read); ``want_pl`` still tells the pooling pass to write ITS result as planes.
-        y.want_pl = 1 if ((v2 or g3) and PLANE_PRODUCERS) else 0
-        # (a 1x1 layer's output is read by the next 1x1 layer or a concat in front of one: always planes)
-        # (``out_planes``: the caller knows a plane reader for this output -- the next decoder stage's transposed convolution)
-        ypl = new_planes(y, 1) if (y.want_pl and (next_cout > 0 or not PLANES_LAZY or g3 or out_planes)) else None
-        if cat_room > 0:
-            # first half of a padded concat: [cout | zeros to the next multiple of 32 | cat_room channels], one plane buffer
-            ob = _rup(cout, 32)
-            ccs = _rup(ob + cat_room, 32)
-            cbuf = torch.empty(y.P * ccs, dtype=torch.bfloat16, device=dev)
-            ypl = y.pl = Planes(cbuf, y.P * ccs, ccs, 0, 1, cw=ob)
-            y.cat_pl = (cbuf, ccs, ob, cat_room)
-        elif cat_into is not None:
-            cbuf, ccs, ob, c2 = cat_into.cat_pl
-            if c2 != cout or cat_into.P != y.P:
-                raise RuntimeError("hyperpri_amd: internal error: concat halves do not match")
-            ypl = y.pl = Planes(cbuf, y.P * ccs, ccs, ob, 1, cw=ccs - ob)
-        if planes_only:
-            y.f32_valid = False
-        cpl = None
-        if ypl is None and y.want_pl and y.parent is not None and PLANES_CONCAT and y.C % 8 == 0:
-            # a skip tensor: its planes go where the decoder's concat will want them -- channels [0, Cskip) of a plane buffer of the
-            # concat's width; up_concat converts only the upsampled half afterwards (half the traffic of converting the concat)
-            par = y.parent
-            cs16 = _rup(par.C, 32)
-            cpl = Planes(torch.empty(par.P * cs16, dtype=torch.bfloat16, device=dev), par.P * cs16, cs16, 0, 1)
-            par.pl_part = (cpl, y.C)
-        # ``next_cout`` > 0: y is the inner tensor of a DoubleConv (the caller says so), read only by the next 3x3 convolution
-        # of ``next_cout`` columns and by that convolution's weight gradient.  When those read planes, nobody reads fp32.
-        if (ypl is not None and next_cout > 0 and PLANES_ONLY_ACT and PLANE_WGRAD and room == 0
-                and _planes_fit(y, max(cout, next_cout))):
-            y.f32_valid = False
-        _lib.call("hpri_bn_apply_relu_x16" if yr16 else "hpri_bn_apply_relu_pl", yr.ptr, yr.cs, yr.coff,
-                  y.ptr if y.f32_valid else ctypes.c_void_p(0), y.cs, y.coff,
-                  _p(scale), _p(shift),
-                  x.P, ppg, cout, y.cw, int(relu),
-                  *(_pl_args(ypl) if cpl is None else (_p(cpl.buf), cpl.plane, cpl.cs, 0, y.C, 1)), _stream())
+        _bn_forward(c, room, next_cout, cat_room, cat_into, planes_only, out_planes)
+    y = c.y
     if not tape.record:
         return y
     if bn is not None and next_cout > 0 and groups == 1 and room == 0:
-        y.bn_src = (yr, st, relu)          # one consumer (the caller says so): its data-gradient kernel may do this stage's reduction
-
-    def bwd(tp: Tape) -> None:
-        g = tp.grads.pop(id(y), None)
-        if g is None:
-            return
-        if bn is not None:
-            # plane mode: when the weight gradient and the data gradient both read the bf16 planes, nobody reads the fp32 form
-            # (1x1 layers: the plane GEMM and the plane weight gradient, gemm_bf16v3.hip / wgrad_bf16v3.hip) -- and it gets no storage
-            want_dpl = (v2 or g3) and (need_dx or (PLANE_WGRAD and weight.requires_grad)) and PLANE_PRODUCERS
-            f32_dead = bool(want_dpl and split == 0 and PLANE_WGRAD and PLANES_ONLY_GRAD and (need_dx or weight.requires_grad)
-                            and ((ks == 3 and PLANE_CONV) or (g3 and _rup(cout, 32) <= 16384)))
-            dyr = (Act(torch.empty(8, dtype=torch.float32, device=dev), x.N, x.H, x.W, cout, _rup(cout, 8), 0) if f32_dead
-                   else Act.new(x.N, x.H, x.W, cout, dev))
-            G = groups if use_batch else 1
-            nblk = ctypes.c_int(); cpart = ctypes.c_int()
-            _lib.call("hpri_col_reduce_plan", x.P // G, G, cout, ctypes.byref(nblk), ctypes.byref(cpart))
-            ws = _ws(2 * (G * nblk.value * 2 * cpart.value + G * 2 * cout), dev)
-            dgam, acc_g = tp.param_slot(bn.weight)
-            dbet, _ = tp.param_slot(bn.bias)
-            db, acc_b = (tp.param_slot(bias) if bias is not None else (None, 0))
-            mean, invstd, varu, scale, shift = (st[i * G * cout:(i + 1) * G * cout] for i in range(5))
-            # read by the data gradient and by the weight gradient
-            dpl = new_planes(dyr, 1) if want_dpl else None
-            dyr.f32_valid = not f32_dead
-            bp = tp.bnpart.pop(id(y), None)
-            _lib.call(*(("hpri_bn_relu_bwd_fused_x16" if yr16 else "hpri_bn_relu_bwd_fused", _p(bp[0]), bp[1], bp[2]) if bp is not None else
-                        (("hpri_bn_relu_bwd_x16_dy16" if g.b16 else "hpri_bn_relu_bwd_x16") if yr16 else "hpri_bn_relu_bwd_pl",)),
-                      g.ptr, g.cs, g.coff, yr.ptr, yr.cs, yr.coff,
-                      ctypes.c_void_p(0) if f32_dead else dyr.ptr, dyr.cs, dyr.coff,
-                      _p(mean), _p(invstd), _p(scale), _p(shift), _p(dgam), _p(dbet), acc_g, _p(db), acc_b,
-                      _p(ws), ws.numel(), x.P, x.P // G, cout, dyr.cw, int(relu), int(use_batch), *_pl_args(dpl), _stream())
-        else:
-            dyr = g
-            if bias is not None:
-                db, acc_b = tp.param_slot(bias)
-                nblk = ctypes.c_int(); cpart = ctypes.c_int()
-                _lib.call("hpri_col_reduce_plan", x.P, 1, cout, ctypes.byref(nblk), ctypes.byref(cpart))
-                ws = _ws(nblk.value * 2 * cpart.value + 2 * cout, dev)
-                _lib.call("hpri_col_sum", dyr.ptr, dyr.cs, dyr.coff, _p(db), acc_b, _p(ws), ws.numel(), x.P, cout, _stream())
-        if not weight.requires_grad:          # frozen (feature_extraction, models.py:17-21): no weight gradient at all
-            pass
-        elif SIDE_STREAM and need_dx and _EVENT_LOG is None and (_GRAD_SINK is None or SIDE_STREAM_WITH_SINK):
-            dw, acc_w = tp.param_slot(weight)
-            main, side = torch.cuda.current_stream(dev), _side(dev)
-            side.wait_stream(main)                      # dyr (and everything before it) is ready
-            with torch.cuda.stream(side):
-                _wgrad(x, dyr, dw, acc_w, cin, cout, ks, bf16=lowp, split=split, gap=k_gap)
-            # what the second stream reads stays alive until the main stream has joined it at the end of backward (then it is
-            # reusable at once; record_stream() instead left the blocks pending at the allocator while the host ran ahead into
-            # the next step: four device allocations per bf16 step, for ever)
-            tp.side_keep.extend((x, dyr, dw))
-            tp.used_side = True
-        else:
-            dw, acc_w = tp.param_slot(weight)
-            _wgrad(x, dyr, dw, acc_w, cin, cout, ks, bf16=lowp, split=split, gap=k_gap)
-        if need_dx:
-            g16 = False
-            if (v2 and BF16_V3 and GRAD_BF16_INNER and x.bn_src is not None and x.bn_src[0].b16 and tp.grads.get(id(x)) is None
-                    and x.colsum_req is None and not FUSE_BN_REDUCE_BF16):
-                ksp = ctypes.c_int(); tl = ctypes.c_int(); wsf_ = ctypes.c_size_t()
-                _lib.call("hpri_conv_bf16v3_plan", x.N, x.H, x.W, _rup(cout, 32), _rup(cin, 64), ctypes.byref(ksp), ctypes.byref(tl),
-                          ctypes.byref(wsf_))
-                g16 = ksp.value == 1
-            if g16:
-                # x is the inner tensor of a DoubleConv: this launch is the only producer of dL/dx and the BatchNorm backward of
-                # the stage that made x its only reader -> bf16 storage (the reader rounds its own result to bf16 anyway)
-                gx = Act(torch.empty(x.P * _rup(cin, 8), dtype=torch.bfloat16, device=dev), x.N, x.H, x.W, cin, _rup(cin, 8), 0)
-                gx.b16, gx.f32_valid = True, False
-                tp.grads[id(x)] = gx
-                acc = False
-            else:
-                gx, acc = tp.grad_slot(x)
-            # the column sums of (a channel range of) this gradient are wanted -- the bias gradient of the ConvTranspose2d that
-            # produced half of a concat: the data-gradient kernel records them per tile in its epilogue (the BatchNorm statistics
-            # machinery) instead of a dedicated pass over the tensor afterwards
-            gstats, gtiles = None, 0
-            if COLSUM_FROM_STATS and x.colsum_req is not None and not acc and (wino_d or v2):
-                tl = ctypes.c_int(); ksp = ctypes.c_int(); wsf_ = ctypes.c_size_t()
-                if wino_d:
-                    _lib.call(f"hpri_conv_{_wino_sfx()}_plan", x.N, x.H, x.W, ctypes.byref(tl))
-                else:
-                    _lib.call(_plane_conv() + "_plan", x.N, x.H, x.W, _rup(cout, 32), _rup(cin, 64), ctypes.byref(ksp), ctypes.byref(tl),
-                              ctypes.byref(wsf_))
-                gtiles = tl.value
-                gstats = torch.empty(gtiles * _rup(cin, 64) * 4, dtype=torch.float32, device=dev)
-            src = x.bn_src
-            v3_red = False
-            if v2 and BF16_V3 and FUSE_BN_REDUCE_BF16 and src is not None and src[0].b16 and not acc and gstats is None:
-                ksp = ctypes.c_int(); tl = ctypes.c_int(); wsf_ = ctypes.c_size_t()
-                _lib.call("hpri_conv_bf16v3_plan", x.N, x.H, x.W, _rup(cout, 32), _rup(cin, 64), ctypes.byref(ksp), ctypes.byref(tl),
-                          ctypes.byref(wsf_))
-                v3_red = ksp.value == 1
-            if v3_red:
-                # bf16 plane mode, same idea as the fp32 branch below: this launch writes the only contribution to dL/dx and
-                # x = ReLU(BN(src[0])), so its epilogue leaves the per-tile partial sums of that BatchNorm's backward
-                wpd, cin_cols_pad = _pack_bf16(weight, 1, cout, cin, T, cin, split=0)
-                xr, xst, xrelu = src
-                part = torch.empty(tl.value * 2 * cin_cols_pad, dtype=torch.float32, device=dev)
-                xm, xi, _xv, xsc, xsh = (xst[i * cin:(i + 1) * cin] for i in range(5))
-                pl = planes_of(dyr, 1)
-                tag = "conv_planes_bf16<3,v3 256x64>" + (f" N{x.N} {x.H}x{x.W} K{_rup(cout, 32)} N{cin}" if SHAPE_TAGS else "")
-                with _timed(tag, 2.0 * x.N * x.H * x.W * cout * cin * 9):
-                    _lib.call("hpri_conv_bf16v3_bnred", _p(pl.buf), pl.cs, pl.coff, _p(wpd), gx.ptr, gx.cs, gx.coff, x.N, x.H, x.W,
-                              _rup(cout, 32), cin, cin_cols_pad, gx.cw, xr.ptr, xr.cs, xr.coff, _p(xm), _p(xi), _p(xsc), _p(xsh),
-                              int(xrelu), _p(part), cin_cols_pad, _stream())
-                tp.bnpart[id(x)] = (part, tl.value, cin_cols_pad)
-            elif (wino_d and WINO4 and FUSE_BN_REDUCE and src is not None and not src[0].b16 and not acc and gstats is None
-                    and src[0].cs - src[0].coff >= _rup(cin, 64)):
-                # this launch writes the ONLY contribution to dL/dx, and x = ReLU(BN(src[0])): its epilogue also leaves the
-                # per-tile partial sums of that BatchNorm's backward (the stage that produced x then skips its reduction sweeps)
-                upd, cin_cols_pad = _pack_wino(weight, 1, cout, cin, cin)
-                xr, xst, xrelu = src
-                tl = ctypes.c_int()
-                _lib.call("hpri_conv_wino4_plan", x.N, x.H, x.W, ctypes.byref(tl))
-                part = torch.empty(tl.value * 2 * cin_cols_pad, dtype=torch.float32, device=dev)
-                xm, xi, _xv, xsc, xsh = (xst[i * cin:(i + 1) * cin] for i in range(5))
-                wtiles = x.N * ((x.H + 1) // 2) * ((x.W + 1) // 2)
-                tag = "conv_winograd_f32<3,F(2x2)>" + (f" N{x.N} {x.H}x{x.W} K{dyr.cw} N{cin}" if SHAPE_TAGS else "")
-                with _timed(tag, 2.0 * x.N * x.H * x.W * cout * cin * 9, executed=2.0 * wtiles * 16 * cout * cin):
-                    _lib.call("hpri_conv_wino4_bnred", dyr.ptr, dyr.cs, dyr.coff, _p(upd), gx.ptr, gx.cs, gx.coff, x.N, x.H, x.W, dyr.cw,
-                              cin, cin_cols_pad, gx.cw, xr.ptr, xr.cs, xr.coff, _p(xm), _p(xi), _p(xsc), _p(xsh), int(xrelu),
-                              _p(part), cin_cols_pad, _stream())
-                tp.bnpart[id(x)] = (part, tl.value, cin_cols_pad)
-            elif wino_d:
-                upd, cin_cols_pad = _pack_wino(weight, 1, cout, cin, cin)
-                _conv_launch_wino(dyr, upd, None, gx, gstats, cout, cin, cin_cols_pad, gx.cw, accumulate=int(acc))
-            elif v2 and g16:
-                wpd, cin_cols_pad = _pack_bf16(weight, 1, cout, cin, T, cin, split=0)
-                _conv_launch_v2(dyr, wpd, None, gx, None, cout, cin, cin_cols_pad, gx.cw, accumulate=4)
-            elif v2:
-                wpd, cin_cols_pad = _pack_bf16(weight, 1, cout, cin, T, cin, split=0)
-                us = x.up_slice
-                y2 = None
-                if us is not None and BF16_V3 and CONVT_PLANES and not acc and us[0] % 64 == 0 and us[1] % 64 == 0:
-                    ksp = ctypes.c_int(); tl = ctypes.c_int(); wsf_ = ctypes.c_size_t()
-                    _lib.call("hpri_conv_bf16v3_plan", x.N, x.H, x.W, _rup(cout, 32), cin_cols_pad, ctypes.byref(ksp), ctypes.byref(tl),
-                              ctypes.byref(wsf_))
-                    if ksp.value == 1:
-                        y2 = torch.empty(x.P * us[1], dtype=torch.bfloat16, device=dev)
-                if y2 is not None:
-                    # the gradient of the upsampled half of this concat also leaves as bf16 rows (its readers, the transposed
-                    # convolution's data and weight gradient, stage planes); with the bias gradient coming from the statistics
-                    # records nobody reads that half in fp32, so it is not written
-                    only = gstats is not None
-                    pl = planes_of(dyr, 1)
-                    with _timed("conv_planes_bf16<3,v3 256x64>" + (f" N{x.N} {x.H}x{x.W} K{_rup(cout, 32)} N{cin}" if SHAPE_TAGS else ""),
-                                2.0 * x.N * x.H * x.W * cout * cin * 9):
-                        _lib.call("hpri_conv_bf16v3_y2", _p(pl.buf), pl.cs, pl.coff, _p(wpd), ctypes.c_void_p(0), gx.ptr, gx.cs, gx.coff,
-                                  _p(gstats), x.N, x.H, x.W, _rup(cout, 32), cin, cin_cols_pad, gx.cw, _p(y2), us[1], 0, us[0], us[1],
-                                  int(only), _stream())
-                    tp.gupl[id(x)] = (Planes(y2, x.P * us[1], us[1], 0, 1), only)
-                else:
-                    _conv_launch_v2(dyr, wpd, None, gx, gstats, cout, cin, cin_cols_pad, gx.cw, accumulate=int(acc))
-            elif g3:
-                wpd, cin_cols_pad = _pack_bf16(weight, 1, cout, x.C if k_gap else cin, T, cin, split=0, gap=k_gap)
-                _gemm_launch(dyr, wpd, None, gx, None, cout, x.C, cin_cols_pad, gx.cw, accumulate=int(acc))
-            elif lowp:
-                wpd, cin_cols_pad = _pack_bf16(weight, 1, cout, cin, T, cin, split=split)
-                _conv_launch_bf16(dyr, wpd, None, gx, None, x.N, x.H, x.W, dyr.cw, cin, cin_cols_pad, gx.cw, ks,
-                                  accumulate=int(acc), cin_true=cout, split=split)
-            else:
-                wpd, cin_cols_pad = _pack(weight, 1, cout, cin, T, 0, cin)
-                _conv_launch(dyr, wpd, None, gx, None, x.N, x.H, x.W, dyr.cw, cin, cin_cols_pad, gx.cw, ks, accumulate=int(acc),
-                             cin_true=cout)
-            if gstats is not None:
-                tp.colsum[id(x)] = (gstats, gtiles, cin_cols_pad)
-
+        y.bn_src = (c.yr, c.st, relu)          # one consumer (the caller says so): its data-gradient kernel may do this stage's reduction
     tape.note_params(weight, bias, *((bn.weight, bn.bias) if bn is not None else ()))
-    tape.nodes.append(bwd)
+    tape.nodes.append(lambda tp: _conv_backward(tp, c))
     return y
+
+
+def _conv_pick_kernels(c, cat_room: int, cat_into: Optional[Act], planes_only: bool) -> None:
+    """Which kernel family serves the stage: ``wino`` / ``wino_d`` (fp32 Winograd forward / data gradient), ``v2`` (bf16 planes,
+    3x3: conv_bf16v3.hip), ``g3`` (bf16 planes, 1x1: gemm_bf16v3.hip); none of them: the direct kernels (fp32, or the round-1
+    bf16 / bf16x3 / bf16x6 forms that convert fp32 while staging).  ``yr16``: the pre-BN tensor is stored as bf16."""
+    x, bn = c.x, c.bn
+    # operands by LDS-DMA from bf16 planes; the DMA offsets are 32-bit per image
+    c.v2 = PLANE_CONV and c.prec == "bf16" and c.ks == 3 and _planes_fit(x, max(c.cin, c.cout))
+    # 1x1 layers of the bf16 mode on planes too (gemm_bf16v3.hip): forward and data gradient
+    c.g3 = PLANE_GEMM and c.prec == "bf16" and c.ks == 1 and (x.f32_valid or x.pl is not None) and _rup(x.C, 32) <= 8192
+    if (cat_room or cat_into is not None or c.k_gap or planes_only) and not (c.g3 and bn is not None and PLANE_WGRAD and PLANE_PRODUCERS):
+        raise RuntimeError("hyperpri_amd: internal error: the plane form of a skip concat needs the plane GEMM path (see plane_gemm_mode)")
+    if not x.f32_valid and not ((c.v2 or c.g3) and x.pl is not None):
+        raise RuntimeError("hyperpri_amd: internal error: a planes-only activation reached a kernel that reads fp32")
+    c.wino = c.prec == "fp32" and c.ks == 3 and c.groups == 1 and _wino_ok(x, c.cout)
+    c.wino_d = c.prec == "fp32" and c.ks == 3 and c.groups == 1 and _wino_ok(x, c.cin)     # the data gradient has Cin columns
+    c.yr16 = False
+    if c.v2 and YR_BF16 and bn is not None and c.groups == 1:
+        c.yr16 = _v3_plan(x, c.cin, c.cout)[0] == 1            # (split-K problems finish in fp32: hpri_splitk_finish)
+    if c.g3 and YR_BF16 and bn is not None:
+        c.yr16 = True
+    if c.use_batch and (x.N * x.H * x.W) // max(c.groups, 1) <= 1:
+        # torch.nn.functional.batch_norm's own check (_verify_batch_size): same error, same message
+        raise ValueError("Expected more than 1 value per channel when training, got input size "
+                         f"torch.Size([{x.N // max(c.groups, 1)}, {c.cout}, {x.H}, {x.W}])")
+
+
+def _v3_plan(x: Act, k: int, ncols: int) -> Tuple[int, int]:
+    """(ksplit, statistics tiles) of the bf16 plane convolution for a K = ``k``, ``ncols``-column problem over x's pixels."""
+    ksp = ctypes.c_int(); tl = ctypes.c_int(); wsf = ctypes.c_size_t()
+    _lib.call("hpri_conv_bf16v3_plan", x.N, x.H, x.W, _rup(k, 32), _rup(ncols, 64), ctypes.byref(ksp), ctypes.byref(tl), ctypes.byref(wsf))
+    return ksp.value, tl.value
+
+
+def _conv_forward(c) -> None:
+    """Pack (cached), allocate the pre-BN tensor and the statistics records, launch.  Leaves c.yr, c.stats, c.tiles, c.cout_pad."""
+    x, weight, bias, dev = c.x, c.weight, c.bias, c.dev
+    if c.wino:
+        wp, cout_pad = _pack_wino(weight, 0, c.cin, c.cout, c.cin)
+    elif c.lowp:
+        wp, cout_pad = _pack_bf16(weight, 0, x.C if c.k_gap else c.cin, c.cout, c.T, c.cin, split=c.split, gap=c.k_gap)
+    else:
+        wp, cout_pad = _pack(weight, 0, c.cin, c.cout, c.T, 0, c.cin)
+    c.cout_pad = cout_pad
+    if c.yr16:
+        yr = Act(torch.empty(x.P * _rup(c.cout, 8), dtype=torch.bfloat16, device=dev), x.N, x.H, x.W, c.cout, _rup(c.cout, 8), 0)
+        yr.b16, yr.f32_valid = True, False
+    else:
+        yr = Act.new(x.N, x.H, x.W, c.cout, dev)
+    stats, tiles = None, 0
+    if c.use_batch:
+        ksp = ctypes.c_int(); tl = ctypes.c_int(); wsf = ctypes.c_size_t()
+        if c.wino:
+            _lib.call("hpri_conv_wino4_plan", x.N, x.H, x.W, ctypes.byref(tl))
+        elif c.v2:
+            _lib.call("hpri_conv_bf16v3_plan", x.N, x.H, x.W, _rup(c.cin, 32), cout_pad, ctypes.byref(ksp), ctypes.byref(tl), ctypes.byref(wsf))
+        elif c.g3:
+            _lib.call("hpri_gemm_bf16v3_plan", x.N, x.H * x.W, ctypes.byref(tl))
+        elif c.lowp:
+            _lib.call("hpri_conv_fwd_bf16_plan", x.N, x.H, x.W, c.cin_pad, cout_pad, c.ks, A_DIRECT, E_DIRECT, c.split,
+                      ctypes.byref(ksp), ctypes.byref(tl), ctypes.byref(wsf))
+        else:
+            _lib.call("hpri_conv_fwd_plan", x.N, x.H, x.W, c.cin_pad, cout_pad, c.ks, A_DIRECT, E_DIRECT, ctypes.byref(ksp),
+                      ctypes.byref(tl), ctypes.byref(wsf))
+        tiles = tl.value
+        stats = torch.empty(tiles * cout_pad * 4, dtype=torch.float32, device=dev)
+    if c.wino:
+        _conv_launch_wino(x, wp, bias, yr, stats, c.cin, c.cout, cout_pad, yr.cw)
+    elif c.v2:
+        _conv_launch_v2(x, wp, bias, yr, stats, c.cin, c.cout, cout_pad, yr.cw, accumulate=4 if c.yr16 else 0)
+    elif c.g3:
+        _gemm_launch(x, wp, bias, yr, stats, x.C, c.cout, cout_pad, yr.cw)
+    elif c.lowp:
+        _conv_launch_bf16(x, wp, bias, yr, stats, x.N, x.H, x.W, c.cin_pad, c.cout, cout_pad, yr.cw, c.ks, cin_true=c.cin, split=c.split)
+    else:
+        _conv_launch(x, wp, bias, yr, stats, x.N, x.H, x.W, c.cin_pad, c.cout, cout_pad, yr.cw, c.ks, cin_true=c.cin)
+    c.yr, c.stats, c.tiles = yr, stats, tiles
+
+
+def _bn_forward(c, room: int, next_cout: int, cat_room: int, cat_into: Optional[Act], planes_only: bool, out_planes: bool) -> None:
+    """BatchNorm finalize (batch statistics from the conv epilogue's records, or the running ones) + normalise + ReLU.  Leaves
+    c.y (the stage's output, with its bf16 planes where a plane reader follows) and c.st (mean, invstd, var, scale, shift)."""
+    global _BN_EPOCH
+    x, bn, yr, dev, cout = c.x, c.bn, c.yr, c.dev, c.cout
+    G = c.groups if c.use_batch else 1
+    st = torch.empty(5 * G * cout, dtype=torch.float32, device=dev)   # mean, invstd, var_unbiased, scale, shift
+    mean, invstd, varu, scale, shift = (st[i * G * cout:(i + 1) * G * cout] for i in range(5))
+    if c.use_batch:
+        _BN_EPOCH += 1
+        _lib.call("hpri_bn_finalize", _p(c.stats), c.tiles // G, G, c.cout_pad, cout, _p(bn.weight), _p(bn.bias),
+                  bn.eps, bn.momentum, _p(mean), _p(invstd), _p(varu), _p(scale), _p(shift),
+                  _p(bn.running_mean), _p(bn.running_var), _p(bn.num_batches_tracked), _stream())
+    else:
+        _lib.call("hpri_bn_eval_prepare", _p(bn.running_mean), _p(bn.running_var), _p(bn.weight), _p(bn.bias),
+                  bn.eps, cout, _p(mean), _p(invstd), _p(scale), _p(shift), _stream())
+    y = Act.new_with_room(x.N, x.H, x.W, cout, room, dev)    # room > 0: a skip tensor, written where its concat needs it
+    ppg = (x.P // G)
+    # bf16 plane mode: the normalise pass also writes y as bf16 planes -- what the next 3x3 convolution (and the
+    # weight gradient) stage by DMA -- so no conversion pass has to read y again
+    # -- for the inner tensor of a DoubleConv (``next_cout`` > 0).  The OUTPUT of a DoubleConv is read by max-pooling, the
+    # transposed convolution, the concat and the 1x1 output layer, all fp32 readers: no planes for it (573 MB of writes per
+    # C2 step that nobody read); ``want_pl`` still tells the pooling pass to write ITS result as planes.
+    y.want_pl = 1 if ((c.v2 or c.g3) and PLANE_PRODUCERS) else 0
+    # (a 1x1 layer's output is read by the next 1x1 layer or a concat in front of one: always planes)
+    # (``out_planes``: the caller knows a plane reader for this output -- the next decoder stage's transposed convolution)
+    ypl = new_planes(y, 1) if (y.want_pl and (next_cout > 0 or not PLANES_LAZY or c.g3 or out_planes)) else None
+    if cat_room > 0:
+        # first half of a padded concat: [cout | zeros to the next multiple of 32 | cat_room channels], one plane buffer
+        ob = _rup(cout, 32)
+        ccs = _rup(ob + cat_room, 32)
+        cbuf = torch.empty(y.P * ccs, dtype=torch.bfloat16, device=dev)
+        ypl = y.pl = Planes(cbuf, y.P * ccs, ccs, 0, 1, cw=ob)
+        y.cat_pl = (cbuf, ccs, ob, cat_room)
+    elif cat_into is not None:
+        cbuf, ccs, ob, c2 = cat_into.cat_pl
+        if c2 != cout or cat_into.P != y.P:
+            raise RuntimeError("hyperpri_amd: internal error: concat halves do not match")
+        ypl = y.pl = Planes(cbuf, y.P * ccs, ccs, ob, 1, cw=ccs - ob)
+    if planes_only:
+        y.f32_valid = False
+    cpl = None
+    if ypl is None and y.want_pl and y.parent is not None and PLANES_CONCAT and y.C % 8 == 0:
+        # a skip tensor: its planes go where the decoder's concat will want them -- channels [0, Cskip) of a plane buffer of the
+        # concat's width; up_concat converts only the upsampled half afterwards (half the traffic of converting the concat)
+        par = y.parent
+        cs16 = _rup(par.C, 32)
+        cpl = Planes(torch.empty(par.P * cs16, dtype=torch.bfloat16, device=dev), par.P * cs16, cs16, 0, 1)
+        par.pl_part = (cpl, y.C)
+    # ``next_cout`` > 0: y is the inner tensor of a DoubleConv (the caller says so), read only by the next 3x3 convolution
+    # of ``next_cout`` columns and by that convolution's weight gradient.  When those read planes, nobody reads fp32.
+    if (ypl is not None and next_cout > 0 and PLANES_ONLY_ACT and PLANE_WGRAD and room == 0
+            and _planes_fit(y, max(cout, next_cout))):
+        y.f32_valid = False
+    _lib.call("hpri_bn_apply_relu_x16" if c.yr16 else "hpri_bn_apply_relu_pl", yr.ptr, yr.cs, yr.coff,
+              y.ptr if y.f32_valid else ctypes.c_void_p(0), y.cs, y.coff,
+              _p(scale), _p(shift),
+              x.P, ppg, cout, y.cw, int(c.relu),
+              *(_pl_args(ypl) if cpl is None else (_p(cpl.buf), cpl.plane, cpl.cs, 0, y.C, 1)), _stream())
+    c.y, c.st = y, st
+
+
+def _conv_backward(tp: Tape, c) -> None:
+    g = tp.grads.pop(id(c.y), None)
+    if g is None:
+        return
+    dyr = _conv_bwd_bn(tp, c, g)
+    _conv_bwd_weight(tp, c, dyr)
+    if c.need_dx:
+        _conv_bwd_data(tp, c, dyr)
+
+
+def _conv_bwd_bn(tp: Tape, c, g: Act) -> Act:
+    """dL/d(pre-BN tensor) from dL/dy: BatchNorm (+ ReLU) backward with its parameter gradients, or -- no BatchNorm -- the bias
+    gradient as a column sum.  In the plane mode the result is written as bf16 planes (and, where every reader reads planes, as
+    planes only)."""
+    x, bn, bias, dev, cout = c.x, c.bn, c.bias, c.dev, c.cout
+    if bn is None:
+        if bias is not None:
+            db, acc_b = tp.param_slot(bias)
+            nblk = ctypes.c_int(); cpart = ctypes.c_int()
+            _lib.call("hpri_col_reduce_plan", x.P, 1, cout, ctypes.byref(nblk), ctypes.byref(cpart))
+            ws = _ws(nblk.value * 2 * cpart.value + 2 * cout, dev)
+            _lib.call("hpri_col_sum", g.ptr, g.cs, g.coff, _p(db), acc_b, _p(ws), ws.numel(), x.P, cout, _stream())
+        return g
+    # plane mode: when the weight gradient and the data gradient both read the bf16 planes, nobody reads the fp32 form
+    # (1x1 layers: the plane GEMM and the plane weight gradient, gemm_bf16v3.hip / wgrad_bf16v3.hip) -- and it gets no storage
+    want_dpl = (c.v2 or c.g3) and (c.need_dx or (PLANE_WGRAD and c.weight.requires_grad)) and PLANE_PRODUCERS
+    f32_dead = bool(want_dpl and c.split == 0 and PLANE_WGRAD and PLANES_ONLY_GRAD and (c.need_dx or c.weight.requires_grad)
+                    and ((c.ks == 3 and PLANE_CONV) or (c.g3 and _rup(cout, 32) <= 16384)))
+    dyr = (Act(torch.empty(8, dtype=torch.float32, device=dev), x.N, x.H, x.W, cout, _rup(cout, 8), 0) if f32_dead
+           else Act.new(x.N, x.H, x.W, cout, dev))
+    G = c.groups if c.use_batch else 1
+    nblk = ctypes.c_int(); cpart = ctypes.c_int()
+    _lib.call("hpri_col_reduce_plan", x.P // G, G, cout, ctypes.byref(nblk), ctypes.byref(cpart))
+    ws = _ws(2 * (G * nblk.value * 2 * cpart.value + G * 2 * cout), dev)
+    dgam, acc_g = tp.param_slot(bn.weight)
+    dbet, _ = tp.param_slot(bn.bias)
+    db, acc_b = (tp.param_slot(bias) if bias is not None else (None, 0))
+    st, yr = c.st, c.yr
+    mean, invstd, varu, scale, shift = (st[i * G * cout:(i + 1) * G * cout] for i in range(5))
+    # read by the data gradient and by the weight gradient
+    dpl = new_planes(dyr, 1) if want_dpl else None
+    dyr.f32_valid = not f32_dead
+    bp = tp.bnpart.pop(id(c.y), None)
+    _lib.call(*(("hpri_bn_relu_bwd_fused", _p(bp[0]), bp[1], bp[2]) if bp is not None else
+                (("hpri_bn_relu_bwd_x16_dy16" if g.b16 else "hpri_bn_relu_bwd_x16") if c.yr16 else "hpri_bn_relu_bwd_pl",)),
+              g.ptr, g.cs, g.coff, yr.ptr, yr.cs, yr.coff,
+              ctypes.c_void_p(0) if f32_dead else dyr.ptr, dyr.cs, dyr.coff,
+              _p(mean), _p(invstd), _p(scale), _p(shift), _p(dgam), _p(dbet), acc_g, _p(db), acc_b,
+              _p(ws), ws.numel(), x.P, x.P // G, cout, dyr.cw, int(c.relu), int(c.use_batch), *_pl_args(dpl), _stream())
+    return dyr
+
+
+def _conv_bwd_weight(tp: Tape, c, dyr: Act) -> None:
+    """dW; on the second stream when a data gradient runs beside it."""
+    if not c.weight.requires_grad:          # frozen (feature_extraction, models.py:17-21): no weight gradient at all
+        return
+    dw, acc_w = tp.param_slot(c.weight)
+    if SIDE_STREAM and c.need_dx and _EVENT_LOG is None and (_GRAD_SINK is None or SIDE_STREAM_WITH_SINK):
+        main, side = torch.cuda.current_stream(c.dev), _side(c.dev)
+        side.wait_stream(main)                      # dyr (and everything before it) is ready
+        with torch.cuda.stream(side):
+            _wgrad(c.x, dyr, dw, acc_w, c.cin, c.cout, c.ks, bf16=c.lowp, split=c.split, gap=c.k_gap)
+        # what the second stream reads stays alive until the main stream has joined it at the end of backward (then it is
+        # reusable at once; record_stream() instead left the blocks pending at the allocator while the host ran ahead into
+        # the next step: four device allocations per bf16 step, for ever)
+        tp.side_keep.extend((c.x, dyr, dw))
+        tp.used_side = True
+    else:
+        _wgrad(c.x, dyr, dw, acc_w, c.cin, c.cout, c.ks, bf16=c.lowp, split=c.split, gap=c.k_gap)
+
+
+def _conv_bwd_data(tp: Tape, c, dyr: Act) -> None:
+    """dL/dx by the stage's kernel family, with the extras a consumer upstream has asked for through ``x``: column sums of the
+    gradient (``colsum_req``: a ConvTranspose2d bias gradient), the upsampled half of a concat as bf16 rows (``up_slice``), the
+    BatchNorm-backward sums of the stage that produced x (``bn_src``), bf16 storage for a single-reader gradient."""
+    x, weight, dev, cin, cout, T = c.x, c.weight, c.dev, c.cin, c.cout, c.T
+    g16 = False
+    if c.v2 and GRAD_BF16_INNER and x.bn_src is not None and x.bn_src[0].b16 and tp.grads.get(id(x)) is None and x.colsum_req is None:
+        g16 = _v3_plan(x, cout, cin)[0] == 1
+    if g16:
+        # x is the inner tensor of a DoubleConv: this launch is the only producer of dL/dx and the BatchNorm backward of
+        # the stage that made x its only reader -> bf16 storage (the reader rounds its own result to bf16 anyway)
+        gx = Act(torch.empty(x.P * _rup(cin, 8), dtype=torch.bfloat16, device=dev), x.N, x.H, x.W, cin, _rup(cin, 8), 0)
+        gx.b16, gx.f32_valid = True, False
+        tp.grads[id(x)] = gx
+        acc = False
+    else:
+        gx, acc = tp.grad_slot(x)
+    # the column sums of (a channel range of) this gradient are wanted -- the bias gradient of the ConvTranspose2d that
+    # produced half of a concat: the data-gradient kernel records them per tile in its epilogue (the BatchNorm statistics
+    # machinery) instead of a dedicated pass over the tensor afterwards
+    gstats, gtiles = None, 0
+    if COLSUM_FROM_STATS and x.colsum_req is not None and not acc and (c.wino_d or c.v2):
+        if c.wino_d:
+            tl = ctypes.c_int()
+            _lib.call("hpri_conv_wino4_plan", x.N, x.H, x.W, ctypes.byref(tl))
+            gtiles = tl.value
+        else:
+            gtiles = _v3_plan(x, cout, cin)[1]
+        gstats = torch.empty(gtiles * _rup(cin, 64) * 4, dtype=torch.float32, device=dev)
+    src = x.bn_src
+    cin_cols_pad = 0
+    if (c.wino_d and FUSE_BN_REDUCE and src is not None and not src[0].b16 and not acc and gstats is None
+            and src[0].cs - src[0].coff >= _rup(cin, 64)):
+        # this launch writes the ONLY contribution to dL/dx, and x = ReLU(BN(src[0])): its epilogue also leaves the
+        # per-tile partial sums of that BatchNorm's backward (the stage that produced x then skips its reduction sweeps)
+        upd, cin_cols_pad = _pack_wino(weight, 1, cout, cin, cin)
+        xr, xst, xrelu = src
+        tl = ctypes.c_int()
+        _lib.call("hpri_conv_wino4_plan", x.N, x.H, x.W, ctypes.byref(tl))
+        part = torch.empty(tl.value * 2 * cin_cols_pad, dtype=torch.float32, device=dev)
+        xm, xi, _xv, xsc, xsh = (xst[i * cin:(i + 1) * cin] for i in range(5))
+        wtiles = x.N * ((x.H + 1) // 2) * ((x.W + 1) // 2)
+        tag = "conv_winograd_f32<3,F(2x2)>" + (f" N{x.N} {x.H}x{x.W} K{dyr.cw} N{cin}" if SHAPE_TAGS else "")
+        with _timed(tag, 2.0 * x.N * x.H * x.W * cout * cin * 9, executed=2.0 * wtiles * 16 * cout * cin):
+            _lib.call("hpri_conv_wino4_bnred", dyr.ptr, dyr.cs, dyr.coff, _p(upd), gx.ptr, gx.cs, gx.coff, x.N, x.H, x.W, dyr.cw,
+                      cin, cin_cols_pad, gx.cw, xr.ptr, xr.cs, xr.coff, _p(xm), _p(xi), _p(xsc), _p(xsh), int(xrelu),
+                      _p(part), cin_cols_pad, _stream())
+        tp.bnpart[id(x)] = (part, tl.value, cin_cols_pad)
+    elif c.wino_d:
+        upd, cin_cols_pad = _pack_wino(weight, 1, cout, cin, cin)
+        _conv_launch_wino(dyr, upd, None, gx, gstats, cout, cin, cin_cols_pad, gx.cw, accumulate=int(acc))
+    elif c.v2:
+        cin_cols_pad = _conv_bwd_data_planes(tp, c, dyr, gx, acc, g16, gstats)
+    elif c.g3:
+        wpd, cin_cols_pad = _pack_bf16(weight, 1, cout, x.C if c.k_gap else cin, T, cin, split=0, gap=c.k_gap)
+        _gemm_launch(dyr, wpd, None, gx, None, cout, x.C, cin_cols_pad, gx.cw, accumulate=int(acc))
+    elif c.lowp:
+        wpd, cin_cols_pad = _pack_bf16(weight, 1, cout, cin, T, cin, split=c.split)
+        _conv_launch_bf16(dyr, wpd, None, gx, None, x.N, x.H, x.W, dyr.cw, cin, cin_cols_pad, gx.cw, c.ks,
+                          accumulate=int(acc), cin_true=cout, split=c.split)
+    else:
+        wpd, cin_cols_pad = _pack(weight, 1, cout, cin, T, 0, cin)
+        _conv_launch(dyr, wpd, None, gx, None, x.N, x.H, x.W, dyr.cw, cin, cin_cols_pad, gx.cw, c.ks, accumulate=int(acc),
+                     cin_true=cout)
+    if gstats is not None:
+        tp.colsum[id(x)] = (gstats, gtiles, cin_cols_pad)
+
+
+def _conv_bwd_data_planes(tp: Tape, c, dyr: Act, gx: Act, acc: bool, g16: bool, gstats: Optional[torch.Tensor]) -> int:
+    """The 3x3 data gradient on bf16 planes (conv_bf16v3.hip, mode-1 pack); returns the padded column count of the pack."""
+    x, cin, cout = c.x, c.cin, c.cout
+    wpd, cin_cols_pad = _pack_bf16(c.weight, 1, cout, cin, c.T, cin, split=0)
+    if g16:
+        _conv_launch_v2(dyr, wpd, None, gx, None, cout, cin, cin_cols_pad, gx.cw, accumulate=4)
+        return cin_cols_pad
+    us = x.up_slice
+    y2 = None
+    if us is not None and CONVT_PLANES and not acc and us[0] % 64 == 0 and us[1] % 64 == 0 and _v3_plan(x, cout, cin_cols_pad)[0] == 1:
+        y2 = torch.empty(x.P * us[1], dtype=torch.bfloat16, device=c.dev)
+    if y2 is None:
+        _conv_launch_v2(dyr, wpd, None, gx, gstats, cout, cin, cin_cols_pad, gx.cw, accumulate=int(acc))
+        return cin_cols_pad
+    # the gradient of the upsampled half of this concat also leaves as bf16 rows (its readers, the transposed
+    # convolution's data and weight gradient, stage planes); with the bias gradient coming from the statistics
+    # records nobody reads that half in fp32, so it is not written
+    only = gstats is not None
+    pl = planes_of(dyr, 1)
+    with _timed("conv_planes_bf16<3,v3 256x64>" + (f" N{x.N} {x.H}x{x.W} K{_rup(cout, 32)} N{cin}" if SHAPE_TAGS else ""),
+                2.0 * x.N * x.H * x.W * cout * cin * 9):
+        _lib.call("hpri_conv_bf16v3_y2", _p(pl.buf), pl.cs, pl.coff, _p(wpd), ctypes.c_void_p(0), gx.ptr, gx.cs, gx.coff,
+                  _p(gstats), x.N, x.H, x.W, _rup(cout, 32), cin, cin_cols_pad, gx.cw, _p(y2), us[1], 0, us[0], us[1],
+                  int(only), _stream())
+    tp.gupl[id(x)] = (Planes(y2, x.P * us[1], us[1], 0, 1), only)
+    return cin_cols_pad
 
 
 # fp32 mode: the BatchNorm-backward reduction of a conv -> BN -> ReLU stage whose output has a single consumer (the inner tensor of a
 # DoubleConv, CubeNET's first layer) is taken in the epilogue of that consumer's Winograd data-gradient launch
 # (hpri_conv_wino4_bnred + hpri_bn_relu_bwd_fused) instead of two sweeps over the gradient and the pre-BN tensor.
 # HPRI_FUSE_BN_REDUCE: 1 (default) / 0.
-FUSE_BN_REDUCE = os.environ.get("HPRI_FUSE_BN_REDUCE", "1") != "0"
-# The same in the bf16 plane mode (hpri_conv_bf16v3_bnred + hpri_bn_relu_bwd_fused_x16).  HPRI_FUSE_BN_REDUCE_BF16: 0 (default) / 1.
-FUSE_BN_REDUCE_BF16 = os.environ.get("HPRI_FUSE_BN_REDUCE_BF16", "0") == "1"
+FUSE_BN_REDUCE = FUSIONS
 # the ConvTranspose2d bias gradient from the epilogue records of the data-gradient kernel that wrote the concat's gradient
-# (hpri_colsum_from_stats) instead of a pass over that tensor (hpri_col_sum).  HPRI_COLSUM_FROM_STATS: 1 (default) / 0.
-COLSUM_FROM_STATS = os.environ.get("HPRI_COLSUM_FROM_STATS", "1") != "0"
+# (hpri_colsum_from_stats) instead of a pass over that tensor (hpri_col_sum).  (HPRI_FUSIONS.)
+COLSUM_FROM_STATS = FUSIONS
 FOLD_EVAL_BN = True   # inference only (no tape): conv + eval-mode BN + ReLU as ONE kernel with BN folded into w and b
 FOLD_LAUNCHES = 0     # folded conv+BN+ReLU stages executed (tests assert that the predict path really takes them)
 
@@ -1155,7 +1160,7 @@ def _conv_folded_eval(x: Act, weight: torch.Tensor, bias: Optional[torch.Tensor]
                   _p(fold[:cout]), _p(fold[cout:]), _stream())
         if wino:   # Winograd layout: the filter transform is linear, so the column scale goes in front of it
             wp = torch.empty(_lib.load().hpri_wino_packed_floats(cin, cout_pad), dtype=torch.float32, device=dev)
-            _lib.call(f"hpri_{_wino_sfx()}_pack", _p(weight), _p(wp), _p(fold[:cout]), 0, cin, cout, cout_pad, cin, _stream())
+            _lib.call("hpri_wino4_pack", _p(weight), _p(wp), _p(fold[:cout]), 0, cin, cout, cout_pad, cin, _stream())
         elif lowp:   # bf16 / bf16x3 / bf16x6 predict path: the same fold, weights scaled in fp32 and then rounded / split
             wp = torch.empty(((cin + 31) // 32) * T * cout_pad * 32 * (split + 1), dtype=torch.bfloat16, device=dev)
             _lib.call("hpri_pack_weight_bf16_scaled", _p(weight), _p(wp), _p(fold[:cout]), cin, cout, cout_pad, T, cin, split,
@@ -1172,7 +1177,7 @@ def _conv_folded_eval(x: Act, weight: torch.Tensor, bias: Optional[torch.Tensor]
             return (t.data_ptr(), -1)
     bn_state = (_BN_EPOCH, ver(bn.running_mean), ver(bn.running_var), ver(bn.weight), ver(bn.bias),
                 None if bias is None else ver(bias))
-    wp, fold = _cached_pack(weight, ("fold", prec, ks, _wino_sfx() if wino else False), build, extra=bn_state,
+    wp, fold = _cached_pack(weight, ("fold", prec, ks, "wino4" if wino else False), build, extra=bn_state,
                             also=(bn.running_mean, bn.running_var, bn.weight, bn.bias, bias))
     fbias = fold[cout:]
     y = Act.new_with_room(x.N, x.H, x.W, cout, room, dev)
@@ -1305,6 +1310,98 @@ def maxpool2(tape: Tape, x: Act) -> Act:
 # --------------------------------------------------------------------------------------------------
 # upsample (ConvTranspose2d k2 s2 | bilinear x2) -> zero-pad -> concat with / multiply by the skip
 # --------------------------------------------------------------------------------------------------
+def _upsample_bwd(tp: Tape, c) -> None:
+    """Backward of ``_upsample_into``: F.pad's backward (drop the ring), the ConvTranspose2d bias / weight / data gradients -- on the
+    plane-fed kernels when the gradient of the upsampled half arrived as bf16 rows -- or the bilinear interpolation's adjoint."""
+    dst, weight, bias, need_dx1, x1, precision, dev = c.dst, c.weight, c.bias, c.need_dx1, c.x1, c.precision, c.dev
+    H2, W2, py0, px0, cup, dY, dX = c.H2, c.W2, c.py0, c.px0, c.cup, c.dY, c.dX
+    gu = tp.grads.pop(id(dst), None)
+    if gu is None:
+        return
+    if weight is None:
+        if need_dx1:
+            gx, acc = tp.grad_slot(x1)
+            _lib.call("hpri_upsample2x_bwd", gu.ptr, gu.cs, gu.coff, gx.ptr, gx.cs, gx.coff, x1.N, x1.H, x1.W, H2, W2,
+                      py0, px0, _rup(cup, 4), int(acc), _stream())
+        return
+    cin = weight.shape[0]
+    if dY or dX:   # F.pad's backward drops the ring
+        _lib.call("hpri_fill_pad", gu.ptr, gu.cs, gu.coff, gu.N, H2, W2, cup, py0, py0 + 2 * x1.H, px0, px0 + 2 * x1.W, _stream())
+    cs = tp.colsum.pop(id(dst), None)
+    if bias is not None:
+        db, acc_b = tp.param_slot(bias)
+        if cs is not None and len(cs) == 4:
+            gstats, gtiles, cpad, c0 = cs
+            _lib.call("hpri_colsum_from_stats", _p(gstats), gtiles, cpad, c0, cup, _p(db), acc_b, _stream())
+        else:
+            nblk = ctypes.c_int(); cpart = ctypes.c_int()
+            _lib.call("hpri_col_reduce_plan", gu.P, 1, cup, ctypes.byref(nblk), ctypes.byref(cpart))
+            ws = _ws(nblk.value * 2 * cpart.value + 2 * cup, dev)
+            _lib.call("hpri_col_sum", gu.ptr, gu.cs, gu.coff, _p(db), acc_b, _p(ws), ws.numel(), gu.P, cup, _stream())
+    bprec = precision or DEFAULT_PRECISION
+    gp = tp.gupl.pop(id(dst), None)
+    gpl = gp[0] if gp is not None else None
+    if gpl is None and not gu.f32_valid:
+        raise RuntimeError("hyperpri_amd: internal error: the gradient of an upsampled tensor exists as planes only, but the planes are gone")
+    pw = gpl is not None and cup % 64 == 0 and _rup(cin, 32) <= 16384          # weight gradient on planes (wgrad_bf16v3.hip)
+    pd = gpl is not None and cup % 32 == 0                                   # data gradient on planes (gemm_bf16v3.hip)
+    if gpl is not None and not gu.f32_valid and not ((pw or not weight.requires_grad) and (pd or not need_dx1)):
+        raise RuntimeError("hyperpri_amd: internal error: a planes-only gradient reached a transposed convolution that reads fp32")
+
+    def wgrad_planes():
+        xp_ = planes_of(x1, 1)
+        sp = ctypes.c_int(); pcr = ctypes.c_int(); pnr = ctypes.c_int()
+        xcw = min(xp_.cw, _rup(cin, 32))
+        _lib.call("hpri_wgrad1x1_bf16v3_plan", x1.P, xcw, 4 * cup, ctypes.byref(sp), ctypes.byref(pcr), ctypes.byref(pnr))
+        pws = _ws(sp.value * pcr.value * pnr.value, dev)
+        with _timed("wgrad_planes_bf16<convT>", 2.0 * x1.P * cin * 4 * cup):
+            _lib.call("hpri_wgrad_convt_bf16v3", _p(xp_.buf), xp_.cs, xp_.coff, xcw, _p(gpl.buf), gpl.cs, gpl.coff, _p(pws), pws.numel(),
+                      x1.N, x1.H, x1.W, xcw, cup, H2, W2, py0, px0, _stream())
+        _lib.call("hpri_wgrad_reduce_ex", _p(pws), _p(dw), sp.value, pcr.value, pnr.value, cin, 4 * cup, 1, 1, cup, acc_w, _stream())
+    if weight.requires_grad and pw:
+        dw, acc_w = tp.param_slot(weight)
+        if SIDE_STREAM and need_dx1 and _EVENT_LOG is None and (_GRAD_SINK is None or SIDE_STREAM_WITH_SINK):
+            main, side = torch.cuda.current_stream(dev), _side(dev)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                wgrad_planes()
+            tp.side_keep.extend((x1, gpl, dw))
+            tp.used_side = True
+        else:
+            wgrad_planes()
+    elif weight.requires_grad:
+        dw, acc_w = tp.param_slot(weight)
+        if SIDE_STREAM and need_dx1 and _EVENT_LOG is None and (_GRAD_SINK is None or SIDE_STREAM_WITH_SINK):
+            # the weight gradient and the data gradient of the transposed convolution only share inputs: second stream
+            main, side = torch.cuda.current_stream(dev), _side(dev)
+            side.wait_stream(main)                  # gu (pad ring dropped) and everything before it is ready
+            with torch.cuda.stream(side):
+                _wgrad(x1, gu, dw, acc_w, cin, 4 * cup, 1, bmode=A_S2D, dst_mode=1, H2=H2, W2=W2, py0=py0, px0=px0, cup=cup,
+                       bf16=bprec in LOWP, split=_SPLIT.get(bprec, 0))
+            tp.side_keep.extend((x1, gu, dw))
+            tp.used_side = True
+        else:
+            _wgrad(x1, gu, dw, acc_w, cin, 4 * cup, 1, bmode=A_S2D, dst_mode=1, H2=H2, W2=W2, py0=py0, px0=px0, cup=cup,
+                   bf16=bprec in LOWP, split=_SPLIT.get(bprec, 0))
+    if need_dx1 and pd:
+        gx, acc = tp.grad_slot(x1)
+        wpd, cols_pad = _pack_bf16(weight, 3, 4 * cup, cin, 1, cup, cup, split=0)
+        with _timed("gemm_planes_bf16<convT,s2d>", 2.0 * x1.N * x1.H * x1.W * cin * 4 * cup):
+            _lib.call("hpri_convt_dgrad_bf16v3", _p(gpl.buf), gpl.cs, gpl.coff, _p(wpd), gx.ptr, gx.cs, gx.coff, x1.N, x1.H, x1.W, cup, cin,
+                      cols_pad, gx.cw, H2, W2, py0, px0, int(acc), _stream())
+    elif need_dx1:
+        gx, acc = tp.grad_slot(x1)
+        if bprec in LOWP:
+            wpd, cols_pad = _pack_bf16(weight, 3, 4 * cup, cin, 1, cup, cup, split=_SPLIT.get(bprec, 0))
+            _conv_launch_bf16(gu, wpd, None, gx, None, x1.N, x1.H, x1.W, 4 * cup, cin, cols_pad, gx.cw, 1,
+                              amode=A_S2D, accumulate=int(acc), H2=H2, W2=W2, py0=py0, px0=px0, cup=cup, cin_true=4 * cup,
+                              split=_SPLIT.get(bprec, 0))
+        else:
+            wpd, cols_pad = _pack(weight, 3, 4 * cup, cin, 1, cup, cup)
+            _conv_launch(gu, wpd, None, gx, None, x1.N, x1.H, x1.W, 4 * cup, cin, cols_pad, gx.cw, 1,
+                         amode=A_S2D, accumulate=int(acc), H2=H2, W2=W2, py0=py0, px0=px0, cup=cup, cin_true=4 * cup)
+
+
 def _upsample_into(tape: Tape, x1: Act, dst: Act, weight: Optional[torch.Tensor], bias: Optional[torch.Tensor],
                    need_dx1: bool, precision: Optional[str] = None, dst_planes=None) -> bool:
     """Write up(x1), zero-padded to dst's H x W (left = floor(d/2), model_parts.py:73-80), into the view ``dst``.
@@ -1385,95 +1482,10 @@ def _upsample_into(tape: Tape, x1: Act, dst: Act, weight: Optional[torch.Tensor]
                   py0, px0, cup, _stream())
     if not tape.record:
         return planes_written
-
-    def bwd(tp: Tape) -> None:
-        gu = tp.grads.pop(id(dst), None)
-        if gu is None:
-            return
-        if weight is None:
-            if need_dx1:
-                gx, acc = tp.grad_slot(x1)
-                _lib.call("hpri_upsample2x_bwd", gu.ptr, gu.cs, gu.coff, gx.ptr, gx.cs, gx.coff, x1.N, x1.H, x1.W, H2, W2,
-                          py0, px0, _rup(cup, 4), int(acc), _stream())
-            return
-        cin = weight.shape[0]
-        if dY or dX:   # F.pad's backward drops the ring
-            _lib.call("hpri_fill_pad", gu.ptr, gu.cs, gu.coff, gu.N, H2, W2, cup, py0, py0 + 2 * x1.H, px0, px0 + 2 * x1.W, _stream())
-        cs = tp.colsum.pop(id(dst), None)
-        if bias is not None:
-            db, acc_b = tp.param_slot(bias)
-            if cs is not None and len(cs) == 4:
-                gstats, gtiles, cpad, c0 = cs
-                _lib.call("hpri_colsum_from_stats", _p(gstats), gtiles, cpad, c0, cup, _p(db), acc_b, _stream())
-            else:
-                nblk = ctypes.c_int(); cpart = ctypes.c_int()
-                _lib.call("hpri_col_reduce_plan", gu.P, 1, cup, ctypes.byref(nblk), ctypes.byref(cpart))
-                ws = _ws(nblk.value * 2 * cpart.value + 2 * cup, dev)
-                _lib.call("hpri_col_sum", gu.ptr, gu.cs, gu.coff, _p(db), acc_b, _p(ws), ws.numel(), gu.P, cup, _stream())
-        bprec = precision or DEFAULT_PRECISION
-        gp = tp.gupl.pop(id(dst), None)
-        gpl = gp[0] if gp is not None else None
-        if gpl is None and not gu.f32_valid:
-            raise RuntimeError("hyperpri_amd: internal error: the gradient of an upsampled tensor exists as planes only, but the planes are gone")
-        pw = gpl is not None and cup % 64 == 0 and _rup(cin, 32) <= 16384          # weight gradient on planes (wgrad_bf16v3.hip)
-        pd = gpl is not None and cup % 32 == 0                                   # data gradient on planes (gemm_bf16v3.hip)
-        if gpl is not None and not gu.f32_valid and not ((pw or not weight.requires_grad) and (pd or not need_dx1)):
-            raise RuntimeError("hyperpri_amd: internal error: a planes-only gradient reached a transposed convolution that reads fp32")
-
-        def wgrad_planes():
-            xp_ = planes_of(x1, 1)
-            sp = ctypes.c_int(); pcr = ctypes.c_int(); pnr = ctypes.c_int()
-            xcw = min(xp_.cw, _rup(cin, 32))
-            _lib.call("hpri_wgrad1x1_bf16v3_plan", x1.P, xcw, 4 * cup, ctypes.byref(sp), ctypes.byref(pcr), ctypes.byref(pnr))
-            pws = _ws(sp.value * pcr.value * pnr.value, dev)
-            with _timed("wgrad_planes_bf16<convT>", 2.0 * x1.P * cin * 4 * cup):
-                _lib.call("hpri_wgrad_convt_bf16v3", _p(xp_.buf), xp_.cs, xp_.coff, xcw, _p(gpl.buf), gpl.cs, gpl.coff, _p(pws), pws.numel(),
-                          x1.N, x1.H, x1.W, xcw, cup, H2, W2, py0, px0, _stream())
-            _lib.call("hpri_wgrad_reduce_ex", _p(pws), _p(dw), sp.value, pcr.value, pnr.value, cin, 4 * cup, 1, 1, cup, acc_w, _stream())
-        if weight.requires_grad and pw:
-            dw, acc_w = tp.param_slot(weight)
-            if SIDE_STREAM and need_dx1 and _EVENT_LOG is None and (_GRAD_SINK is None or SIDE_STREAM_WITH_SINK):
-                main, side = torch.cuda.current_stream(dev), _side(dev)
-                side.wait_stream(main)
-                with torch.cuda.stream(side):
-                    wgrad_planes()
-                tp.side_keep.extend((x1, gpl, dw))
-                tp.used_side = True
-            else:
-                wgrad_planes()
-        elif weight.requires_grad:
-            dw, acc_w = tp.param_slot(weight)
-            if SIDE_STREAM and need_dx1 and _EVENT_LOG is None and (_GRAD_SINK is None or SIDE_STREAM_WITH_SINK):
-                # the weight gradient and the data gradient of the transposed convolution only share inputs: second stream
-                main, side = torch.cuda.current_stream(dev), _side(dev)
-                side.wait_stream(main)                  # gu (pad ring dropped) and everything before it is ready
-                with torch.cuda.stream(side):
-                    _wgrad(x1, gu, dw, acc_w, cin, 4 * cup, 1, bmode=A_S2D, dst_mode=1, H2=H2, W2=W2, py0=py0, px0=px0, cup=cup,
-                           bf16=bprec in LOWP, split=_SPLIT.get(bprec, 0))
-                tp.side_keep.extend((x1, gu, dw))
-                tp.used_side = True
-            else:
-                _wgrad(x1, gu, dw, acc_w, cin, 4 * cup, 1, bmode=A_S2D, dst_mode=1, H2=H2, W2=W2, py0=py0, px0=px0, cup=cup,
-                       bf16=bprec in LOWP, split=_SPLIT.get(bprec, 0))
-        if need_dx1 and pd:
-            gx, acc = tp.grad_slot(x1)
-            wpd, cols_pad = _pack_bf16(weight, 3, 4 * cup, cin, 1, cup, cup, split=0)
-            with _timed("gemm_planes_bf16<convT,s2d>", 2.0 * x1.N * x1.H * x1.W * cin * 4 * cup):
-                _lib.call("hpri_convt_dgrad_bf16v3", _p(gpl.buf), gpl.cs, gpl.coff, _p(wpd), gx.ptr, gx.cs, gx.coff, x1.N, x1.H, x1.W, cup, cin,
-                          cols_pad, gx.cw, H2, W2, py0, px0, int(acc), _stream())
-        elif need_dx1:
-            gx, acc = tp.grad_slot(x1)
-            if bprec in LOWP:
-                wpd, cols_pad = _pack_bf16(weight, 3, 4 * cup, cin, 1, cup, cup, split=_SPLIT.get(bprec, 0))
-                _conv_launch_bf16(gu, wpd, None, gx, None, x1.N, x1.H, x1.W, 4 * cup, cin, cols_pad, gx.cw, 1,
-                                  amode=A_S2D, accumulate=int(acc), H2=H2, W2=W2, py0=py0, px0=px0, cup=cup, cin_true=4 * cup,
-                                  split=_SPLIT.get(bprec, 0))
-            else:
-                wpd, cols_pad = _pack(weight, 3, 4 * cup, cin, 1, cup, cup)
-                _conv_launch(gu, wpd, None, gx, None, x1.N, x1.H, x1.W, 4 * cup, cin, cols_pad, gx.cw, 1,
-                             amode=A_S2D, accumulate=int(acc), H2=H2, W2=W2, py0=py0, px0=px0, cup=cup, cin_true=4 * cup)
+    c = types.SimpleNamespace(dst=dst, weight=weight, bias=bias, need_dx1=need_dx1, x1=x1, precision=precision, dev=dev, H2=H2, W2=W2,
+                              py0=py0, px0=px0, cup=cup, dY=dY, dX=dX)
     tape.note_params(weight, bias)
-    tape.nodes.append(bwd)
+    tape.nodes.append(lambda tp: _upsample_bwd(tp, c))
     return planes_written
 
 
@@ -1614,20 +1626,20 @@ def plane_gemm_mode(module, bnorm: bool = True) -> bool:
 
 # bf16 mode, decoder stages: ConvTranspose2d forward, data gradient and weight gradient on the plane-fed kernels (gemm_bf16v3.hip,
 # wgrad_bf16v3.hip); the gradient of the upsampled half of the concat arrives as bf16 rows from the data-gradient launch that
-# produces it (hpri_conv_bf16v3_y2).  HPRI_CONVT_PLANES=0: the round-1 kernels that convert fp32 while staging.
-CONVT_PLANES = os.environ.get("HPRI_CONVT_PLANES", "1") != "0"
+# produces it (hpri_conv_bf16v3_y2).  (HPRI_FUSIONS.)
+CONVT_PLANES = FUSIONS
 # bf16 mode: the gradient of the INNER tensor of a DoubleConv (one producer: the second convolution's data-gradient launch; one
-# reader: the first stage's BatchNorm backward) is stored as bf16: 6 instead of 12 bytes of traffic per element.  HPRI_GRAD_BF16_INNER=0: fp32.
-GRAD_BF16_INNER = os.environ.get("HPRI_GRAD_BF16_INNER", "1") != "0"
+# reader: the first stage's BatchNorm backward) is stored as bf16: 6 instead of 12 bytes of traffic per element.  (HPRI_FUSIONS.)
+GRAD_BF16_INNER = FUSIONS
 
 
 def convt_planes_mode(module) -> bool:
     prec = getattr(module, "hpri_precision", None) or DEFAULT_PRECISION
-    return bool(prec == "bf16" and CONVT_PLANES and PLANE_CONV and PLANE_WGRAD and PLANE_PRODUCERS and BF16_V3 and PLANES_CONVT and PLANES_CONCAT)
+    return bool(prec == "bf16" and CONVT_PLANES and PLANE_CONV and PLANE_WGRAD and PLANE_PRODUCERS and PLANES_CONVT and PLANES_CONCAT)
 
 
-# HPRI_PLANES_CAT1=0: SpectralUNET's skips are concatenated in fp32 by copies (and converted to planes afterwards), as before.
-PLANES_CAT1 = os.environ.get("HPRI_PLANES_CAT1", "1") != "0"
+# (HPRI_FUSIONS off: SpectralUNET's skips are concatenated in fp32 by copies and converted to planes afterwards.)
+PLANES_CAT1 = FUSIONS
 
 
 def concat_planes(tape: Tape, a: Act, b: Act) -> Tuple[Act, Tuple[int, int]]:

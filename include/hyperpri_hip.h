@@ -47,8 +47,8 @@ int hpri_version(void);
  * on them, only block order and (for weight gradients) the number of partial slabs, i.e. the summation order. */
 int hpri_set_option(const char* name, int value);
 /* A non-blocking stream of the lowest priority the current device offers (*priority receives it); the caller owns it. */
-int hpri_stream_create_low_priority(void** stream, int* priority);
-int hpri_stream_destroy(void* stream);
+
+
 int hpri_get_option(const char* name);
 const char* hpri_last_error(void);
 
@@ -91,29 +91,22 @@ int hpri_conv_fwd(const float* x, int x_cs, int x_coff, const float* wp, const f
                   int KS, int amode, int epi, int accumulate, int H2, int W2, int py0, int px0, int Cup, float* ws,
                   size_t ws_floats, hipStream_t stream);
 
-/* ---- Winograd F(2x2,3x3), exact fp32 MFMA (conv_wino.hip) ---------------------------------------------------------
+/* ---- Winograd F(2x2,3x3), exact fp32 MFMA (conv_wino4.hip) --------------------------------------------------------
  * 3x3 / pad 1 / stride 1 convolutions (model_parts.py:22,25; models.py:169,177), forward and data gradient, with 16 instead
- * of 36 multiplies per 2x2 outputs.  hpri_wino_pack transforms the filters (U = G g G^T; mode 0 forward, mode 1 data
- * gradient, optional per-column scale for the eval-mode BN fold) into [K/8][16][8][Ncols_pad]; hpri_conv_wino_plan gives
- * the number of BatchNorm partial records (one per 16x16-pixel tile); `accumulate` bit 0: y += result, bit 1: ReLU. */
+ * of 36 multiplies per 2x2 outputs: 4-wave workgroups of 16 x 8 pixels, two per CU, wave = frequency row.  hpri_wino4_pack
+ * transforms the filters (U = G g G^T; mode 0 forward, mode 1 data gradient, optional per-column scale for the eval-mode BN
+ * fold) into [K/8][16][Ncols_pad][8] (hpri_wino_packed_floats floats); hpri_conv_wino4_plan gives the number of BatchNorm partial
+ * records (one per 16 x 8-pixel tile); `accumulate` bit 0: y += result, bit 1: ReLU.  x: fp32 NHWC view with channels
+ * [Cin, Cin_pad) zero (Cin_pad a multiple of 8).  (The first form of this kernel, conv_wino.hip, lives in the diagnostics build:
+ * hyperpri_hip_diag.h.) */
 size_t hpri_wino_packed_floats(int K, int Ncols_pad);
-int hpri_wino_pack(const float* w, float* up, const float* colscale, int mode, int K, int Ncols, int Ncols_pad, int src_d1,
-                   hipStream_t stream);
-int hpri_conv_wino_plan(int N, int H, int W, int* stat_tiles);
-int hpri_conv_wino(const float* x, int x_cs, int x_coff, const float* up, const float* bias, float* y, int y_cs, int y_coff,
-                   float* stats, int N, int H, int W, int Cin_pad, int Cout, int Cout_pad, int y_cw, int accumulate,
-                   hipStream_t stream);
-/* Second form of the fused Winograd kernel (conv_wino4.hip): 4-wave workgroups of 16 x 8 pixels, two per CU, wave = frequency
- * row, weights packed with k innermost (hpri_wino4_pack: same size as hpri_wino_packed_floats, different layout); same
- * argument contract as hpri_conv_wino; statistics records per 16 x 8-pixel tile (hpri_conv_wino4_plan). */
 int hpri_wino4_pack(const float* w, float* up, const float* colscale, int mode, int K, int Ncols, int Ncols_pad, int src_d1,
                     hipStream_t stream);
 int hpri_conv_wino4_plan(int N, int H, int W, int* stat_tiles);
 int hpri_conv_wino4(const float* x, int x_cs, int x_coff, const float* up, const float* bias, float* y, int y_cs, int y_coff,
                     float* stats, int N, int H, int W, int Cin_pad, int Cout, int Cout_pad, int y_cw, int accumulate,
                     hipStream_t stream);
-/* diagnostic builds (-DHPRI_STAMPS, tools/build_wino4_diag.sh) only; the product library returns HPRI_ERR_UNSUPPORTED */
-int hpri_wino4_set_stamps(unsigned long long* stamps);
+
 /* hpri_conv_wino4 as a DATA GRADIENT (mode-1 pack, no bias, no accumulate) that also leaves the BatchNorm-backward partial sums of the
  * conv -> BN -> ReLU stage whose output gradient y it writes (model_parts.py:22-27's autograd): bn_x = that stage's pre-BN tensor
  * (fp32 NHWC view, same pixels / channels as y, Cout_pad channels wide), its per-channel mean / invstd / scale / shift, bn_relu;
@@ -166,37 +159,31 @@ int hpri_convt_fwd_bf16_pl(const float* x, int x_cs, int x_coff, const void* wp,
                            int y_coff, int N, int H, int W, int Cin_pad, int Cout, int Cout_pad, int H2, int W2, int py0, int px0,
                            int Cup, void* planes, int pl_cs, int pl_coff, hipStream_t stream);
 
-/* bf16 activation PLANES (conv_bf16v2.hip): in the bf16 modes the producer of an activation writes it as bf16 NHWC
+/* bf16 activation PLANES: in the bf16 modes the producer of an activation writes it as bf16 NHWC
  * planes (plane 0 = bf16(x), plane 1 = bf16(x - hi), ...; `plane_stride` elements apart, `cs16` elements per pixel,
  * channels [C, cw16) zero), so the 3x3 convolution (model_parts.py:22,25; models.py:169,177; forward, or data gradient
  * with the mode-1 pack) brings BOTH operands into LDS by LDS-DMA.  hpri_to_planes is the generic producer (fp32 NHWC
  * view -> planes); plan / workspace / statistics contract as hpri_conv_fwd (split-K finish: hpri_splitk_finish). */
 int hpri_to_planes(const float* x, int cs, int coff, void* planes, long long plane_stride, int cs16, int coff16,
                    long long P, int C, int cw16, int npl, hipStream_t stream);
-int hpri_conv_bf16v2_plan(int N, int H, int W, int Cin_pad, int Cout_pad, int* ksplit, int* stat_tiles,
-                          size_t* ws_floats);
-int hpri_conv_bf16v2(const void* xp, long long x_plane, int x_cs, int x_coff, const void* wp, const float* bias, float* y,
-                     int y_cs, int y_coff, float* stats, int N, int H, int W, int Cin_pad, int Cout, int Cout_pad, int y_cw,
-                     int accumulate, int split, float* ws, size_t ws_floats, hipStream_t stream);
+
+
 int hpri_splitk_finish(const float* ws, int ksplit, int Cout_pad, const float* bias, float* y, int y_cs, int y_coff,
                        float* stats, int N, int HW, int Cout, int y_cw, int accumulate, int relu, hipStream_t stream);
 /* Third form of the plane convolution (conv_bf16v3.hip): 4-wave workgroups of 256 pixels x 64 channels, TWO per CU (one's
  * prologue / store + statistics epilogue runs under the other's MFMAs), v_mfma_f32_16x16x32_bf16 with the weights as the A
  * operand (a lane's accumulator registers are consecutive channels of one pixel: 16-byte stores without an LDS transpose).
- * Same argument, workspace and statistics contract as hpri_conv_bf16v2 (records per 256-pixel tile: hpri_conv_bf16v3_plan);
- * the output view must be float4-aligned.  Bit 2 of `accumulate` (value 4): the output view is bf16 (y points at bf16 elements,
+ * x_plane is unused (one plane); `split` must be 0; `accumulate` bit 0: y += result, bit 1: ReLU; plan / workspace / statistics
+ * contract as hpri_conv_fwd (records per 256-pixel tile: hpri_conv_bf16v3_plan); the output view must be float4-aligned.  Bit 2 of `accumulate` (value 4): the output view is bf16 (y points at bf16 elements,
  * y_cs / y_coff in elements; not with bit 0, not for split-K problems) -- the pre-BN tensor at 2 bytes per element, read by
- * hpri_bn_apply_relu_x16 / hpri_bn_relu_bwd_x16.  _dbg: the same with the one-off delay of each CU's second occupant (cycles) given by
- * the caller and, in -DHPRI_STAMPS builds, a stamp buffer ([workgroups][8] u64; ignored otherwise). */
+ * hpri_bn_apply_relu_x16 / hpri_bn_relu_bwd_x16.  (Its predecessor conv_bf16v2.hip, the _dbg entry with a caller-given stagger and stamp
+ * buffer, and the variant with BatchNorm-backward sums in the epilogue live in the diagnostics build: hyperpri_hip_diag.h.) */
 int hpri_conv_bf16v3_plan(int N, int H, int W, int Cin_pad, int Cout_pad, int* ksplit, int* stat_tiles,
                           size_t* ws_floats);
 int hpri_conv_bf16v3(const void* xp, long long x_plane, int x_cs, int x_coff, const void* wp, const float* bias, float* y,
                      int y_cs, int y_coff, float* stats, int N, int H, int W, int Cin_pad, int Cout, int Cout_pad, int y_cw,
                      int accumulate, int split, float* ws, size_t ws_floats, hipStream_t stream);
-int hpri_conv_bf16v3_dbg(const void* xp, long long x_plane, int x_cs, int x_coff, const void* wp, const float* bias, float* y,
-                         int y_cs, int y_coff, float* stats, int N, int H, int W, int Cin_pad, int Cout, int Cout_pad, int y_cw,
-                         int accumulate, int split, float* ws, size_t ws_floats, unsigned long long* stamps,
-                         int stagger_cycles, hipStream_t stream);
+
 
 /* hpri_conv_bf16v3 (no accumulate; hpri_conv_bf16v3_plan must report ksplit 1) whose result channels [y2_c0, y2_c0 + y2_cw) -- whole
  * 64-channel blocks -- are also (y2_only != 0: only) written as bf16 rows, y2 + pixel * y2_cs + y2_coff + (channel - y2_c0): the
@@ -204,15 +191,7 @@ int hpri_conv_bf16v3_dbg(const void* xp, long long x_plane, int x_cs, int x_coff
 int hpri_conv_bf16v3_y2(const void* xp, int x_cs, int x_coff, const void* wp, const float* bias, float* y, int y_cs, int y_coff,
                         float* stats, int N, int H, int W, int Cin_pad, int Cout, int Cout_pad, int y_cw, void* y2, int y2_cs,
                         int y2_coff, int y2_c0, int y2_cw, int y2_only, hipStream_t stream);
-/* The data gradient of a 3x3 layer in the bf16 plane mode whose input x = ReLU(BN(bn_x16)) has no other consumer, with that
- * BatchNorm's backward reduction taken in the epilogue (bf16 counterpart of hpri_conv_wino4_bnred): bn_x16 = the pre-BN tensor as
- * bf16 (what hpri_conv_bf16v3 wrote with accumulate bit 2; same pixels as y, stride / offset in elements, multiples of 4);
- * bn_part[stat_tiles][2][bn_cpart] (stat_tiles from hpri_conv_bf16v3_plan, which must report ksplit 1; bn_cpart >= Cout) receives
- * sum g*[y>0] and sum g*[y>0]*xhat per tile.  Finish with hpri_bn_relu_bwd_fused. */
-int hpri_conv_bf16v3_bnred(const void* xp, int x_cs, int x_coff, const void* wp, float* y, int y_cs, int y_coff, int N, int H,
-                           int W, int Cin_pad, int Cout, int Cout_pad, int y_cw, const void* bn_x16, int bn_x_cs, int bn_x_coff,
-                           const float* bn_mean, const float* bn_invstd, const float* bn_scale, const float* bn_shift,
-                           int bn_relu, float* bn_part, int bn_cpart, hipStream_t stream);
+
 
 /* ---- plane-fed GEMM for the 1x1 forms of the bf16 mode (gemm_bf16v3.hip): nn.Linear / Conv2d(k=1) forward and data gradient
  * (models.py:105-115,143; model_parts.py:96) and ConvTranspose2d(k=2,s=2) forward / data gradient (model_parts.py:63-64).
@@ -321,12 +300,7 @@ int hpri_bn_relu_bwd_pl(const float* dy, int dy_cs, int dy_coff, const float* x,
 int hpri_bn_apply_relu_x16(const void* x16, int x_cs, int x_coff, float* y, int y_cs, int y_coff, const float* scale,
                            const float* shift, long long P, long long pix_per_group, int C, int Cw, int relu, void* planes,
                            long long plane_stride, int pl_cs, int pl_coff, int pl_cw, int npl, hipStream_t stream);
-int hpri_bn_relu_bwd_fused_x16(const float* partials, int part_blocks, int part_cpart, const float* dy, int dy_cs, int dy_coff,
-                               const void* x16, int x_cs, int x_coff, float* dx, int dx_cs, int dx_coff, const float* mean,
-                               const float* invstd, const float* scale, const float* shift, float* dgamma, float* dbeta,
-                               int accumulate_param_grads, float* dbias, int accumulate_dbias, float* workspace, size_t ws_floats,
-                               long long P, long long pix_per_group, int C, int Cw, int relu, int use_batch_stats, void* planes,
-                               long long plane_stride, int pl_cs, int pl_coff, int pl_cw, int npl, hipStream_t stream);
+
 int hpri_bn_relu_bwd_x16(const float* dy, int dy_cs, int dy_coff, const void* x16, int x_cs, int x_coff, float* dx,
                          int dx_cs, int dx_coff, const float* mean, const float* invstd, const float* scale,
                          const float* shift, float* dgamma, float* dbeta, int accumulate_param_grads, float* dbias,

@@ -88,9 +88,9 @@ def test_split_k_is_priced_by_its_slab_traffic():
     lib = _lib.load()
     k = ctypes.c_int(); tl = ctypes.c_int(); ws = ctypes.c_size_t()
     for (N, H, W, cin, cout) in [(2, 38, 60, 512, 1024), (2, 76, 121, 1024, 512), (2, 152, 242, 256, 256), (2, 608, 968, 256, 64)]:
-        assert lib.hpri_conv_bf16v2_plan(N, H, W, cin, cout, ctypes.byref(k), ctypes.byref(tl), ctypes.byref(ws)) == 0
+        assert lib.hpri_conv_bf16v3_plan(N, H, W, cin, cout, ctypes.byref(k), ctypes.byref(tl), ctypes.byref(ws)) == 0
         assert k.value == 1 and ws.value == 0, (H, W, cin, cout, k.value)
-    assert lib.hpri_conv_bf16v2_plan(1, 16, 24, 1024, 64, ctypes.byref(k), ctypes.byref(tl), ctypes.byref(ws)) == 0
+    assert lib.hpri_conv_bf16v3_plan(1, 16, 24, 1024, 64, ctypes.byref(k), ctypes.byref(tl), ctypes.byref(ws)) == 0
     assert k.value > 1 and ws.value == k.value * 16 * 24 * 64       # a tiny problem: slices fill the chip
 
 

@@ -48,6 +48,8 @@ GEOM = [(1, 17, 23, 5, 7), (2, 36, 50, 64, 64), (1, 76, 121, 128, 192), (2, 38, 
 def _wino_fns(lib, kern):
     """(pack, plan, conv) of one of the two fused Winograd kernels: conv_wino4.hip (the default: 16x8-pixel workgroups, two
     per CU) or conv_wino.hip (16x16 pixels, one per CU).  Same argument contract, different weight layouts."""
+    if not hasattr(lib, f"hpri_conv_{kern}"):
+        pytest.skip(f"conv_{kern} is part of the diagnostics build only (HPRI_DIAG=1; include/hyperpri_hip_diag.h)")
     return getattr(lib, f"hpri_{kern}_pack"), getattr(lib, f"hpri_conv_{kern}_plan"), getattr(lib, f"hpri_conv_{kern}")
 
 
@@ -175,6 +177,8 @@ def test_bf16_plane_conv_vs_fp64_of_rounded_operands(lib, shape, kern):
     (written by hpri_to_planes), products accumulate in fp32.  The reference is conv2d in fp64 of the SAME bf16-rounded
     operands, so the only difference is fp32 summation order."""
     N, H, W, Cin, Cout = shape
+    if not hasattr(lib, f"hpri_conv_{kern}"):
+        pytest.skip(f"conv_{kern} is part of the diagnostics build only (HPRI_DIAG=1; include/hyperpri_hip_diag.h)")
     plan_fn, conv_fn = getattr(lib, f"hpri_conv_{kern}_plan"), getattr(lib, f"hpri_conv_{kern}")
     torch.manual_seed(31)
     cs, cs16, cout_pad = rup(Cin, 8), rup(Cin, 32), rup(Cout, 64)
@@ -275,7 +279,11 @@ def test_bf16_plane_conv_v3_bn_backward_partials_in_the_epilogue(lib, shape, rel
     """hpri_conv_bf16v3_bnred: the data gradient g of a 3x3 layer plus, per 256-pixel tile, sum g*[BN(x) > 0] and
     sum g*[BN(x) > 0]*xhat of the BatchNorm(+ReLU) stage whose bf16 pre-BN tensor x sits at g's positions; then
     hpri_bn_relu_bwd_fused_x16 on those partial rows against hpri_bn_relu_bwd_x16 doing its own two sweeps (the last shape
-    has enough tiles for the folding launch in front of the finalize)."""
+    has enough tiles for the folding launch in front of the finalize).  Diagnostics build only since round 4 (the variant measured
+    neutral to -3 % and left the product library: include/hyperpri_hip_diag.h; run with HPRI_DIAG=1 after
+    ``HPRI_DIAG=1 python -m hyperpri_amd.build``)."""
+    if not hasattr(lib, "hpri_conv_bf16v3_bnred"):
+        pytest.skip("hpri_conv_bf16v3_bnred is part of the diagnostics build only (HPRI_DIAG=1)")
     N, H, W, K, Cols = shape
     torch.manual_seed(11)
     cs16, cols_pad, cw = rup(K, 32), rup(Cols, 64), rup(Cols, 8)

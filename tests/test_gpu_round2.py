@@ -380,48 +380,6 @@ def test_training_step_uses_the_fused_loss():
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())
 
 
-@pytest.mark.parametrize("kind", ["unet", "cube64"])
-def test_bf16_mode_bn_backward_reduction_in_the_data_gradient_epilogue(kind):
-    """HPRI_FUSE_BN_REDUCE_BF16=1, the bf16 plane mode (hpri_conv_bf16v3_bnred + hpri_bn_relu_bwd_fused_x16): the inner BatchNorm of
-    every DoubleConv gets its backward sums from the consumer's data-gradient launch.  Only the order of fp32 summation
-    changes; through the bf16 rounding of the BatchNorm-backward output a few last-place flips reach the gradients upstream."""
-    import hyperpri_amd as H
-    from hyperpri_amd import engine as E
-    net, x, m = _net(kind)
-    H.set_precision(net, "bf16")
-    sd = {k: v.clone() for k, v in net.state_dict().items()}
-    assert E.BF16_V3
-    seen = []
-    was = E.FUSE_BN_REDUCE_BF16
-    E.FUSE_BN_REDUCE_BF16 = True
-    real = E._lib.call
-
-    def spy(name, *a):
-        seen.append(name)
-        return real(name, *a)
-    E._lib.call = spy
-    try:
-        lg1, g1 = _step(net, x, m)
-    finally:
-        E._lib.call = real
-        E.FUSE_BN_REDUCE_BF16 = False
-    assert "hpri_conv_bf16v3_bnred" in seen and "hpri_bn_relu_bwd_fused_x16" in seen
-    try:
-        net.load_state_dict(sd)
-        lg2, g2 = _step(net, x, m)
-    finally:
-        E.FUSE_BN_REDUCE_BF16 = was
-    assert torch.equal(lg1, lg2)
-    worst = 0.0
-    for (k, _), a, b in zip(net.named_parameters(), g1, g2):
-        ref = float(b.double().norm())
-        if ref < 1e-6:
-            continue
-        worst = max(worst, float((a.double() - b.double()).norm()) / ref)
-    record_margin(f"bf16_bnred_switch_{kind}", worst, 5e-2)
-    assert worst <= 5e-2, worst          # (measured 1.5e-2 on these tiny nets: the distance between two correct bf16 paths there)
-
-
 @pytest.mark.parametrize("kind", ["unet", "cube64", "cube128"])
 def test_bf16_mode_transposed_convolutions_on_planes(kind):
     """HPRI_CONVT_PLANES (default on): ConvTranspose2d forward, data gradient and weight gradient on the plane-fed kernels, the gradient

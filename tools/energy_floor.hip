@@ -20,10 +20,12 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
 #define MAKE_RSRC(p_, n_) __builtin_amdgcn_make_buffer_rsrc((void*)(p_), 0, (int)(n_), 0x00020000)
 #define LDS_DMA16(rs_, lds_, v_, s_) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_, lds_, 16, v_, s_, 0, 0)
+#define LOAD16(rs_, v_, s_) __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_, v_, s_, 0))
 #else      // (the host pass drops a kernel template that mentions the device-only descriptor type)
 typedef int rsrc_t;
 #define MAKE_RSRC(p_, n_) 0
 #define LDS_DMA16(rs_, lds_, v_, s_) ((void)(rs_))
+#define LOAD16(rs_, v_, s_) f32x4{0.f, 0.f, 0.f, 0.f}
 #endif
 
 #define LDS_FRAG_BYTES (64 * 1024)     // fragment image (random bf16), read lane-linear: conflict-free ds_read_b128
@@ -41,7 +43,9 @@ struct Args {
 // RG: in RG of the 3 groups of a stage the fragments are re-read from LDS (0: they stay in registers, the bare loop).  NVG vector-ALU instructions per group
 // (v_and / v_sub_f32 / v_perm round robin: the 3-plane split's mix).  NDR / NDS: LDS-DMA pieces per STAGE from the resident / the
 // streamed buffer.  MINW: waves per SIMD the launch is built for (2: two 4-wave workgroups per CU; 1: one, 512 registers).
-template <int SHAPE, int P, int Q, int RG, int NVG, int NDR, int NDS, int MINW>
+// NRS: 16-byte-per-lane pieces per STAGE that are REGISTER-staged instead (buffer_load_dwordx4 -> registers -> ds_write_b128 one stage
+// later): an operand that vector instructions must touch on its way into LDS (BatchNorm-apply + ReLU fused into a consumer's staging).
+template <int SHAPE, int P, int Q, int RG, int NVG, int NDR, int NDS, int MINW, int NRS = 0>
 __global__ __launch_bounds__(256, MINW) void floor_kernel(Args a) {
   __shared__ __attribute__((aligned(1024))) unsigned char smem[LDS_FRAG_BYTES + LDS_DMA_BYTES];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -79,6 +83,9 @@ __global__ __launch_bounds__(256, MINW) void floor_kernel(Args a) {
   const rsrc_t rs_s = MAKE_RSRC((((unsigned long long)shi << 32) | slo), (slice > 0x7FFFFF00ull ? 0x7FFFFF00ull : slice));
   const unsigned lane16 = lane * 16;
   unsigned rpos = wave * 1024u, spos = wave * 1024u;
+  f32x4 rs_reg[NRS > 0 ? NRS : 1];
+#pragma unroll
+  for (int i = 0; i < (NRS > 0 ? NRS : 1); ++i) rs_reg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   auto lds_dst = [&](int i) { return (__attribute__((address_space(3))) void*)(smem + LDS_FRAG_BYTES + ((wave * 2 + (i & 1)) << 10)); };
 
   unsigned long long t0, t1, r0, r1;
@@ -86,6 +93,14 @@ __global__ __launch_bounds__(256, MINW) void floor_kernel(Args a) {
   asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r0)::"memory");
   for (int s = 0; s < a.stages; ++s) {
     if (NDR + NDS > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDR + NDS) : "memory");
+    if (NRS > 0) {
+#pragma unroll
+      for (int i = 0; i < NRS; ++i) {
+        *reinterpret_cast<f32x4*>(smem + LDS_FRAG_BYTES + ((wave * 2 + (i & 1)) << 10) + lane16) = rs_reg[i];      // ds_write_b128 (waits for its load)
+        rs_reg[i] = LOAD16(rs_s, lane16, spos);
+        spos += 4096u; if ((unsigned long long)spos + 1024u > slice || spos > 0x7FFFF000u) spos = wave * 1024u;
+      }
+    }
 #pragma unroll
     for (int g = 0; g < 3; ++g) {
       if (g < RG) {
@@ -137,6 +152,8 @@ __global__ __launch_bounds__(256, MINW) void floor_kernel(Args a) {
       for (int r = 0; r < NACC; ++r) sum += acc[p][q][r];
 #pragma unroll
   for (int i = 0; i < 8; ++i) sum += vx[i] + (float)vi[i];
+#pragma unroll
+  for (int i = 0; i < (NRS > 0 ? NRS : 1); ++i) sum += rs_reg[i][0];
   if (sum == 12345.678f) a.out[0] = 1;
   if (tid == 0) { a.out[4 + blockIdx.x * 4 + 0] = t1 - t0; a.out[4 + blockIdx.x * 4 + 1] = r1 - r0; }
 }
@@ -144,7 +161,7 @@ __global__ __launch_bounds__(256, MINW) void floor_kernel(Args a) {
 static unsigned char *g_res, *g_str; static unsigned long long g_str_bytes; static unsigned long long* g_out;
 static const char* g_filter = nullptr;
 
-template <int SHAPE, int P, int Q, int RG, int NVG, int NDR, int NDS, int MINW>
+template <int SHAPE, int P, int Q, int RG, int NVG, int NDR, int NDS, int MINW, int NRS = 0>
 void run(const char* name, int zero = 0) {
   if (g_filter && !strstr(name, g_filter)) return;
   int ncu = 256; hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, 0);
@@ -159,7 +176,7 @@ void run(const char* name, int zero = 0) {
   if (stages < 8) stages = 8;
   Args a{g_res, 256u * 1024u, g_str, g_str_bytes, g_out, stages, zero};
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  auto launch = [&]() { hipLaunchKernelGGL((floor_kernel<SHAPE, P, Q, RG, NVG, NDR, NDS, MINW>), dim3(grid), dim3(256), 0, 0, a); };
+  auto launch = [&]() { hipLaunchKernelGGL((floor_kernel<SHAPE, P, Q, RG, NVG, NDR, NDS, MINW, NRS>), dim3(grid), dim3(256), 0, 0, a); };
   // settle: >= 2 s of back-to-back launches
   hipEventRecord(e0); launch(); hipEventRecord(e1); hipDeviceSynchronize();
   float ms1; hipEventElapsedTime(&ms1, e0, e1);
@@ -181,10 +198,10 @@ void run(const char* name, int zero = 0) {
   const double cyc_per_mfma_simd = cy[cy.size() / 2] / ((double)stages * mfma_stage * MINW);
   const double dma_bytes = (double)(NDR + NDS) * 1024.0 * 4.0 * grid * stages;
   printf("{\"name\": \"%s\", \"mfma\": \"%s\", \"wave_tile\": \"%dx%d\", \"waves_per_simd\": %d, \"ds_read_b128_per_mfma\": %.3f, \"valu_per_mfma\": %.2f, "
-         "\"dma_pieces_per_stage_resident\": %d, \"dma_pieces_per_stage_streamed\": %d, \"data\": \"%s\", \"settle_s\": %.1f, \"ms\": %.3f, \"tflops\": %.1f, \"frac_of_2.5PF\": %.3f, "
+         "\"dma_pieces_per_stage_resident\": %d, \"dma_pieces_per_stage_streamed\": %d, \"register_staged_pieces_per_stage\": %d, \"data\": \"%s\", \"settle_s\": %.1f, \"ms\": %.3f, \"tflops\": %.1f, \"frac_of_2.5PF\": %.3f, "
          "\"in_kernel_ghz_median\": %.3f, \"cycles_per_mfma_per_simd\": %.2f, \"ideal_cycles\": %.0f, \"dma_TBps\": %.2f, \"stream_TBps\": %.2f}\n",
          name, SHAPE == 0 ? "16x16x32" : "32x32x16", (SHAPE == 0 ? 16 : 32) * P, (SHAPE == 0 ? 16 : 32) * Q, MINW,
-         (double)RG * (P + Q) / (3.0 * P * Q), (double)NVG / (P * Q), NDR, NDS, zero ? "zeros" : "random", warm_s, ms, tf, tf / 2500.0,
+         (double)RG * (P + Q) / (3.0 * P * Q), (double)NVG / (P * Q), NDR, NDS, NRS, zero ? "zeros" : "random", warm_s, ms, tf, tf / 2500.0,
          clk.empty() ? 0.0 : clk[clk.size() / 2], cyc_per_mfma_simd, cyc, dma_bytes / (ms * 1e-3) / 1e12,
          (double)NDS * 1024.0 * 4.0 * grid * stages / (ms * 1e-3) / 1e12);
   fflush(stdout);
@@ -229,5 +246,22 @@ int main(int argc, char** argv) {
   run<0, 4, 4, 1, 37, 3, 2, 2>("wino6 16x16x32 Q=4: 2.33 valu/mfma + dma, reads 1 group in 3");
   run<1, 2, 2, 3, 19, 3, 2, 2>("wino6 32x32x16 Q=2x32: 4.67 valu/mfma32 + dma");
   run<1, 2, 4, 3, 19, 3, 2, 1>("wino6 32x32x16 Q=4x32: 2.33 valu/mfma32 + dma w1");
+  // ---- the Winograd-domain 3-plane split (fp32-class emulation) forward main loop, per wave and 32-channel stage of
+  //      the conv_wino4 decomposition (32 tiles x 64 channels x 4 frequencies per wave, 128 accumulators): 192 MFMAs (4 freq x 2 tile
+  //      frags x 4 channel frags x 6 products), ~480 VALU (input transform 128 + exact hi|mid|lo split of 64 values 352), 48 U-plane
+  //      fragment reads + 32 raw halo reads, DMA: U planes 48 KB per wave (L2-resident), fp32 halo 6 KB per wave (streamed).
+  //      Stage of the model = 3 groups of 4 x 8 tiles = 96 MFMAs: half a real stage.
+  run<0, 4, 8, 3, 80, 24, 3, 2>("wino6 model: 2.5 valu/mfma, U dma 24 + halo 3 per 96 mfma, w2");
+  run<0, 4, 8, 3, 80, 12, 3, 2>("wino6 model: U stream shared by two workgroups (12 + 3)");
+  run<0, 4, 8, 3, 80, 0, 3, 2>("wino6 model: no U dma at all (0 + 3)");
+  run<0, 4, 8, 3, 40, 24, 3, 2>("wino6 model: V shared by 128 channels (1.25 valu/mfma)");
+  run<0, 4, 8, 3, 0, 24, 3, 2>("wino6 model: no valu (0 + dma 24 + 3)");
+  // ---- BatchNorm-apply + ReLU in the consumer's operand staging, on the plane GEMM's mix (gemm_bf16v3: wave tile
+  //      64 px x 128 columns, 32 MFMAs + 12 fragment reads per k32 stage; per wave and stage A = 4 DMA pieces streamed, B = 2 pieces
+  //      L2-resident).  Fused form: the 4 A pieces come through registers (buffer_load -> 28 VALU per 16 bytes: unpack, fma, max,
+  //      pack -> ds_write_b128) = 112 VALU per 32 MFMAs.  Model stage = 3 k32 stages.
+  run<0, 4, 8, 3, 0, 6, 12, 2>("gemm16 64x128 w2: A and B by LDS-DMA (as built)");
+  run<0, 4, 8, 3, 112, 6, 0, 2, 12>("gemm16 64x128 w2: A register-staged + 3.5 valu/mfma (BN-apply fused)");
+  run<0, 4, 8, 3, 0, 6, 0, 2, 12>("gemm16 64x128 w2: A register-staged, no valu");
   return 0;
 }

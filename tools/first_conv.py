@@ -82,8 +82,7 @@ def measure(reps=20, modes=("bf16_planes", "fp32"), settle_s=1.0):
             assert lib.hpri_to_planes(P(x), cs, 0, P(planes), 0, cs16, 0, N * H * W, CIN, cs16, 1, st) == 0
             wp = torch.empty((cs16 // 32) * 9 * cout_pad * 32, dtype=torch.bfloat16, device=dev)
             assert lib.hpri_pack_weight_bf16(P(w), P(wp), 0, CIN, COUT, cout_pad, 9, CIN, 0, 0, st) == 0
-            from hyperpri_amd import engine as _E
-            kern = "hpri_conv_bf16v3" if _E.BF16_V3 else "hpri_conv_bf16v2"        # the kernel the bf16 mode runs (HPRI_BF16_V3)
+            kern = "hpri_conv_bf16v3"        # the kernel the bf16 mode runs
             getattr(lib, kern + "_plan")(N, H, W, cs16, cout_pad, ctypes.byref(k), ctypes.byref(tl), ctypes.byref(wsf))
             stats = torch.empty(tl.value * cout_pad * 4, device=dev)
             ws = torch.empty(max(wsf.value, 4), device=dev)

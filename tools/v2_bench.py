@@ -2,6 +2,8 @@
 """A/B of the round-1 bf16 convolution (fp32 activations, VGPR staging) against the bf16-PLANE kernel
 (conv_bf16v2.hip, LDS-DMA for both operands) on the CubeNET layer shapes: interleaved rounds in one process on the
 same random data (rule 24), outputs and BN partial statistics compared.   usage: v2_bench.py [out.json]"""
+import os as _os
+_os.environ.setdefault("HPRI_DIAG", "1")     # uses entry points of the DIAGNOSTICS build (include/hyperpri_hip_diag.h): HPRI_DIAG=1 python -m hyperpri_amd.build
 import ctypes
 import json
 import os

@@ -3,6 +3,8 @@
 Prints the median over workgroups of: prologue (first DMA -> first stage visible), main loop, store epilogue,
 statistics epilogue, for the early (waves 0-3) and late (waves 4-7) wave group.  Shares, not run times (stamps
 perturb the kernel)."""
+import os as _os
+_os.environ.setdefault("HPRI_DIAG", "1")     # uses entry points of the DIAGNOSTICS build (include/hyperpri_hip_diag.h): HPRI_DIAG=1 python -m hyperpri_amd.build
 import ctypes
 import json
 import os

@@ -3,6 +3,8 @@
 CU, 32x32x16 MFMA) against conv_bf16v3.hip (two 4-wave workgroups per CU, 16x16x32 MFMA, stores from the accumulators).
 Interleaved rounds in one process on the same random data (rule 24); outputs and BN partial statistics compared.
     usage: v3_bench.py [out.json]      env: SHAPES='[[N,H,W,Cin,Cout],...]'  STAGGER='0,3000,6000' (extra v3 arms via _dbg)"""
+import os as _os
+_os.environ.setdefault("HPRI_DIAG", "1")     # uses entry points of the DIAGNOSTICS build (include/hyperpri_hip_diag.h): HPRI_DIAG=1 python -m hyperpri_amd.build
 import ctypes
 import json
 import os

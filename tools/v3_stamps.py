@@ -3,6 +3,8 @@
 the main loop removed.  Per variant: kernel time by HIP events, and the median over workgroups of main-loop cycles per stage
 (ideal: 2 waves x 48 MFMAs x 16 cycles = 1536 with two workgroups on the CU), cycles between a stage's top and the end of its
 barrier, store / statistics epilogue, and the in-kernel clock.  Shares, not run times (stamps perturb the kernel)."""
+import os as _os
+_os.environ.setdefault("HPRI_DIAG", "1")     # uses entry points of the DIAGNOSTICS build (include/hyperpri_hip_diag.h): HPRI_DIAG=1 python -m hyperpri_amd.build
 import ctypes
 import json
 import os

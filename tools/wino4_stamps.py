@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Cycle shares of a conv_wino4 workgroup (4 waves, 16x8 pixels; two stamp groups = waves 0-1 / 2-3) (diagnostic build, tools/build_stamps.sh): main loop | output transform + stores |
 statistics, median over workgroups."""
+import os as _os
+_os.environ.setdefault("HPRI_DIAG", "1")     # uses entry points of the DIAGNOSTICS build (include/hyperpri_hip_diag.h): HPRI_DIAG=1 python -m hyperpri_amd.build
 import ctypes, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

@@ -2,6 +2,8 @@
 """Winograd F(2x2,3x3) fp32 kernel (conv_wino.hip) against the direct fp32 MFMA kernel: outputs, BatchNorm partial
 statistics (as per-channel mean / variance), accumulate + ReLU epilogues, data-gradient pack, odd geometries; and an
 interleaved A/B timing on the CubeNET layer shapes.   usage: wino_check.py [out.json]"""
+import os as _os
+_os.environ.setdefault("HPRI_DIAG", "1")     # uses entry points of the DIAGNOSTICS build (include/hyperpri_hip_diag.h): HPRI_DIAG=1 python -m hyperpri_amd.build
 import ctypes
 import json
 import os
