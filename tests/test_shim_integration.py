@@ -76,6 +76,7 @@ TRAINER_SHAPED = '''
 DRIVER = '''
     import importlib, json, sys
     import torch
+    from torch import nn
     mode = sys.argv[1]
     P = importlib.import_module("src.Experiments.params_shaped")
     T = importlib.import_module("src.trainer_shaped")
