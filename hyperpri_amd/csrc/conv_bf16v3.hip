@@ -182,6 +182,12 @@ __global__ __launch_bounds__(256, 2) void conv_bf16v3_kernel(ConvV3Args a) {
 #ifndef V3_DIAG
 #define V3_DIAG 0
 #endif
+#ifndef V3_PREFETCH_A
+#define V3_PREFETCH_A 0
+#endif
+#ifndef V3_FAST_EPILOGUE
+#define V3_FAST_EPILOGUE 1
+#endif
 // (buffer indices are compile-time: the chunk loop is unrolled by two, so LDS addresses are immediates of the reads)
 #define V3_DMA_B_(buf_, s_, q_)                                                                                       \
   HPRI_LDS_DMA16(rs_b, b_lds + (buf_) * V3_B_BYTES + ((q_) * 4 + wave) * 1024, goff, ((s_) * 3 + (q_)) * tap_bytes)
@@ -260,11 +266,13 @@ __global__ __launch_bounds__(256, 2) void conv_bf16v3_kernel(ConvV3Args a) {
   //           stage s-1, whose weight buffer (and, on dy = 0, the halo buffer of chunk c-1) may now be refilled
   //   body    weight pieces of stage s+1 first, then (dy = 0, 1) one half of the next chunk's halo, issued between the MFMAs
   // A fragment is read one tap ahead of its MFMAs.
-#define V3_READ_TAP(fa_, fb_, ab_, bb_, dy_, dx_)                                                                     \
+#define V3_READ_TAP_A(fa_, ab_, dy_, dx_)                                                                             \
   _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                                                    \
-      fa_[mt] = *reinterpret_cast<const bf16x8*>((ab_) + aofs[mt][(dy_) * 3 + (dx_)]);                                \
+      fa_[mt] = *reinterpret_cast<const bf16x8*>((ab_) + aofs[mt][(dy_) * 3 + (dx_)]);
+#define V3_READ_TAP_B(fb_, bb_, dx_)                                                                                  \
   _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                                    \
       fb_[nt] = *reinterpret_cast<const bf16x8*>((bb_) + (dx_) * 4096 + nt * 1024);
+#define V3_READ_TAP(fa_, fb_, ab_, bb_, dy_, dx_) V3_READ_TAP_A(fa_, ab_, dy_, dx_) V3_READ_TAP_B(fb_, bb_, dx_)
 #define V3_MFMA_TAP(fa_, fb_, dma0_, dma1_)                                                                           \
   _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) {                                                                  \
     _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                                  \
@@ -276,18 +284,21 @@ __global__ __launch_bounds__(256, 2) void conv_bf16v3_kernel(ConvV3Args a) {
   {                                                                                                                   \
     const int s_ = c * 3 + (dy_);                                                                                     \
     constexpr int bb_i = ((par_) * 3 + (dy_)) & 1;                                                                    \
+    const unsigned char* ab_ = a_lds + (par_) * V3_A_BYTES;                                                           \
+    const unsigned char* bb_ = b_lds + bb_i * V3_B_BYTES + bofs;                                                      \
+    bf16x8 fa0[4], fb0[4], fa1[4], fb1[4];                                                                            \
+    /* the chunk's halo became visible at its dy = 0 stage: on dy = 1, 2 the pixel fragments of the first tap can be on their way \
+       while this wave waits for the stage's weights (with the partner workgroup in its epilogue nothing else covers that wait) */ \
+    if (V3_PREFETCH_A && (dy_) > 0) { V3_READ_TAP_A(fa0, ab_, dy_, 0) }                                               \
     V3_TOP_BEGIN()                                                                                                    \
     if (!(V3_DIAG & 8) || s_ == S0) {                                                                                 \
       if ((dy_) == 0 || !more_c) V3_WAIT_VM(0); else V3_WAIT_VM(3);                                                   \
       V3_BARRIER();                                                                                                   \
     }                                                                                                                 \
     V3_TOP_END()                                                                                                      \
-    const unsigned char* ab_ = a_lds + (par_) * V3_A_BYTES;                                                           \
-    const unsigned char* bb_ = b_lds + bb_i * V3_B_BYTES + bofs;                                                      \
     const bool more_b = s_ + 1 < S;                                                                                   \
     const bool more_a = (dy_) < 2 && more_c;                                                                          \
-    bf16x8 fa0[4], fb0[4], fa1[4], fb1[4];                                                                            \
-    V3_READ_TAP(fa0, fb0, ab_, bb_, dy_, 0)                                                                           \
+    if (V3_PREFETCH_A && (dy_) > 0) { V3_READ_TAP_B(fb0, bb_, 0) } else { V3_READ_TAP(fa0, fb0, ab_, bb_, dy_, 0) }   \
     if (!(V3_DIAG & 4)) { V3_READ_TAP(fa1, fb1, ab_, bb_, dy_, 1) }                                                   \
     else { _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) { fa1[i_] = fa0[i_]; fb1[i_] = fb0[i_]; } }                \
     V3_ISSUE_FIRST(V3_I0 V3_I1 V3_I2 V3_I3(par_, dy_) V3_I4(par_, dy_) V3_I5(par_, dy_))                              \
@@ -363,6 +374,9 @@ __global__ __launch_bounds__(256, 2) void conv_bf16v3_kernel(ConvV3Args a) {
       }
     }
 
+#ifdef HPRI_STAMPS
+    if (ntiles_done == 0) { V3_STAMP(10) }
+#endif
     // ------------------------------- epilogue -------------------------------
     // acc[mt][nt][r]: pixel (wave*4 + mt)*16 + li of the tile, channel nb*64 + nt*16 + 4*lq + r
     const bool raw = a.ksplit > 1;             // split-K: raw partial sums into the workspace slab of this K slice
@@ -436,6 +450,142 @@ __global__ __launch_bounds__(256, 2) void conv_bf16v3_kernel(ConvV3Args a) {
     }                                                                                                                 \
   }
     const bool to_y2 = !BNRED && !raw && a.y2 != nullptr && cur.nb * 64 >= a.y2_c0 && cur.nb * 64 < a.y2_c0 + a.y2_cw;
+    // ---- round 4: the common case (a whole 64-channel block inside the written width, no second output, no split-K slab) goes out
+    //      through a per-wave transposition in LDS.  Straight from the accumulators a store instruction covered 16 pixel rows x 64
+    //      bytes -- 16 partial lines per instruction, 11.7 k cycles of store issue per item with a partner on the CU
+    //      (tools/v3_stamps.py), another 7.5 k for the statistics' 128 DPP row sums.  Transposed, a lane holds channels 4 c .. 4 c + 3
+    //      (c = lane & 15) of pixel 4 k + (lane >> 4) of an M-tile: one store instruction writes FOUR WHOLE pixel rows (1 KB
+    //      contiguous for fp32; consecutive pixels of a tile row are consecutive in memory), and the statistics need two cross-lane
+    //      steps per value instead of four DPP steps per accumulator register.  Scratch: 16 rows of 272 bytes per wave in halo
+    //      buffer 1 (free until the next item's second chunk), private to the wave: no barrier.
+    const bool fast = !BNRED && !raw && full && !to_y2 && V3_FAST_EPILOGUE;
+    if (fast) {
+      // (the lane-derived LDS addresses of this block are recomputed per item from an opaque copy of the lane id: hoisted out of the
+      //  persistent loop by hipcc they stayed live across the main loop -- 8 registers it does not have)
+      int lane_e = lane;
+      asm volatile("" : "+v"(lane_e));
+      const int li_e = lane_e & 15, lq_e = lane_e >> 4;
+      unsigned char* tb = smem + V3_A_BYTES + wave * (16 * 272);
+      const int lg = lane_e >> 4, lc = lane_e & 15;
+      // the transposed values take the accumulators' own registers (a second array next to them spilled 200 registers):
+      // from here on acc[mt][k] = pixel (wave*4 + mt)*16 + 4 k + lg, channels nb*64 + 4 lc + (0..3)
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) *reinterpret_cast<f32x4*>(tb + li_e * 272 + nt * 64 + lq_e * 16) = acc[mt][nt];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) acc[mt][kk] = *reinterpret_cast<const f32x4*>(tb + (4 * kk + lg) * 272 + lc * 16);
+      }
+#ifdef HPRI_STAMPS
+      if (ntiles_done == 0) { V3_STAMP(11) }
+#endif
+      unsigned vm = 0u;                        // bit 4 mt + k: that pixel lies inside the image
+      unsigned poff[4][4];                     // element offset inside this image's view (< 2^32: the launcher bounds one image)
+      float* const ybase = dst + (size_t)cur.img * a.H * a.W * dcs + dco + cur.nb * 64 + 4 * lc;
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          const int p = (wave * 4 + mt) * 16 + 4 * kk + lg;
+          const int iy = cur.y0 + (p >> twl), ix = cur.x0 + (p & (TW - 1));
+          if (iy < a.H && ix < cur.xlim) vm |= 1u << (4 * mt + kk);
+          poff[mt][kk] = (unsigned)((min(iy, a.H - 1) * a.W + min(ix, a.W - 1)) * dcs);
+        }
+      if (a.y16) {
+        __bf16* d16 = reinterpret_cast<__bf16*>(a.y) + (ybase - dst);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk)
+            if ((vm >> (4 * mt + kk)) & 1u) {
+              bf16x4_t h;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) h[r] = (__bf16)acc[mt][kk][r];
+              *reinterpret_cast<bf16x4_t*>(d16 + poff[mt][kk]) = h;
+            }
+      } else {
+        if (a.accumulate) {
+          // in two halves of eight pixel rows: all loads of a half before its stores (a wait for a load behind a store would wait
+          // for the store as well), and 32 instead of 64 registers of old values next to the accumulators
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh) {
+            f32x4 old_[2][4];
+#pragma unroll
+            for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+              for (int kk = 0; kk < 4; ++kk) {
+                const int mt = 2 * hh + m2;
+                old_[m2][kk] = ((vm >> (4 * mt + kk)) & 1u) ? *reinterpret_cast<const f32x4*>(ybase + poff[mt][kk]) : f32x4{0.f, 0.f, 0.f, 0.f};
+              }
+#pragma unroll
+            for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+              for (int kk = 0; kk < 4; ++kk) {
+                const int mt = 2 * hh + m2;
+                acc[mt][kk] += old_[m2][kk];
+                if ((vm >> (4 * mt + kk)) & 1u) *reinterpret_cast<f32x4*>(ybase + poff[mt][kk]) = acc[mt][kk];
+              }
+          }
+        } else {
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+              if ((vm >> (4 * mt + kk)) & 1u) *reinterpret_cast<f32x4*>(ybase + poff[mt][kk]) = acc[mt][kk];
+        }
+      }
+#ifdef HPRI_STAMPS
+      if (ntiles_done == 0) { V3_STAMP(12) }
+#endif
+      if (a.stats != nullptr) {
+        // exact two-pass record of this wave's 64 pixels per channel (sum, then squared deviations from the wave's own mean), the
+        // four lane groups of a channel quad met by two butterfly steps; the four wave records are merged below as before
+        auto xsum = [](float v) { v += __shfl_xor(v, 16); v += __shfl_xor(v, 32); return v; };
+        const float cntw = xsum((float)__builtin_popcount(vm)) ;
+        const float inv = cntw > 0.f ? 1.f / cntw : 0.f;
+        f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f}, mw;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk)
+            if ((vm >> (4 * mt + kk)) & 1u) s1 += acc[mt][kk];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mw[r] = xsum(s1[r]) * inv;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk)
+            if ((vm >> (4 * mt + kk)) & 1u) { const f32x4 d = acc[mt][kk] - mw; s2 += d * d; }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s2[r] = xsum(s2[r]);
+        float* red = reinterpret_cast<float*>(smem + V3_A_BYTES + 4 * (16 * 272));      // behind the transposition rows
+        if (lg == 0) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            red[(wave * 64 + 4 * lc + r) * 2 + 0] = mw[r];
+            red[(wave * 64 + 4 * lc + r) * 2 + 1] = s2[r];
+          }
+        }
+        if (lane == 0) red[4 * 128 + wave] = cntw;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        V3_BARRIER();
+        if (tid < 64) {
+          float n = 0.f, mean = 0.f, m2 = 0.f;
+#pragma unroll
+          for (int w2 = 0; w2 < 4; ++w2) {
+            const float nb_ = red[4 * 128 + w2];
+            if (nb_ > 0.f) {
+              const float mb = red[(w2 * 64 + tid) * 2 + 0], qb = red[(w2 * 64 + tid) * 2 + 1];
+              const float tot = n + nb_, delta = mb - mean, f = __builtin_amdgcn_rcpf(tot) * nb_;
+              mean += delta * f;
+              m2 += qb + delta * delta * (n * f);
+              n = tot;
+            }
+          }
+          a.stats[(size_t)cur.bx * a.Cout_pad + cur.nb * 64 + tid] = make_float4(mean, m2, n, 0.f);
+        }
+      }
+    }
     if (to_y2) {
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) {
@@ -453,7 +603,9 @@ __global__ __launch_bounds__(256, 2) void conv_bf16v3_kernel(ConvV3Args a) {
         }
       }
     }
-    if (to_y2 && a.y2_only) {
+    if (fast) {
+      // (written above)
+    } else if (to_y2 && a.y2_only) {
       // (this block of the result exists as bf16 rows only)
     } else if (!BNRED && !raw && a.y16) {
       // bf16 output: a lane's four channels are one 8-byte store (round-to-nearest-even, v_cvt_pk_bf16_f32)
@@ -481,7 +633,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16v3_kernel(ConvV3Args a) {
 #ifdef HPRI_STAMPS
     if (ntiles_done == 0) { V3_STAMP(2) }
 #endif
-    if (!BNRED && !raw && a.stats != nullptr) {
+    if (!fast && !BNRED && !raw && a.stats != nullptr) {
       // per-tile, per-channel (mean, M2, count): each wave makes an exact two-pass record of its own 64 pixels (sum, then
       // squared deviations from its own mean); the four wave records of a channel are merged with Chan's update after one
       // barrier.  (raw barriers: __syncthreads() would also wait for the output stores above.)
@@ -602,6 +754,8 @@ __global__ __launch_bounds__(256, 2) void conv_bf16v3_kernel(ConvV3Args a) {
 #undef V3_ISSUE_MID
 #undef V3_MFMA_TAP
 #undef V3_READ_TAP
+#undef V3_READ_TAP_A
+#undef V3_READ_TAP_B
 #undef V3_SETPRIO
 #undef V3_PROLOGUE_LOADS
 #undef V3_DMA_A

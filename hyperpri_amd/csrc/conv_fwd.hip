@@ -78,7 +78,9 @@ __global__ __launch_bounds__(256, (WM == 2) ? 3 : 2) void conv_fwd_kernel(ConvFw
   constexpr int NLD_B = (32 * BN / 4) / 256;     // float4 loads per thread per B panel
   // Panel buffers.  The 2x2 shape keeps ONE (45 KB of LDS, 168 VGPRs): three workgroups then share a CU, and a third
   // workgroup covers the panel's DMA latency better than the double buffer inside the workgroup did (+1..4 %, bit-identical).
-  constexpr int NBUF = (WM == 2) ? 1 : 2;
+  // (1x1 forms: the staged tile is 128 pixels, 18 KB, so TWO panel buffers still leave room for three workgroups per CU (50 KB each) and the
+  //  panel of stage s+1 lands under the MFMAs of stage s instead of behind a second barrier: round 4)
+  constexpr int NBUF = (WM == 2 && KS == 3) ? 1 : 2;
   __shared__ __attribute__((aligned(16))) float smem[MAXHP * CS + NBUF * 32 * BN];
   float* a_lds = smem;
   float* b_lds = smem + MAXHP * CS;

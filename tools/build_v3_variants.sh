@@ -4,7 +4,7 @@
 set -e
 cd "$(dirname "$0")/../hyperpri_amd"
 F="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Icsrc"
-OBJS=$(ls lib/*.o | grep -v conv_bf16v3.o)
+OBJS=$(ls lib/*.o | grep -v conv_bf16v3.o | grep -v _diag.o)
 for spec in $1; do
   name=${spec%%:*}; flags=${spec#*:}; flags=${flags//,/ }
   [ "$flags" = "$name" ] && flags=""

@@ -81,6 +81,10 @@ def main():
                   f" | top wait+barrier {wait.median() / nstages:4.0f}/stage | store {store.median():5.0f} | stats {stat.median():5.0f}"
                   f" | {per_item:7.0f} cyc/item ({per_item / nstages:5.0f}/stage; MFMA-bound with a partner {2 * 48 * 16}) | items/wg {t[:, 9].median():.0f}"
                   f" | clock {clk:.2f} GHz | {len(t)} wgs")
+            if (t[:, 10] > 0).any():          # round 4: inside the epilogue of the first item (wave 0): loop end -> next item's prologue issued
+                e = t[t[:, 10] > 0]           #          -> transposition done -> stores issued -> statistics written
+                print(f"      epilogue of the first item: next-item set-up + prologue DMA {(e[:, 10] - e[:, 1]).median():6.0f} | bias + transposition "
+                      f"{(e[:, 11] - e[:, 10]).median():6.0f} | addresses + stores {(e[:, 12] - e[:, 11]).median():6.0f} | statistics {(e[:, 2] - e[:, 12]).median():6.0f}")
 
 
 if __name__ == "__main__":
