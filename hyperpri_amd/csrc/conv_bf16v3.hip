@@ -93,10 +93,11 @@ struct V3Tile { int img, y0, x0, xlim, twl, nb, bx; };
 
 template <bool BNRED>
 __global__ __launch_bounds__(256, 2) void conv_bf16v3_kernel(ConvV3Args a) {
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * V3_A_BYTES + 2 * V3_B_BYTES + 512];
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * V3_A_BYTES + 2 * V3_B_BYTES + 512 + 16];
   unsigned char* a_lds = smem;
   unsigned char* b_lds = smem + 2 * V3_A_BYTES;
   float* bias_lds = reinterpret_cast<float*>(smem + 2 * V3_A_BYTES + 2 * V3_B_BYTES);   // [2 slots][64]: a block's biases (0 beyond Cout)
+  unsigned* arrive_lds = reinterpret_cast<unsigned*>(smem + 2 * V3_A_BYTES + 2 * V3_B_BYTES + 512);   // waves that have left their statistics record
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, lq = lane >> 4;
@@ -255,6 +256,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16v3_kernel(ConvV3Args a) {
   long long wait_cycles = 0;                   // cycles wave 0 spent between the top of a stage and the end of its barrier
   int ntiles_done = 0;
 #endif
+  if (tid == 0) *arrive_lds = 0u;              // (visible behind the first stage's barrier, long before its first use)
   V3_STAMP(0)
   V3_PROLOGUE_LOADS()
   constexpr bool in_loop = true;
@@ -540,7 +542,16 @@ __global__ __launch_bounds__(256, 2) void conv_bf16v3_kernel(ConvV3Args a) {
       if (a.stats != nullptr) {
         // exact two-pass record of this wave's 64 pixels per channel (sum, then squared deviations from the wave's own mean), the
         // four lane groups of a channel quad met by two butterfly steps; the four wave records are merged below as before
-        auto xsum = [](float v) { v += __shfl_xor(v, 16); v += __shfl_xor(v, 32); return v; };
+        // sum over the four 16-lane rows (lanes c, c + 16, c + 32, c + 48): two half-exchanges in the vector ALU instead of two trips
+        // through the LDS crossbar (v_permlane16_swap: rows 1, 3 of vdst <-> rows 0, 2 of src; v_permlane32_swap: upper half of vdst
+        // <-> lower half of src; s_nop 1 = the two wait states a VALU write needs in front of a permlane read, T21)
+        auto xsum = [](float v) {
+          float p = v, q = v;
+          asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(p), "+v"(q));
+          float t = p + q, u = t;
+          asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(t), "+v"(u));
+          return t + u;
+        };
         const float cntw = xsum((float)__builtin_popcount(vm)) ;
         const float inv = cntw > 0.f ? 1.f / cntw : 0.f;
         f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f}, mw;
@@ -567,22 +578,29 @@ __global__ __launch_bounds__(256, 2) void conv_bf16v3_kernel(ConvV3Args a) {
           }
         }
         if (lane == 0) red[4 * 128 + wave] = cntw;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        V3_BARRIER();
-        if (tid < 64) {
+        // No workgroup barrier here (it cost every wave the skew of the slowest one, ~3-4 k cycles of a 19 k epilogue): the wave
+        // that arrives LAST merges the four records, in wave order as before; the others go on to the next item.  Its first
+        // stage barrier -- which the merging wave joins too -- comes before any DMA that could overwrite this scratch.
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's record is in LDS before it counts itself in
+        unsigned arrived = 0u;
+        if (lane == 0) arrived = __hip_atomic_fetch_add(arrive_lds, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        arrived = (unsigned)__builtin_amdgcn_readfirstlane((int)arrived);
+        if (arrived == 3u) {
+          if (lane == 0) *arrive_lds = 0u;
+          const int ch = lane;                   // one channel per lane
           float n = 0.f, mean = 0.f, m2 = 0.f;
 #pragma unroll
           for (int w2 = 0; w2 < 4; ++w2) {
             const float nb_ = red[4 * 128 + w2];
             if (nb_ > 0.f) {
-              const float mb = red[(w2 * 64 + tid) * 2 + 0], qb = red[(w2 * 64 + tid) * 2 + 1];
+              const float mb = red[(w2 * 64 + ch) * 2 + 0], qb = red[(w2 * 64 + ch) * 2 + 1];
               const float tot = n + nb_, delta = mb - mean, f = __builtin_amdgcn_rcpf(tot) * nb_;
               mean += delta * f;
               m2 += qb + delta * delta * (n * f);
               n = tot;
             }
           }
-          a.stats[(size_t)cur.bx * a.Cout_pad + cur.nb * 64 + tid] = make_float4(mean, m2, n, 0.f);
+          a.stats[(size_t)cur.bx * a.Cout_pad + cur.nb * 64 + ch] = make_float4(mean, m2, n, 0.f);
         }
       }
     }
