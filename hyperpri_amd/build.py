@@ -18,7 +18,7 @@ LIBDIR = os.path.join(HERE, "lib")
 # family per precision mode and form.
 DIAG = os.environ.get("HPRI_DIAG", "0") == "1"
 LIB = os.path.join(LIBDIR, "libhyperpri_hip_diag.so" if DIAG else "libhyperpri_hip.so")
-SOURCES = ["api.cpp", "conv_fwd.hip", *(["conv_bf16v2.hip"] if DIAG else []), "conv_bf16v3.hip", "gemm_bf16v3.hip", "wgrad_bf16v3.hip", "conv_wino.hip", "conv_wino4.hip", "conv_wgrad.hip", "conv_wgrad_bf16v2.hip", "pack.hip", "bn.hip", "elementwise.hip", "step.hip", "ingest.hip"]
+SOURCES = ["api.cpp", "conv_fwd.hip", *(["conv_bf16v2.hip"] if DIAG else []), "conv_bf16v3.hip", "gemm_bf16v3.hip", "gemm_f32v2.hip", "wgrad_bf16v3.hip", "conv_wino.hip", "conv_wino4.hip", "conv_wgrad.hip", "conv_wgrad_bf16v2.hip", "pack.hip", "bn.hip", "elementwise.hip", "step.hip", "ingest.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", *(["-DHPRI_DIAG_KERNELS"] if DIAG else [])]
 
 

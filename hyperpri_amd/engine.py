@@ -714,6 +714,27 @@ def _pack(w: torch.Tensor, mode: int, K: int, ncols: int, T: int, cup: int, d1: 
     return _cached_pack(w, ("f32", mode, K, ncols, T, cup, d1), build), ncols_pad
 
 
+# fp32 mode: the ConvTranspose2d forms on gemm_f32v2.hip (persistent, two workgroups per CU, both operands by LDS-DMA) instead of the
+# direct 1x1 kernel, where the shapes allow (Cin % 16 == 0 forward, Cup % 16 == 0 data gradient: every stage of the reference's
+# networks).  A module attribute for A/B measurements, no environment switch.
+GEMM_F32V2 = True
+# ... its data-gradient form measured SLOWER than the direct kernel's gather on the C2 shapes (86.6 vs 95.1 TFLOP/s: 64-byte pieces of
+# 16 different high-resolution pixels per DMA instruction; profiles/r04_convt_f32v2_ab.txt), the forward +7 % (97.5 vs 90.8): forward only.
+GEMM_F32V2_DGRAD = False
+
+
+def _pack_f32k16(w: torch.Tensor, mode: int, K: int, ncols: int, cup: int, d1: int = 0) -> Tuple[torch.Tensor, int]:
+    ncols_pad = _rup(ncols, 64)
+
+    def build():
+        global PACK_LAUNCHES
+        wp = torch.empty(_lib.load().hpri_packed_weight_f32k16_floats(K, ncols_pad), dtype=torch.float32, device=w.device)
+        _lib.call("hpri_pack_weight_f32k16", _p(w), _p(wp), mode, K, ncols, ncols_pad, cup, d1, _stream())
+        PACK_LAUNCHES += 1
+        return wp
+    return _cached_pack(w, ("f32k16", mode, K, ncols, cup, d1), build), ncols_pad
+
+
 def _pack_bf16(w: torch.Tensor, mode: int, K: int, ncols: int, T: int, d1: int, cup: int = 0,
                split: int = 0, gap: Optional[Tuple[int, int]] = None) -> Tuple[torch.Tensor, int]:
     """``gap`` = (first channel, length) of structural-zero channels on the layer's input-channel axis (modes 0 / 1, one plane):
@@ -1396,6 +1417,11 @@ def _upsample_bwd(tp: Tape, c) -> None:
             _conv_launch_bf16(gu, wpd, None, gx, None, x1.N, x1.H, x1.W, 4 * cup, cin, cols_pad, gx.cw, 1,
                               amode=A_S2D, accumulate=int(acc), H2=H2, W2=W2, py0=py0, px0=px0, cup=cup, cin_true=4 * cup,
                               split=_SPLIT.get(bprec, 0))
+        elif GEMM_F32V2_DGRAD and cup % 16 == 0 and H2 * W2 * gu.cs * 4 < 0x7FFFFF00 and x1.N * H2 * W2 < (1 << 31):
+            wpd, cols_pad = _pack_f32k16(weight, 3, 4 * cup, cin, cup)
+            with _timed("gemm_f32v2<convT,s2d>", 2.0 * x1.N * x1.H * x1.W * cin * 4 * cup):
+                _lib.call("hpri_convt_dgrad_f32v2", gu.ptr, gu.cs, gu.coff, _p(wpd), gx.ptr, gx.cs, gx.coff, x1.N, x1.H, x1.W, cup, cin, cols_pad,
+                          gx.cw, H2, W2, py0, px0, int(acc), _stream())
         else:
             wpd, cols_pad = _pack(weight, 3, 4 * cup, cin, 1, cup, cup)
             _conv_launch(gu, wpd, None, gx, None, x1.N, x1.H, x1.W, 4 * cup, cin, cols_pad, gx.cw, 1,
@@ -1470,6 +1496,11 @@ def _upsample_into(tape: Tape, x1: Act, dst: Act, weight: Optional[torch.Tensor]
             wp, ncols_pad = _pack_bf16(weight, 2, cin, 4 * cup, 1, cup, cup, split=usplit)
             _conv_launch_bf16(x1, wp, bias, dst, None, x1.N, x1.H, x1.W, x1.cw, 4 * cup, ncols_pad, 4 * cup, 1,
                               epi=E_D2S, H2=H2, W2=W2, py0=py0, px0=px0, cup=cup, cin_true=cin, split=usplit)
+        elif GEMM_F32V2 and cin % 16 == 0 and x1.N * H2 * W2 < (1 << 31):
+            wp, ncols_pad = _pack_f32k16(weight, 2, cin, 4 * cup, cup)
+            with _timed("gemm_f32v2<convT,d2s>", 2.0 * x1.N * x1.H * x1.W * cin * 4 * cup):
+                _lib.call("hpri_convt_fwd_f32v2", x1.ptr, x1.cs, x1.coff, _p(wp), _p(bias), dst.ptr, dst.cs, dst.coff, x1.N, x1.H, x1.W, cin,
+                          cup, ncols_pad, H2, W2, py0, px0, _stream())
         else:
             wp, ncols_pad = _pack(weight, 2, cin, 4 * cup, 1, cup, cup)
             _conv_launch(x1, wp, bias, dst, None, x1.N, x1.H, x1.W, x1.cw, 4 * cup, ncols_pad, 4 * cup, 1,

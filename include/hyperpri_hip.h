@@ -193,6 +193,25 @@ int hpri_conv_bf16v3_y2(const void* xp, int x_cs, int x_coff, const void* wp, co
                         int y2_coff, int y2_c0, int y2_cw, int y2_only, hipStream_t stream);
 
 
+/* ---- fp32 GEMM for the 1x1 forms of the exact-fp32 mode, second form (gemm_f32v2.hip, round 4): ConvTranspose2d(k=2,s=2) forward and
+ * data gradient (model_parts.py:63-64; models.py:198) and the plain row GEMM, on v_mfma_f32_32x32x2_f32 with both operands by LDS-DMA,
+ * two persistent 4-wave workgroups of 256 pixels x 128 columns per CU.  hpri_pack_weight_f32k16 packs [chunk of 16 k][Ncols_pad][16]
+ * (modes as hpri_pack_weight: 0 Linear forward W[n][k], 1 its data gradient, 2 ConvTranspose2d forward (column = tap*Cup + co), 3 its
+ * data gradient (k = tap*Cup + co); src_d1 = dim 1 of the source tensor for modes 0 / 1).  x rows: x_cs floats apart (multiple of 4),
+ * K_pad (multiple of 16) of them read from x_coff on; pad channels must hold zeros or meet zero weights.  `accumulate` bit 0: y +=
+ * result (not for the depth-to-space form).  No statistics epilogue: layers in front of a BatchNorm keep hpri_conv_fwd. */
+size_t hpri_packed_weight_f32k16_floats(int K, int Ncols_pad);
+int hpri_pack_weight_f32k16(const float* w, float* wp, int mode, int K, int Ncols, int Ncols_pad, int Cup, int src_d1,
+                            hipStream_t stream);
+int hpri_gemm_f32v2(const float* x, int x_cs, int x_coff, const float* wp, const float* bias, float* y, int y_cs, int y_coff,
+                    int N, long long HW, int K_pad, int Ncols, int Ncols_pad, int y_cw, int accumulate, hipStream_t stream);
+int hpri_convt_fwd_f32v2(const float* x, int x_cs, int x_coff, const float* wp, const float* bias, float* y, int y_cs,
+                         int y_coff, int N, int H, int W, int K_pad, int Cup, int Ncols_pad, int H2, int W2, int py0, int px0,
+                         hipStream_t stream);
+int hpri_convt_dgrad_f32v2(const float* dy, int dy_cs, int dy_coff, const float* wp, float* dx, int dx_cs, int dx_coff, int N,
+                           int H, int W, int Cup, int Cin, int Cin_pad, int dx_cw, int H2, int W2, int py0, int px0,
+                           int accumulate, hipStream_t stream);
+
 /* ---- plane-fed GEMM for the 1x1 forms of the bf16 mode (gemm_bf16v3.hip): nn.Linear / Conv2d(k=1) forward and data gradient
  * (models.py:105-115,143; model_parts.py:96) and ConvTranspose2d(k=2,s=2) forward / data gradient (model_parts.py:63-64).
  * hpri_gemm_bf16v3: y[p, n] (+)= sum_k x[p, k] w[n, k] + bias[n]; x = bf16 planes of N*HW rows (x_cs elements per row, K_pad read

@@ -30,7 +30,7 @@ from hyperpri_amd import build as B  # noqa: E402
 # registers.  Anything else in the library (diagnostic entry points, superseded forms kept for A/B) is reported, not gated.
 HOT = (
     "conv_wino4_kernel", "conv_wino_wgrad_kernel", "wino_wgrad_reduce_kernel", "wino_wgrad_reduce_wide_kernel",
-    "conv_bf16v3_kernel", "conv_wgrad_bf16v2_kernel", "gemm_bf16v3_kernel", "wgrad1x1_bf16v3_kernel",
+    "conv_bf16v3_kernel", "conv_wgrad_bf16v2_kernel", "gemm_bf16v3_kernel", "gemm_f32v2_kernel", "wgrad1x1_bf16v3_kernel",
     "conv_fwd_kernel", "conv_wgrad_kernel", "splitk_finish_kernel", "wgrad_reduce", "conv_wino6", "wino6",
     "bn_", "col_", "maxpool2", "nchw_to_nhwc", "outconv", "bce_", "adam", "copy_slice", "fill_pad", "to_planes",
 )
