@@ -111,7 +111,7 @@ def first_conv_traffic():
     kern, why = _replayable(files[-1])
     if kern is None:
         return None, "NOT REPLAYED: " + why
-    src = os.path.relpath(files[-1], ROOT) + " (replayed: rocprofv3 --pmc passes of tools/first_conv.py, not measured in this run)"
+    src = os.path.relpath(files[-1], ROOT) + " (replayed: rocprofv3 --pmc passes of `tools/first_conv.py 10 bf16_out_only`, not measured in this run)"
     for k, v in kern.items():
         if "conv_bf16v3" in k or (("conv_bf16v2" in k) and not any("conv_bf16v3" in q for q in kern)):
             return round(v["hbm_bytes_per_launch"]), src
@@ -298,7 +298,7 @@ def main():
                     help="skip the `value_training_shaped` leg (the same loop with FusedAdam.step() after every backward)")
     ap.add_argument("--no-configs", action="store_true",
                     help="skip the `configs` leg (BASELINE.json's other configurations C1 / C3 / C5 per GPU, fp32 and bf16, 3 + 3 steps each)")
-    ap.add_argument("--bf16-steps", type=int, default=5,
+    ap.add_argument("--bf16-steps", type=int, default=10,
                     help="extra steps in each of the precision modes bf16x6, bf16x3 and bf16 (reported as 'bf16x6_mode' / 'bf16x3_mode' / "
                          "'bf16_mode', never as 'value'); 0 = skip")
     ap.add_argument("--settle-seconds", type=float, default=0.0,
@@ -540,10 +540,14 @@ def main():
                           "note": "4 reads + 3 writes of fp32 per element; not part of `value`"}
 
     # ---- secondary lines: the same workload in the other precision modes (never the headline) ----
+    ms_step_hint = {"bf16": 0.010, "bf16x3": 0.024, "bf16x6": 0.039}      # seconds per step, for sizing the warm-up (~0.25 s) only
     def timed_mode(mode):
         time.sleep(2.0)            # let the clocks recover from the previous mode (DVFS give-back), outside any timed region
         HP.set_precision(net, mode)
-        for _ in range(4):         # (untimed: the caching allocator meets this mode's buffer shapes -- a device allocation inside the timed steps costs ~40 ms)
+        # untimed: the caching allocator meets this mode's buffer shapes (a device allocation inside the timed steps costs ~40 ms),
+        # and the chip, idle during the sleep above, is back at the clock it holds under this load (it rises over tens of
+        # milliseconds: profiles/r04_first_conv_ramp.txt; 4 bf16 steps = 40 ms were not enough: 204.4 vs 207.9 cubes/s over 20 steps)
+        for _ in range(max(4, int(0.25 / max(ms_step_hint.get(mode, 0.02), 1e-3)))):
             step()
         fence()
         m0 = torch.cuda.memory_stats(dev).get("num_device_alloc", 0)
@@ -628,21 +632,23 @@ def main():
         r = FC.measure(reps=10, settle_s=1.0)
         fc_bytes, fc_src = first_conv_traffic()
         bp, b16 = r["bf16_planes"], r.get("bf16_planes_bf16_out")
+        top = b16 or bp          # the form the bf16 step launches (engine.YR_BF16): bf16 planes in, bf16 pre-BN tensor out
         first_conv = {"layer": "CubeNET-64 first_conv 238->64, 3x3, batch 2, forward (bias + BN partial statistics in the epilogue)",
-                      "mode": "bf16 operand planes resident in HBM, both operands by LDS-DMA, " + r.get("bf16_kernel", "") + ", f32 accumulate "
-                              "and f32 output (precision mode 'bf16'; the layout pass that writes the planes is a separate kernel); "
-                              "operands: the workload's synthetic cube u in [0,1) and default-bound weights",
+                      "mode": "bf16 operand planes resident in HBM, both operands by LDS-DMA, " + r.get("bf16_kernel", "") + ", f32 accumulate, "
+                              + ("bf16 pre-BN output written from the accumulators -- the launch the bf16 step makes for this layer "
+                                 "(SURVEY.md 7.3-2: bf16-in / bf16-out); `f32_out` = the same kernel writing an f32 output" if b16 else "f32 output")
+                              + " (the layout pass that writes the input planes is a separate kernel); operands: the workload's synthetic "
+                                "cube u in [0,1) and default-bound weights",
                       "timing": "HIP events over 50 back-to-back launches after 1 s of back-to-back launches of the same kernel (the state the "
                                 "kernel is in inside a step); `*_burst_from_idle`: 10 launches right after three warm-up launches on an idle "
                                 "chip, the protocol of rounds 1-3 (the clock is still rising: tools/first_conv.py, profiles/r04_first_conv_ramp.txt)",
-                      "ms": bp["ms"], "TF": bp["tflops"], "frac_of_2.5PF": bp["frac_of_2.5PF"],
-                      "ms_burst_from_idle": bp["ms_burst_from_idle"], "TF_burst_from_idle": bp["tflops_burst_from_idle"],
-                      "hbm_bytes_algorithmic": int(bp["algorithmic_hbm_mb"] * 1e6),
+                      "ms": top["ms"], "TF": top["tflops"], "frac_of_2.5PF": top["frac_of_2.5PF"],
+                      "ms_burst_from_idle": top["ms_burst_from_idle"],
+                      "hbm_bytes_algorithmic": int(top["algorithmic_hbm_mb"] * 1e6),
                       "hbm_bytes_measured": fc_bytes, "hbm_bytes_measured_source": fc_src,
-                      # what the bf16 step itself launches for this layer: bf16 pre-BN output (fp16-in / fp16-out)
-                      "bf16_in_bf16_out": None if b16 is None else {"ms": b16["ms"], "TF": b16["tflops"], "frac_of_2.5PF": b16["frac_of_2.5PF"],
-                                                                   "hbm_bytes_algorithmic": int(b16["algorithmic_hbm_mb"] * 1e6),
-                                                                   "ms_burst_from_idle": b16["ms_burst_from_idle"]},
+                      "f32_out": {"ms": bp["ms"], "TF": bp["tflops"], "frac_of_2.5PF": bp["frac_of_2.5PF"],
+                                  "hbm_bytes_algorithmic": int(bp["algorithmic_hbm_mb"] * 1e6),
+                                  "ms_burst_from_idle": bp["ms_burst_from_idle"], "TF_burst_from_idle": bp["tflops_burst_from_idle"]},
                       "energy_floor": "profiles/r04_energy_floor.jsonl: a bare loop with this kernel's MFMA / ds_read / LDS-DMA mix per stage and "
                                       "no epilogue sustains 1297-1300 TF = 0.52 of 2.5 PF at 1.54-1.55 GHz in-kernel on random operands",
                       "fp32_kernel_same_layer": r["fp32"], "fp32_winograd_same_layer": r.get("fp32_winograd")}

@@ -504,6 +504,9 @@ def event_log_summary():
 # workgroups fill those tails.  34.35 -> 33.25 ms/step (+3.3 %), bit-identical results.  HPRI_SIDE_STREAM=0 disables it.
 # Under a gradient sink (ddp.GradSync) it needs 8 hardware queues, see SIDE_STREAM_WITH_SINK below.
 SIDE_STREAM = os.environ.get("HPRI_SIDE_STREAM", "1") != "0"
+# (Queueing dW of layer L behind dX of layer L instead -- so that it runs beside the HBM-bound BatchNorm backward of layer L-1
+# rather than beside another MFMA kernel -- measured worse: bf16 207.9 -> 204.1 cubes/s, fp32 63.42 -> 63.11;
+# profiles/r04_ab_wgrad_late.txt.)
 # With a gradient sink installed three or four streams are live during backward (main, weight gradients, RCCL, bucket
 # hand-over).  The HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), and streams that share a
 # queue serialise: with 4 queues the second stream measured -1.6 % under a sink (one rank over RCCL), with 8 it keeps its
