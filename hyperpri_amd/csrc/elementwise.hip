@@ -292,19 +292,24 @@ __global__ __launch_bounds__(256) void outconv_fwd_kernel(const float* __restric
         for (int j = 0; j < 4; ++j)
           if (j < nj) v[u][j] = *reinterpret_cast<const float4*>(xp + qi[j]);
       }
+      // the butterfly leaves every lane of the group with the pixel's sum: lane u (< 4) keeps pixel u, so the bias, the store and
+      // the loss element run once for the four pixels instead of four times behind a one-lane-in-sixteen condition (the exp / log1p
+      // of the loss made this kernel VALU-bound: 2.1 TB/s)
+      float mine = 0.f;
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const long long pg = pg0 + u * ngrp;
         float s = 0.f;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           if (j < nj) { s += v[u][j].x * wq[j].x; s += v[u][j].y * wq[j].y; s += v[u][j].z * wq[j].z; s += v[u][j].w * wq[j].w; }
         s += __shfl_xor(s, 8, 16); s += __shfl_xor(s, 4, 16); s += __shfl_xor(s, 2, 16); s += __shfl_xor(s, 1, 16);
-        if (gl == 0 && pg < NP) {
-          const float o = s + b0;
-          y[pg] = o;
-          if (BCE) bsum += (double)oc_bce_elem(o, target[pg]);
-        }
+        if (gl == u) mine = s;
+      }
+      const long long pgm = pg0 + gl * ngrp;
+      if (gl < 4 && pgm < NP) {
+        const float o = mine + b0;
+        y[pgm] = o;
+        if (BCE) bsum += (double)oc_bce_elem(o, target[pgm]);
       }
     }
   } else
@@ -364,8 +369,19 @@ __global__ void outconv_bwd_data_kernel(const float* __restrict__ dy, const floa
       for (int u = 0; u < 4; ++u) {
         const long long pg = min(pg0 + u * step, NP - 1);
         g[u] = dy[pg];
-        if (BCE) g[u] = oc_bce_grad(g[u], target[pg]) * gs;
+        if (BCE && (C4 < 4 || C4 > 64)) g[u] = oc_bce_grad(g[u], target[pg]) * gs;
         old[u] = accumulate ? *reinterpret_cast<const float4*>(dx + pg * dx_cs + dx_coff + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      if (BCE && C4 >= 4 && C4 <= 64) {
+        // the C4 lanes of a pixel would each evaluate the same exp and division: lane u of the group does it for pixel u and hands
+        // the result round (the four pixels of a thread belong to its whole group: same threadIdx.x / C4)
+        float lg = 0.f, lt = 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (qd == u) { lg = g[u]; lt = target[min(pg0 + u * step, NP - 1)]; }
+        const float mine = oc_bce_grad(lg, lt) * gs;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) g[u] = __shfl(mine, (threadIdx.x & 63 & ~(C4 - 1)) + u, 64);
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -430,8 +446,17 @@ __global__ void outconv_bwd_weight_kernel(const float* __restrict__ dy, const fl
       for (int u = 0; u < 4; ++u) {
         const long long pg = pgs + u * rows;
         g[u] = dy[pg];
-        if (BCE) g[u] = oc_bce_grad(g[u], target[pg]) * gs;
+        if (BCE && (CQ < 4 || CQ > 64)) g[u] = oc_bce_grad(g[u], target[pg]) * gs;
         v[u] = c < C ? *reinterpret_cast<const float4*>(x + pg * x_cs + x_coff + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      if (BCE && CQ >= 4 && CQ <= 64) {      // one exp + division per pixel instead of one per lane (outconv_bwd_data_kernel's exchange)
+        float lg = 0.f, lt = 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (cq == u) { lg = g[u]; lt = target[pgs + u * rows]; }
+        const float mine = oc_bce_grad(lg, lt) * gs;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) g[u] = __shfl(mine, (threadIdx.x & 63 & ~(CQ - 1)) + u, 64);
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
