@@ -243,6 +243,7 @@ __global__ void fill_kernel(float* __restrict__ d, long long n, float v) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) d[i] = v;
 }
 
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // ---------------------------------- 1x1 output conv ---------------------------------------------
 // logits[n][k][p] = sum_c x[n][p][c] * w[k][c] + b[k]   (NHWC in, NCHW out).  One 16-lane group per pixel.
 // BCE-with-logits pieces for the fused head (the loss inside the last layer's kernels; the stand-alone forms
@@ -256,7 +257,17 @@ __device__ __forceinline__ float oc_bce_grad(float xi, float yi) {           // 
 
 // BCE = true: also the per-block fp64 partial sum of BCEWithLogits(y, target) (nn.BCEWithLogitsLoss of PLTrainer.py:86 on the
 // logits this kernel has just produced): one pass over the logits less, the loss finishes with step.hip's finalize kernel
-template <bool BCE>
+// XB: the source is bf16 NHWC rows (plane 0 of an activation's plane buffer; strides and offsets in elements) instead of fp32
+template <bool XB>
+__device__ __forceinline__ float4 oc_load4(const float* __restrict__ x, size_t idx) {
+  if (XB) {
+    const bf16x4_t v = *reinterpret_cast<const bf16x4_t*>(reinterpret_cast<const __bf16*>(x) + idx);
+    return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+  }
+  return *reinterpret_cast<const float4*>(x + idx);
+}
+
+template <bool BCE, bool XB>
 __global__ __launch_bounds__(256) void outconv_fwd_kernel(const float* __restrict__ x, int x_cs, int x_coff, const float* __restrict__ w,
                                    const float* __restrict__ b, float* __restrict__ y, int N, long long P, int C, int K,
                                    const float* __restrict__ target, double* __restrict__ partial) {
@@ -266,7 +277,7 @@ __global__ __launch_bounds__(256) void outconv_fwd_kernel(const float* __restric
   const long long grp = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
   const long long ngrp = ((long long)gridDim.x * blockDim.x) >> 4;
   const int C4 = (C + 3) >> 2;
-  if (K == 1 && (C & 3) == 0 && C4 <= 64) {
+  if (!XB && K == 1 && (C & 3) == 0 && C4 <= 64) {
     // one class, up to 256 channels (every head of the reference: model_parts.py:96 with n_classes = 1): the lane's weight quads live
     // in registers, four pixels are in flight per 16-lane group, no per-pixel division.  Same products in the same order as the
     // generic loop below (bit-identical logits): that loop paid four dependent scalar weight loads, each behind a condition, and a
@@ -314,11 +325,10 @@ __global__ __launch_bounds__(256) void outconv_fwd_kernel(const float* __restric
     }
   } else
   for (long long pg = grp; pg < (long long)N * P; pg += ngrp) {
-    const float* xp = x + pg * x_cs + x_coff;
     for (int k = 0; k < K; ++k) {
       float s = 0.f;
       for (int q = gl; q < C4; q += 16) {
-        const float4 v = *reinterpret_cast<const float4*>(xp + q * 4);
+        const float4 v = oc_load4<XB>(x, (size_t)pg * x_cs + x_coff + q * 4);
         const float* wk = w + (long long)k * C + q * 4;
         s += v.x * wk[0];
         if (q * 4 + 1 < C) s += v.y * wk[1];
@@ -345,48 +355,123 @@ __global__ __launch_bounds__(256) void outconv_fwd_kernel(const float* __restric
   }
 }
 
+// One class over MANY channels (SpectralUNET's Linear(2F, 1), models.py:103: 3300 channels) or over bf16 rows: the weight row sits
+// in LDS (zero beyond C), a 16-lane group walks its pixel in 16-byte pieces per lane (4 fp32 / 8 bf16 channels) with four pixels in
+// flight.  fp32 sources: lane gl adds the quads gl, gl + 16, ... in that order, then the butterfly -- the sums of the kernel above.
+// (That kernel's generic loop on 3300 channels: a 64-bit division per pixel and four conditional scalar weight loads per quad,
+// 1.1 TB/s.)
+template <bool BCE, bool XB>
+__global__ __launch_bounds__(256) void outconv_fwd_wide_kernel(const float* __restrict__ x, int x_cs, int x_coff, const float* __restrict__ w,
+                                                               const float* __restrict__ b, float* __restrict__ y, long long NP, int C,
+                                                               const float* __restrict__ target, double* __restrict__ partial) {
+  extern __shared__ float wl[];                       // C rounded up to a whole round of the 16 lanes
+  __shared__ double bred[256];
+  constexpr int VEC = XB ? 8 : 4;
+  const int Cr = ((C + 16 * VEC - 1) / (16 * VEC)) * (16 * VEC);
+  for (int i = threadIdx.x; i < Cr; i += 256) wl[i] = i < C ? w[i] : 0.f;
+  __syncthreads();
+  const int Cv = ((C + VEC - 1) / VEC) * VEC;         // channels the source holds in whole pieces (its pad channels are zeros)
+  double bsum = 0.0;
+  const int gl = threadIdx.x & 15;
+  const long long grp = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+  const long long ngrp = ((long long)gridDim.x * blockDim.x) >> 4;
+  const float b0 = b ? b[0] : 0.f;
+  for (long long pg0 = grp; pg0 < NP; pg0 += 4 * ngrp) {
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    size_t base[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) base[u] = (size_t)min(pg0 + u * ngrp, NP - 1) * x_cs + x_coff;
+    for (int c = gl * VEC; c < Cv; c += 16 * VEC) {
+      float4 v[4][VEC / 4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (XB) {
+          const bf16x8 t = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(x) + base[u] + c);
+          v[u][0] = make_float4((float)t[0], (float)t[1], (float)t[2], (float)t[3]);
+          v[u][VEC / 4 - 1] = make_float4((float)t[4], (float)t[5], (float)t[6], (float)t[7]);
+        } else {
+          v[u][0] = *reinterpret_cast<const float4*>(x + base[u] + c);
+        }
+      }
+#pragma unroll
+      for (int h = 0; h < VEC / 4; ++h) {
+        const float4 wv = *reinterpret_cast<const float4*>(wl + c + 4 * h);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          s[u] += v[u][h].x * wv.x; s[u] += v[u][h].y * wv.y; s[u] += v[u][h].z * wv.z; s[u] += v[u][h].w * wv.w;
+        }
+      }
+    }
+    float mine = 0.f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float t = s[u];
+      t += __shfl_xor(t, 8, 16); t += __shfl_xor(t, 4, 16); t += __shfl_xor(t, 2, 16); t += __shfl_xor(t, 1, 16);
+      if (gl == u) mine = t;
+    }
+    const long long pgm = pg0 + gl * ngrp;
+    if (gl < 4 && pgm < NP) {
+      const float o = mine + b0;
+      y[pgm] = o;
+      if (BCE) bsum += (double)oc_bce_elem(o, target[pgm]);
+    }
+  }
+  if (BCE) {
+    bred[threadIdx.x] = bsum;
+    __syncthreads();
+    for (int wd = 128; wd > 0; wd >>= 1) {
+      if (threadIdx.x < wd) bred[threadIdx.x] += bred[threadIdx.x + wd];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = bred[0];
+  }
+}
+
 // dx[n][p][c] = sum_k dy[n][k][p] * w[k][c]  (written, or accumulated into dx)
 // BCE = true: dy is not a gradient tensor but the LOGITS; the gradient of the mean BCE-with-logits loss is formed on the fly,
 // g = (sigmoid(logit) - target) * gscale[0] / (N*K*P)
 template <bool BCE>
 __global__ void outconv_bwd_data_kernel(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx,
                                         int dx_cs, int dx_coff, int N, long long P, int C, int Cw, int K, int accumulate,
-                                        const float* __restrict__ target, const float* __restrict__ gscale) {
+                                        const float* __restrict__ target, const float* __restrict__ gscale, int CQ) {
   const float gs = BCE ? (gscale ? gscale[0] : 1.f) / (float)((double)N * K * P) : 1.f;
   const int C4 = Cw >> 2;
   const long long total = (long long)N * P * C4;
-  if (K == 1 && C4 <= 256 && (C4 & (C4 - 1)) == 0 && (C & 3) == 0) {
-    // one class, a power-of-two number of channel quads: a thread keeps ONE quad of the weight row and walks pixels, four in flight
-    // (the generic loop below: a 64-bit division and four conditional scalar weight loads per element)
-    const int qd = threadIdx.x & (C4 - 1), rows = blockDim.x / C4;
-    const int c = qd * 4;
-    const float4 wv = c < C ? *reinterpret_cast<const float4*>(w + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+  if (K == 1) {
+    // one class (grid.y = blocks of CQ channel quads, CQ a power of two <= 64): a thread keeps ONE quad of the weight row and walks
+    // pixels, four in flight (the generic loop below: a 64-bit division and four conditional scalar weight loads per element)
+    const int qd = threadIdx.x & (CQ - 1), rows = blockDim.x / CQ;
+    const int c = (blockIdx.y * CQ + qd) * 4;
+    const bool live = c < Cw;
+    float4 wv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c + 3 < C) wv = *reinterpret_cast<const float4*>(w + c);
+    else { if (c < C) wv.x = w[c]; if (c + 1 < C) wv.y = w[c + 1]; if (c + 2 < C) wv.z = w[c + 2]; }
     const long long NP = (long long)N * P, step = (long long)gridDim.x * rows;
-    for (long long pg0 = (long long)blockIdx.x * rows + threadIdx.x / C4; pg0 < NP; pg0 += 4 * step) {
+    for (long long pg0 = (long long)blockIdx.x * rows + threadIdx.x / CQ; pg0 < NP; pg0 += 4 * step) {
       float g[4];
       float4 old[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const long long pg = min(pg0 + u * step, NP - 1);
         g[u] = dy[pg];
-        if (BCE && (C4 < 4 || C4 > 64)) g[u] = oc_bce_grad(g[u], target[pg]) * gs;
-        old[u] = accumulate ? *reinterpret_cast<const float4*>(dx + pg * dx_cs + dx_coff + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (BCE && CQ < 4) g[u] = oc_bce_grad(g[u], target[pg]) * gs;
+        old[u] = (accumulate && live) ? *reinterpret_cast<const float4*>(dx + pg * dx_cs + dx_coff + c) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
-      if (BCE && C4 >= 4 && C4 <= 64) {
-        // the C4 lanes of a pixel would each evaluate the same exp and division: lane u of the group does it for pixel u and hands
-        // the result round (the four pixels of a thread belong to its whole group: same threadIdx.x / C4)
+      if (BCE && CQ >= 4) {
+        // the CQ lanes of a pixel would each evaluate the same exp and division: lane u of the group does it for pixel u and hands
+        // the result round (the four pixels of a thread belong to its whole group: same threadIdx.x / CQ)
         float lg = 0.f, lt = 0.f;
 #pragma unroll
         for (int u = 0; u < 4; ++u)
           if (qd == u) { lg = g[u]; lt = target[min(pg0 + u * step, NP - 1)]; }
         const float mine = oc_bce_grad(lg, lt) * gs;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) g[u] = __shfl(mine, (threadIdx.x & 63 & ~(C4 - 1)) + u, 64);
+        for (int u = 0; u < 4; ++u) g[u] = __shfl(mine, (threadIdx.x & 63 & ~(CQ - 1)) + u, 64);
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const long long pg = pg0 + u * step;
-        if (pg < NP) {
+        if (pg < NP && live) {
           // (0 + g*w, then + old: the generic loop's order)
           float o0 = 0.f + g[u] * wv.x, o1 = 0.f + g[u] * wv.y, o2 = 0.f + g[u] * wv.z, o3 = 0.f + g[u] * wv.w;
           if (accumulate) { o0 += old[u].x; o1 += old[u].y; o2 += old[u].z; o3 += old[u].w; }
@@ -419,7 +504,7 @@ __global__ void outconv_bwd_data_kernel(const float* __restrict__ dy, const floa
 
 // partial[blk][k][c] = sum over the block's pixels of dy[k][p] * x[p][c]; partial_b[blk][k] = sum dy[k][p]
 // grid = (nblk, ceil(C4/CQ), K); block = 256 = ROWS x CQ
-template <bool BCE>
+template <bool BCE, bool XB>
 __global__ void outconv_bwd_weight_kernel(const float* __restrict__ dy, const float* __restrict__ x, int x_cs, int x_coff,
                                           int N, long long P, int C, int K, int CQ, float* __restrict__ part, int Cpart,
                                           const float* __restrict__ target, const float* __restrict__ gscale) {
@@ -447,7 +532,7 @@ __global__ void outconv_bwd_weight_kernel(const float* __restrict__ dy, const fl
         const long long pg = pgs + u * rows;
         g[u] = dy[pg];
         if (BCE && (CQ < 4 || CQ > 64)) g[u] = oc_bce_grad(g[u], target[pg]) * gs;
-        v[u] = c < C ? *reinterpret_cast<const float4*>(x + pg * x_cs + x_coff + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        v[u] = c < C ? oc_load4<XB>(x, (size_t)pg * x_cs + x_coff + c) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
       if (BCE && CQ >= 4 && CQ <= 64) {      // one exp + division per pixel instead of one per lane (outconv_bwd_data_kernel's exchange)
         float lg = 0.f, lt = 0.f;
@@ -471,7 +556,7 @@ __global__ void outconv_bwd_weight_kernel(const float* __restrict__ dy, const fl
     if (BCE) g = oc_bce_grad(g, target[(n * K + k) * P + p]) * gs;
     sb += g;
     if (c < C) {
-      const float4 v = *reinterpret_cast<const float4*>(x + pg * x_cs + x_coff + c);
+      const float4 v = oc_load4<XB>(x, (size_t)pg * x_cs + x_coff + c);
       s[0] += g * v.x; s[1] += g * v.y; s[2] += g * v.z; s[3] += g * v.w;
     }
   }
@@ -646,15 +731,39 @@ extern "C" int hpri_fill(float* dst, long long n, float value, hipStream_t strea
   return HPRI_OK;
 }
 
-extern "C" int hpri_outconv_fwd(const float* x, int x_cs, int x_coff, const float* w, const float* b, float* y, int N,
-                                long long P, int C, int K, hipStream_t stream) {
+// forward of the head over fp32 rows (XB = false) or bf16 rows (XB = true); target != nullptr: with the loss partials
+template <bool XB>
+static int outconv_fwd_impl(const float* x, int x_cs, int x_coff, const float* w, const float* b, float* y, const float* target,
+                            double* partial, size_t partial_doubles, int N, long long P, int C, int K, hipStream_t stream) {
+  constexpr int VEC = XB ? 8 : 4;
   HPRI_REQUIRE(x && w && y && N > 0 && P > 0 && C > 0 && K > 0, "outconv_fwd: bad arguments");
-  HPRI_REQ_V4(x_cs, x_coff);
-  HPRI_REQUIRE(((C + 3) / 4) * 4 + x_coff <= x_cs, "outconv_fwd: channel stride too small for float4 reads");
-  hipLaunchKernelGGL(outconv_fwd_kernel<false>, dim3(ew_blocks((long long)N * P * 16)), dim3(256), 0, stream, x, x_cs, x_coff, w, b,
-                     y, N, P, C, K, (const float*)nullptr, (double*)nullptr);
+  HPRI_REQUIRE(x_cs % 4 == 0 && x_coff % 4 == 0, "outconv_fwd: channel stride / offset must be multiples of 4");
+  HPRI_REQUIRE(((C + 3) / 4) * 4 + x_coff <= x_cs, "outconv_fwd: channel stride too small for 4-channel reads");
+  const int nb = ew_blocks((long long)N * P * 16);
+  if (target != nullptr && (size_t)nb > partial_doubles) return hpri_set_error(HPRI_ERR_WORKSPACE, "outconv_fwd_bce: partial buffer too small");
+  const int Cr = ((C + 16 * VEC - 1) / (16 * VEC)) * (16 * VEC);
+  const bool wide = K == 1 && (XB || C > 256 || (C & 3) != 0) && Cr <= 12288 && x_cs % VEC == 0 && x_coff % VEC == 0 &&
+                    ((C + VEC - 1) / VEC) * VEC + x_coff <= x_cs;
+  if (wide) {
+    if (target != nullptr)
+      hipLaunchKernelGGL((outconv_fwd_wide_kernel<true, XB>), dim3(nb), dim3(256), Cr * sizeof(float), stream, x, x_cs, x_coff, w, b, y,
+                         (long long)N * P, C, target, partial);
+    else
+      hipLaunchKernelGGL((outconv_fwd_wide_kernel<false, XB>), dim3(nb), dim3(256), Cr * sizeof(float), stream, x, x_cs, x_coff, w, b, y,
+                         (long long)N * P, C, (const float*)nullptr, (double*)nullptr);
+  } else if (target != nullptr) {
+    hipLaunchKernelGGL((outconv_fwd_kernel<true, XB>), dim3(nb), dim3(256), 0, stream, x, x_cs, x_coff, w, b, y, N, P, C, K, target, partial);
+  } else {
+    hipLaunchKernelGGL((outconv_fwd_kernel<false, XB>), dim3(nb), dim3(256), 0, stream, x, x_cs, x_coff, w, b, y, N, P, C, K,
+                       (const float*)nullptr, (double*)nullptr);
+  }
   HPRI_CHECK_LAUNCH();
   return HPRI_OK;
+}
+
+extern "C" int hpri_outconv_fwd(const float* x, int x_cs, int x_coff, const float* w, const float* b, float* y, int N,
+                                long long P, int C, int K, hipStream_t stream) {
+  return outconv_fwd_impl<false>(x, x_cs, x_coff, w, b, y, nullptr, nullptr, 0, N, P, C, K, stream);
 }
 
 // The same head with nn.BCEWithLogitsLoss() (mean) of its logits against `target` (N, K, P) computed on the way: `partial` receives
@@ -662,14 +771,17 @@ extern "C" int hpri_outconv_fwd(const float* x, int x_cs, int x_coff, const floa
 extern "C" size_t hpri_outconv_fwd_bce_blocks(int N, long long P) { return (size_t)ew_blocks((long long)N * P * 16); }
 extern "C" int hpri_outconv_fwd_bce(const float* x, int x_cs, int x_coff, const float* w, const float* b, float* y, const float* target,
                                     double* partial, size_t partial_doubles, int N, long long P, int C, int K, hipStream_t stream) {
-  HPRI_REQUIRE(x && w && y && target && partial && N > 0 && P > 0 && C > 0 && K > 0, "outconv_fwd_bce: bad arguments");
-  HPRI_REQ_V4(x_cs, x_coff);
-  HPRI_REQUIRE(((C + 3) / 4) * 4 + x_coff <= x_cs, "outconv_fwd_bce: channel stride too small for float4 reads");
-  const int nb = ew_blocks((long long)N * P * 16);
-  if ((size_t)nb > partial_doubles) return hpri_set_error(HPRI_ERR_WORKSPACE, "outconv_fwd_bce: partial buffer too small");
-  hipLaunchKernelGGL(outconv_fwd_kernel<true>, dim3(nb), dim3(256), 0, stream, x, x_cs, x_coff, w, b, y, N, P, C, K, target, partial);
-  HPRI_CHECK_LAUNCH();
-  return HPRI_OK;
+  HPRI_REQUIRE(target && partial, "outconv_fwd_bce: bad arguments");
+  return outconv_fwd_impl<false>(x, x_cs, x_coff, w, b, y, target, partial, partial_doubles, N, P, C, K, stream);
+}
+
+// ... over bf16 rows: the input is plane 0 of an activation's plane buffer (bf16 NHWC, x_cs / x_coff in elements, pad channels zero):
+// the head of the bf16 mode reads what the last BatchNorm pass wrote for it, and no fp32 copy of that tensor exists.
+// target == nullptr: logits only.
+extern "C" int hpri_outconv_fwd_x16(const void* x16, int x_cs, int x_coff, const float* w, const float* b, float* y, const float* target,
+                                    double* partial, size_t partial_doubles, int N, long long P, int C, int K, hipStream_t stream) {
+  HPRI_REQUIRE(target == nullptr || partial != nullptr, "outconv_fwd_x16: bad arguments");
+  return outconv_fwd_impl<true>(reinterpret_cast<const float*>(x16), x_cs, x_coff, w, b, y, target, partial, partial_doubles, N, P, C, K, stream);
 }
 
 static inline int pick_cq(int c4) { int q = 1; while (q < c4 && q < 64) q <<= 1; return q; }
@@ -685,6 +797,7 @@ extern "C" int hpri_outconv_bwd_plan(int N, long long P, int C, int K, int* nblk
 }
 
 // dx (optional), dw, db of the 1x1 output conv.  workspace: nblk*K*2*Cpart floats (hpri_outconv_bwd_plan)
+template <bool XB>
 static int outconv_bwd_impl(const float* dy, const float* target, const float* gscale, const float* x, int x_cs, int x_coff,
                             const float* w, float* dx, int dx_cs, int dx_coff, int dx_cw, int dx_accumulate, float* dw, float* db,
                             int accumulate_param_grads, float* workspace, size_t ws_floats, int N, long long P, int C,
@@ -695,12 +808,22 @@ static int outconv_bwd_impl(const float* dy, const float* target, const float* g
   if (dx != nullptr) {
     HPRI_REQ_V4(dx_cs, dx_coff);
     HPRI_REQUIRE(dx_cw % 4 == 0 && dx_cw >= C && dx_cw + dx_coff <= dx_cs, "outconv_bwd: dx channel layout");
+    dim3 grid(ew_blocks((long long)N * P * (dx_cw / 4)));
+    int dq = 1;
+    if (K == 1) {                          // (nbx, blocks of dq channel quads)
+      dq = pick_cq(dx_cw / 4);
+      const int ycols = hpri_cdiv(dx_cw / 4, dq), rows = 256 / dq;
+      long long nbx = hpri_cdiv((long long)N * P, (long long)rows * 4);
+      const long long cap = 8192 / ycols > 0 ? 8192 / ycols : 1;
+      if (nbx > cap) nbx = cap;
+      grid = dim3((unsigned)nbx, ycols);
+    }
     if (bce)
-      hipLaunchKernelGGL(outconv_bwd_data_kernel<true>, dim3(ew_blocks((long long)N * P * (dx_cw / 4))), dim3(256), 0, stream, dy, w,
-                         dx, dx_cs, dx_coff, N, P, C, dx_cw, K, dx_accumulate, target, gscale);
+      hipLaunchKernelGGL(outconv_bwd_data_kernel<true>, grid, dim3(256), 0, stream, dy, w,
+                         dx, dx_cs, dx_coff, N, P, C, dx_cw, K, dx_accumulate, target, gscale, dq);
     else
-      hipLaunchKernelGGL(outconv_bwd_data_kernel<false>, dim3(ew_blocks((long long)N * P * (dx_cw / 4))), dim3(256), 0, stream, dy, w,
-                         dx, dx_cs, dx_coff, N, P, C, dx_cw, K, dx_accumulate, (const float*)nullptr, (const float*)nullptr);
+      hipLaunchKernelGGL(outconv_bwd_data_kernel<false>, grid, dim3(256), 0, stream, dy, w,
+                         dx, dx_cs, dx_coff, N, P, C, dx_cw, K, dx_accumulate, (const float*)nullptr, (const float*)nullptr, dq);
     HPRI_CHECK_LAUNCH();
   }
   int nblk, Cpart;
@@ -708,10 +831,10 @@ static int outconv_bwd_impl(const float* dy, const float* target, const float* g
   if ((size_t)nblk * K * 2 * Cpart > ws_floats) return hpri_set_error(HPRI_ERR_WORKSPACE, "outconv_bwd: workspace too small");
   const int c4 = hpri_cdiv(C, 4), cq = pick_cq(c4);
   if (bce)
-    hipLaunchKernelGGL(outconv_bwd_weight_kernel<true>, dim3(nblk, hpri_cdiv(c4, cq), K), dim3(256), 0, stream, dy, x, x_cs, x_coff,
+    hipLaunchKernelGGL((outconv_bwd_weight_kernel<true, XB>), dim3(nblk, hpri_cdiv(c4, cq), K), dim3(256), 0, stream, dy, x, x_cs, x_coff,
                        N, P, C, K, cq, workspace, Cpart, target, gscale);
   else
-    hipLaunchKernelGGL(outconv_bwd_weight_kernel<false>, dim3(nblk, hpri_cdiv(c4, cq), K), dim3(256), 0, stream, dy, x, x_cs, x_coff,
+    hipLaunchKernelGGL((outconv_bwd_weight_kernel<false, XB>), dim3(nblk, hpri_cdiv(c4, cq), K), dim3(256), 0, stream, dy, x, x_cs, x_coff,
                        N, P, C, K, cq, workspace, Cpart, (const float*)nullptr, (const float*)nullptr);
   HPRI_CHECK_LAUNCH();
   hipLaunchKernelGGL(outconv_bwd_weight_finalize_kernel, dim3(K * (C + 1)), dim3(256), 0, stream, workspace,
@@ -724,7 +847,7 @@ extern "C" int hpri_outconv_bwd(const float* dy, const float* x, int x_cs, int x
                                 int dx_cs, int dx_coff, int dx_cw, int dx_accumulate, float* dw, float* db,
                                 int accumulate_param_grads, float* workspace, size_t ws_floats, int N, long long P, int C,
                                 int K, hipStream_t stream) {
-  return outconv_bwd_impl(dy, nullptr, nullptr, x, x_cs, x_coff, w, dx, dx_cs, dx_coff, dx_cw, dx_accumulate, dw, db,
+  return outconv_bwd_impl<false>(dy, nullptr, nullptr, x, x_cs, x_coff, w, dx, dx_cs, dx_coff, dx_cw, dx_accumulate, dw, db,
                           accumulate_param_grads, workspace, ws_floats, N, P, C, K, stream);
 }
 
@@ -736,8 +859,18 @@ extern "C" int hpri_outconv_bwd_bce(const float* logits, const float* target, co
                                     float* db, int accumulate_param_grads, float* workspace, size_t ws_floats, int N, long long P,
                                     int C, int K, hipStream_t stream) {
   HPRI_REQUIRE(target != nullptr, "outconv_bwd_bce: null target");
-  return outconv_bwd_impl(logits, target, gscale, x, x_cs, x_coff, w, dx, dx_cs, dx_coff, dx_cw, dx_accumulate, dw, db,
-                          accumulate_param_grads, workspace, ws_floats, N, P, C, K, stream);
+  return outconv_bwd_impl<false>(logits, target, gscale, x, x_cs, x_coff, w, dx, dx_cs, dx_coff, dx_cw, dx_accumulate, dw, db,
+                                 accumulate_param_grads, workspace, ws_floats, N, P, C, K, stream);
+}
+
+// Backward of the head over bf16 rows (hpri_outconv_fwd_x16): dw / db read x16; dx (fp32, optional) as hpri_outconv_bwd.
+// target != nullptr: `dy` holds the LOGITS and the loss gradient is formed inside the kernels (hpri_outconv_bwd_bce).
+extern "C" int hpri_outconv_bwd_x16(const float* dy, const float* target, const float* gscale, const void* x16, int x_cs, int x_coff,
+                                    const float* w, float* dx, int dx_cs, int dx_coff, int dx_cw, int dx_accumulate, float* dw,
+                                    float* db, int accumulate_param_grads, float* workspace, size_t ws_floats, int N, long long P,
+                                    int C, int K, hipStream_t stream) {
+  return outconv_bwd_impl<true>(dy, target, gscale, reinterpret_cast<const float*>(x16), x_cs, x_coff, w, dx, dx_cs, dx_coff, dx_cw,
+                                dx_accumulate, dw, db, accumulate_param_grads, workspace, ws_floats, N, P, C, K, stream);
 }
 
 extern "C" int hpri_synth_fill(float* dst, long long n, unsigned long long seed, int mode, float thr, float scale,
@@ -908,7 +1041,6 @@ extern "C" int hpri_copy_slice_any(const float* src, int s_cs, int s_coff, float
   return HPRI_OK;
 }
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // ---- fp32 NHWC view -> bf16 planes (generic producer; fused producers write planes themselves) ---------------------------
 // planes[p][pixel][cs16]: plane 0 = bf16(x), plane 1 = bf16(x - hi), plane 2 = bf16(x - hi - mid); channels [C, cw16) = 0
 __global__ void to_planes_kernel(const float* __restrict__ x, int cs, int coff, __bf16* __restrict__ pl, long long plane,

@@ -802,7 +802,7 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
                  train: bool, ks: int, groups: int = 1, relu: bool = True, need_dx: bool = True,
                  precision: Optional[str] = None, room: int = 0, next_cout: int = 0, cat_room: int = 0,
                  cat_into: Optional[Act] = None, k_gap: Optional[Tuple[int, int]] = None, planes_only: bool = False,
-                 out_planes: bool = False) -> Act:
+                 out_planes: bool = False, head_next: bool = False) -> Act:
     """Conv2d(k=ks, pad=ks//2) -> BatchNorm -> ReLU  (model_parts.py:22-27; models.py:169-180 with the
     Conv3d weight (F,1,D,3,3) read as (F,D,3,3); models.py:108-114 for Linear -> BatchNorm1d -> ReLU with
     ks = 1 and ``groups`` = images, each image being its own BN batch, models.py:132).
@@ -811,7 +811,10 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
     present): ``cat_room`` = C2 > 0: the result's planes are the first half of a padded concat [this | zeros to a multiple of
     32 | C2 channels]; ``cat_into`` = a: the result's planes are the second half of ``a``'s concat (``concat_planes`` then has
     nothing to copy); ``k_gap``: ``x`` is such a concat -- (first, length) of its structural-zero channels, which the weight does
-    not have; ``planes_only``: every consumer of the result reads planes (no fp32 copy is written)."""
+    not have; ``planes_only``: every consumer of the result reads planes (no fp32 copy is written).
+
+    ``head_next``: the only reader of the result is the 1x1 output layer (``out_conv``): in the bf16 mode the result is written as
+    bf16 planes only and the head reads those (``head_planes_mode``)."""
     T = ks * ks
     cout = weight.shape[0]
     cin = weight.numel() // (cout * T)
@@ -830,7 +833,7 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
     if bn is None:
         c.y, c.st = c.yr, None
     else:
-        _bn_forward(c, room, next_cout, cat_room, cat_into, planes_only, out_planes)
+        _bn_forward(c, room, next_cout, cat_room, cat_into, planes_only, out_planes, head_next)
     y = c.y
     if not tape.record:
         return y
@@ -919,7 +922,8 @@ def _conv_forward(c) -> None:
     c.yr, c.stats, c.tiles = yr, stats, tiles
 
 
-def _bn_forward(c, room: int, next_cout: int, cat_room: int, cat_into: Optional[Act], planes_only: bool, out_planes: bool) -> None:
+def _bn_forward(c, room: int, next_cout: int, cat_room: int, cat_into: Optional[Act], planes_only: bool, out_planes: bool,
+                head_next: bool = False) -> None:
     """BatchNorm finalize (batch statistics from the conv epilogue's records, or the running ones) + normalise + ReLU.  Leaves
     c.y (the stage's output, with its bf16 planes where a plane reader follows) and c.st (mean, invstd, var, scale, shift)."""
     global _BN_EPOCH
@@ -959,6 +963,10 @@ def _bn_forward(c, room: int, next_cout: int, cat_room: int, cat_into: Optional[
             raise RuntimeError("hyperpri_amd: internal error: concat halves do not match")
         ypl = y.pl = Planes(cbuf, y.P * ccs, ccs, ob, 1, cw=ccs - ob)
     if planes_only:
+        y.f32_valid = False
+    if head_next and HEAD_PLANES and c.v2 and y.want_pl and room == 0 and ypl is None and c.prec == "bf16":
+        # the head is the only reader: planes for it, no fp32 copy (301 MB less written and 150 MB less read per C2 step)
+        ypl = new_planes(y, 1)
         y.f32_valid = False
     cpl = None
     if ypl is None and y.want_pl and y.parent is not None and PLANES_CONCAT and y.C % 8 == 0:
@@ -1674,6 +1682,10 @@ def convt_planes_mode(module) -> bool:
 
 # (HPRI_FUSIONS off: SpectralUNET's skips are concatenated in fp32 by copies and converted to planes afterwards.)
 PLANES_CAT1 = FUSIONS
+# bf16 mode: the 1x1 output layer reads the bf16 planes its producer wrote for it (hpri_outconv_*_x16) -- the last DoubleConv of the
+# U-Nets, the plane concat [tail | up4] of SpectralUNET -- instead of an fp32 copy (and, SpectralUNET, instead of a copied fp32
+# concat of 2 x 1650 channels: 9 of 135 ms per C3 step).  (HPRI_FUSIONS.)
+HEAD_PLANES = FUSIONS
 
 
 def concat_planes(tape: Tape, a: Act, b: Act) -> Tuple[Act, Tuple[int, int]]:
@@ -1725,16 +1737,41 @@ def pending_bce(target: torch.Tensor):
         _PENDING.bce = prev
 
 
-def out_conv(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.Tensor], need_dx: bool = True, fuse_loss: bool = True):
+def _head_weight_gapped(weight: torch.Tensor, K: int, Cw: int, gap: Tuple[int, int]) -> torch.Tensor:
+    """The head's (K, Cw) weight with ``gap`` = (first, length) zero columns inserted: the layout of a padded plane concat."""
+    g0, gl = gap
+
+    def build():
+        wg = torch.empty(K * (Cw + gl), dtype=torch.float32, device=weight.device)
+        _lib.call("hpri_copy_slice_any", _p(weight), Cw, 0, _p(wg), Cw + gl, 0, K, g0, g0 + gl, 0, _stream())
+        _lib.call("hpri_copy_slice_any", _p(weight), Cw, g0, _p(wg), Cw + gl, g0 + gl, K, Cw - g0, 0, 0, _stream())
+        return wg
+    return _cached_pack(weight, ("head_gap", g0, gl), build)
+
+
+def out_conv(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.Tensor], need_dx: bool = True, fuse_loss: bool = True,
+             k_gap: Optional[Tuple[int, int]] = None):
     """nn.Conv2d(C, n_classes, 1) (model_parts.py:96) / nn.Linear(2F, n_classes) (models.py:103,143).
     Returns (logits NCHW tensor, register_grad) -- the caller hands the incoming NCHW gradient to
     ``register_grad`` before running the tape backwards.  ``fuse_loss=False``: the caller re-orders the logits afterwards,
-    so a pending forward_loss() target does not line up with them element by element."""
+    so a pending forward_loss() target does not line up with them element by element.
+
+    bf16 mode: when the producer of ``x`` wrote bf16 planes for this reader (``conv_bn_relu(head_next=True)``, or the plane concat
+    of SpectralUNET's last skip: ``k_gap`` = (first, length) of its structural-zero channels, which the weight does not have) the
+    head reads those rows (hpri_outconv_*_x16) and no fp32 copy of ``x`` exists."""
     K = weight.shape[0]
-    C = weight.numel() // K
+    Cw = weight.numel() // K
+    C = Cw + (k_gap[1] if k_gap else 0)
     if C != x.C:
         raise RuntimeError(f"hyperpri_amd: out conv expects {C} channels, got {x.C}")
     dev = x.buf.device
+    x16 = x.pl is not None and not x.f32_valid
+    if not x.f32_valid and x.pl is None:
+        raise RuntimeError("hyperpri_amd: internal error: a planes-only activation without planes reached the head")
+    if k_gap and not x16:
+        raise RuntimeError("hyperpri_amd: internal error: a gapped concat reaches the head on planes only")
+    wsrc = _head_weight_gapped(weight, K, Cw, k_gap) if k_gap else weight
+    xa = (_p(x.pl.buf), x.pl.cs, x.pl.coff) if x16 else (x.ptr, x.cs, x.coff)
     y = torch.empty((x.N, K, x.H, x.W), dtype=torch.float32, device=dev)
     holder: Dict[str, torch.Tensor] = {}
     slot = getattr(_PENDING, "bce", None)
@@ -1744,7 +1781,7 @@ def out_conv(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.Tens
         nblk = _lib.load().hpri_outconv_fwd_bce_blocks(x.N, x.H * x.W)
         part = torch.empty(nblk, dtype=torch.float64, device=dev)
         loss = torch.empty((), dtype=torch.float32, device=dev)
-        _lib.call("hpri_outconv_fwd_bce", x.ptr, x.cs, x.coff, _p(weight), _p(bias), _p(y), _p(tgt), _p(part), nblk,
+        _lib.call("hpri_outconv_fwd_x16" if x16 else "hpri_outconv_fwd_bce", *xa, _p(wsrc), _p(bias), _p(y), _p(tgt), _p(part), nblk,
                   x.N, x.H * x.W, C, K, _stream())
         _lib.call("hpri_bce_finish", _p(part), nblk, y.numel(), _p(loss), _stream())
         # a DETACHED alias of the logits (same storage, same version counter, no grad_fn): holding ``y`` itself would close the
@@ -1752,6 +1789,9 @@ def out_conv(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.Tens
         holder["bce_y"], holder["bce_t"] = y.detach(), tgt
         holder["bce_ver"] = (y._version, tgt._version)
         slot.used, slot.loss, slot.holder = True, loss, holder
+    elif x16:
+        _lib.call("hpri_outconv_fwd_x16", *xa, _p(wsrc), _p(bias), _p(y), ctypes.c_void_p(0), ctypes.c_void_p(0), 0,
+                  x.N, x.H * x.W, C, K, _stream())
     else:
         _lib.call("hpri_outconv_fwd", x.ptr, x.cs, x.coff, _p(weight), _p(bias), _p(y), x.N, x.H * x.W, C, K, _stream())
     if tape.record:
@@ -1787,12 +1827,26 @@ def out_conv(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.Tens
                 gxp, gcs, gco, gcw = gx.ptr, gx.cs, gx.coff, gx.cw
             else:
                 gxp, gcs, gco, gcw, acc = ctypes.c_void_p(0), 0, 0, 0, False
-            if fused:
+            # a gapped weight: its gradient lands in a (K, C) scratch row and moves to the parameter's layout afterwards
+            dwk = torch.empty(K * C, dtype=torch.float32, device=dev) if k_gap else dw
+            dbk = torch.empty(K, dtype=torch.float32, device=dev) if (k_gap and db is not None) else db
+            acc_k = 0 if k_gap else acc_w
+            if x16:
+                _lib.call("hpri_outconv_bwd_x16", _p(gy), _p(tgt) if fused else ctypes.c_void_p(0), _p(gs) if fused else ctypes.c_void_p(0),
+                          *xa, _p(wsrc), gxp, gcs, gco, gcw, int(acc), _p(dwk), _p(dbk), acc_k, _p(ws), ws.numel(),
+                          x.N, x.H * x.W, C, K, _stream())
+            elif fused:
                 _lib.call("hpri_outconv_bwd_bce", _p(gy), _p(tgt), _p(gs), x.ptr, x.cs, x.coff, _p(weight), gxp, gcs, gco, gcw,
                           int(acc), _p(dw), _p(db), acc_w, _p(ws), ws.numel(), x.N, x.H * x.W, C, K, _stream())
             else:
                 _lib.call("hpri_outconv_bwd", _p(gy), x.ptr, x.cs, x.coff, _p(weight), gxp, gcs, gco, gcw, int(acc),
                           _p(dw), _p(db), acc_w, _p(ws), ws.numel(), x.N, x.H * x.W, C, K, _stream())
+            if k_gap:
+                g0, gl = k_gap
+                _lib.call("hpri_copy_slice_any", _p(dwk), C, 0, _p(dw), Cw, 0, K, g0, 0, acc_w, _stream())
+                _lib.call("hpri_copy_slice_any", _p(dwk), C, g0 + gl, _p(dw), Cw, g0, K, Cw - g0, 0, acc_w, _stream())
+                if db is not None:
+                    _lib.call("hpri_copy_slice_any", _p(dbk), 1, 0, _p(db), 1, 0, K, 1, 0, acc_w, _stream())
         tape.note_params(weight, bias)
         tape.nodes.append(bwd)
     return y, holder

@@ -61,7 +61,7 @@ class UNet(nn.Module):
                 y = self.up1._ops(tape, x5, x4, out_planes=cp)
                 y = self.up2._ops(tape, y, x3, out_planes=cp)
                 y = self.up3._ops(tape, y, x2, out_planes=cp)
-                y = self.up4._ops(tape, y, x1)
+                y = self.up4._ops(tape, y, x1, head_next=True)          # (bf16 mode: the head reads its input as bf16 planes)
                 return self.outc._ops(tape, y)
             logits = run(prog, [x], list(self.parameters()), input_planes=E.input_planes_for(self), name="unet")
         else:
@@ -122,7 +122,8 @@ class SpectralUNET(torch.nn.Module):
                 # padded plane buffer ([skip | zeros to a multiple of 32 | up]), the consumer's weight packs carry the gap -- and the
                 # tensors between the layers exist as planes only (torch.cat of models.py:139-143 without a byte moved)
                 f = self.layer_feats[0]
-                x0 = L(tape, a[0], self.tail, need[0])
+                hp = E.HEAD_PLANES
+                x0 = L(tape, a[0], self.tail, need[0], **({"cat_room": f, "planes_only": True} if hp else {}))
                 x1 = L(tape, x0, self.down1, cat_room=f, planes_only=True)
                 x2 = L(tape, x1, self.down2, cat_room=f, planes_only=True)
                 x3 = L(tape, x2, self.down3, cat_room=f, planes_only=True)
@@ -133,6 +134,11 @@ class SpectralUNET(torch.nn.Module):
                 c, gap = E.concat_planes(tape, x2, t)
                 t = L(tape, c, self.up3, k_gap=gap, cat_into=x1, planes_only=True)
                 c, gap = E.concat_planes(tape, x1, t)
+                if hp:
+                    # ... and so is the last one: the head reads the padded plane concat [tail | up4] through a weight row with the gap
+                    t = L(tape, c, self.up4, k_gap=gap, cat_into=x0, planes_only=True)
+                    c, gap = E.concat_planes(tape, x0, t)
+                    return E.out_conv(tape, c, self.outc.weight, self.outc.bias, fuse_loss=self.n_classes == 1, k_gap=gap)
                 t = L(tape, c, self.up4, k_gap=gap)
                 return E.out_conv(tape, E.concat_channels(tape, x0, t), self.outc.weight, self.outc.bias, fuse_loss=self.n_classes == 1)
             x0 = L(tape, a[0], self.tail, need[0])
@@ -198,14 +204,14 @@ class CubeNET(torch.nn.Module):
         params = list(self.inc.parameters()) + list(self.inc2.parameters())
         return run(lambda tape, a, need: self._stem_ops(tape, a[0], need[0]), [x], params, name="cubenet_stem")
 
-    def _up4_ops(self, tape, y, x1, need_dx1=True):
+    def _up4_ops(self, tape, y, x1, need_dx1=True, head_next=False):
         """Last decoder stage: ``up4`` (first_depth 64) or the inline upsample4 -> pad -> cat -> upconv4 (models.py:229-240)."""
         if self.first_depth == 64:
-            return self.up4._ops(tape, y, x1, need_dx1)
+            return self.up4._ops(tape, y, x1, need_dx1, head_next=head_next)
         w4 = None if self.bilinear else self.upsample4.weight
         b4 = None if self.bilinear else self.upsample4.bias
         cat = E.up_concat(tape, y, x1, w4, b4, need_dx1=need_dx1, precision=getattr(self, "hpri_precision", None))
-        return self.upconv4._ops(tape, cat)
+        return self.upconv4._ops(tape, cat, head_next=head_next)
 
     fused_tape = True       # see UNet.fused_tape
 
@@ -225,7 +231,7 @@ class CubeNET(torch.nn.Module):
                 y = self.up1._ops(tape, x5, x4, out_planes=cp)
                 y = self.up2._ops(tape, y, x3, out_planes=cp)
                 y = self.up3._ops(tape, y, x2, out_planes=cp)
-                y = self._up4_ops(tape, y, x1)
+                y = self._up4_ops(tape, y, x1, head_next=True)
                 return self.outc._ops(tape, y)
             logits = run(prog, [x], list(self.parameters()), input_planes=E.input_planes_for(self), name="cubenet")
         else:

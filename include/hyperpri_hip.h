@@ -376,6 +376,16 @@ int hpri_outconv_bwd_bce(const float* logits, const float* target, const float* 
                          const float* w, float* dx, int dx_cs, int dx_coff, int dx_cw, int dx_accumulate, float* dw, float* db,
                          int accumulate_param_grads, float* workspace, size_t ws_floats, int N, long long P, int C, int K,
                          hipStream_t stream);
+/* The head of the bf16 mode (model_parts.py:96 / models.py:103,143 after a bf16-mode layer): the input is plane 0 of the last
+ * activation's plane buffer -- bf16 NHWC rows, x_cs / x_coff in elements (multiples of 8), pad channels zero -- so no fp32 copy of
+ * that tensor is written or read.  target != NULL: with the loss partials (forward) / `dy` holds the logits and the loss gradient is
+ * formed inside the kernels (backward), as hpri_outconv_fwd_bce / hpri_outconv_bwd_bce.  dx stays fp32. */
+int hpri_outconv_fwd_x16(const void* x16, int x_cs, int x_coff, const float* w, const float* b, float* y, const float* target,
+                         double* partial, size_t partial_doubles, int N, long long P, int C, int K, hipStream_t stream);
+int hpri_outconv_bwd_x16(const float* dy, const float* target, const float* gscale, const void* x16, int x_cs, int x_coff,
+                         const float* w, float* dx, int dx_cs, int dx_coff, int dx_cw, int dx_accumulate, float* dw, float* db,
+                         int accumulate_param_grads, float* workspace, size_t ws_floats, int N, long long P, int C, int K,
+                         hipStream_t stream);
 /* nn.Upsample(scale_factor=2, 'bilinear', align_corners=True) (model_parts.py:57; models.py:195) writing at a pixel
  * offset of a padded destination, its gather-form gradient, and the element-wise "attention" product x2*x1
  * (model_parts.py:84-85). */

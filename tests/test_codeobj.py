@@ -15,7 +15,7 @@ def test_hot_path_kernels_do_not_spill():
     names = {k["demangled"].split("(")[0].replace("void ", "") for k in rep["kernels"]}
     # the report really covers the kernels a step launches
     for must in ("conv_wino4_kernel", "conv_bf16v3_kernel<false>", "gemm_bf16v3_kernel<1>", "wino_wgrad_reduce_wide_kernel<16>",
-                 "conv_wino_wgrad_kernel", "wgrad1x1_bf16v3_kernel<0>", "outconv_fwd_kernel<true>"):
+                 "conv_wino_wgrad_kernel", "wgrad1x1_bf16v3_kernel<0>", "outconv_fwd_kernel<true, false>", "outconv_fwd_wide_kernel<true, true>"):
         assert must in names, f"{must} missing from the code-object report"
     hot = [k for k in rep["kernels"] if k["hot"]]
     assert len(hot) >= 40

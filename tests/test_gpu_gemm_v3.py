@@ -257,7 +257,9 @@ def test_transposed_convolution_weight_gradient_from_planes(lib, shape):
 @pytest.mark.parametrize("only", [0, 1])
 def test_bf16_plane_conv_v3_second_output(lib, shape, only):
     """hpri_conv_bf16v3_y2: the data gradient of the first convolution of a decoder stage also (only = 1: only) leaves the channel
-    blocks of the upsampled half as bf16 rows; everything else is the plain launch bit for bit, statistics included."""
+    blocks of the upsampled half as bf16 rows; everything else is the plain launch bit for bit.  The per-tile statistics are the same
+    records up to summation order (round 4: the plain launch sums them after its LDS transposition, this form straight from the
+    accumulators): counts equal, means and M2 to 1e-5 of their scale."""
     N, H, W, K, Cols, c0, cw2 = shape
     torch.manual_seed(19)
     cs16, cols_pad, cw = rup(K, 32), rup(Cols, 64), rup(Cols, 8)
@@ -283,7 +285,10 @@ def test_bf16_plane_conv_v3_second_output(lib, shape, only):
                                  cw2, only, _st())
     assert rc == 0, lib.hpri_last_error()
     torch.cuda.synchronize()
-    assert torch.equal(st1, st2)
+    r1, r2 = st1.view(-1, 4), st2.view(-1, 4)
+    assert torch.equal(r1[:, 2], r2[:, 2])
+    for j in (0, 1):
+        assert float((r1[:, j] - r2[:, j]).abs().max()) <= 1e-5 * max(1.0, float(r1[:, j].abs().max()))
     assert torch.equal(y2[:, 4:4 + cw2], g_plain[:, c0:c0 + cw2].to(torch.bfloat16))
     assert float(y2[:, :4].float().sub(5.0).abs().max()) == 0.0 and float(y2[:, 4 + cw2:].float().sub(5.0).abs().max()) == 0.0
     assert torch.equal(g[:, :c0], g_plain[:, :c0]) and torch.equal(g[:, c0 + cw2:], g_plain[:, c0 + cw2:])

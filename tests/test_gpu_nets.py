@@ -305,6 +305,8 @@ def test_full_size_spectral1650_bf16_vs_reference_fixture():
     finally:
         E._lib.call = real
     assert "hpri_gemm_bf16v3" in seen and "hpri_wgrad1x1_bf16v3" in seen and "hpri_conv_fwd_bf16" not in seen and "hpri_conv_wgrad_bf16" not in seen
+    # ... and the head reads the plane concat [tail | up4] (round 4): no fp32 concat is built
+    assert "hpri_outconv_fwd_x16" in seen and "hpri_outconv_bwd_x16" in seen and "hpri_outconv_fwd_bce" not in seen
     stride = int(z["stride"])
     sub = lg.reshape(-1)[::stride].numpy()
     d = np.abs(sub - z["logits_sub"])

@@ -220,8 +220,9 @@ def test_plane_mode_traffic_savings_do_not_change_results(kind):
     assert all(getattr(E, n) for n in names)          # the defaults under test
     # (the transposed convolutions stay on ONE kernel family in both runs: their plane-fed kernels -- CONVT_PLANES, which needs
     # PLANES_CONCAT / PLANES_CONVT -- sum in another order; that switch has its own test below)
-    convt = E.CONVT_PLANES
-    E.CONVT_PLANES = False
+    # (... and so does the head: reading its input as bf16 planes -- HEAD_PLANES -- rounds that tensor; own test below)
+    convt, head = E.CONVT_PLANES, E.HEAD_PLANES
+    E.CONVT_PLANES = E.HEAD_PLANES = False
     saved = {n: getattr(E, n) for n in names}
     try:
         lg1, g1 = _step(net, x, m)
@@ -231,7 +232,7 @@ def test_plane_mode_traffic_savings_do_not_change_results(kind):
         net.load_state_dict(sd)
         lg2, g2 = _step(net, x, m)
     finally:
-        E.CONVT_PLANES = convt
+        E.CONVT_PLANES, E.HEAD_PLANES = convt, head
         for n, v in saved.items():
             setattr(E, n, v)
     assert torch.equal(lg1, lg2)
@@ -420,6 +421,49 @@ def test_bf16_mode_transposed_convolutions_on_planes(kind):
         worst = max(worst, float((a.double() - b.double()).norm()) / ref)
     record_margin(f"bf16_convt_planes_switch_{kind}", worst, 1e-3)
     assert worst <= 1e-3, worst          # (measured 1.5e-7: same rounded operands, fp32 summation order only)
+
+
+@pytest.mark.parametrize("kind", ["unet", "cube64", "cube128"])
+def test_bf16_mode_head_reads_planes(kind):
+    """HEAD_PLANES (default on, round 4): the last DoubleConv writes its result as bf16 planes only and the 1x1 output layer reads those
+    (hpri_outconv_fwd_x16 / hpri_outconv_bwd_x16) instead of an fp32 copy.  One more rounding to bf16 of a tensor every other reader of
+    the mode sees rounded as well: logits move by bf16 steps of a 64-channel dot product, gradients like between any two bf16 paths."""
+    import hyperpri_amd as H
+    from hyperpri_amd import engine as E
+    net, x, m = _net(kind)
+    H.set_precision(net, "bf16")
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    assert E.HEAD_PLANES
+    seen = []
+    real = E._lib.call
+
+    def spy(name, *a):
+        seen.append(name)
+        return real(name, *a)
+    E._lib.call = spy
+    try:
+        lg1, g1 = _step(net, x, m)
+    finally:
+        E._lib.call = real
+    assert "hpri_outconv_fwd_x16" in seen and "hpri_outconv_bwd_x16" in seen and "hpri_outconv_fwd_bce" not in seen and "hpri_outconv_fwd" not in seen
+    try:
+        E.HEAD_PLANES = False
+        net.load_state_dict(sd)
+        lg2, g2 = _step(net, x, m)
+    finally:
+        E.HEAD_PLANES = True
+    dl = float((lg1 - lg2).abs().max()) / max(1.0, float(lg2.abs().max()))
+    record_margin(f"bf16_head_planes_switch_logits_{kind}", dl, 2e-2)
+    assert dl <= 2e-2
+    worst = 0.0
+    for (k, _), a, b in zip(net.named_parameters(), g1, g2):
+        assert torch.isfinite(a).all(), k
+        ref = float(b.double().norm())
+        if ref < 1e-6:
+            continue
+        worst = max(worst, float((a.double() - b.double()).norm()) / ref)
+    record_margin(f"bf16_head_planes_switch_grads_{kind}", worst, 0.1)
+    assert worst <= 0.1, worst
 
 
 @pytest.mark.parametrize("kind", ["unet", "cube64"])
