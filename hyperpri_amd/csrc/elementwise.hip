@@ -1032,9 +1032,44 @@ __global__ void copy_slice_any_kernel(const float* __restrict__ s, int s_cs, int
   }
 }
 
+// the same for wide rows (SpectralUNET's 1650-channel halves): a block walks whole pixel rows, its threads the row's channels in
+// pieces of V floats (V = 2 when every stride, offset and count is even: 1650 is) -- no division per element, 8-byte accesses.
+// (The element loop above: 3.1 TB/s on the 2.8 GB halves of config C3.)
+template <int V>
+__global__ void copy_slice_rows_kernel(const float* __restrict__ s, int s_cs, int s_coff, float* __restrict__ d, int d_cs,
+                                       int d_coff, long long P, int C, int Cz, int accumulate) {
+  typedef float vec_t __attribute__((ext_vector_type(V)));
+  const int per = Cz > C ? Cz : C;
+  for (long long p = blockIdx.x; p < P; p += gridDim.x) {
+    const float* sp = s + p * s_cs + s_coff;
+    float* dp = d + p * d_cs + d_coff;
+    for (int c = threadIdx.x * V; c < per; c += 256 * V) {
+      if (c < C) {
+        vec_t v = *reinterpret_cast<const vec_t*>(sp + c);
+        if (accumulate) v += *reinterpret_cast<const vec_t*>(dp + c);
+        *reinterpret_cast<vec_t*>(dp + c) = v;
+      } else if (!accumulate) {
+        vec_t z = {};
+        *reinterpret_cast<vec_t*>(dp + c) = z;
+      }
+    }
+  }
+}
+
 extern "C" int hpri_copy_slice_any(const float* src, int s_cs, int s_coff, float* dst, int d_cs, int d_coff, long long P,
                                    int C, int Cz, int accumulate, hipStream_t stream) {
   HPRI_REQUIRE(src && dst && P > 0 && C > 0 && C + s_coff <= s_cs && (Cz > C ? Cz : C) + d_coff <= d_cs, "copy_slice_any: bad arguments");
+  const int per = Cz > C ? Cz : C;
+  if (per >= 256) {
+    const bool even = ((s_cs | s_coff | d_cs | d_coff | C | per) & 1) == 0 && (((uintptr_t)src | (uintptr_t)dst) & 7) == 0;
+    const unsigned nb = (unsigned)(P < 16384 ? P : 16384);
+    if (even)
+      hipLaunchKernelGGL(copy_slice_rows_kernel<2>, dim3(nb), dim3(256), 0, stream, src, s_cs, s_coff, dst, d_cs, d_coff, P, C, Cz, accumulate);
+    else
+      hipLaunchKernelGGL(copy_slice_rows_kernel<1>, dim3(nb), dim3(256), 0, stream, src, s_cs, s_coff, dst, d_cs, d_coff, P, C, Cz, accumulate);
+    HPRI_CHECK_LAUNCH();
+    return HPRI_OK;
+  }
   hipLaunchKernelGGL(copy_slice_any_kernel, dim3(ew_blocks(P * (Cz > C ? Cz : C))), dim3(256), 0, stream, src, s_cs, s_coff, dst,
                      d_cs, d_coff, P, C, Cz, accumulate);
   HPRI_CHECK_LAUNCH();

@@ -422,3 +422,25 @@ def test_maxpool_backward_one_thread_per_window(lib, shape, accumulate):
     want = ref + (prior.double().cpu()[:, off:off + C] if accumulate else 0)
     assert torch.equal(got[:, off:off + C].float(), want.float())
     assert torch.equal(got[:, :off], prior.double().cpu()[:, :off]) and torch.equal(got[:, off + C:], prior.double().cpu()[:, off + C:])
+
+
+@pytest.mark.parametrize("case", [  # P, s_cs, s_coff, d_cs, d_coff, C, Cz
+    (500, 1656, 0, 3304, 0, 1650, 0), (500, 1656, 0, 3304, 1650, 1650, 1654), (300, 3304, 1650, 1656, 0, 1650, 1656),
+    (257, 1001, 3, 2051, 7, 997, 1000), (64, 300, 1, 301, 2, 256, 0), (1000, 56, 0, 112, 50, 50, 54), (1, 3300, 1650, 3314, 1664, 1650, 0)])
+@pytest.mark.parametrize("acc", [0, 1])
+def test_copy_slice_any_rows_and_elements(lib, case, acc):
+    """hpri_copy_slice_any (SpectralUNET's 1650-channel concat halves, models.py:139-143): the row-walking form (wide rows; 8-byte
+    pieces when every stride, offset and count is even, single floats otherwise) and the element loop (narrow rows) copy / add the
+    slice, zero-fill [C, Cz) and leave every other element of the destination alone -- bit-exact."""
+    Pn, scs, sco, dcs, dco, C, Cz = case
+    torch.manual_seed(2)
+    s = torch.randn(Pn, scs, device=DEV)
+    d0 = torch.randn(Pn, dcs, device=DEV)
+    d = d0.clone()
+    assert lib.hpri_copy_slice_any(P(s), scs, sco, P(d), dcs, dco, Pn, C, Cz, acc, _st()) == 0, lib.hpri_last_error()
+    torch.cuda.synchronize()
+    want = d0.clone()
+    want[:, dco:dco + C] = s[:, sco:sco + C] + (d0[:, dco:dco + C] if acc else 0)
+    if Cz > C and not acc:
+        want[:, dco + C:dco + Cz] = 0
+    assert torch.equal(d, want)
