@@ -263,6 +263,15 @@ def self_launch(args, argv):
     print(line, flush=True)
 
 
+def trace(msg: str) -> None:
+    """HPRI_BENCH_TRACE=1: leg-by-leg progress on stderr (one line per rank and leg) -- where a multi-rank run stopped, if it did."""
+    if os.environ.get("HPRI_BENCH_TRACE") == "1":
+        print(f"[bench rank {os.environ.get('RANK', '0')} +{time.perf_counter() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+_T0 = time.perf_counter()
+
+
 def dry_launch_rank():
     """Launcher rehearsal on CPU (tests/test_bench_launcher.py): gloo ranks, the contract's barrier + max-over-ranks
     timing around a trivial all-reduce, one JSON line from rank 0.  No GPU work, no claims."""
@@ -425,9 +434,11 @@ def main():
         settle = {"bursts": len(seen), "steps_per_burst": burst, "ms_per_step": [round(t * 1e3, 2) for t in seen[:6]] + (["..."] if len(seen) > 6 else []),
                   "device_mallocs": int(ms1.get("num_device_alloc", 0) - ms0.get("num_device_alloc", 0)),
                   "reserved_gib": round(ms1.get("reserved_bytes.all.current", 0) / 2 ** 30, 1)}
+    trace("warm-up steps")
     for _ in range(args.warmup):
         step()
     fence()
+    trace("timed steps")
     mallocs0 = torch.cuda.memory_stats(dev).get("num_device_alloc", 0)
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -480,6 +491,7 @@ def main():
     #      parameters frozen and therefore pays 0 pack launches.  Reported beside `value`, never as it (SURVEY.md 8d excludes the
     #      optimizer from the metric).  All ranks take part (a step holds collectives); parameters are restored afterwards.
     training_shaped = None
+    trace("timed steps done; training-shaped leg")
     if not args.no_training_shaped:
         with torch.no_grad():
             saved = [p.detach().clone() for p in net.parameters()]
@@ -566,6 +578,7 @@ def main():
                 "device_mallocs_in_timed_steps": torch.cuda.memory_stats(dev).get("num_device_alloc", 0) - m0}
 
     bf16_mode = bf16x3_mode = bf16x6_mode = None
+    trace("precision-mode legs")
     if args.bf16_steps > 0:
         bf16x6_mode = timed_mode("bf16x6")
         bf16x6_mode.update({
@@ -589,15 +602,18 @@ def main():
                       "kernels); NOT the headline value"})
 
     roofline = None
-    if rank == 0 and not args.no_roofline:
+    trace("per-kernel event pass")
+    if not args.no_roofline:
         # per-kernel HIP events on the launching stream over 2 extra steps (events perturb the timing
-        # slightly, so they are kept out of the headline region)
-        engine.enable_event_log(True)
+        # slightly, so they are kept out of the headline region).  EVERY rank takes the two steps -- a step holds the gradient
+        # collectives, and a rank stepping alone would wait for its peers for ever (tests/test_bench_rank_symmetry.py) -- rank 0 logs.
+        engine.enable_event_log(rank == 0)
         for _ in range(2):
             step()
         torch.cuda.synchronize()
         summ = engine.event_log_summary()
         engine.enable_event_log(False)
+    if rank == 0 and not args.no_roofline:
         dom = max(summ.items(), key=lambda kv: kv[1]["total_ms"])
         traffic, traffic_src = pmc_traffic(dom[0])
         wino = "winograd" in dom[0]
@@ -670,6 +686,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline()
 
+    trace("rank-0 legs done; closing barrier")
     if use_pg:
         dist.barrier()
     if rank == 0:
