@@ -559,7 +559,7 @@ def main():
         # untimed: the caching allocator meets this mode's buffer shapes (a device allocation inside the timed steps costs ~40 ms),
         # and the chip, idle during the sleep above, is back at the clock it holds under this load (it rises over tens of
         # milliseconds: profiles/r04_first_conv_ramp.txt; 4 bf16 steps = 40 ms were not enough: 204.4 vs 207.9 cubes/s over 20 steps)
-        for _ in range(max(4, int(0.25 / max(ms_step_hint.get(mode, 0.02), 1e-3)))):
+        for _ in range(1 if one_gpu else max(4, int(0.25 / max(ms_step_hint.get(mode, 0.02), 1e-3)))):     # (one-GPU rehearsal: ranks time-slice one chip, ~40 s per step)
             step()
         fence()
         m0 = torch.cuda.memory_stats(dev).get("num_device_alloc", 0)
