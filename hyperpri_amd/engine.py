@@ -824,7 +824,8 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
     if prec not in PRECISIONS:
         raise RuntimeError(f"hyperpri_amd: unknown precision {prec!r}; choose from {PRECISIONS}")
     if bn is not None and not train and not tape.record and FOLD_EVAL_BN:
-        return _conv_folded_eval(x, weight, bias, bn, ks, cin, cout, relu, prec, room)
+        return _conv_folded_eval(x, weight, bias, bn, ks, cin, cout, relu, prec, room,
+                                 inner=(next_cout > 0 or (head_next and HEAD_PLANES)) and groups == 1)
     c = types.SimpleNamespace(x=x, weight=weight, bias=bias, bn=bn, ks=ks, T=T, groups=groups, relu=relu, need_dx=need_dx, prec=prec,
                               cin=cin, cout=cout, cin_pad=x.cw, k_gap=k_gap, dev=x.buf.device, lowp=prec in LOWP,
                               split=_SPLIT.get(prec, 0), use_batch=bn is not None and train)
@@ -1169,10 +1170,11 @@ FOLD_LAUNCHES = 0     # folded conv+BN+ReLU stages executed (tests assert that t
 
 
 def _conv_folded_eval(x: Act, weight: torch.Tensor, bias: Optional[torch.Tensor], bn: BNRef, ks: int, cin: int, cout: int,
-                      relu: bool, prec: str = "fp32", room: int = 0) -> Act:
+                      relu: bool, prec: str = "fp32", room: int = 0, inner: bool = False) -> Act:
     """Eval-mode Conv -> BatchNorm -> ReLU (running statistics) without the normalise pass: w' = w*gamma/sqrt(var+eps),
     b' = (b-mean)*gamma/sqrt(var+eps)+beta, ReLU in the conv epilogue.  Used when nothing is recorded for backward
-    (torch.no_grad / inference_mode: PLTrainer.py:530,626)."""
+    (torch.no_grad / inference_mode: PLTrainer.py:530,626).  ``inner``: the result is the inner tensor of a DoubleConv, or the head's input; in the bf16
+    mode the plane kernel then writes it as bf16 rows, which ARE the next convolution's planes (no fp32 copy, no conversion pass)."""
     global FOLD_LAUNCHES
     FOLD_LAUNCHES += 1
     dev = x.buf.device
@@ -1216,6 +1218,16 @@ def _conv_folded_eval(x: Act, weight: torch.Tensor, bias: Optional[torch.Tensor]
     if wino:
         _conv_launch_wino(x, wp, fbias, y, None, cin, cout, cout_pad, y.cw, accumulate=2 if relu else 0)
     elif lowp and PLANE_CONV and prec == "bf16" and ks == 3 and _planes_fit(x, max(cin, cout)):
+        if (inner and room == 0 and cout % 32 == 0 and PLANES_ONLY_ACT and PLANE_PRODUCERS
+                and _v3_plan(x, cin, cout)[0] == 1 and _planes_fit(y, cout)):
+            # (cout a multiple of 32: the rows have no pad channels to zero; split-K problems finish in fp32)
+            rows = Act(torch.empty(y.P * cout, dtype=torch.bfloat16, device=dev), x.N, x.H, x.W, cout, cout, 0)
+            rows.b16 = True
+            _conv_launch_v2(x, wp, fbias, rows, None, cin, cout, cout_pad, cout, accumulate=(2 if relu else 0) | 4)
+            y = Act(torch.empty(8, dtype=torch.float32, device=dev), x.N, x.H, x.W, cout, _rup(cout, 8), 0)
+            y.f32_valid = False
+            y.pl = Planes(rows.buf, y.P * cout, cout, 0, 1)
+            return y
         _conv_launch_v2(x, wp, fbias, y, None, cin, cout, cout_pad, y.cw, accumulate=2 if relu else 0)
     elif lowp:
         _conv_launch_bf16(x, wp, fbias, y, None, x.N, x.H, x.W, x.cw, cout, cout_pad, y.cw, ks, accumulate=2 if relu else 0,
