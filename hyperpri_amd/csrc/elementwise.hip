@@ -96,6 +96,37 @@ __global__ void nhwc_to_nchw_kernel(const float* __restrict__ src, float* __rest
 }
 
 // ---------------------------------- MaxPool2d(2) ------------------------------------------------
+// XB / DXB: the tensor is stored as bf16 rows (plane 0 of a plane buffer; strides and offsets in elements): bf16 mode, round 4 --
+// the skip tensors of the U-Nets and their gradients have plane readers only
+template <bool B16>
+__device__ __forceinline__ float4 ew_load4(const float* __restrict__ p) {
+  if (B16) {
+    const bf16x4_t v = *reinterpret_cast<const bf16x4_t*>(p);
+    return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+  }
+  return *reinterpret_cast<const float4*>(p);
+}
+template <bool B16>
+__device__ __forceinline__ void ew_store4(float* __restrict__ p, float4 v) {
+  if (B16) {
+    bf16x4_t h;
+    h[0] = (__bf16)v.x; h[1] = (__bf16)v.y; h[2] = (__bf16)v.z; h[3] = (__bf16)v.w;
+    *reinterpret_cast<bf16x4_t*>(p) = h;
+  } else {
+    *reinterpret_cast<float4*>(p) = v;
+  }
+}
+// element pointer into a tensor of either storage type (the float* carries bf16 elements when B16)
+template <bool B16>
+__device__ __forceinline__ const float* ew_at(const float* base, long long idx) {
+  return B16 ? reinterpret_cast<const float*>(reinterpret_cast<const __bf16*>(base) + idx) : base + idx;
+}
+template <bool B16>
+__device__ __forceinline__ float* ew_at(float* base, long long idx) {
+  return B16 ? reinterpret_cast<float*>(reinterpret_cast<__bf16*>(base) + idx) : base + idx;
+}
+
+template <bool XB>
 __global__ void maxpool2_fwd_kernel(const float* __restrict__ x, int x_cs, int x_coff, float* __restrict__ y, int y_cs,
                                     int y_coff, int N, int H, int W, int OH, int OW, int C4v, int C4, PlaneOut pl) {
   // C4v = channel quads with fp32 data, C4 >= C4v = quads covered (the extra ones only zero-fill plane pad channels)
@@ -108,17 +139,17 @@ __global__ void maxpool2_fwd_kernel(const float* __restrict__ x, int x_cs, int x
     const int n = (int)(r / OH);
     const size_t opix = (size_t)(((long long)n * OH + oy) * OW + ox);
     if (c >= C4v * 4) { plane_store4(pl, opix, c, 0.f, 0.f, 0.f, 0.f); continue; }
-    const float* b = x + (((long long)n * H + 2 * oy) * W + 2 * ox) * x_cs + x_coff + c;
-    const float4 v00 = *reinterpret_cast<const float4*>(b);
-    const float4 v01 = *reinterpret_cast<const float4*>(b + x_cs);
-    const float4 v10 = *reinterpret_cast<const float4*>(b + (long long)W * x_cs);
-    const float4 v11 = *reinterpret_cast<const float4*>(b + (long long)W * x_cs + x_cs);
+    const long long b = (((long long)n * H + 2 * oy) * W + 2 * ox) * x_cs + x_coff + c;
+    const float4 v00 = ew_load4<XB>(ew_at<XB>(x, b));
+    const float4 v01 = ew_load4<XB>(ew_at<XB>(x, b + x_cs));
+    const float4 v10 = ew_load4<XB>(ew_at<XB>(x, b + (long long)W * x_cs));
+    const float4 v11 = ew_load4<XB>(ew_at<XB>(x, b + (long long)W * x_cs + x_cs));
     float4 m;
     m.x = fmaxf(fmaxf(v00.x, v01.x), fmaxf(v10.x, v11.x));
     m.y = fmaxf(fmaxf(v00.y, v01.y), fmaxf(v10.y, v11.y));
     m.z = fmaxf(fmaxf(v00.z, v01.z), fmaxf(v10.z, v11.z));
     m.w = fmaxf(fmaxf(v00.w, v01.w), fmaxf(v10.w, v11.w));
-    *reinterpret_cast<float4*>(y + opix * y_cs + y_coff + c) = m;
+    if (y != nullptr) *reinterpret_cast<float4*>(y + opix * y_cs + y_coff + c) = m;
     if (pl.p != nullptr) plane_store4(pl, opix, c, m.x, m.y, m.z, m.w);
   }
 }
@@ -138,6 +169,7 @@ __device__ __forceinline__ int first_argmax4(float a, float b, float c, float d)
 // times the load instructions, three 64-bit divisions per element): the window's four values and the pooled gradient are read once,
 // the four results written (or accumulated) from the same thread.  Windows of the last row / column of an odd-sized map have no
 // pooled value: their pixels get 0.  32-bit index arithmetic (host: N * ceil(H/2) * ceil(W/2) * C4 < 2^31).
+template <bool XB, bool DXB>
 __global__ void maxpool2_bwd_kernel(const float* __restrict__ x, int x_cs, int x_coff, const float* __restrict__ dy,
                                     int dy_cs, int dy_coff, float* __restrict__ dx, int dx_cs, int dx_coff, int N, int H,
                                     int W, int OH, int OW, int C4, int accumulate) {
@@ -155,11 +187,11 @@ __global__ void maxpool2_bwd_kernel(const float* __restrict__ x, int x_cs, int x
     float4 o[4] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f),
                    make_float4(0.f, 0.f, 0.f, 0.f)};
     if (pooled) {
-      const float* b = x + pix * x_cs + x_coff + c;
-      const float4 v00 = *reinterpret_cast<const float4*>(b);
-      const float4 v01 = *reinterpret_cast<const float4*>(b + x_cs);
-      const float4 v10 = *reinterpret_cast<const float4*>(b + (long long)W * x_cs);
-      const float4 v11 = *reinterpret_cast<const float4*>(b + (long long)W * x_cs + x_cs);
+      const long long b = pix * x_cs + x_coff + c;
+      const float4 v00 = ew_load4<XB>(ew_at<XB>(x, b));
+      const float4 v01 = ew_load4<XB>(ew_at<XB>(x, b + x_cs));
+      const float4 v10 = ew_load4<XB>(ew_at<XB>(x, b + (long long)W * x_cs));
+      const float4 v11 = ew_load4<XB>(ew_at<XB>(x, b + (long long)W * x_cs + x_cs));
       const float4 g = *reinterpret_cast<const float4*>(dy + (((long long)n * OH + wy) * OW + wx) * dy_cs + dy_coff + c);
       const int kx = first_argmax4(v00.x, v01.x, v10.x, v11.x), ky = first_argmax4(v00.y, v01.y, v10.y, v11.y);
       const int kz = first_argmax4(v00.z, v01.z, v10.z, v11.z), kw = first_argmax4(v00.w, v01.w, v10.w, v11.w);
@@ -168,19 +200,20 @@ __global__ void maxpool2_bwd_kernel(const float* __restrict__ x, int x_cs, int x
         o[m].x = kx == m ? g.x : 0.f; o[m].y = ky == m ? g.y : 0.f; o[m].z = kz == m ? g.z : 0.f; o[m].w = kw == m ? g.w : 0.f;
       }
     }
-    float* p = dx + pix * dx_cs + dx_coff + c;
-    float* pm[4] = {p, p + dx_cs, p + (long long)W * dx_cs, p + (long long)W * dx_cs + dx_cs};
+    const long long p = pix * dx_cs + dx_coff + c;
+    float* pm[4] = {ew_at<DXB>(dx, p), ew_at<DXB>(dx, p + dx_cs), ew_at<DXB>(dx, p + (long long)W * dx_cs),
+                    ew_at<DXB>(dx, p + (long long)W * dx_cs + dx_cs)};
     const bool ok[4] = {true, col1, row1, row1 && col1};
     if (accumulate) {
       float4 old[4];
 #pragma unroll
-      for (int m = 0; m < 4; ++m) old[m] = ok[m] ? *reinterpret_cast<const float4*>(pm[m]) : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int m = 0; m < 4; ++m) old[m] = ok[m] ? ew_load4<DXB>(pm[m]) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
       for (int m = 0; m < 4; ++m) { o[m].x += old[m].x; o[m].y += old[m].y; o[m].z += old[m].z; o[m].w += old[m].w; }
     }
 #pragma unroll
     for (int m = 0; m < 4; ++m)
-      if (ok[m]) *reinterpret_cast<float4*>(pm[m]) = o[m];
+      if (ok[m]) ew_store4<DXB>(pm[m], o[m]);
   }
 }
 
@@ -667,19 +700,37 @@ extern "C" int hpri_maxpool2_fwd(const float* x, int x_cs, int x_coff, float* y,
 }
 
 // MaxPool2d(2), also writing the pooled map as bf16 planes (planes == nullptr: fp32 only)
-extern "C" int hpri_maxpool2_fwd_pl(const float* x, int x_cs, int x_coff, float* y, int y_cs, int y_coff, int N, int H,
-                                    int W, int C, void* planes, long long plane_stride, int pl_cs, int pl_coff, int pl_cw,
-                                    int npl, hipStream_t stream) {
-  HPRI_REQUIRE(x && y && N > 0 && H >= 2 && W >= 2 && C > 0 && C % 4 == 0, "maxpool2_fwd: bad arguments");
-  HPRI_REQ_V4(x_cs, x_coff); HPRI_REQ_V4(y_cs, y_coff);
+template <bool XB>
+static int maxpool2_fwd_impl(const float* x, int x_cs, int x_coff, float* y, int y_cs, int y_coff, int N, int H,
+                             int W, int C, void* planes, long long plane_stride, int pl_cs, int pl_coff, int pl_cw,
+                             int npl, hipStream_t stream) {
+  HPRI_REQUIRE(x && (y || planes) && N > 0 && H >= 2 && W >= 2 && C > 0 && C % 4 == 0, "maxpool2_fwd: bad arguments");
+  HPRI_REQ_V4(x_cs, x_coff);
+  if (y != nullptr) { HPRI_REQ_V4(y_cs, y_coff); }
   PlaneOut po;
   { const int rc_ = hpri_plane_out(&po, planes, plane_stride, pl_cs, pl_coff, pl_cw, npl, C); if (rc_ != HPRI_OK) return rc_; }
   const int OH = H / 2, OW = W / 2;
   const int c4 = (C > po.cw ? C : po.cw) / 4;
-  hipLaunchKernelGGL(maxpool2_fwd_kernel, dim3(ew_blocks((long long)N * OH * OW * c4)), dim3(256), 0, stream, x, x_cs,
+  hipLaunchKernelGGL(maxpool2_fwd_kernel<XB>, dim3(ew_blocks((long long)N * OH * OW * c4)), dim3(256), 0, stream, x, x_cs,
                      x_coff, y, y_cs, y_coff, N, H, W, OH, OW, C / 4, c4, po);
   HPRI_CHECK_LAUNCH();
   return HPRI_OK;
+}
+
+extern "C" int hpri_maxpool2_fwd_pl(const float* x, int x_cs, int x_coff, float* y, int y_cs, int y_coff, int N, int H,
+                                    int W, int C, void* planes, long long plane_stride, int pl_cs, int pl_coff, int pl_cw,
+                                    int npl, hipStream_t stream) {
+  HPRI_REQUIRE(y != nullptr, "maxpool2_fwd: bad arguments");
+  return maxpool2_fwd_impl<false>(x, x_cs, x_coff, y, y_cs, y_coff, N, H, W, C, planes, plane_stride, pl_cs, pl_coff, pl_cw, npl, stream);
+}
+
+// bf16 mode: MaxPool2d(2) over bf16 rows (plane 0 of the skip tensor's planes: rounding is monotonic, so the pooled bf16 values are
+// the ones the fp32 form would have written as planes); y (fp32) is optional.
+extern "C" int hpri_maxpool2_fwd_x16(const void* x16, int x_cs, int x_coff, float* y, int y_cs, int y_coff, int N, int H,
+                                     int W, int C, void* planes, long long plane_stride, int pl_cs, int pl_coff, int pl_cw,
+                                     int npl, hipStream_t stream) {
+  return maxpool2_fwd_impl<true>(reinterpret_cast<const float*>(x16), x_cs, x_coff, y, y_cs, y_coff, N, H, W, C, planes, plane_stride,
+                                 pl_cs, pl_coff, pl_cw, npl, stream);
 }
 
 extern "C" int hpri_maxpool2_bwd(const float* x, int x_cs, int x_coff, const float* dy, int dy_cs, int dy_coff, float* dx,
@@ -688,8 +739,30 @@ extern "C" int hpri_maxpool2_bwd(const float* x, int x_cs, int x_coff, const flo
   HPRI_REQ_V4(x_cs, x_coff); HPRI_REQ_V4(dy_cs, dy_coff); HPRI_REQ_V4(dx_cs, dx_coff);
   const long long windows = (long long)N * ((H + 1) / 2) * ((W + 1) / 2) * (C / 4);
   HPRI_REQUIRE(windows < (1ll << 31), "maxpool2_bwd: more than 2^31 window quads");
-  hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(ew_blocks(windows)), dim3(256), 0, stream, x, x_cs,
+  hipLaunchKernelGGL((maxpool2_bwd_kernel<false, false>), dim3(ew_blocks(windows)), dim3(256), 0, stream, x, x_cs,
                      x_coff, dy, dy_cs, dy_coff, dx, dx_cs, dx_coff, N, H, W, H / 2, W / 2, C / 4, accumulate);
+  HPRI_CHECK_LAUNCH();
+  return HPRI_OK;
+}
+
+// bf16 mode: the pooled tensor's input is read as bf16 rows (x_bf16; the first maximum among the ROUNDED values takes the gradient),
+// and / or the input gradient is stored as bf16 rows (dx_bf16: written, or read - added - rounded).  dy is fp32.
+extern "C" int hpri_maxpool2_bwd_x16(const void* x, int x_bf16, int x_cs, int x_coff, const float* dy, int dy_cs, int dy_coff, void* dx,
+                                     int dx_bf16, int dx_cs, int dx_coff, int N, int H, int W, int C, int accumulate, hipStream_t stream) {
+  HPRI_REQUIRE(x && dy && dx && N > 0 && H >= 2 && W >= 2 && C > 0 && C % 4 == 0, "maxpool2_bwd_x16: bad arguments");
+  HPRI_REQ_V4(x_cs, x_coff); HPRI_REQ_V4(dy_cs, dy_coff); HPRI_REQ_V4(dx_cs, dx_coff);
+  const long long windows = (long long)N * ((H + 1) / 2) * ((W + 1) / 2) * (C / 4);
+  HPRI_REQUIRE(windows < (1ll << 31), "maxpool2_bwd_x16: more than 2^31 window quads");
+  const float* xf = reinterpret_cast<const float*>(x);
+  float* dxf = reinterpret_cast<float*>(dx);
+#define HPRI_MP_BWD(XB_, DXB_)                                                                                              \
+  hipLaunchKernelGGL((maxpool2_bwd_kernel<XB_, DXB_>), dim3(ew_blocks(windows)), dim3(256), 0, stream, xf, x_cs, x_coff, dy, \
+                     dy_cs, dy_coff, dxf, dx_cs, dx_coff, N, H, W, H / 2, W / 2, C / 4, accumulate)
+  if (x_bf16 && dx_bf16) HPRI_MP_BWD(true, true);
+  else if (x_bf16) HPRI_MP_BWD(true, false);
+  else if (dx_bf16) HPRI_MP_BWD(false, true);
+  else HPRI_MP_BWD(false, false);
+#undef HPRI_MP_BWD
   HPRI_CHECK_LAUNCH();
   return HPRI_OK;
 }

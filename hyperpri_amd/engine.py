@@ -977,6 +977,12 @@ def _bn_forward(c, room: int, next_cout: int, cat_room: int, cat_into: Optional[
         cs16 = _rup(par.C, 32)
         cpl = Planes(torch.empty(par.P * cs16, dtype=torch.bfloat16, device=dev), par.P * cs16, cs16, 0, 1)
         par.pl_part = (cpl, y.C)
+        if (SKIP_PLANES_ONLY and c.v2 and c.prec == "bf16" and y.C % 32 == 0 and PLANE_CONV and PLANE_WGRAD and PLANES_ONLY_ACT
+                and _planes_fit(par, par.C)):
+            # the skip's readers -- max-pooling (hpri_maxpool2_*_x16), the decoder's concat (this plane buffer), the pooling
+            # backward -- all read these planes: no fp32 copy of the skip is written (564 MB per C2 step) or read (2 x 564 MB)
+            y.pl = Planes(cpl.buf, cpl.plane, cpl.cs, 0, 1, cw=y.C)
+            y.f32_valid = False
     # ``next_cout`` > 0: y is the inner tensor of a DoubleConv (the caller says so), read only by the next 3x3 convolution
     # of ``next_cout`` columns and by that convolution's weight gradient.  When those read planes, nobody reads fp32.
     if (ypl is not None and next_cout > 0 and PLANES_ONLY_ACT and PLANE_WGRAD and room == 0
@@ -1333,20 +1339,37 @@ def maxpool2(tape: Tape, x: Act) -> Act:
     """nn.MaxPool2d(2) (floor), model_parts.py:40."""
     if x.H < 2 or x.W < 2:
         raise RuntimeError("hyperpri_amd: MaxPool2d(2) needs H, W >= 2")
-    y = Act.new(x.N, x.H // 2, x.W // 2, x.C, x.buf.device)
+    dev = x.buf.device
+    x16 = not x.f32_valid                         # bf16 mode: the skip exists as planes only (SKIP_PLANES_ONLY)
+    if x16 and (x.pl is None or x.pl.npl != 1):
+        raise RuntimeError("hyperpri_amd: internal error: a planes-only activation without planes reached max-pooling")
     # plane mode (the input carries bf16 planes): the pooled map is written as planes too, for the next 3x3 convolution
     npl = x.pl.npl if x.pl is not None else x.want_pl
+    # ... and as planes ONLY when its input was: the pooled map's readers are then the next DoubleConv's plane kernels
+    only = x16 and npl == 1 and PLANE_PRODUCERS and _planes_fit(Act(x.buf, x.N, x.H // 2, x.W // 2, 2 * x.C, 2 * x.C), 2 * x.C)
+    y = (Act(torch.empty(8, dtype=torch.float32, device=dev), x.N, x.H // 2, x.W // 2, x.C, _rup(x.C, 8), 0) if only
+         else Act.new(x.N, x.H // 2, x.W // 2, x.C, dev))
     ypl = new_planes(y, npl) if (npl > 0 and PLANE_PRODUCERS) else None
     y.want_pl = npl
-    _lib.call("hpri_maxpool2_fwd_pl", x.ptr, x.cs, x.coff, y.ptr, y.cs, y.coff, x.N, x.H, x.W, x.cw, *_pl_args(ypl), _stream())
+    y.f32_valid = not only
+    if x16:
+        _lib.call("hpri_maxpool2_fwd_x16", _p(x.pl.buf), x.pl.cs, x.pl.coff, ctypes.c_void_p(0) if only else y.ptr, y.cs, y.coff,
+                  x.N, x.H, x.W, _rup(x.C, 4), *_pl_args(ypl), _stream())
+    else:
+        _lib.call("hpri_maxpool2_fwd_pl", x.ptr, x.cs, x.coff, y.ptr, y.cs, y.coff, x.N, x.H, x.W, x.cw, *_pl_args(ypl), _stream())
     if tape.record:
         def bwd(tp: Tape) -> None:
             g = tp.grads.pop(id(y), None)
             if g is None:
                 return
             gx, acc = tp.grad_slot(x)
-            _lib.call("hpri_maxpool2_bwd", x.ptr, x.cs, x.coff, g.ptr, g.cs, g.coff, gx.ptr, gx.cs, gx.coff,
-                      x.N, x.H, x.W, _rup(x.C, 4), int(acc), _stream())
+            if x16 or gx.b16:
+                _lib.call("hpri_maxpool2_bwd_x16", _p(x.pl.buf) if x16 else x.ptr, int(x16), x.pl.cs if x16 else x.cs,
+                          x.pl.coff if x16 else x.coff, g.ptr, g.cs, g.coff, gx.ptr, int(gx.b16), gx.cs, gx.coff,
+                          x.N, x.H, x.W, _rup(x.C, 4), int(acc), _stream())
+            else:
+                _lib.call("hpri_maxpool2_bwd", x.ptr, x.cs, x.coff, g.ptr, g.cs, g.coff, gx.ptr, gx.cs, gx.coff,
+                          x.N, x.H, x.W, _rup(x.C, 4), int(acc), _stream())
         tape.nodes.append(bwd)
     return y
 
@@ -1559,6 +1582,8 @@ def up_concat(tape: Tape, x1: Act, skip: Act, weight: Optional[torch.Tensor], bi
     if par is not None and par.C == skip.C + cup and par.coff == skip.coff and par.buf is skip.buf:
         cat = par                  # the skip was produced in place (Act.new_with_room): nothing to copy
     else:
+        if not skip.f32_valid:
+            raise RuntimeError("hyperpri_amd: internal error: a planes-only skip tensor reached the copying form of the concat")
         cat = Act.new(skip.N, skip.H, skip.W, skip.C + cup, dev)
         _lib.call("hpri_copy_slice", skip.ptr, skip.cs, skip.coff, cat.ptr, cat.cs, cat.coff, cat.P, skip.C, 0, _stream())
     if cat.cw > cat.C:
@@ -1576,6 +1601,8 @@ def up_concat(tape: Tape, x1: Act, skip: Act, weight: Optional[torch.Tensor], bi
         # convolution itself, or -- pad ring, other precisions, bilinear -- by a conversion of that half only
         global PLANE_CONVERSIONS
         pl = cat.pl_part[0]
+        if not skip.f32_valid:
+            cat.f32_valid = False                   # the skip half exists as planes only (SKIP_PLANES_ONLY)
         if wrote:
             cat.f32_valid = False                   # channels [Cskip, Cskip + Cup) exist as planes only
         else:
@@ -1698,6 +1725,10 @@ PLANES_CAT1 = FUSIONS
 # U-Nets, the plane concat [tail | up4] of SpectralUNET -- instead of an fp32 copy (and, SpectralUNET, instead of a copied fp32
 # concat of 2 x 1650 channels: 9 of 135 ms per C3 step).  (HPRI_FUSIONS.)
 HEAD_PLANES = FUSIONS
+# bf16 mode: a skip tensor of the U-Nets (the output of an encoder DoubleConv, produced inside its decoder concat) exists as bf16 planes
+# only, and so does the pooled map behind it; max-pooling reads and writes bf16 rows (hpri_maxpool2_fwd_x16 / _bwd_x16).  Rounding is
+# monotonic, so the pooled values are bit-identical; the pooling backward picks the first maximum among the rounded values.  (HPRI_FUSIONS.)
+SKIP_PLANES_ONLY = FUSIONS
 
 
 def concat_planes(tape: Tape, a: Act, b: Act) -> Tuple[Act, Tuple[int, int]]:

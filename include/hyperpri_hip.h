@@ -347,6 +347,13 @@ int hpri_maxpool2_fwd(const float* x, int x_cs, int x_coff, float* y, int y_cs, 
                       hipStream_t stream);
 int hpri_maxpool2_bwd(const float* x, int x_cs, int x_coff, const float* dy, int dy_cs, int dy_coff, float* dx,
                       int dx_cs, int dx_coff, int N, int H, int W, int C, int accumulate, hipStream_t stream);
+/* bf16 mode (round 4): max-pooling over / into bf16 rows -- the skip tensors of the U-Nets (model_parts.py:40 after a bf16-mode
+ * DoubleConv) exist as planes only.  _fwd_x16: input = plane 0 of the skip's planes, y (fp32) optional (NULL: planes only).
+ * _bwd_x16: x_bf16 / dx_bf16 select the storage of the pool's input and of its gradient; dy is fp32. */
+int hpri_maxpool2_fwd_x16(const void* x16, int x_cs, int x_coff, float* y, int y_cs, int y_coff, int N, int H, int W, int C,
+                          void* planes, long long plane_stride, int pl_cs, int pl_coff, int pl_cw, int npl, hipStream_t stream);
+int hpri_maxpool2_bwd_x16(const void* x, int x_bf16, int x_cs, int x_coff, const float* dy, int dy_cs, int dy_coff, void* dx,
+                          int dx_bf16, int dx_cs, int dx_coff, int N, int H, int W, int C, int accumulate, hipStream_t stream);
 int hpri_copy_slice(const float* src, int s_cs, int s_coff, float* dst, int d_cs, int d_coff, long long P, int C,
                     int accumulate, hipStream_t stream);
 int hpri_copy_slice_any(const float* src, int s_cs, int s_coff, float* dst, int d_cs, int d_coff, long long P, int C,

@@ -444,3 +444,45 @@ def test_copy_slice_any_rows_and_elements(lib, case, acc):
     if Cz > C and not acc:
         want[:, dco + C:dco + Cz] = 0
     assert torch.equal(d, want)
+
+
+@pytest.mark.parametrize("shape", [(2, 8, 10, 64), (1, 9, 7, 32), (2, 5, 121, 96)])
+def test_maxpool_over_bf16_rows(lib, shape):
+    """hpri_maxpool2_fwd_x16 / hpri_maxpool2_bwd_x16 (round 4; model_parts.py:40 on a planes-only skip): forward == the fp32 kernel on the
+    same (bf16-exact) values, fp32 output optional; backward == the fp32 kernel on those values, the gradient written / accumulated as
+    fp32 or as bf16 rows (rounded once per write)."""
+    N, H, W, C = shape
+    torch.manual_seed(6)
+    xs = C + 32                                               # the skip half of a wider plane buffer
+    x16 = torch.zeros(N * H * W, xs, dtype=torch.bfloat16, device=DEV)
+    x16[:, :C] = torch.randn(N * H * W, C, device=DEV).to(torch.bfloat16)
+    xf = x16[:, :C].float().contiguous()
+    OH, OW = H // 2, W // 2
+    y_ref = torch.empty(N * OH * OW, C, device=DEV)
+    pl_ref = torch.empty(N * OH * OW, C, dtype=torch.bfloat16, device=DEV)
+    assert lib.hpri_maxpool2_fwd_pl(P(xf), C, 0, P(y_ref), C, 0, N, H, W, C, P(pl_ref), N * OH * OW * C, C, 0, C, 1, _st()) == 0
+    y = torch.empty_like(y_ref)
+    pl = torch.empty_like(pl_ref)
+    assert lib.hpri_maxpool2_fwd_x16(P(x16), xs, 0, P(y), C, 0, N, H, W, C, P(pl), N * OH * OW * C, C, 0, C, 1, _st()) == 0, lib.hpri_last_error()
+    pl2 = torch.empty_like(pl_ref)
+    assert lib.hpri_maxpool2_fwd_x16(P(x16), xs, 0, P(None), 0, 0, N, H, W, C, P(pl2), N * OH * OW * C, C, 0, C, 1, _st()) == 0     # planes only
+    assert lib.hpri_maxpool2_fwd_x16(P(x16), xs, 0, P(None), 0, 0, N, H, W, C, P(None), 0, 0, 0, 0, 0, _st()) != 0                 # nothing to write
+    torch.cuda.synchronize()
+    assert torch.equal(y, y_ref) and torch.equal(pl, pl_ref) and torch.equal(pl2, pl_ref)
+    dy = torch.randn(N * OH * OW, C, device=DEV)
+    for acc in (0, 1):
+        d0 = torch.randn(N * H * W, C, device=DEV)
+        want = d0.clone()
+        assert lib.hpri_maxpool2_bwd(P(xf), C, 0, P(dy), C, 0, P(want), C, 0, N, H, W, C, acc, _st()) == 0
+        got = d0.clone()
+        assert lib.hpri_maxpool2_bwd_x16(P(x16), 1, xs, 0, P(dy), C, 0, P(got), 0, C, 0, N, H, W, C, acc, _st()) == 0, lib.hpri_last_error()
+        d16 = d0.to(torch.bfloat16)
+        want16 = d16.float()
+        assert lib.hpri_maxpool2_bwd(P(xf), C, 0, P(dy), C, 0, P(want16), C, 0, N, H, W, C, acc, _st()) == 0
+        got16 = d16.clone()
+        assert lib.hpri_maxpool2_bwd_x16(P(x16), 1, xs, 0, P(dy), C, 0, P(got16), 1, C, 0, N, H, W, C, acc, _st()) == 0
+        gotf = d16.clone()                                   # fp32 input of the pool, bf16 gradient rows
+        assert lib.hpri_maxpool2_bwd_x16(P(xf), 0, C, 0, P(dy), C, 0, P(gotf), 1, C, 0, N, H, W, C, acc, _st()) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(got, want)
+        assert torch.equal(got16, want16.to(torch.bfloat16)) and torch.equal(gotf, got16)

@@ -221,8 +221,9 @@ def test_plane_mode_traffic_savings_do_not_change_results(kind):
     # (the transposed convolutions stay on ONE kernel family in both runs: their plane-fed kernels -- CONVT_PLANES, which needs
     # PLANES_CONCAT / PLANES_CONVT -- sum in another order; that switch has its own test below)
     # (... and so does the head: reading its input as bf16 planes -- HEAD_PLANES -- rounds that tensor; own test below)
-    convt, head = E.CONVT_PLANES, E.HEAD_PLANES
-    E.CONVT_PLANES = E.HEAD_PLANES = False
+    # (... and max-pooling over planes-only skips -- SKIP_PLANES_ONLY -- picks its maxima among the rounded values: own test below)
+    convt, head, skipo = E.CONVT_PLANES, E.HEAD_PLANES, E.SKIP_PLANES_ONLY
+    E.CONVT_PLANES = E.HEAD_PLANES = E.SKIP_PLANES_ONLY = False
     saved = {n: getattr(E, n) for n in names}
     try:
         lg1, g1 = _step(net, x, m)
@@ -232,7 +233,7 @@ def test_plane_mode_traffic_savings_do_not_change_results(kind):
         net.load_state_dict(sd)
         lg2, g2 = _step(net, x, m)
     finally:
-        E.CONVT_PLANES, E.HEAD_PLANES = convt, head
+        E.CONVT_PLANES, E.HEAD_PLANES, E.SKIP_PLANES_ONLY = convt, head, skipo
         for n, v in saved.items():
             setattr(E, n, v)
     assert torch.equal(lg1, lg2)
@@ -421,6 +422,48 @@ def test_bf16_mode_transposed_convolutions_on_planes(kind):
         worst = max(worst, float((a.double() - b.double()).norm()) / ref)
     record_margin(f"bf16_convt_planes_switch_{kind}", worst, 1e-3)
     assert worst <= 1e-3, worst          # (measured 1.5e-7: same rounded operands, fp32 summation order only)
+
+
+@pytest.mark.parametrize("kind", ["unet", "cube64", "cube128"])
+def test_bf16_mode_skips_as_planes_only(kind):
+    """SKIP_PLANES_ONLY (default on, round 4): an encoder DoubleConv's output exists as the skip half of its decoder concat's plane
+    buffer and nowhere else; max-pooling reads those bf16 rows and writes the pooled map as planes only.  Rounding is monotonic:
+    the pooled planes -- and with them the logits -- are bit-identical; the pooling backward picks the first maximum among rounded
+    values, so gradients move where two window values differ by less than a bf16 step (like between any two bf16 paths)."""
+    import hyperpri_amd as H
+    from hyperpri_amd import engine as E
+    net, x, m = _net(kind)
+    H.set_precision(net, "bf16")
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    assert E.SKIP_PLANES_ONLY
+    seen = []
+    real = E._lib.call
+
+    def spy(name, *a):
+        seen.append(name)
+        return real(name, *a)
+    E._lib.call = spy
+    try:
+        lg1, g1 = _step(net, x, m)
+    finally:
+        E._lib.call = real
+    assert seen.count("hpri_maxpool2_fwd_x16") == 4 and seen.count("hpri_maxpool2_bwd_x16") == 4 and "hpri_maxpool2_fwd_pl" not in seen
+    try:
+        E.SKIP_PLANES_ONLY = False
+        net.load_state_dict(sd)
+        lg2, g2 = _step(net, x, m)
+    finally:
+        E.SKIP_PLANES_ONLY = True
+    assert torch.equal(lg1, lg2)
+    worst = 0.0
+    for (k, _), a, b in zip(net.named_parameters(), g1, g2):
+        assert torch.isfinite(a).all(), k
+        ref = float(b.double().norm())
+        if ref < 1e-6:
+            continue
+        worst = max(worst, float((a.double() - b.double()).norm()) / ref)
+    record_margin(f"bf16_skip_planes_only_switch_grads_{kind}", worst, 0.1)
+    assert worst <= 0.1, worst
 
 
 @pytest.mark.parametrize("kind", ["unet", "cube64", "cube128"])
