@@ -877,6 +877,11 @@ static int v3_launch(const void* xp, long long x_plane, int x_cs, int x_coff, co
   a.stats = reinterpret_cast<float4*>(stats);
   a.N = N; a.H = H; a.W = W; a.Cin_pad = Cin_pad; a.Cout = Cout; a.Cout_pad = Cout_pad;
   a.y_cw = y_cw < Cout ? Cout : y_cw; a.accumulate = accumulate & 1; a.relu = (accumulate >> 1) & 1; a.y16 = (accumulate >> 2) & 1;
+  if (o2 != nullptr && o2->only && a.y16) {
+    // a compact bf16 main output: it holds the channels below the second output's range and nothing else
+    HPRI_REQUIRE(y_cw >= o2->c0 && o2->c0 + o2->cw >= Cout, "conv_bf16v3_y2: a bf16 main output must cover every channel below the second output's range, which must reach Cout");
+    a.y_cw = y_cw;
+  }
   HPRI_REQUIRE(a.y_cw + y_coff <= y_cs, "conv_bf16v3: output channels exceed the channel stride");
   HPRI_REQUIRE(!(a.y16 && a.accumulate), "conv_bf16v3: a bf16 output cannot accumulate");
   HPRI_REQUIRE(y_cs % 4 == 0 && y_coff % 4 == 0 && a.y_cw % 4 == 0 && ((uintptr_t)y & 15) == 0,
@@ -909,8 +914,8 @@ static int v3_launch(const void* xp, long long x_plane, int x_cs, int x_coff, co
   dim3 grid((unsigned)(nloc * 8), 1u, (unsigned)a.ksplit);
   a.y2 = nullptr; a.y2_cs = a.y2_coff = a.y2_c0 = a.y2_cw = a.y2_only = 0;
   if (o2 != nullptr) {
-    HPRI_REQUIRE(o2->y2 != nullptr && bn == nullptr && a.ksplit == 1 && !a.accumulate && !a.y16,
-                 "conv_bf16v3_y2: the second output is not for split-K problems (hpri_conv_bf16v3_plan), accumulating launches or bf16 results");
+    HPRI_REQUIRE(o2->y2 != nullptr && bn == nullptr && a.ksplit == 1 && !a.accumulate,
+                 "conv_bf16v3_y2: the second output is not for split-K problems (hpri_conv_bf16v3_plan) or accumulating launches");
     HPRI_REQUIRE(o2->c0 % 64 == 0 && o2->cw % 64 == 0 && o2->cw > 0 && o2->c0 + o2->cw <= Cout_pad, "conv_bf16v3_y2: the channel range must be whole 64-channel blocks");
     HPRI_REQUIRE(o2->cs % 4 == 0 && o2->coff % 4 == 0 && o2->coff + o2->cw <= o2->cs && ((uintptr_t)o2->y2 & 7) == 0,
                  "conv_bf16v3_y2: the bf16 view must be 8-byte aligned and hold the channel range");
@@ -975,9 +980,11 @@ extern "C" int hpri_conv_bf16v3_bnred(const void* xp, int x_cs, int x_coff, cons
 extern "C" int hpri_conv_bf16v3_y2(const void* xp, int x_cs, int x_coff, const void* wp, const float* bias, float* y, int y_cs, int y_coff,
                                    float* stats, int N, int H, int W, int Cin_pad, int Cout, int Cout_pad, int y_cw, void* y2, int y2_cs,
                                    int y2_coff, int y2_c0, int y2_cw, int y2_only, hipStream_t stream) {
-  const V3Out2 o2{y2, y2_cs, y2_coff, y2_c0, y2_cw, y2_only};
-  return v3_launch(xp, 0, x_cs, x_coff, wp, bias, y, y_cs, y_coff, stats, N, H, W, Cin_pad, Cout, Cout_pad, y_cw, 0, 0, nullptr, 0, nullptr,
-                   V3_STAGGER_CYCLES, nullptr, stream, &o2);
+  // y2_only: bit 0 = the blocks of [c0, c0 + cw) exist as bf16 rows only; bit 1 (round 4) = the MAIN output y is bf16 rows too (y_cs in
+  // elements; the gradient of a planes-only skip tensor: its readers -- pooling backward, BatchNorm backward -- read bf16)
+  const V3Out2 o2{y2, y2_cs, y2_coff, y2_c0, y2_cw, y2_only & 1};
+  return v3_launch(xp, 0, x_cs, x_coff, wp, bias, y, y_cs, y_coff, stats, N, H, W, Cin_pad, Cout, Cout_pad, y_cw, (y2_only & 2) ? 4 : 0, 0,
+                   nullptr, 0, nullptr, V3_STAGGER_CYCLES, nullptr, stream, &o2);
 }
 
 // 3x3 pad-1 convolution (forward, or data gradient with the flipped pack) over bf16 activation planes: same argument

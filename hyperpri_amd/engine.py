@@ -65,7 +65,7 @@ class Act:
 
     Invariant: channels [C, cw) (cw = C rounded up to 8) exist inside the stride and hold zeros, so
     consumers may run their K loop over ``cw`` channels."""
-    __slots__ = ("buf", "N", "H", "W", "C", "cs", "coff", "pl", "parent", "f32_valid", "want_pl", "pl_part", "colsum_req", "b16", "bn_src", "cat_pl", "up_slice")
+    __slots__ = ("buf", "N", "H", "W", "C", "cs", "coff", "pl", "parent", "f32_valid", "want_pl", "pl_part", "colsum_req", "b16", "bn_src", "cat_pl", "up_slice", "yr16", "skip_g16")
 
     def __init__(self, buf: torch.Tensor, N: int, H: int, W: int, C: int, cs: int, coff: int = 0):
         self.buf, self.N, self.H, self.W, self.C, self.cs, self.coff = buf, N, H, W, C, cs, coff
@@ -79,6 +79,8 @@ class Act:
         self.up_slice = None                    # (first channel, channels): the upsampled half of a decoder concat whose gradient its ConvTranspose2d wants as bf16 rows
         self.cat_pl = None                      # (plane buffer, cs, offset of the second half, its channels): this tensor's planes are the first half of a padded concat
         self.bn_src = None                      # (pre-BN Act, statistics, relu): this tensor is BN(+ReLU) of that one and has ONE consumer
+        self.yr16 = False                       # the pre-BN tensor behind this one is stored as bf16 (its BatchNorm backward can read a bf16 gradient)
+        self.skip_g16 = False                   # a decoder concat whose skip half's gradient is stored as bf16 rows (SKIP_GRAD_BF16)
 
     @property
     def cw(self) -> int:
@@ -362,6 +364,8 @@ class Tape:
         g = self.grads.get(id(a))
         if g is None:
             self.grads[id(a)] = view
+        elif view.b16 or g.b16:
+            raise RuntimeError("hyperpri_amd: internal error: a bf16 gradient view met an earlier gradient of the same tensor")
         else:
             _lib.call("hpri_copy_slice", view.ptr, view.cs, view.coff, g.ptr, g.cs, g.coff, g.P, _rup(a.C, 4), 1, _stream())
 
@@ -993,6 +997,7 @@ def _bn_forward(c, room: int, next_cout: int, cat_room: int, cat_into: Optional[
               _p(scale), _p(shift),
               x.P, ppg, cout, y.cw, int(c.relu),
               *(_pl_args(ypl) if cpl is None else (_p(cpl.buf), cpl.plane, cpl.cs, 0, y.C, 1)), _stream())
+    y.yr16 = bool(c.yr16)
     c.y, c.st = y, st
 
 
@@ -1082,6 +1087,8 @@ def _conv_bwd_data(tp: Tape, c, dyr: Act) -> None:
         gx.b16, gx.f32_valid = True, False
         tp.grads[id(x)] = gx
         acc = False
+    elif c.v2 and x.skip_g16 and tp.grads.get(id(x)) is None and _y2_ok(x, cout, cin, False):
+        gx, acc = None, False          # the skip half as bf16 rows, the upsampled half as planes: made in _conv_bwd_data_planes
     else:
         gx, acc = tp.grad_slot(x)
     # the column sums of (a channel range of) this gradient are wanted -- the bias gradient of the ConvTranspose2d that
@@ -1135,7 +1142,14 @@ def _conv_bwd_data(tp: Tape, c, dyr: Act) -> None:
         tp.colsum[id(x)] = (gstats, gtiles, cin_cols_pad)
 
 
-def _conv_bwd_data_planes(tp: Tape, c, dyr: Act, gx: Act, acc: bool, g16: bool, gstats: Optional[torch.Tensor]) -> int:
+def _y2_ok(x: Act, cout: int, cin: int, acc: bool) -> bool:
+    """The data gradient of a decoder concat ``x`` can leave its upsampled half as bf16 rows (hpri_conv_bf16v3_y2)."""
+    us = x.up_slice
+    return bool(us is not None and CONVT_PLANES and not acc and us[0] % 64 == 0 and us[1] % 64 == 0
+                and _v3_plan(x, cout, _rup(cin, 64))[0] == 1)
+
+
+def _conv_bwd_data_planes(tp: Tape, c, dyr: Act, gx: Optional[Act], acc: bool, g16: bool, gstats: Optional[torch.Tensor]) -> int:
     """The 3x3 data gradient on bf16 planes (conv_bf16v3.hip, mode-1 pack); returns the padded column count of the pack."""
     x, cin, cout = c.x, c.cin, c.cout
     wpd, cin_cols_pad = _pack_bf16(c.weight, 1, cout, cin, c.T, cin, split=0)
@@ -1144,8 +1158,10 @@ def _conv_bwd_data_planes(tp: Tape, c, dyr: Act, gx: Act, acc: bool, g16: bool, 
         return cin_cols_pad
     us = x.up_slice
     y2 = None
-    if us is not None and CONVT_PLANES and not acc and us[0] % 64 == 0 and us[1] % 64 == 0 and _v3_plan(x, cout, cin_cols_pad)[0] == 1:
+    if _y2_ok(x, cout, cin, acc):
         y2 = torch.empty(x.P * us[1], dtype=torch.bfloat16, device=c.dev)
+    if gx is None and (y2 is None or gstats is None):
+        gx, acc = tp.grad_slot(x)              # (the bf16 form of the skip half needs the second output AND the records)
     if y2 is None:
         _conv_launch_v2(dyr, wpd, None, gx, gstats, cout, cin, cin_cols_pad, gx.cw, accumulate=int(acc))
         return cin_cols_pad
@@ -1153,12 +1169,19 @@ def _conv_bwd_data_planes(tp: Tape, c, dyr: Act, gx: Act, acc: bool, g16: bool, 
     # convolution's data and weight gradient, stage planes); with the bias gradient coming from the statistics
     # records nobody reads that half in fp32, so it is not written
     only = gstats is not None
+    flags = int(only)
+    if gx is None:
+        # SKIP_GRAD_BF16: the main output is the skip half alone, as bf16 rows of width Cskip
+        gx = Act(torch.empty(x.P * us[0], dtype=torch.bfloat16, device=c.dev), x.N, x.H, x.W, us[0], us[0], 0)
+        gx.b16, gx.f32_valid = True, False
+        tp.grads[id(x)] = gx
+        flags |= 2
     pl = planes_of(dyr, 1)
     with _timed("conv_planes_bf16<3,v3 256x64>" + (f" N{x.N} {x.H}x{x.W} K{_rup(cout, 32)} N{cin}" if SHAPE_TAGS else ""),
                 2.0 * x.N * x.H * x.W * cout * cin * 9):
         _lib.call("hpri_conv_bf16v3_y2", _p(pl.buf), pl.cs, pl.coff, _p(wpd), ctypes.c_void_p(0), gx.ptr, gx.cs, gx.coff,
-                  _p(gstats), x.N, x.H, x.W, _rup(cout, 32), cin, cin_cols_pad, gx.cw, _p(y2), us[1], 0, us[0], us[1],
-                  int(only), _stream())
+                  _p(gstats), x.N, x.H, x.W, _rup(cout, 32), cin, cin_cols_pad, us[0] if gx.b16 else gx.cw, _p(y2), us[1], 0, us[0], us[1],
+                  flags, _stream())
     tp.gupl[id(x)] = (Planes(y2, x.P * us[1], us[1], 0, 1), only)
     return cin_cols_pad
 
@@ -1617,13 +1640,25 @@ def up_concat(tape: Tape, x1: Act, skip: Act, weight: Optional[torch.Tensor], bi
         #  per-GPU batches of ~29 and more at 608x968 with 64 upsampled channels -- the fp32 half stays and the round-1 kernels run)
         if (weight is not None and wrote and CONVT_PLANES and cat.P * cup * 2 < 0x7FFFFF00 and _rup(weight.shape[0], 32) <= 16384):
             cat.up_slice = (skip.C, cup)       # plane mode: the consumer's data-gradient launch leaves this half's gradient as bf16 rows
+            # ... and the skip half's as bf16 rows too, when nobody reads it in fp32: the skip is planes-only (its pooling backward
+            # then runs on bf16), its BatchNorm backward reads bf16 gradients, and the upsampled half's fp32 form is not needed at
+            # all (bias gradient from the statistics records: ``only`` in _conv_bwd_data_planes)
+            cat.skip_g16 = bool(SKIP_GRAD_BF16 and not skip.f32_valid and skip.yr16 and COLSUM_FROM_STATS
+                                and cat.colsum_req is not None and skip.C % 64 == 0 and cup % 64 == 0)
 
         def bwd(tp: Tape) -> None:
             g = tp.grads.pop(id(cat), None)
             if g is None:
                 return
-            tp.set_grad_view(skip, g.slice(0, skip.C))
-            gu = g.slice(skip.C, cup)
+            if g.b16:
+                # only the skip half exists, as bf16 rows of width Cskip; the upsampled half arrived as planes (tp.gupl)
+                gs = Act(g.buf, g.N, g.H, g.W, skip.C, g.cs, g.coff)
+                gs.b16, gs.f32_valid = True, False
+                tp.set_grad_view(skip, gs)
+                gu = Act(torch.empty(8, dtype=torch.float32, device=dev), g.N, g.H, g.W, cup, _rup(cup, 8), 0)
+            else:
+                tp.set_grad_view(skip, g.slice(0, skip.C))
+                gu = g.slice(skip.C, cup)
             gp = tp.gupl.pop(id(cat), None)
             if gp is not None:
                 tp.gupl[id(ups)] = gp
@@ -1729,6 +1764,10 @@ HEAD_PLANES = FUSIONS
 # only, and so does the pooled map behind it; max-pooling reads and writes bf16 rows (hpri_maxpool2_fwd_x16 / _bwd_x16).  Rounding is
 # monotonic, so the pooled values are bit-identical; the pooling backward picks the first maximum among the rounded values.  (HPRI_FUSIONS.)
 SKIP_PLANES_ONLY = FUSIONS
+# ... and the GRADIENT of such a skip is stored as bf16 rows: written by the decoder's data-gradient launch (hpri_conv_bf16v3_y2, main
+# output as bf16), added to by the pooling backward (hpri_maxpool2_bwd_x16), read by the BatchNorm backward of the stage that made the
+# skip (hpri_bn_relu_bwd_x16_dy16): 10 of 20 bytes per element of the four skip gradients.  (HPRI_FUSIONS.)
+SKIP_GRAD_BF16 = FUSIONS
 
 
 def concat_planes(tape: Tape, a: Act, b: Act) -> Tuple[Act, Tuple[int, int]]:

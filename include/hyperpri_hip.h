@@ -186,8 +186,9 @@ int hpri_conv_bf16v3(const void* xp, long long x_plane, int x_cs, int x_coff, co
 
 
 /* hpri_conv_bf16v3 (no accumulate; hpri_conv_bf16v3_plan must report ksplit 1) whose result channels [y2_c0, y2_c0 + y2_cw) -- whole
- * 64-channel blocks -- are also (y2_only != 0: only) written as bf16 rows, y2 + pixel * y2_cs + y2_coff + (channel - y2_c0): the
- * gradient of the upsampled half of a decoder concat for the plane-fed transposed-convolution kernels. */
+ * 64-channel blocks -- are also (y2_only bit 0: only) written as bf16 rows, y2 + pixel * y2_cs + y2_coff + (channel - y2_c0): the
+ * gradient of the upsampled half of a decoder concat for the plane-fed transposed-convolution kernels.  y2_only bit 1 (round 4): the
+ * main output y holds bf16 rows as well (y_cs / y_coff in elements) -- the gradient of a planes-only skip tensor. */
 int hpri_conv_bf16v3_y2(const void* xp, int x_cs, int x_coff, const void* wp, const float* bias, float* y, int y_cs, int y_coff,
                         float* stats, int N, int H, int W, int Cin_pad, int Cout, int Cout_pad, int y_cw, void* y2, int y2_cs,
                         int y2_coff, int y2_c0, int y2_cw, int y2_only, hipStream_t stream);

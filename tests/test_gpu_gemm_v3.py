@@ -298,3 +298,17 @@ def test_bf16_plane_conv_v3_second_output(lib, shape, only):
         assert torch.equal(g[:, c0:c0 + cw2], g_plain[:, c0:c0 + cw2])
     assert lib.hpri_conv_bf16v3_y2(P(planes), cs16, 0, P(wpd), P(None), P(g), cw, 0, P(st2), N, H, W, cs16, Cols, cols_pad, cw, P(y2), y2cs, 4, c0 + 32,
                                    cw2, only, _st()) != 0
+    if only and c0 + cw2 == Cols and c0 > 0:
+        # flags bit 1 (round 4): the main output as COMPACT bf16 rows of the channels below the second output's range
+        g16 = torch.full((npx, c0 + 8), 9.0, dtype=torch.bfloat16, device=DEV)
+        y2b = torch.full_like(y2, 5.0)
+        st3 = torch.empty_like(st1)
+        rc = lib.hpri_conv_bf16v3_y2(P(planes), cs16, 0, P(wpd), P(None), P(g16), c0 + 8, 0, P(st3), N, H, W, cs16, Cols, cols_pad, c0, P(y2b), y2cs, 4,
+                                     c0, cw2, 3, _st())
+        assert rc == 0, lib.hpri_last_error()
+        torch.cuda.synchronize()
+        assert torch.equal(g16[:, :c0], g_plain[:, :c0].to(torch.bfloat16)) and float(g16[:, c0:].float().sub(9.0).abs().max()) == 0.0
+        assert torch.equal(y2b, y2) and torch.equal(st3, st2)
+        # ... which must reach Cout from below the range
+        assert lib.hpri_conv_bf16v3_y2(P(planes), cs16, 0, P(wpd), P(None), P(g16), c0 + 8, 0, P(st3), N, H, W, cs16, Cols, cols_pad, c0 - 4,
+                                       P(y2b), y2cs, 4, c0, cw2, 3, _st()) != 0

@@ -268,8 +268,26 @@ def test_full_size_cubenet128_bf16_vs_reference_fixture():
     """BASELINE config C5's arithmetic (bf16 MFMA) at full size against the REFERENCE fixture (not against this
     repository's fp32 mode): bf16 operands move logits by ~2e-2, so the bars are loss, sign agreement
     and Dice/IoU level, plus gradient norms."""
+    from hyperpri_amd import engine as E
     z = _load("net_cubenet128_300_full")
-    net, xd, mask, lg, loss = _full_size_step("c5", "bf16")
+    calls = []
+    real = E._lib.call
+
+    def spy(name, *a):
+        if name in ("hpri_conv_bf16v3_y2", "hpri_maxpool2_bwd_x16", "hpri_maxpool2_fwd_x16", "hpri_outconv_fwd_x16"):
+            calls.append((name, a))
+        return real(name, *a)
+    E._lib.call = spy
+    try:
+        net, xd, mask, lg, loss = _full_size_step("c5", "bf16")
+    finally:
+        E._lib.call = real
+    # round 4: the step under these gates is the one with planes-only skips, bf16 skip gradients and the head on planes
+    names = [n for n, _ in calls]
+    assert names.count("hpri_maxpool2_fwd_x16") == 4 and "hpri_outconv_fwd_x16" in names
+    n16 = sum(1 for n, a in calls if n == "hpri_conv_bf16v3_y2" and a[-2] == 3)
+    assert n16 >= 2                                                        # (the 76x121 level has a pad ring: fp32 there)
+    assert sum(1 for n, a in calls if n == "hpri_maxpool2_bwd_x16" and a[8] == 1) == n16
     stride = int(z["stride"])
     sub = lg.reshape(-1)[::stride].numpy()
     d = np.abs(sub - z["logits_sub"])

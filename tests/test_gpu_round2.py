@@ -399,6 +399,10 @@ def test_bf16_mode_transposed_convolutions_on_planes(kind):
     def spy(name, *a):
         seen.append(name)
         return real(name, *a)
+    # (the bf16 storage of the skip gradients rides on the second output of the same launch -- SKIP_GRAD_BF16 -- and rounds them:
+    #  held off in both runs, own test below)
+    skg = E.SKIP_GRAD_BF16
+    E.SKIP_GRAD_BF16 = False
     E._lib.call = spy
     try:
         lg1, g1 = _step(net, x, m)
@@ -412,6 +416,7 @@ def test_bf16_mode_transposed_convolutions_on_planes(kind):
         lg2, g2 = _step(net, x, m)
     finally:
         E.CONVT_PLANES = True
+        E.SKIP_GRAD_BF16 = skg
     assert float((lg1 - lg2).abs().max()) <= 2e-2 * max(1.0, float(lg2.abs().max()))
     worst = 0.0
     for (k, _), a, b in zip(net.named_parameters(), g1, g2):
@@ -463,6 +468,53 @@ def test_bf16_mode_skips_as_planes_only(kind):
             continue
         worst = max(worst, float((a.double() - b.double()).norm()) / ref)
     record_margin(f"bf16_skip_planes_only_switch_grads_{kind}", worst, 0.1)
+    assert worst <= 0.1, worst
+
+
+@pytest.mark.parametrize("kind", ["unet", "cube64", "cube128"])
+def test_bf16_mode_skip_gradients_as_bf16_rows(kind):
+    """SKIP_GRAD_BF16 (default on, round 4): the gradient of a planes-only skip is written as bf16 rows by the decoder's data-gradient
+    launch (second bit of hpri_conv_bf16v3_y2's flags), added to by the pooling backward in bf16 and read by the BatchNorm backward
+    as bf16.  Two more roundings to bf16 of a tensor whose reader rounds its own result the same way: logits untouched, gradients move
+    like between any two bf16 paths on this tiny net."""
+    import hyperpri_amd as H
+    from hyperpri_amd import engine as E
+    net, x, m = _net(kind)
+    H.set_precision(net, "bf16")
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    assert E.SKIP_GRAD_BF16 and E.SKIP_PLANES_ONLY
+    calls = []
+    real = E._lib.call
+
+    def spy(name, *a):
+        calls.append((name, a))
+        return real(name, *a)
+    E._lib.call = spy
+    try:
+        lg1, g1 = _step(net, x, m)
+    finally:
+        E._lib.call = real
+    y2 = [a for n, a in calls if n == "hpri_conv_bf16v3_y2"]
+    pool = [a for n, a in calls if n == "hpri_maxpool2_bwd_x16"]
+    # (which levels qualify depends on the size: no pad ring, no split-K in the skip's producer; at full size three of four do --
+    #  tests/test_gpu_nets.py::test_full_size_cubenet128_bf16_vs_reference_fixture counts them)
+    n16 = sum(1 for a in y2 if a[-2] == 3)                               # only + bf16 main output
+    assert sum(1 for a in pool if a[8] == 1) == n16                      # ... and the pooling backward adds into bf16 rows exactly there
+    try:
+        E.SKIP_GRAD_BF16 = False
+        net.load_state_dict(sd)
+        lg2, g2 = _step(net, x, m)
+    finally:
+        E.SKIP_GRAD_BF16 = True
+    assert torch.equal(lg1, lg2)
+    worst = 0.0
+    for (k, _), a, b in zip(net.named_parameters(), g1, g2):
+        assert torch.isfinite(a).all(), k
+        ref = float(b.double().norm())
+        if ref < 1e-6:
+            continue
+        worst = max(worst, float((a.double() - b.double()).norm()) / ref)
+    record_margin(f"bf16_skip_grad_bf16_switch_grads_{kind}", worst, 0.1)
     assert worst <= 0.1, worst
 
 
