@@ -463,7 +463,7 @@ __global__ __launch_bounds__(256) void outconv_fwd_wide_kernel(const float* __re
 // dx[n][p][c] = sum_k dy[n][k][p] * w[k][c]  (written, or accumulated into dx)
 // BCE = true: dy is not a gradient tensor but the LOGITS; the gradient of the mean BCE-with-logits loss is formed on the fly,
 // g = (sigmoid(logit) - target) * gscale[0] / (N*K*P)
-template <bool BCE>
+template <bool BCE, bool DXB = false>
 __global__ void outconv_bwd_data_kernel(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx,
                                         int dx_cs, int dx_coff, int N, long long P, int C, int Cw, int K, int accumulate,
                                         const float* __restrict__ target, const float* __restrict__ gscale, int CQ) {
@@ -488,7 +488,7 @@ __global__ void outconv_bwd_data_kernel(const float* __restrict__ dy, const floa
         const long long pg = min(pg0 + u * step, NP - 1);
         g[u] = dy[pg];
         if (BCE && CQ < 4) g[u] = oc_bce_grad(g[u], target[pg]) * gs;
-        old[u] = (accumulate && live) ? *reinterpret_cast<const float4*>(dx + pg * dx_cs + dx_coff + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        old[u] = (accumulate && live) ? ew_load4<DXB>(ew_at<DXB>(dx, pg * dx_cs + dx_coff + c)) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
       if (BCE && CQ >= 4) {
         // the CQ lanes of a pixel would each evaluate the same exp and division: lane u of the group does it for pixel u and hands
@@ -508,7 +508,7 @@ __global__ void outconv_bwd_data_kernel(const float* __restrict__ dy, const floa
           // (0 + g*w, then + old: the generic loop's order)
           float o0 = 0.f + g[u] * wv.x, o1 = 0.f + g[u] * wv.y, o2 = 0.f + g[u] * wv.z, o3 = 0.f + g[u] * wv.w;
           if (accumulate) { o0 += old[u].x; o1 += old[u].y; o2 += old[u].z; o3 += old[u].w; }
-          *reinterpret_cast<float4*>(dx + pg * dx_cs + dx_coff + c) = make_float4(o0, o1, o2, o3);
+          ew_store4<DXB>(ew_at<DXB>(dx, pg * dx_cs + dx_coff + c), make_float4(o0, o1, o2, o3));
         }
       }
     }
@@ -874,7 +874,7 @@ template <bool XB>
 static int outconv_bwd_impl(const float* dy, const float* target, const float* gscale, const float* x, int x_cs, int x_coff,
                             const float* w, float* dx, int dx_cs, int dx_coff, int dx_cw, int dx_accumulate, float* dw, float* db,
                             int accumulate_param_grads, float* workspace, size_t ws_floats, int N, long long P, int C,
-                            int K, hipStream_t stream) {
+                            int K, hipStream_t stream, int dx_bf16 = 0) {
   const bool bce = target != nullptr;
   HPRI_REQUIRE(dy && x && w && dw && workspace && N > 0 && P > 0 && C > 0 && K > 0, "outconv_bwd: bad arguments");
   HPRI_REQ_V4(x_cs, x_coff);
@@ -891,7 +891,14 @@ static int outconv_bwd_impl(const float* dy, const float* target, const float* g
       if (nbx > cap) nbx = cap;
       grid = dim3((unsigned)nbx, ycols);
     }
-    if (bce)
+    HPRI_REQUIRE(!dx_bf16 || K == 1, "outconv_bwd: a bf16 input gradient is built for one class");
+    if (dx_bf16 && bce)
+      hipLaunchKernelGGL((outconv_bwd_data_kernel<true, true>), grid, dim3(256), 0, stream, dy, w,
+                         dx, dx_cs, dx_coff, N, P, C, dx_cw, K, dx_accumulate, target, gscale, dq);
+    else if (dx_bf16)
+      hipLaunchKernelGGL((outconv_bwd_data_kernel<false, true>), grid, dim3(256), 0, stream, dy, w,
+                         dx, dx_cs, dx_coff, N, P, C, dx_cw, K, dx_accumulate, (const float*)nullptr, (const float*)nullptr, dq);
+    else if (bce)
       hipLaunchKernelGGL(outconv_bwd_data_kernel<true>, grid, dim3(256), 0, stream, dy, w,
                          dx, dx_cs, dx_coff, N, P, C, dx_cw, K, dx_accumulate, target, gscale, dq);
     else
@@ -936,14 +943,16 @@ extern "C" int hpri_outconv_bwd_bce(const float* logits, const float* target, co
                                  accumulate_param_grads, workspace, ws_floats, N, P, C, K, stream);
 }
 
-// Backward of the head over bf16 rows (hpri_outconv_fwd_x16): dw / db read x16; dx (fp32, optional) as hpri_outconv_bwd.
+// Backward of the head over bf16 rows (hpri_outconv_fwd_x16): dw / db read x16; dx (optional) as hpri_outconv_bwd, or -- dx_bf16, one
+// class -- as bf16 rows (strides in elements): its one reader, the last BatchNorm backward, reads bf16.
 // target != nullptr: `dy` holds the LOGITS and the loss gradient is formed inside the kernels (hpri_outconv_bwd_bce).
 extern "C" int hpri_outconv_bwd_x16(const float* dy, const float* target, const float* gscale, const void* x16, int x_cs, int x_coff,
-                                    const float* w, float* dx, int dx_cs, int dx_coff, int dx_cw, int dx_accumulate, float* dw,
+                                    const float* w, void* dx, int dx_bf16, int dx_cs, int dx_coff, int dx_cw, int dx_accumulate, float* dw,
                                     float* db, int accumulate_param_grads, float* workspace, size_t ws_floats, int N, long long P,
                                     int C, int K, hipStream_t stream) {
-  return outconv_bwd_impl<true>(dy, target, gscale, reinterpret_cast<const float*>(x16), x_cs, x_coff, w, dx, dx_cs, dx_coff, dx_cw,
-                                dx_accumulate, dw, db, accumulate_param_grads, workspace, ws_floats, N, P, C, K, stream);
+  return outconv_bwd_impl<true>(dy, target, gscale, reinterpret_cast<const float*>(x16), x_cs, x_coff, w, reinterpret_cast<float*>(dx),
+                                dx_cs, dx_coff, dx_cw, dx_accumulate, dw, db, accumulate_param_grads, workspace, ws_floats, N, P, C, K,
+                                stream, dx_bf16);
 }
 
 extern "C" int hpri_synth_fill(float* dst, long long n, unsigned long long seed, int mode, float thr, float scale,

@@ -471,3 +471,13 @@ extern "C" int hpri_convt_dgrad_bf16v3(const void* dyp, int dy_cs, int dy_coff, 
   return g3_launch(2, dyp, dy_cs, dy_coff, wp, nullptr, dx, dx_cs, dx_coff, dx_cw, nullptr, 0, 0, nullptr, 0, N, (long long)H * W, W, H2, W2,
                    py0, px0, Cup, 4 * Cup, Cin, Cin_pad, accumulate & 1, stream);
 }
+
+// ... written as bf16 rows (no accumulate): the input of a decoder stage has this one reader of its gradient, the BatchNorm backward
+// of the stage that produced it, which reads bf16 (hpri_bn_relu_bwd_x16_dy16)
+extern "C" int hpri_convt_dgrad_bf16v3_y16(const void* dyp, int dy_cs, int dy_coff, const void* wp, void* dx16, int dx_cs, int dx_coff, int N,
+                                           int H, int W, int Cup, int Cin, int Cin_pad, int dx_cw, int H2, int W2, int py0, int px0,
+                                           hipStream_t stream) {
+  HPRI_REQUIRE(dx16 != nullptr, "convt_dgrad_bf16v3_y16: null pointer");
+  return g3_launch(2, dyp, dy_cs, dy_coff, wp, nullptr, nullptr, 0, 0, dx_cw, dx16, dx_cs, dx_coff, nullptr, 0, N, (long long)H * W, W, H2, W2,
+                   py0, px0, Cup, 4 * Cup, Cin, Cin_pad, 0, stream);
+}

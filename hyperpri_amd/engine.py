@@ -349,10 +349,13 @@ class Tape:
                 if p is not None and p.requires_grad:
                     self.uses[id(p)] = self.uses.get(id(p), 0) + 1
 
-    def grad_slot(self, a: Act) -> Tuple[Act, bool]:
-        """(gradient view for ``a``, accumulate?) -- allocates a fresh buffer the first time."""
+    def grad_slot(self, a: Act, b16_ok: bool = False) -> Tuple[Act, bool]:
+        """(gradient view for ``a``, accumulate?) -- allocates a fresh buffer the first time.  ``b16_ok``: the caller can add into
+        a gradient stored as bf16 rows (the pooling backward); everybody else writes fp32."""
         g = self.grads.get(id(a))
         if g is not None:
+            if g.b16 and not b16_ok:
+                raise RuntimeError("hyperpri_amd: internal error: an fp32 writer met a gradient stored as bf16 rows")
             return g, True
         g = Act.new(a.N, a.H, a.W, a.C, a.buf.device)
         self.grads[id(a)] = g
@@ -1385,7 +1388,7 @@ def maxpool2(tape: Tape, x: Act) -> Act:
             g = tp.grads.pop(id(y), None)
             if g is None:
                 return
-            gx, acc = tp.grad_slot(x)
+            gx, acc = tp.grad_slot(x, b16_ok=True)
             if x16 or gx.b16:
                 _lib.call("hpri_maxpool2_bwd_x16", _p(x.pl.buf) if x16 else x.ptr, int(x16), x.pl.cs if x16 else x.cs,
                           x.pl.coff if x16 else x.coff, g.ptr, g.cs, g.coff, gx.ptr, int(gx.b16), gx.cs, gx.coff,
@@ -1474,11 +1477,20 @@ def _upsample_bwd(tp: Tape, c) -> None:
             _wgrad(x1, gu, dw, acc_w, cin, 4 * cup, 1, bmode=A_S2D, dst_mode=1, H2=H2, W2=W2, py0=py0, px0=px0, cup=cup,
                    bf16=bprec in LOWP, split=_SPLIT.get(bprec, 0))
     if need_dx1 and pd:
-        gx, acc = tp.grad_slot(x1)
         wpd, cols_pad = _pack_bf16(weight, 3, 4 * cup, cin, 1, cup, cup, split=0)
-        with _timed("gemm_planes_bf16<convT,s2d>", 2.0 * x1.N * x1.H * x1.W * cin * 4 * cup):
-            _lib.call("hpri_convt_dgrad_bf16v3", _p(gpl.buf), gpl.cs, gpl.coff, _p(wpd), gx.ptr, gx.cs, gx.coff, x1.N, x1.H, x1.W, cup, cin,
-                      cols_pad, gx.cw, H2, W2, py0, px0, int(acc), _stream())
+        if GRAD_BF16_SINGLE and x1.yr16 and tp.grads.get(id(x1)) is None and cin % 8 == 0:
+            # x1 (the bottleneck, or the previous decoder stage's output) has this one consumer: bf16 rows for its BatchNorm backward
+            gx = Act(torch.empty(x1.P * cin, dtype=torch.bfloat16, device=dev), x1.N, x1.H, x1.W, cin, cin, 0)
+            gx.b16, gx.f32_valid = True, False
+            tp.grads[id(x1)] = gx
+            with _timed("gemm_planes_bf16<convT,s2d>", 2.0 * x1.N * x1.H * x1.W * cin * 4 * cup):
+                _lib.call("hpri_convt_dgrad_bf16v3_y16", _p(gpl.buf), gpl.cs, gpl.coff, _p(wpd), gx.ptr, gx.cs, gx.coff, x1.N, x1.H, x1.W,
+                          cup, cin, cols_pad, cin, H2, W2, py0, px0, _stream())
+        else:
+            gx, acc = tp.grad_slot(x1)
+            with _timed("gemm_planes_bf16<convT,s2d>", 2.0 * x1.N * x1.H * x1.W * cin * 4 * cup):
+                _lib.call("hpri_convt_dgrad_bf16v3", _p(gpl.buf), gpl.cs, gpl.coff, _p(wpd), gx.ptr, gx.cs, gx.coff, x1.N, x1.H, x1.W, cup,
+                          cin, cols_pad, gx.cw, H2, W2, py0, px0, int(acc), _stream())
     elif need_dx1:
         gx, acc = tp.grad_slot(x1)
         if bprec in LOWP:
@@ -1768,6 +1780,10 @@ SKIP_PLANES_ONLY = FUSIONS
 # output as bf16), added to by the pooling backward (hpri_maxpool2_bwd_x16), read by the BatchNorm backward of the stage that made the
 # skip (hpri_bn_relu_bwd_x16_dy16): 10 of 20 bytes per element of the four skip gradients.  (HPRI_FUSIONS.)
 SKIP_GRAD_BF16 = FUSIONS
+# ... as are the other single-producer, single-reader activation gradients that were still fp32: the input of every decoder stage
+# (written by the transposed convolution's data gradient: hpri_convt_dgrad_bf16v3_y16) and the head's input (hpri_outconv_bwd_x16,
+# dx_bf16); their one reader is the BatchNorm backward of the stage that produced the tensor.  (HPRI_FUSIONS.)
+GRAD_BF16_SINGLE = FUSIONS
 
 
 def concat_planes(tape: Tape, a: Act, b: Act) -> Tuple[Act, Tuple[int, int]]:
@@ -1904,7 +1920,14 @@ def out_conv(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.Tens
             nblk = ctypes.c_int(); cpart = ctypes.c_int()
             _lib.call("hpri_outconv_bwd_plan", x.N, x.H * x.W, C, K, ctypes.byref(nblk), ctypes.byref(cpart))
             ws = _ws(nblk.value * K * 2 * cpart.value, dev)
-            if need_dx:
+            g16 = 0
+            if need_dx and x16 and GRAD_BF16_SINGLE and K == 1 and not k_gap and x.yr16 and tp.grads.get(id(x)) is None and C % 8 == 0:
+                # the head is the only reader of x: its gradient as bf16 rows for the last BatchNorm backward
+                gx = Act(torch.empty(x.P * C, dtype=torch.bfloat16, device=dev), x.N, x.H, x.W, C, C, 0)
+                gx.b16, gx.f32_valid = True, False
+                tp.grads[id(x)] = gx
+                gxp, gcs, gco, gcw, acc, g16 = gx.ptr, C, 0, C, False, 1
+            elif need_dx:
                 gx, acc = tp.grad_slot(x)
                 gxp, gcs, gco, gcw = gx.ptr, gx.cs, gx.coff, gx.cw
             else:
@@ -1915,7 +1938,7 @@ def out_conv(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.Tens
             acc_k = 0 if k_gap else acc_w
             if x16:
                 _lib.call("hpri_outconv_bwd_x16", _p(gy), _p(tgt) if fused else ctypes.c_void_p(0), _p(gs) if fused else ctypes.c_void_p(0),
-                          *xa, _p(wsrc), gxp, gcs, gco, gcw, int(acc), _p(dwk), _p(dbk), acc_k, _p(ws), ws.numel(),
+                          *xa, _p(wsrc), gxp, g16, gcs, gco, gcw, int(acc), _p(dwk), _p(dbk), acc_k, _p(ws), ws.numel(),
                           x.N, x.H * x.W, C, K, _stream())
             elif fused:
                 _lib.call("hpri_outconv_bwd_bce", _p(gy), _p(tgt), _p(gs), x.ptr, x.cs, x.coff, _p(weight), gxp, gcs, gco, gcw,

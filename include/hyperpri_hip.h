@@ -232,6 +232,10 @@ int hpri_convt_fwd_bf16v3(const void* xp, int x_cs, int x_coff, const void* wp, 
 int hpri_convt_dgrad_bf16v3(const void* dyp, int dy_cs, int dy_coff, const void* wp, float* dx, int dx_cs, int dx_coff, int N,
                             int H, int W, int Cup, int Cin, int Cin_pad, int dx_cw, int H2, int W2, int py0, int px0,
                             int accumulate, hipStream_t stream);
+/* ... the same written as bf16 rows (round 4; no accumulate): a decoder stage's input has one reader of its gradient. */
+int hpri_convt_dgrad_bf16v3_y16(const void* dyp, int dy_cs, int dy_coff, const void* wp, void* dx16, int dx_cs, int dx_coff, int N,
+                                int H, int W, int Cup, int Cin, int Cin_pad, int dx_cw, int H2, int W2, int py0, int px0,
+                                hipStream_t stream);
 
 /* ---- weight gradients, fp32 MFMA, deterministic split-K (conv_wgrad.hip) --------------------------
  * Replaces the wgrad half of autograd for the same layers.  dst_mode 0 writes OIHW / (out,in),
@@ -387,12 +391,12 @@ int hpri_outconv_bwd_bce(const float* logits, const float* target, const float* 
 /* The head of the bf16 mode (model_parts.py:96 / models.py:103,143 after a bf16-mode layer): the input is plane 0 of the last
  * activation's plane buffer -- bf16 NHWC rows, x_cs / x_coff in elements (multiples of 8), pad channels zero -- so no fp32 copy of
  * that tensor is written or read.  target != NULL: with the loss partials (forward) / `dy` holds the logits and the loss gradient is
- * formed inside the kernels (backward), as hpri_outconv_fwd_bce / hpri_outconv_bwd_bce.  dx stays fp32. */
+ * formed inside the kernels (backward), as hpri_outconv_fwd_bce / hpri_outconv_bwd_bce.  dx: fp32, or (dx_bf16, one class) bf16 rows. */
 int hpri_outconv_fwd_x16(const void* x16, int x_cs, int x_coff, const float* w, const float* b, float* y, const float* target,
                          double* partial, size_t partial_doubles, int N, long long P, int C, int K, hipStream_t stream);
 int hpri_outconv_bwd_x16(const float* dy, const float* target, const float* gscale, const void* x16, int x_cs, int x_coff,
-                         const float* w, float* dx, int dx_cs, int dx_coff, int dx_cw, int dx_accumulate, float* dw, float* db,
-                         int accumulate_param_grads, float* workspace, size_t ws_floats, int N, long long P, int C, int K,
+                         const float* w, void* dx, int dx_bf16, int dx_cs, int dx_coff, int dx_cw, int dx_accumulate, float* dw,
+                         float* db, int accumulate_param_grads, float* workspace, size_t ws_floats, int N, long long P, int C, int K,
                          hipStream_t stream);
 /* nn.Upsample(scale_factor=2, 'bilinear', align_corners=True) (model_parts.py:57; models.py:195) writing at a pixel
  * offset of a padded destination, its gather-form gradient, and the element-wise "attention" product x2*x1

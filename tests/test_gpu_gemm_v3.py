@@ -172,6 +172,15 @@ def test_transposed_convolution_forward_and_data_gradient(lib, shape):
     errd = float((dx.double().cpu()[:, :Cin] - prior.double().cpu()[:, :Cin] - refd).abs().max())
     record_margin(f"gemm_bf16v3/convt_dgrad/{N}x{H}x{W}x{Cin}x{Cup}", errd, 2e-5 * scd)
     assert errd < 2e-5 * scd, (shape, errd)
+    # the same written as bf16 rows (round 4): the fp32 result, rounded once
+    dxf = torch.zeros(N * H * W, dcw, device=DEV)
+    assert lib.hpri_convt_dgrad_bf16v3(P(dyp), dcs, 32, P(wpd), P(dxf), dcw, 0, N, H, W, Cup, Cin, cinp, dcw, H2, W2, py0, px0, 0, _st()) == 0
+    d16 = torch.full((N * H * W, dcw + 8), 3.0, dtype=torch.bfloat16, device=DEV)
+    rc = lib.hpri_convt_dgrad_bf16v3_y16(P(dyp), dcs, 32, P(wpd), P(d16), dcw + 8, 0, N, H, W, Cup, Cin, cinp, dcw, H2, W2, py0, px0, _st())
+    assert rc == 0, lib.hpri_last_error()
+    torch.cuda.synchronize()
+    assert torch.equal(d16[:, :dcw], dxf.to(torch.bfloat16)) and float(d16[:, dcw:].float().sub(3.0).abs().max()) == 0.0
+    assert lib.hpri_convt_dgrad_bf16v3_y16(P(dyp), dcs, 32, P(wpd), P(None), dcw + 8, 0, N, H, W, Cup, Cin, cinp, dcw, H2, W2, py0, px0, _st()) != 0
 
 
 @pytest.mark.parametrize("shape", [(300, 40, 24), (5000, 238, 150), (70000, 330, 520), (33, 8, 8), (20000, 1650, 264)])

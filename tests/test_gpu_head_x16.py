@@ -107,7 +107,7 @@ def test_head_backward(lib, case, bce, acc):
     ws = torch.empty(nblk.value * K * 2 * cpart.value, device=DEV)
     common = (P(w), P(dx), dcs, doff, dcw, acc, P(dw), P(db), acc, P(ws), ws.numel(), N, HW, C, K, _st())
     if bf16:
-        rc = lib.hpri_outconv_bwd_x16(P(src), P(tgt) if bce else P(None), P(gs) if bce else P(None), P(x), cs, coff, *common)
+        rc = lib.hpri_outconv_bwd_x16(P(src), P(tgt) if bce else P(None), P(gs) if bce else P(None), P(x), cs, coff, P(w), P(dx), 0, *common[2:])
     elif bce:
         rc = lib.hpri_outconv_bwd_bce(P(src), P(tgt), P(gs), P(x), cs, coff, *common)
     else:
@@ -126,6 +126,35 @@ def test_head_backward(lib, case, bce, acc):
     tol = 2e-5 * (N * HW) ** 0.5 * scale * max(1.0, xr.abs().max().item())
     assert (dw.double() - want_dw).abs().max().item() <= tol + 1e-6 * want_dw.abs().max().item()
     assert (db.double() - want_db).abs().max().item() <= tol + 1e-6 * want_db.abs().max().item()
+
+
+@pytest.mark.parametrize("bce", [False, True])
+@pytest.mark.parametrize("acc", [0, 1])
+def test_head_backward_writes_bf16_rows(lib, bce, acc):
+    """dx_bf16: the input gradient of the one-class head as bf16 rows == the fp32 result rounded once (accumulate: read, add, round)."""
+    N, HW, C, K = 2, 777, 64, 1
+    torch.manual_seed(5)
+    x, cs, xr = _source(N, HW, C, True, 0)
+    w = torch.randn(K, C, device=DEV) / C ** 0.5
+    tgt = (torch.rand(N, K, HW, device=DEV) > 0.7).float()
+    src = torch.randn(N, K, HW, device=DEV)
+    gs = torch.tensor([0.5], device=DEV)
+    nblk, cpart = ctypes.c_int(), ctypes.c_int()
+    lib.hpri_outconv_bwd_plan(N, HW, C, K, ctypes.byref(nblk), ctypes.byref(cpart))
+    ws = torch.empty(nblk.value * K * 2 * cpart.value, device=DEV)
+    d16 = torch.randn(N * HW, C, device=DEV).to(torch.bfloat16)
+    want = d16.float()
+    dw, db = torch.zeros(K, C, device=DEV), torch.zeros(K, device=DEV)
+    args = (P(src), P(tgt) if bce else P(None), P(gs) if bce else P(None), P(x), cs, 0, P(w))
+    tail = (C, 0, C, acc, P(dw), P(db), 0, P(ws), ws.numel(), N, HW, C, K, _st())
+    assert lib.hpri_outconv_bwd_x16(*args, P(want), 0, *tail) == 0, lib.hpri_last_error()
+    got = d16.clone()
+    assert lib.hpri_outconv_bwd_x16(*args, P(got), 1, *tail) == 0, lib.hpri_last_error()
+    torch.cuda.synchronize()
+    assert torch.equal(got, want.to(torch.bfloat16))
+    w3 = torch.randn(3, C, device=DEV)
+    assert lib.hpri_outconv_bwd_x16(P(torch.randn(N, 3, HW, device=DEV)), P(None), P(None), P(x), cs, 0, P(w3), P(got), 1, C, 0, C, 0,
+                                    P(torch.zeros(3, C, device=DEV)), P(None), 0, P(torch.empty(1 << 20, device=DEV)), 1 << 20, N, HW, C, 3, _st()) != 0
 
 
 def test_head_rejects_bad_layouts(lib):

@@ -274,7 +274,8 @@ def test_full_size_cubenet128_bf16_vs_reference_fixture():
     real = E._lib.call
 
     def spy(name, *a):
-        if name in ("hpri_conv_bf16v3_y2", "hpri_maxpool2_bwd_x16", "hpri_maxpool2_fwd_x16", "hpri_outconv_fwd_x16"):
+        if name in ("hpri_conv_bf16v3_y2", "hpri_maxpool2_bwd_x16", "hpri_maxpool2_fwd_x16", "hpri_outconv_fwd_x16", "hpri_outconv_bwd_x16",
+                    "hpri_convt_dgrad_bf16v3_y16"):
             calls.append((name, a))
         return real(name, *a)
     E._lib.call = spy
@@ -288,6 +289,8 @@ def test_full_size_cubenet128_bf16_vs_reference_fixture():
     n16 = sum(1 for n, a in calls if n == "hpri_conv_bf16v3_y2" and a[-2] == 3)
     assert n16 >= 2                                                        # (the 76x121 level has a pad ring: fp32 there)
     assert sum(1 for n, a in calls if n == "hpri_maxpool2_bwd_x16" and a[8] == 1) == n16
+    # ... and single-reader gradients as bf16 rows: the head's input and the decoder stages' inputs
+    assert [a[8] for n, a in calls if n == "hpri_outconv_bwd_x16"] == [1] and names.count("hpri_convt_dgrad_bf16v3_y16") >= 2
     stride = int(z["stride"])
     sub = lg.reshape(-1)[::stride].numpy()
     d = np.abs(sub - z["logits_sub"])

@@ -401,8 +401,8 @@ def test_bf16_mode_transposed_convolutions_on_planes(kind):
         return real(name, *a)
     # (the bf16 storage of the skip gradients rides on the second output of the same launch -- SKIP_GRAD_BF16 -- and rounds them:
     #  held off in both runs, own test below)
-    skg = E.SKIP_GRAD_BF16
-    E.SKIP_GRAD_BF16 = False
+    skg, sng = E.SKIP_GRAD_BF16, E.GRAD_BF16_SINGLE
+    E.SKIP_GRAD_BF16 = E.GRAD_BF16_SINGLE = False
     E._lib.call = spy
     try:
         lg1, g1 = _step(net, x, m)
@@ -416,7 +416,7 @@ def test_bf16_mode_transposed_convolutions_on_planes(kind):
         lg2, g2 = _step(net, x, m)
     finally:
         E.CONVT_PLANES = True
-        E.SKIP_GRAD_BF16 = skg
+        E.SKIP_GRAD_BF16, E.GRAD_BF16_SINGLE = skg, sng
     assert float((lg1 - lg2).abs().max()) <= 2e-2 * max(1.0, float(lg2.abs().max()))
     worst = 0.0
     for (k, _), a, b in zip(net.named_parameters(), g1, g2):
@@ -515,6 +515,52 @@ def test_bf16_mode_skip_gradients_as_bf16_rows(kind):
             continue
         worst = max(worst, float((a.double() - b.double()).norm()) / ref)
     record_margin(f"bf16_skip_grad_bf16_switch_grads_{kind}", worst, 0.1)
+    assert worst <= 0.1, worst
+
+
+@pytest.mark.parametrize("kind", ["unet", "cube64", "cube128"])
+def test_bf16_mode_single_reader_gradients_as_bf16_rows(kind):
+    """GRAD_BF16_SINGLE (default on, round 4): the gradient of every decoder stage's input (hpri_convt_dgrad_bf16v3_y16) and of the
+    head's input (hpri_outconv_bwd_x16, dx_bf16) is written as bf16 rows for its one reader, the BatchNorm backward of the producing
+    stage.  One more rounding to bf16 per tensor; logits untouched."""
+    import hyperpri_amd as H
+    from hyperpri_amd import engine as E
+    net, x, m = _net(kind)
+    H.set_precision(net, "bf16")
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    assert E.GRAD_BF16_SINGLE
+    calls = []
+    real = E._lib.call
+
+    def spy(name, *a):
+        calls.append((name, a))
+        return real(name, *a)
+    E._lib.call = spy
+    try:
+        lg1, g1 = _step(net, x, m)
+    finally:
+        E._lib.call = real
+    head = [a for n, a in calls if n == "hpri_outconv_bwd_x16"]
+    names = [n for n, _ in calls]
+    # (a tensor whose producer finished in split-K keeps an fp32 gradient: its pre-BN tensor is fp32 and so is the kernel that reads
+    #  both -- on this tiny net that is most of them; the full-size count is in tests/test_gpu_nets.py, C5 bf16)
+    assert len(head) == 1 and head[0][8] in (0, 1)
+    assert names.count("hpri_convt_dgrad_bf16v3_y16") >= 1
+    try:
+        E.GRAD_BF16_SINGLE = False
+        net.load_state_dict(sd)
+        lg2, g2 = _step(net, x, m)
+    finally:
+        E.GRAD_BF16_SINGLE = True
+    assert torch.equal(lg1, lg2)
+    worst = 0.0
+    for (k, _), a, b in zip(net.named_parameters(), g1, g2):
+        assert torch.isfinite(a).all(), k
+        ref = float(b.double().norm())
+        if ref < 1e-6:
+            continue
+        worst = max(worst, float((a.double() - b.double()).norm()) / ref)
+    record_margin(f"bf16_grad_bf16_single_switch_grads_{kind}", worst, 0.1)
     assert worst <= 0.1, worst
 
 
