@@ -36,6 +36,7 @@ struct GemmV3Args {
   const float* bias;                         // per output channel (mode 1: per Cup channel), or nullptr
   float* y; int y_cs, y_coff, y_cw;          // fp32 output view (nullptr: none)
   __bf16* y16; int y16_cs, y16_coff;         // bf16 output view (nullptr: none)
+  int acc16;                                 // mode 0: add the bf16 view's old contents (accumulate flag with no fp32 view)
   float4* stats; int stat_cp;                // mode 0: [tile][stat_cp] (mean, M2, count) records, or nullptr
   int N, HW;                                 // images, GEMM rows per image (mode 1 / 2: H * W of the low-resolution grid)
   int W, H2, W2, py0, px0, cup;              // transposed-convolution geometry (modes 1, 2)
@@ -292,6 +293,24 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16v3_kernel(GemmV3Args a) {
         }
       }
       if (a.y16 != nullptr) {
+        if (MODE == 0 && a.acc16) {
+          // round 4: the bf16 rows hold an earlier contribution to the same gradient (SpectralUNET's skips have two consumers):
+          // read, add in fp32, round once on the way back.  All loads of the half before its stores (32 registers of old values).
+          bf16x4_t o16[4][4];
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const bf16x4_t z = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+              o16[mt][q] = (((vmask >> mt) & 1u) && cok[q]) ? *reinterpret_cast<const bf16x4_t*>(a.y16 + orow[mt] * a.y16_cs + a.y16_coff + coff[q]) : z;
+            }
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) acc[mt][h * 4 + q][r] += (float)o16[mt][q][r];
+        }
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
           if ((vmask >> mt) & 1u) {
@@ -402,7 +421,12 @@ static int g3_launch(int mode, const void* xp, int x_cs, int x_coff, const void*
     HPRI_REQUIRE(y_cs % 4 == 0 && y_coff % 4 == 0 && ((uintptr_t)y & 15) == 0, "gemm_bf16v3: the fp32 output view must be float4-aligned");
   if (y16 != nullptr)
     HPRI_REQUIRE(y16_cs % 4 == 0 && y16_coff % 4 == 0 && ((uintptr_t)y16 & 7) == 0, "gemm_bf16v3: the bf16 output view must be 8-byte aligned");
-  HPRI_REQUIRE(!(a.accumulate && y == nullptr), "gemm_bf16v3: accumulate needs the fp32 output");
+  a.acc16 = 0;
+  if (a.accumulate && y == nullptr) {
+    // accumulate with a bf16 view only: the plain row GEMM adds into the bf16 rows (a gradient with two producers stored as bf16)
+    HPRI_REQUIRE(mode == 0 && y16 != nullptr && !a.relu && bias == nullptr, "gemm_bf16v3: accumulating into bf16 rows is the plain data-gradient form (mode 0, no bias, no ReLU)");
+    a.acc16 = 1; a.accumulate = 0;
+  }
   HPRI_REQUIRE(!(a.accumulate && mode == 1), "gemm_bf16v3: the depth-to-space form does not accumulate");
   if (mode == 0 || mode == 2) {
     HPRI_REQUIRE(y_cw % 4 == 0 && y_cw >= Ncols && y_cw <= ((Ncols_pad + G3_BN - 1) / G3_BN) * G3_BN, "gemm_bf16v3: written width must be a multiple of 4 in [Ncols, column blocks]");

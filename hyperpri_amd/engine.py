@@ -114,7 +114,10 @@ class Act:
     def slice(self, c0: int, C: int) -> "Act":
         if c0 % 4:
             raise RuntimeError("hyperpri_amd: channel slices must start at a multiple of 4")
-        return Act(self.buf, self.N, self.H, self.W, C, self.cs, self.coff + c0)
+        v = Act(self.buf, self.N, self.H, self.W, C, self.cs, self.coff + c0)
+        if self.b16:                       # a channel slice of bf16 rows (a gradient stored as bf16) is bf16 rows
+            v.b16, v.f32_valid = True, False
+        return v
 
     def to_tensor(self) -> torch.Tensor:
         """Logical (N,C,H,W) tensor aliasing this view (channels-last strides, no copy)."""
@@ -1092,6 +1095,14 @@ def _conv_bwd_data(tp: Tape, c, dyr: Act) -> None:
         acc = False
     elif c.v2 and x.skip_g16 and tp.grads.get(id(x)) is None and _y2_ok(x, cout, cin, False):
         gx, acc = None, False          # the skip half as bf16 rows, the upsampled half as planes: made in _conv_bwd_data_planes
+    elif c.g3 and GRAD_BF16_GEMM and x.yr16 and x.colsum_req is None:
+        # a 1x1 layer of the plane-GEMM path whose input's BatchNorm backward (or, a plane concat, both halves') reads bf16 gradients
+        gx = tp.grads.get(id(x))
+        acc = gx is not None
+        if gx is None:
+            gx = tp.grads[id(x)] = _new_grad16(x)
+        elif not gx.b16:
+            gx, acc = tp.grad_slot(x)
     else:
         gx, acc = tp.grad_slot(x)
     # the column sums of (a channel range of) this gradient are wanted -- the bias gradient of the ConvTranspose2d that
@@ -1143,6 +1154,14 @@ def _conv_bwd_data(tp: Tape, c, dyr: Act) -> None:
                      cin_true=cout)
     if gstats is not None:
         tp.colsum[id(x)] = (gstats, gtiles, cin_cols_pad)
+
+
+def _new_grad16(x: Act) -> Act:
+    """A gradient for ``x`` stored as bf16 rows (row stride = C rounded up to 8; every writer fills the pad columns with zeros)."""
+    cs = _rup(x.C, 8)
+    g = Act(torch.empty(x.P * cs, dtype=torch.bfloat16, device=x.buf.device), x.N, x.H, x.W, x.C, cs, 0)
+    g.b16, g.f32_valid = True, False
+    return g
 
 
 def _y2_ok(x: Act, cout: int, cin: int, acc: bool) -> bool:
@@ -1784,6 +1803,10 @@ SKIP_GRAD_BF16 = FUSIONS
 # (written by the transposed convolution's data gradient: hpri_convt_dgrad_bf16v3_y16) and the head's input (hpri_outconv_bwd_x16,
 # dx_bf16); their one reader is the BatchNorm backward of the stage that produced the tensor.  (HPRI_FUSIONS.)
 GRAD_BF16_SINGLE = FUSIONS
+# SpectralUNET on the plane GEMMs: every activation gradient is stored as bf16 rows -- written by the data-gradient GEMM (bf16 view
+# only), ADDED to by the second consumer's data-gradient GEMM (gemm_bf16v3's accumulate-into-bf16 form), split into channel-slice views
+# for the two halves of a plane concat, read by hpri_bn_relu_bwd_x16_dy16: 6 instead of 12 bytes per element and layer.  (HPRI_FUSIONS.)
+GRAD_BF16_GEMM = FUSIONS
 
 
 def concat_planes(tape: Tape, a: Act, b: Act) -> Tuple[Act, Tuple[int, int]]:
@@ -1797,6 +1820,7 @@ def concat_planes(tape: Tape, a: Act, b: Act) -> Tuple[Act, Tuple[int, int]]:
     cat = Act(torch.empty(8, dtype=torch.float32, device=a.buf.device), a.N, a.H, a.W, C, _rup(C, 8), 0)
     cat.f32_valid = False
     cat.pl = Planes(cbuf, a.P * ccs, ccs, 0, 1)
+    cat.yr16 = a.yr16 and b.yr16               # both halves' BatchNorm backward read bf16 gradients: so may the concat's be stored
     if tape.record:
         def bwd(tp: Tape) -> None:
             g = tp.grads.pop(id(cat), None)
@@ -1804,7 +1828,7 @@ def concat_planes(tape: Tape, a: Act, b: Act) -> Tuple[Act, Tuple[int, int]]:
                 return
             # both halves start at multiples of 32 channels of the consumer's input gradient: views (the gap columns hold exact
             # zeros: their weights are zero in the data-gradient pack)
-            tp.set_grad_view(a, Act(g.buf, g.N, g.H, g.W, a.C, g.cs, g.coff))
+            tp.set_grad_view(a, g.slice(0, a.C))
             tp.set_grad_view(b, g.slice(ob, b.C))
         tape.nodes.append(bwd)
     return cat, (a.C, ob - a.C)
@@ -1921,12 +1945,12 @@ def out_conv(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.Tens
             _lib.call("hpri_outconv_bwd_plan", x.N, x.H * x.W, C, K, ctypes.byref(nblk), ctypes.byref(cpart))
             ws = _ws(nblk.value * K * 2 * cpart.value, dev)
             g16 = 0
-            if need_dx and x16 and GRAD_BF16_SINGLE and K == 1 and not k_gap and x.yr16 and tp.grads.get(id(x)) is None and C % 8 == 0:
-                # the head is the only reader of x: its gradient as bf16 rows for the last BatchNorm backward
-                gx = Act(torch.empty(x.P * C, dtype=torch.bfloat16, device=dev), x.N, x.H, x.W, C, C, 0)
-                gx.b16, gx.f32_valid = True, False
-                tp.grads[id(x)] = gx
-                gxp, gcs, gco, gcw, acc, g16 = gx.ptr, C, 0, C, False, 1
+            if (need_dx and x16 and K == 1 and x.yr16 and tp.grads.get(id(x)) is None
+                    and (GRAD_BF16_GEMM if k_gap else GRAD_BF16_SINGLE)):
+                # the head is the first writer of this gradient and its readers read bf16: bf16 rows for the last BatchNorm
+                # backward (U-Nets), or for the views of SpectralUNET's last plane concat (tail's half is added to later)
+                gx = tp.grads[id(x)] = _new_grad16(x)
+                gxp, gcs, gco, gcw, acc, g16 = gx.ptr, gx.cs, 0, gx.cw, False, 1
             elif need_dx:
                 gx, acc = tp.grad_slot(x)
                 gxp, gcs, gco, gcw = gx.ptr, gx.cs, gx.coff, gx.cw

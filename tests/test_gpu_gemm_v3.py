@@ -115,6 +115,19 @@ def test_linear_data_gradient(lib, shape):
     err = float((dx.double().cpu()[:, :Cin] - prior.double().cpu()[:, :Cin] - ref).abs().max())
     record_margin(f"gemm_bf16v3/dgrad/{N}x{HW}x{Cout}x{Cin}", err, 2e-5 * sc)
     assert err < 2e-5 * sc, (shape, err)
+    # round 4: the same product ADDED into bf16 rows (a gradient with two producers stored as bf16) == bf16(fp32 sum of the old rows
+    # and the fp32 product); a bias, ReLU or the transposed-convolution forms refuse that combination
+    fresh = torch.zeros(N * HW, cw, device=DEV)
+    assert lib.hpri_gemm_bf16v3(P(dyp), kp, 0, P(wp), P(None), P(fresh), cw, 0, P(None), 0, 0, P(None), 0, N, HW, kp, Cin, cp, cw, 0, _st()) == 0
+    old16 = torch.randn(N * HW, cw + 8, device=DEV).to(torch.bfloat16)
+    got16 = old16.clone()
+    rc = lib.hpri_gemm_bf16v3(P(dyp), kp, 0, P(wp), P(None), P(None), 0, 0, P(got16), cw + 8, 0, P(None), 0, N, HW, kp, Cin, cp, cw, 1, _st())
+    assert rc == 0, lib.hpri_last_error()
+    torch.cuda.synchronize()
+    assert torch.equal(got16[:, :cw], (old16[:, :cw].float() + fresh).to(torch.bfloat16)) and torch.equal(got16[:, cw:], old16[:, cw:])
+    b = torch.zeros(Cin, device=DEV)
+    assert lib.hpri_gemm_bf16v3(P(dyp), kp, 0, P(wp), P(b), P(None), 0, 0, P(got16), cw + 8, 0, P(None), 0, N, HW, kp, Cin, cp, cw, 1, _st()) != 0
+    assert lib.hpri_gemm_bf16v3(P(dyp), kp, 0, P(wp), P(None), P(None), 0, 0, P(got16), cw + 8, 0, P(None), 0, N, HW, kp, Cin, cp, cw, 3, _st()) != 0
 
 
 @pytest.mark.parametrize("shape", [(2, 9, 15, 128, 64, 0, 0), (1, 19, 30, 64, 32, 1, 1), (2, 5, 7, 96, 48, 0, 1), (1, 38, 60, 256, 128, 0, 0)])

@@ -26,6 +26,8 @@ def _net(kind):
         net, x = H.UNet(3, 1, bilinear=False), _u(1234, (2, 3, 36, 50))
     elif kind == "cube64":
         net, x = H.CubeNET(6, 1, first_depth=64, bilinear=False), _u(1235, (2, 1, 6, 36, 50))
+    elif kind == "spectral":
+        net, x = H.SpectralUNET(6, 1, 48), _u(1237, (2, 1, 6, 36, 50))
     else:
         net, x = H.CubeNET(6, 1, first_depth=128, bilinear=False), _u(1236, (2, 1, 6, 36, 50))
     shapes = OrderedDict((k, tuple(v.shape)) for k, v in net.state_dict().items())
@@ -515,6 +517,52 @@ def test_bf16_mode_skip_gradients_as_bf16_rows(kind):
             continue
         worst = max(worst, float((a.double() - b.double()).norm()) / ref)
     record_margin(f"bf16_skip_grad_bf16_switch_grads_{kind}", worst, 0.1)
+    assert worst <= 0.1, worst
+
+
+def test_bf16_mode_spectral_gradients_as_bf16_rows():
+    """GRAD_BF16_GEMM (default on, round 4): on the plane-GEMM path of SpectralUNET every activation gradient is bf16 rows -- the head
+    and the data-gradient GEMMs write them, the second consumer of a skip ADDS into them (gemm_bf16v3, accumulate with a bf16 view only),
+    the halves of a plane concat are channel-slice views, the BatchNorm backward reads bf16.  Logits untouched; gradients move like
+    between any two bf16 paths."""
+    import hyperpri_amd as H
+    from hyperpri_amd import engine as E
+    net, x, m = _net("spectral")
+    H.set_precision(net, "bf16")
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    assert E.GRAD_BF16_GEMM and E.plane_gemm_mode(net)
+    calls = []
+    real = E._lib.call
+
+    def spy(name, *a):
+        calls.append((name, a))
+        return real(name, *a)
+    E._lib.call = spy
+    try:
+        lg1, g1 = _step(net, x, m)
+    finally:
+        E._lib.call = real
+    names = [n for n, _ in calls]
+    assert names.count("hpri_bn_relu_bwd_x16_dy16") == 9 and "hpri_bn_relu_bwd_x16" not in names
+    null = lambda p: not getattr(p, "value", p)
+    dgrad = [a for n, a in calls if n == "hpri_gemm_bf16v3" and null(a[4])]              # no bias: the data-gradient launches
+    assert len(dgrad) == 8 and all(null(a[5]) and not null(a[8]) for a in dgrad)          # bf16 view only
+    assert sum(1 for a in dgrad if a[-2] == 1) == 4                                     # x0 .. x3: the second consumer adds
+    try:
+        E.GRAD_BF16_GEMM = False
+        net.load_state_dict(sd)
+        lg2, g2 = _step(net, x, m)
+    finally:
+        E.GRAD_BF16_GEMM = True
+    assert torch.equal(lg1, lg2)
+    worst = 0.0
+    for (k, _), a, b in zip(net.named_parameters(), g1, g2):
+        assert torch.isfinite(a).all(), k
+        ref = float(b.double().norm())
+        if ref < 1e-6:
+            continue
+        worst = max(worst, float((a.double() - b.double()).norm()) / ref)
+    record_margin("bf16_grad_bf16_gemm_switch_grads_spectral", worst, 0.1)
     assert worst <= 0.1, worst
 
 
