@@ -1064,7 +1064,9 @@ def _conv_bwd_weight(tp: Tape, c, dyr: Act) -> None:
     if not c.weight.requires_grad:          # frozen (feature_extraction, models.py:17-21): no weight gradient at all
         return
     dw, acc_w = tp.param_slot(c.weight)
-    if SIDE_STREAM and c.need_dx and _EVENT_LOG is None and (_GRAD_SINK is None or SIDE_STREAM_WITH_SINK):
+    # (not for the plane GEMMs of SpectralUNET: two persistent MFMA kernels of several milliseconds side by side share one power budget
+    #  and one set of CUs -- measured on one box, C3 bf16: 118.0 ms per step with the second stream, 113.8 without)
+    if SIDE_STREAM and c.need_dx and not c.g3 and _EVENT_LOG is None and (_GRAD_SINK is None or SIDE_STREAM_WITH_SINK):
         main, side = torch.cuda.current_stream(c.dev), _side(c.dev)
         side.wait_stream(main)                      # dyr (and everything before it) is ready
         with torch.cuda.stream(side):
