@@ -87,3 +87,30 @@ def test_parameter_whose_last_announcing_node_returns_early_is_still_handed_over
         engine.set_grad_sink(None)
     assert sink.order == [id(w)]
     assert torch.equal(sink.seen_at_ready[id(w)], torch.full((3,), 4.0))
+
+
+def test_bf16_gradient_storage_guards():
+    """Round 4: activation gradients may be stored as bf16 rows (skips, single-reader tensors, the plane-GEMM path).  Host logic only: a
+    channel slice of bf16 rows is bf16 rows; Tape.grad_slot hands an existing bf16 gradient only to a caller that says it can add
+    into bf16 (the pooling backward) -- an fp32 writer meeting one is an internal error, not silent corruption; a bf16 view never
+    meets an earlier gradient of the same tensor."""
+    import pytest
+    buf = torch.zeros(2 * 3 * 4 * 16, dtype=torch.bfloat16)
+    g = engine.Act(buf, 2, 3, 4, 16, 16, 0)
+    g.b16, g.f32_valid = True, False
+    v = g.slice(8, 8)
+    assert v.b16 and not v.f32_valid and v.coff == 8 and v.cs == 16 and v.buf is buf
+    f = engine.Act(torch.zeros(2 * 3 * 4 * 16), 2, 3, 4, 16, 16, 0)
+    assert not f.slice(4, 8).b16 and f.slice(4, 8).f32_valid
+    x = engine.Act(torch.zeros(8), 2, 3, 4, 16, 16, 0)
+    tape = engine.Tape(True)
+    tape.grads[id(x)] = g
+    got, acc = tape.grad_slot(x, b16_ok=True)
+    assert got is g and acc
+    with pytest.raises(RuntimeError, match="bf16 rows"):
+        tape.grad_slot(x)
+    with pytest.raises(RuntimeError, match="bf16 gradient view"):
+        tape.set_grad_view(x, v)
+    y = engine.Act(torch.zeros(8), 2, 3, 4, 8, 8, 0)
+    tape.set_grad_view(y, v)                               # first gradient of y: the view is taken as it is
+    assert tape.grads[id(y)] is v
