@@ -32,6 +32,124 @@ def _as4d(t: torch.Tensor) -> torch.Tensor:
     return t
 
 
+# ---- segmented tapes ---------------------------------------------------------------------------------------------------------------
+# A whole network as ONE autograd node hands all its parameter gradients to autograd at the very end of backward: stock
+# DistributedDataParallel (Lightning strategy="ddp", PLTrainer.py:434-442) -- whose reducer sends a bucket when the AccumulateGrad
+# nodes of its parameters have run -- would then start its first all-reduce after the last kernel of backward.  Under a process group
+# the networks therefore run as a CHAIN of a few autograd nodes that share one tape: the program is a generator that yields at its
+# stage boundaries (module by module), consecutive stages are grouped into segments of at least SEGMENT_MB of parameters (counted from
+# the end of the network: the order backward reaches them), node k's forward advances the generator through its stages, node k's
+# backward runs its slice of the shared tape and returns the gradients of ITS parameters.  The kernels, their order and the buffers
+# (skip gradients accumulate inside the tape's own gradient table as before -- autograd never adds two activation gradients) are
+# those of the one-node tape, so logits and gradients are bit-identical; between the nodes autograd carries a one-element token.
+SEGMENT_MB = float(os.environ.get("HPRI_SEGMENT_MB", "8"))
+_TOKEN = object()
+_token_grads: dict = {}
+
+
+def _token_grad(device) -> torch.Tensor:
+    g = _token_grads.get(device)
+    if g is None:
+        g = _token_grads[device] = torch.zeros(1, dtype=torch.float32, device=device)
+    return g
+
+
+class _SharedTape:
+    __slots__ = ("tape", "gen", "gen_fn")
+
+    def __init__(self, gen_fn):
+        self.tape, self.gen, self.gen_fn = Tape(True), None, gen_fn
+
+
+class _Segment:
+    """The tape program of one node of the chain: advances the shared generator by ``nstages`` stages."""
+    __slots__ = ("shared", "nstages", "first", "last")
+
+    def __init__(self, shared: _SharedTape, nstages: int, first: bool, last: bool):
+        self.shared, self.nstages, self.first, self.last = shared, nstages, first, last
+
+    def __call__(self, tape, acts, need):
+        sh = self.shared
+        if self.first:
+            sh.gen = sh.gen_fn(tape, acts, need)
+        try:
+            for _ in range(self.nstages):
+                next(sh.gen)
+        except StopIteration as stop:
+            if not self.last:
+                raise RuntimeError("hyperpri_amd: internal error: the tape program has fewer stages than its stage list")
+            sh.gen = None
+            return stop.value
+        if self.last:
+            raise RuntimeError("hyperpri_amd: internal error: the tape program has more stages than its stage list")
+        return _TOKEN
+
+
+def drain(gen_fn: Callable) -> Callable:
+    """A staged (generator) tape program as a plain one: all stages in one go."""
+    def program(tape, acts, need):
+        g = gen_fn(tape, acts, need)
+        try:
+            while True:
+                next(g)
+        except StopIteration as stop:
+            return stop.value
+    return program
+
+
+def plan_segments(stage_params: Sequence[Sequence[torch.Tensor]], min_bytes: int) -> List[int]:
+    """Stage counts of the chain's nodes, in forward order.  Cuts are placed walking the stages from the END of the network (the
+    order backward finishes them): a segment is closed once it holds ``min_bytes`` of parameters; what is left at the front
+    forms the segment whose gradients leave last."""
+    counts, n, size = [], 0, 0
+    for params in reversed(list(stage_params)):
+        n += 1
+        size += sum(p.numel() * p.element_size() for p in params)
+        if size >= min_bytes:
+            counts.append(n)
+            n, size = 0, 0
+    if n:
+        counts.append(n)
+    return counts[::-1]
+
+
+def segmentation_wanted(mode) -> bool:
+    """``fused_tape`` of a network: "segmented" forces the chain, True picks it whenever a process group exists and no GradSync
+    gradient sink is installed (the sink overlaps from inside one node and needs no chain)."""
+    if mode == "segmented":
+        return True
+    if mode is not True or not SEGMENT_AUTO:
+        return False
+    from . import engine
+    import torch.distributed as dist
+    return engine._GRAD_SINK is None and dist.is_available() and dist.is_initialized()
+
+
+SEGMENT_AUTO = os.environ.get("HPRI_SEGMENT_TAPE", "1") != "0"
+LAST_PLAN: List[int] = []          # stage counts of the most recent segmented forward (tests / bench)
+
+
+def run_staged(gen_fn: Callable, inputs: Sequence[torch.Tensor], stages: Sequence[Sequence[torch.Tensor]], mode=True,
+               input_planes: int = 0, name: str = "run_program") -> torch.Tensor:
+    """Run a staged tape program (a generator yielding after each of its ``len(stages)`` stages but the last; ``stages[i]`` = the
+    parameters stage i reads) -- as one autograd node, or, when ``segmentation_wanted(mode)``, as a chain of nodes."""
+    params = [p for st in stages for p in st]
+    if not (torch.is_grad_enabled() and segmentation_wanted(mode) and all(p.requires_grad for p in params)):
+        return run(drain(gen_fn), inputs, params, input_planes, name)
+    counts = plan_segments(stages, int(SEGMENT_MB * (1 << 20)))
+    LAST_PLAN[:] = counts
+    if len(counts) < 2:
+        return run(drain(gen_fn), inputs, params, input_planes, name)
+    shared = _SharedTape(gen_fn)
+    out, s0 = None, 0
+    for k, n in enumerate(counts):
+        seg = _Segment(shared, n, first=(k == 0), last=(k == len(counts) - 1))
+        seg_params = [p for st in stages[s0:s0 + n] for p in st]
+        out = run(seg, list(inputs) if k == 0 else [out], seg_params, input_planes if k == 0 else 0, "segment")
+        s0 += n
+    return out
+
+
 class _HipFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, program: Callable, n_in: int, params: Sequence[torch.Tensor], grad_on, *tensors: torch.Tensor):
@@ -46,13 +164,27 @@ class _HipFn(torch.autograd.Function):
         # needs_input_grad is True for trainable parameters even under torch.no_grad() / inference_mode(), and
         # is_grad_enabled() is always False inside Function.forward: the caller's grad mode is passed in by run()
         record = grad_on and any(need)
-        tape = Tape(record)
+        seg = program if isinstance(program, _Segment) else None
+        if seg is not None:
+            # one slice of a segmented network (run_segmented): the tape is shared by the chain's nodes; only the first node
+            # sees the network's inputs, the others a token that carries nothing but the graph edge
+            if not record:
+                raise RuntimeError("hyperpri_amd: internal error: a tape segment without a recorded tape")
+            tape = seg.shared.tape
+            inputs = inputs if seg.first else ()
+        else:
+            tape = Tape(record)
         acts: List[Act] = []
         for t in inputs:
             _require_cuda(t, "input tensor")
             acts.append(Act.from_tensor(_as4d(t), input_planes))
+        lo = len(tape.nodes)
         out = program(tape, acts, need[:n_in])
-        if isinstance(out, Act):
+        ctx.slice = (lo, len(tape.nodes)) if seg is not None else None
+        if out is _TOKEN:
+            res = torch.empty(1, dtype=torch.float32, device=tensors[0].device)
+            ctx.out_act, ctx.holder = None, None
+        elif isinstance(out, Act):
             res = out.to_tensor()
             ctx.out_act, ctx.holder = out, None
         else:
@@ -77,9 +209,12 @@ class _HipFn(torch.autograd.Function):
         ctx.tape = None
         if ctx.out_act is not None:
             tape.grads[id(ctx.out_act)] = Act.from_tensor(gout)
-        else:
+        elif ctx.holder is not None:
             ctx.holder["g"] = gout
-        tape.backward()
+        if ctx.slice is not None:
+            tape.backward(*ctx.slice)       # (an inner segment's incoming gradient is its token's: nothing to read)
+        else:
+            tape.backward()
         if tape.used_side:
             join_side(gout.device)          # weight gradients issued on the side stream
         tape.side_keep.clear()              # (what that stream read may be recycled now: the main stream is ordered behind it)
@@ -93,6 +228,17 @@ class _HipFn(torch.autograd.Function):
                 res.append(g.to_tensor())
             else:
                 res.append(g.to_nchw().reshape(ctx.in_shapes[i]))
+        if ctx.slice is not None and ctx.slice[0] > 0:
+            # an inner or last segment: its own parameters' gradients leave now -- stock DistributedDataParallel's reducer sees them
+            # (and sends its buckets) while the segments in front of this one still run their backward; the gradient of the token
+            # that stands for the previous segment is a constant
+            res = [_token_grad(gout.device)]
+            for j, p in enumerate(ctx.params):
+                sunk = id(p) in tape.sunk
+                res.append(tape.param_grads.pop(id(p), None) if (need[ctx.n_in + j] and not sunk) else None)
+                tape.delivered.add(id(p))
+            ctx.acts = ctx.params = ctx.out_act = ctx.holder = None
+            return (None, None, None, None, *res)
         for j, p in enumerate(ctx.params):
             # gradients the engine wrote into a GradSync bucket are handed over by GradSync.finish(), not by autograd
             sunk = id(p) in tape.sunk
@@ -113,7 +259,7 @@ class _HipFn(torch.autograd.Function):
 # reference module stands for, closed over the module for its BatchNorm buffers, which a training-mode forward updates in place as
 # nn.BatchNorm does); the kernels behind it are reached through the C ABI (include/hyperpri_hip.h) exactly as from _HipFn.
 # HPRI_DISPATCHER=0 routes the modules through the plain autograd.Function instead (same tape, same kernels, same results).
-OP_NAMES = ("unet", "cubenet", "cubenet_stem", "cubenet_up4", "spectral_unet", "double_conv", "down", "up", "out_conv", "run_program")
+OP_NAMES = ("unet", "cubenet", "cubenet_stem", "cubenet_up4", "spectral_unet", "double_conv", "down", "up", "out_conv", "run_program", "segment")
 USE_DISPATCHER = os.environ.get("HPRI_DISPATCHER", "1") != "0"
 _PROGRAMS: dict = {}
 _HANDLES = itertools.count(1)

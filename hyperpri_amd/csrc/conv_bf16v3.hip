@@ -583,9 +583,14 @@ __global__ __launch_bounds__(256, 2) void conv_bf16v3_kernel(ConvV3Args a) {
         // stage barrier -- which the merging wave joins too -- comes before any DMA that could overwrite this scratch.
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's record is in LDS before it counts itself in
         unsigned arrived = 0u;
-        if (lane == 0) arrived = __hip_atomic_fetch_add(arrive_lds, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        // release on the count (this wave's record happens-before it), acquire for the merging wave (the other three waves' records
+        // happen-before its reads): at workgroup scope on LDS both are waitcnts only, but the compiler may no longer move the
+        // red[] loads below above the atomic
+        if (lane == 0) arrived = __hip_atomic_fetch_add(arrive_lds, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
         arrived = (unsigned)__builtin_amdgcn_readfirstlane((int)arrived);
+        asm volatile("" ::: "memory");
         if (arrived == 3u) {
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");      // (lanes 1..63 did not take part in the atomic)
           if (lane == 0) *arrive_lds = 0u;
           const int ch = lane;                   // one channel per lane
           float n = 0.f, mean = 0.f, m2 = 0.f;

@@ -342,6 +342,7 @@ class Tape:
         self.bnpart: Dict[int, tuple] = {}          # id(Act) -> (partial sums, blocks, Cpart) of its BatchNorm backward, left by the same kind of kernel
         self.uses: Dict[int, int] = {}              # id(parameter) -> ops recorded on this tape that will produce a gradient for it
         self._touched: List[int] = []               # parameters the running node asked a gradient slot for
+        self.delivered: set = set()                 # segmented tape: parameters whose gradient has left with an earlier slice
 
     def note_params(self, *params: Optional[torch.Tensor]) -> None:
         """Called by an op while it records its backward node: it will contribute to these parameters' gradients.  A
@@ -376,6 +377,9 @@ class Tape:
             _lib.call("hpri_copy_slice", view.ptr, view.cs, view.coff, g.ptr, g.cs, g.coff, g.P, _rup(a.C, 4), 1, _stream())
 
     def param_slot(self, p: torch.Tensor) -> Tuple[torch.Tensor, int]:
+        if id(p) in self.delivered:
+            raise RuntimeError("hyperpri_amd: internal error: a tape node adds to a parameter gradient that an earlier segment has "
+                               "already handed to autograd (the parameter is listed under the wrong stage)")
         self._touched.append(id(p))
         g = self.param_grads.get(id(p))
         if g is not None:
@@ -393,9 +397,14 @@ class Tape:
         self.param_grads[id(p)] = g
         return g, 0
 
-    def backward(self) -> None:
+    def backward(self, lo: int = 0, hi: Optional[int] = None) -> None:
+        """Run the recorded nodes ``[lo, hi)`` in reverse.  The whole tape by default; a segmented network (autograd.run_segmented:
+        several chained autograd nodes sharing this tape) runs one slice per node, last slice first, and the bookkeeping is
+        released with the slice that starts at 0."""
         sink = _GRAD_SINK
-        for node in reversed(self.nodes):
+        hi = len(self.nodes) if hi is None else hi
+        for i in range(hi - 1, lo - 1, -1):
+            node, self.nodes[i] = self.nodes[i], None       # (a slice's closures go as they run)
             self._touched.clear()
             node(self)
             if sink is None or not self._touched:
@@ -418,6 +427,8 @@ class Tape:
                         sink.ready(p)
                 else:
                     sink.ready(p)
+        if lo > 0:
+            return
         if sink is not None:
             # a parameter announced by several nodes (note_params) whose LAST announcing node never asked for its slot -- e.g. a
             # module called twice inside one tape with one result unused (that node returns before param_slot) -- still holds a
@@ -440,6 +451,7 @@ class Tape:
         self.colsum.clear()
         self.bnpart.clear()
         self.gupl.clear()
+        self.delivered.clear()
 
 
 class BNRef:

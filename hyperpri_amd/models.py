@@ -10,9 +10,26 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import engine as E
-from .autograd import run
+from .autograd import run, run_staged
 from .model_parts import *  # noqa: F401,F403  (the reference's callers star-import everything)
 from .model_parts import DoubleConv, Down, OutConv, Up, has_hooks, skip_room
+
+
+def _stage_params(net):
+    """Per stage of ``net._stages()`` the parameters its modules own, each parameter once (CubeNET's ``first_conv`` is also
+    ``inc[0]``), and all of ``net.parameters()`` accounted for."""
+    seen, out = set(), []
+    for mods in net._stages():
+        ps = []
+        for m in mods:
+            for p in m.parameters():
+                if id(p) not in seen:
+                    seen.add(id(p))
+                    ps.append(p)
+        out.append(ps)
+    if any(id(p) not in seen for p in net.parameters()):
+        raise RuntimeError("hyperpri_amd: internal error: a parameter of the network belongs to no stage of its tape program")
+    return out
 
 
 def set_parameter_requires_grad(model, feature_extraction):
@@ -42,9 +59,17 @@ class UNet(nn.Module):
 
     # One autograd node for the whole network (default): the skip tensors x1..x4 feed two consumers each, and inside
     # one tape their two gradient contributions are summed by the HIP kernels (accumulating epilogues) instead of by
-    # autograd's ATen add.  ``fused_tape = False`` (or forward hooks on a child) calls the children one by one, each its
+    # autograd's ATen add.  Under a process group without a GradSync sink (stock DistributedDataParallel: Lightning
+    # strategy="ddp", PLTrainer.py:434-442) the same tape is cut into a chain of a few nodes so that the reducer receives the
+    # decoder's and the bottleneck's gradients while the encoder's backward still runs (autograd.run_staged; "segmented"
+    # forces the chain).  ``fused_tape = False`` (or forward hooks on a child) calls the children one by one, each its
     # own node -- what a foreign composition of these modules gets anyway.
     fused_tape = True
+
+    def _stages(self):
+        """The modules of each stage of the tape program below, in order (their parameters leave together under a chain)."""
+        return [[self.inc], [self.down1], [self.down2], [self.down3], [self.down4], [self.up1], [self.up2], [self.up3],
+                [self.up4, self.outc]]
 
     def forward(self, x):
         E.throttle(x.device)
@@ -52,18 +77,26 @@ class UNet(nn.Module):
             def prog(tape, a, need):
                 # the four skip tensors are produced inside the buffers their concats will use (model_parts.py:87)
                 x1 = self.inc._ops(tape, a[0], need[0], room=skip_room(self.up4))
+                yield
                 x2 = self.down1._ops(tape, x1, room=skip_room(self.up3))
+                yield
                 x3 = self.down2._ops(tape, x2, room=skip_room(self.up2))
+                yield
                 x4 = self.down3._ops(tape, x3, room=skip_room(self.up1))
+                yield
                 # (bf16 mode: what feeds a transposed convolution is also written as planes by its producer)
                 cp = E.convt_planes_mode(self) and not self.bilinear and not self.use_attention
                 x5 = self.down4._ops(tape, x4, out_planes=cp)
+                yield
                 y = self.up1._ops(tape, x5, x4, out_planes=cp)
+                yield
                 y = self.up2._ops(tape, y, x3, out_planes=cp)
+                yield
                 y = self.up3._ops(tape, y, x2, out_planes=cp)
+                yield
                 y = self.up4._ops(tape, y, x1, head_next=True)          # (bf16 mode: the head reads its input as bf16 planes)
                 return self.outc._ops(tape, y)
-            logits = run(prog, [x], list(self.parameters()), input_planes=E.input_planes_for(self), name="unet")
+            logits = run_staged(prog, [x], _stage_params(self), self.fused_tape, input_planes=E.input_planes_for(self), name="unet")
         else:
             x1 = self.inc(x)
             x2 = self.down1(x1)
@@ -113,6 +146,12 @@ class SpectralUNET(torch.nn.Module):
         return E.conv_bn_relu(tape, x, seq[0].weight, seq[0].bias, bn, self.training, 1, groups=x.N, need_dx=need_dx,
                               precision=getattr(self, "hpri_precision", None), **kw)
 
+    fused_tape = True       # see UNet.fused_tape (no per-child route here: the reference's forward is one loop over images)
+
+    def _stages(self):
+        return [[self.tail], [self.down1], [self.down2], [self.down3], [self.down4], [self.up1], [self.up2], [self.up3],
+                [self.up4, self.outc]]
+
     def forward(self, x):
         E.throttle(x.device)
         def prog(tape, a, need):
@@ -124,15 +163,23 @@ class SpectralUNET(torch.nn.Module):
                 f = self.layer_feats[0]
                 hp = E.HEAD_PLANES
                 x0 = L(tape, a[0], self.tail, need[0], **({"cat_room": f, "planes_only": True} if hp else {}))
+                yield
                 x1 = L(tape, x0, self.down1, cat_room=f, planes_only=True)
+                yield
                 x2 = L(tape, x1, self.down2, cat_room=f, planes_only=True)
+                yield
                 x3 = L(tape, x2, self.down3, cat_room=f, planes_only=True)
+                yield
                 x4 = L(tape, x3, self.down4, planes_only=True)
+                yield
                 t = L(tape, x4, self.up1, cat_into=x3, planes_only=True)
+                yield
                 c, gap = E.concat_planes(tape, x3, t)
                 t = L(tape, c, self.up2, k_gap=gap, cat_into=x2, planes_only=True)
+                yield
                 c, gap = E.concat_planes(tape, x2, t)
                 t = L(tape, c, self.up3, k_gap=gap, cat_into=x1, planes_only=True)
+                yield
                 c, gap = E.concat_planes(tape, x1, t)
                 if hp:
                     # ... and so is the last one: the head reads the padded plane concat [tail | up4] through a weight row with the gap
@@ -142,16 +189,24 @@ class SpectralUNET(torch.nn.Module):
                 t = L(tape, c, self.up4, k_gap=gap)
                 return E.out_conv(tape, E.concat_channels(tape, x0, t), self.outc.weight, self.outc.bias, fuse_loss=self.n_classes == 1)
             x0 = L(tape, a[0], self.tail, need[0])
+            yield
             x1 = L(tape, x0, self.down1)
+            yield
             x2 = L(tape, x1, self.down2)
+            yield
             x3 = L(tape, x2, self.down3)
+            yield
             x4 = L(tape, x3, self.down4)
+            yield
             t = L(tape, x4, self.up1)
+            yield
             t = L(tape, E.concat_channels(tape, x3, t), self.up2)
+            yield
             t = L(tape, E.concat_channels(tape, x2, t), self.up3)
+            yield
             t = L(tape, E.concat_channels(tape, x1, t), self.up4)
             return E.out_conv(tape, E.concat_channels(tape, x0, t), self.outc.weight, self.outc.bias, fuse_loss=self.n_classes == 1)
-        out = run(prog, [x], list(self.parameters()), name="spectral_unet")
+        out = run_staged(prog, [x], _stage_params(self), self.fused_tape, name="spectral_unet")
         if self.n_classes != 1:
             # models.py:144 stores each image's (R*C, n_classes) result with .reshape(n_classes, R, C): the FLAT order is
             # pixel-major, class-minor.  `out` holds true class planes (N, K, R, C); re-order to the reference's element order
@@ -215,6 +270,11 @@ class CubeNET(torch.nn.Module):
 
     fused_tape = True       # see UNet.fused_tape
 
+    def _stages(self):
+        last = [self.up4] if self.first_depth == 64 else [self.upsample4, self.upconv4]
+        return [[self.inc, self.inc2], [self.down1], [self.down2], [self.down3], [self.down4], [self.up1], [self.up2], [self.up3],
+                last + [self.outc]]
+
     def forward(self, x):
         if x.dim() != 5 or x.shape[2] != self.depth:
             raise ValueError(f"CubeNET expects (N,1,{self.depth},R,C), got {tuple(x.shape)}")
@@ -223,17 +283,25 @@ class CubeNET(torch.nn.Module):
             def prog(tape, a, need):
                 up4 = self.up4 if self.first_depth == 64 else self.upsample4
                 x1 = self._stem_ops(tape, a[0], need[0], room=skip_room(up4))
+                yield
                 x2 = self.down1._ops(tape, x1, room=skip_room(self.up3))
+                yield
                 x3 = self.down2._ops(tape, x2, room=skip_room(self.up2))
+                yield
                 x4 = self.down3._ops(tape, x3, room=skip_room(self.up1))
+                yield
                 cp = E.convt_planes_mode(self) and not self.bilinear and not self.use_attention     # see UNet.forward
                 x5 = self.down4._ops(tape, x4, out_planes=cp)
+                yield
                 y = self.up1._ops(tape, x5, x4, out_planes=cp)
+                yield
                 y = self.up2._ops(tape, y, x3, out_planes=cp)
+                yield
                 y = self.up3._ops(tape, y, x2, out_planes=cp)
+                yield
                 y = self._up4_ops(tape, y, x1, head_next=True)
                 return self.outc._ops(tape, y)
-            logits = run(prog, [x], list(self.parameters()), input_planes=E.input_planes_for(self), name="cubenet")
+            logits = run_staged(prog, [x], _stage_params(self), self.fused_tape, input_planes=E.input_planes_for(self), name="cubenet")
         else:
             x1 = self._stem(x)
             x2 = self.down1(x1)
