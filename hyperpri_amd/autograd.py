@@ -55,18 +55,30 @@ def _token_grad(device) -> torch.Tensor:
 
 
 class _SharedTape:
-    __slots__ = ("tape", "gen", "gen_fn")
+    __slots__ = ("tape", "gen", "gen_fn", "bounds")
 
     def __init__(self, gen_fn):
         self.tape, self.gen, self.gen_fn = Tape(True), None, gen_fn
+        self.bounds: List[int] = []        # tape length after each stage, in stage order
 
 
 class _Segment:
-    """The tape program of one node of the chain: advances the shared generator by ``nstages`` stages."""
-    __slots__ = ("shared", "nstages", "first", "last")
+    """The tape program of one node of the chain: advances the shared generator by ``nstages`` stages (``s0``: index of its
+    first stage in the network's stage list)."""
+    __slots__ = ("shared", "nstages", "s0", "last")
 
-    def __init__(self, shared: _SharedTape, nstages: int, first: bool, last: bool):
-        self.shared, self.nstages, self.first, self.last = shared, nstages, first, last
+    def __init__(self, shared: _SharedTape, nstages: int, s0: int, last: bool):
+        self.shared, self.nstages, self.s0, self.last = shared, nstages, s0, last
+
+    @property
+    def first(self) -> bool:
+        return self.s0 == 0
+
+    def ahead(self) -> int:
+        """Tape index at which the stage in FRONT of this node's first stage begins: the node's backward runs on into that stage
+        before it hands its gradients over (see _HipFn._backward)."""
+        b = self.shared.bounds
+        return b[self.s0 - 2] if self.s0 >= 2 else 0
 
     def __call__(self, tape, acts, need):
         sh = self.shared
@@ -75,10 +87,12 @@ class _Segment:
         try:
             for _ in range(self.nstages):
                 next(sh.gen)
+                sh.bounds.append(len(tape.nodes))
         except StopIteration as stop:
-            if not self.last:
+            if not self.last or len(sh.bounds) != self.s0 + self.nstages - 1:
                 raise RuntimeError("hyperpri_amd: internal error: the tape program has fewer stages than its stage list")
             sh.gen = None
+            sh.bounds.append(len(tape.nodes))
             return stop.value
         if self.last:
             raise RuntimeError("hyperpri_amd: internal error: the tape program has more stages than its stage list")
@@ -126,6 +140,18 @@ def segmentation_wanted(mode) -> bool:
 
 
 SEGMENT_AUTO = os.environ.get("HPRI_SEGMENT_TAPE", "1") != "0"
+RUN_AHEAD = True                   # see _HipFn._backward (False: every node joins the weight-gradient stream at the end of its slice)
+
+
+def _side_mark(device):
+    from .engine import _side
+    ev = torch.cuda.Event()
+    ev.record(_side(device))
+    return ev
+
+
+def _wait_mark(device, mark) -> None:
+    torch.cuda.current_stream(device).wait_event(mark)
 LAST_PLAN: List[int] = []          # stage counts of the most recent segmented forward (tests / bench)
 
 
@@ -143,7 +169,7 @@ def run_staged(gen_fn: Callable, inputs: Sequence[torch.Tensor], stages: Sequenc
     shared = _SharedTape(gen_fn)
     out, s0 = None, 0
     for k, n in enumerate(counts):
-        seg = _Segment(shared, n, first=(k == 0), last=(k == len(counts) - 1))
+        seg = _Segment(shared, n, s0, last=(k == len(counts) - 1))
         seg_params = [p for st in stages[s0:s0 + n] for p in st]
         out = run(seg, list(inputs) if k == 0 else [out], seg_params, input_planes if k == 0 else 0, "segment")
         s0 += n
@@ -180,7 +206,7 @@ class _HipFn(torch.autograd.Function):
             acts.append(Act.from_tensor(_as4d(t), input_planes))
         lo = len(tape.nodes)
         out = program(tape, acts, need[:n_in])
-        ctx.slice = (lo, len(tape.nodes)) if seg is not None else None
+        ctx.slice = (lo, len(tape.nodes), seg.ahead()) if seg is not None else None
         if out is _TOKEN:
             res = torch.empty(1, dtype=torch.float32, device=tensors[0].device)
             ctx.out_act, ctx.holder = None, None
@@ -212,12 +238,31 @@ class _HipFn(torch.autograd.Function):
         elif ctx.holder is not None:
             ctx.holder["g"] = gout
         if ctx.slice is not None:
-            tape.backward(*ctx.slice)       # (an inner segment's incoming gradient is its token's: nothing to read)
+            # (an inner segment's incoming gradient is its token's: nothing to read)
+            lo, hi, ahead = ctx.slice
+            tape.backward(lo, hi if tape.done_to is None else min(hi, tape.done_to))
+            if lo > 0 and tape.used_side and RUN_AHEAD:
+                # The gradients that leave with this node were written on the weight-gradient stream; whoever receives them (the
+                # reducer's copy into its bucket) runs on the main stream, which must wait for that stream.  Waiting right here
+                # would idle the main stream until the last weight gradient of the slice has finished (0.8 % of an fp32 step and
+                # 1.4 % of a bf16 step over four cuts: profiles/r05_segment_ab.json) -- so the node first enqueues the stage in
+                # FRONT of its slice (the next node's last stage) and only then makes the main stream wait for the point the
+                # weight-gradient stream had reached when the slice ended: that stage's kernels cover the wait.
+                dev = gout.device
+                mark, nkeep = _side_mark(dev), len(tape.side_keep)
+                tape.backward(ahead, lo)
+                tape.done_to = ahead
+                _wait_mark(dev, mark)
+                del tape.side_keep[:nkeep]   # (what that stream had read up to the mark may be recycled now)
+            else:
+                if tape.used_side:
+                    join_side(gout.device)
+                tape.side_keep.clear()
         else:
             tape.backward()
-        if tape.used_side:
-            join_side(gout.device)          # weight gradients issued on the side stream
-        tape.side_keep.clear()              # (what that stream read may be recycled now: the main stream is ordered behind it)
+            if tape.used_side:
+                join_side(gout.device)          # weight gradients issued on the side stream
+            tape.side_keep.clear()              # (what that stream read may be recycled now: the main stream is ordered behind it)
         need = ctx.needs_input_grad[4:]
         res = []
         for i, a in enumerate(ctx.acts):

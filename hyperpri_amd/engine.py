@@ -343,6 +343,7 @@ class Tape:
         self.uses: Dict[int, int] = {}              # id(parameter) -> ops recorded on this tape that will produce a gradient for it
         self._touched: List[int] = []               # parameters the running node asked a gradient slot for
         self.delivered: set = set()                 # segmented tape: parameters whose gradient has left with an earlier slice
+        self.done_to: Optional[int] = None          # segmented tape: the backward has run down to this node index (a slice's node runs one stage ahead)
 
     def note_params(self, *params: Optional[torch.Tensor]) -> None:
         """Called by an op while it records its backward node: it will contribute to these parameters' gradients.  A

@@ -17,15 +17,29 @@ from .autograd import run
 __all__ = ["DoubleConv", "Down", "Up", "OutConv", "torch", "nn", "F", "set_precision"]     # (skip_room, has_hooks: internal)
 
 
-def _double_conv_ops(tape, x, seq, train, need_dx=True, precision=None, room=0, out_planes=False, head_next=False):
-    """(conv3x3 -> BN -> ReLU) x 2 on an Act; ``seq`` is the 6-entry nn.Sequential container.  ``room``: channels to keep
-    free behind the result (it is a skip tensor: the decoder's concat is then in place).  ``out_planes``: the result feeds a
-    transposed convolution that reads bf16 planes (bf16 mode): its BatchNorm-apply pass writes them.  ``head_next``: the result is
-    read by the 1x1 output layer only (engine.conv_bn_relu)."""
+def _drain(gen):
+    """Run a staged tape program (a generator that yields at its stage boundaries: autograd.run_staged) to its end."""
+    try:
+        while True:
+            next(gen)
+    except StopIteration as stop:
+        return stop.value
+
+
+def _double_conv_gen(tape, x, seq, train, need_dx=True, precision=None, room=0, out_planes=False, head_next=False):
+    """(conv3x3 -> BN -> ReLU) x 2 on an Act, as a staged program (one stage per convolution); ``seq`` is the 6-entry
+    nn.Sequential container.  ``room``: channels to keep free behind the result (it is a skip tensor: the decoder's concat is
+    then in place).  ``out_planes``: the result feeds a transposed convolution that reads bf16 planes (bf16 mode): its
+    BatchNorm-apply pass writes them.  ``head_next``: the result is read by the 1x1 output layer only (engine.conv_bn_relu)."""
     h = E.conv_bn_relu(tape, x, seq[0].weight, seq[0].bias, E.BNRef(seq[1]), train, 3, need_dx=need_dx, precision=precision,
                        next_cout=seq[3].weight.shape[0])       # h is read by the second convolution only
+    yield
     return E.conv_bn_relu(tape, h, seq[3].weight, seq[3].bias, E.BNRef(seq[4]), train, 3, precision=precision, room=room,
                           out_planes=out_planes, head_next=head_next)
+
+
+def _double_conv_ops(*args, **kw):
+    return _drain(_double_conv_gen(*args, **kw))
 
 
 def skip_room(up):
@@ -68,9 +82,17 @@ class DoubleConv(nn.Module):
                   nn.ReLU(inplace=True)]
         self.double_conv = nn.Sequential(*layers)
 
-    def _ops(self, tape, x, need_dx=True, room=0, out_planes=False, head_next=False):
-        return _double_conv_ops(tape, x, self.double_conv, self.training, need_dx, getattr(self, "hpri_precision", None), room,
+    def _gen(self, tape, x, need_dx=True, room=0, out_planes=False, head_next=False):
+        return _double_conv_gen(tape, x, self.double_conv, self.training, need_dx, getattr(self, "hpri_precision", None), room,
                                 out_planes, head_next)
+
+    def _ops(self, *args, **kw):
+        return _drain(self._gen(*args, **kw))
+
+    def _stages(self):
+        """Modules per stage of ``_gen`` (whose parameters' gradients are final once backward has passed the stage)."""
+        seq = self.double_conv
+        return [[seq[0], seq[1]], [seq[3], seq[4]]]
 
     def forward(self, x):
         return run(lambda tape, a, need: self._ops(tape, a[0], need[0]), [x], list(self.parameters()), name="double_conv")
@@ -83,8 +105,14 @@ class Down(nn.Module):
         super().__init__()
         self.maxpool_conv = nn.Sequential(nn.MaxPool2d(2), DoubleConv(in_channels, out_channels))
 
-    def _ops(self, tape, x, room=0, out_planes=False):
-        return self.maxpool_conv[1]._ops(tape, E.maxpool2(tape, x), room=room, out_planes=out_planes)
+    def _gen(self, tape, x, room=0, out_planes=False):
+        return self.maxpool_conv[1]._gen(tape, E.maxpool2(tape, x), room=room, out_planes=out_planes)
+
+    def _ops(self, *args, **kw):
+        return _drain(self._gen(*args, **kw))
+
+    def _stages(self):
+        return self.maxpool_conv[1]._stages()
 
     def forward(self, x):
         return run(lambda tape, a, need: self._ops(tape, a[0]), [x], list(self.parameters()), name="down")
@@ -109,12 +137,19 @@ class Up(nn.Module):
             self.up = nn.ConvTranspose2d(in_channels, in_channels // 2, kernel_size=2, stride=2)
             self.conv = DoubleConv(in_channels // 2 if use_attention else in_channels, out_channels)
 
-    def _ops(self, tape, x1, x2, need_dx1=True, out_planes=False, head_next=False):
+    def _gen(self, tape, x1, x2, need_dx1=True, out_planes=False, head_next=False):
         w = None if self.bilinear else self.up.weight
         b = None if self.bilinear else self.up.bias
         join = E.up_attention if self.use_attention else E.up_concat
-        return self.conv._ops(tape, join(tape, x1, x2, w, b, need_dx1=need_dx1,
+        return self.conv._gen(tape, join(tape, x1, x2, w, b, need_dx1=need_dx1,
                                          precision=getattr(self, "hpri_precision", None)), out_planes=out_planes, head_next=head_next)
+
+    def _ops(self, *args, **kw):
+        return _drain(self._gen(*args, **kw))
+
+    def _stages(self):
+        first, second = self.conv._stages()
+        return [[self.up] + first, second]            # (nn.Upsample has no parameters)
 
     def forward(self, x1, x2):
         return run(lambda tape, a, need: self._ops(tape, a[0], a[1], need[0]), [x1, x2], list(self.parameters()), name="up")

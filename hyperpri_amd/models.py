@@ -12,7 +12,7 @@ import torch.nn.functional as F
 from . import engine as E
 from .autograd import run, run_staged
 from .model_parts import *  # noqa: F401,F403  (the reference's callers star-import everything)
-from .model_parts import DoubleConv, Down, OutConv, Up, has_hooks, skip_room
+from .model_parts import DoubleConv, Down, OutConv, Up, _drain, has_hooks, skip_room
 
 
 def _stage_params(net):
@@ -68,33 +68,36 @@ class UNet(nn.Module):
 
     def _stages(self):
         """The modules of each stage of the tape program below, in order (their parameters leave together under a chain)."""
-        return [[self.inc], [self.down1], [self.down2], [self.down3], [self.down4], [self.up1], [self.up2], [self.up3],
-                [self.up4, self.outc]]
+        st = []
+        for m in (self.inc, self.down1, self.down2, self.down3, self.down4, self.up1, self.up2, self.up3, self.up4):
+            st += m._stages()
+        st[-1] = st[-1] + [self.outc]
+        return st
 
     def forward(self, x):
         E.throttle(x.device)
         if self.fused_tape and not has_hooks(self):
             def prog(tape, a, need):
                 # the four skip tensors are produced inside the buffers their concats will use (model_parts.py:87)
-                x1 = self.inc._ops(tape, a[0], need[0], room=skip_room(self.up4))
+                x1 = yield from self.inc._gen(tape, a[0], need[0], room=skip_room(self.up4))
                 yield
-                x2 = self.down1._ops(tape, x1, room=skip_room(self.up3))
+                x2 = yield from self.down1._gen(tape, x1, room=skip_room(self.up3))
                 yield
-                x3 = self.down2._ops(tape, x2, room=skip_room(self.up2))
+                x3 = yield from self.down2._gen(tape, x2, room=skip_room(self.up2))
                 yield
-                x4 = self.down3._ops(tape, x3, room=skip_room(self.up1))
+                x4 = yield from self.down3._gen(tape, x3, room=skip_room(self.up1))
                 yield
                 # (bf16 mode: what feeds a transposed convolution is also written as planes by its producer)
                 cp = E.convt_planes_mode(self) and not self.bilinear and not self.use_attention
-                x5 = self.down4._ops(tape, x4, out_planes=cp)
+                x5 = yield from self.down4._gen(tape, x4, out_planes=cp)
                 yield
-                y = self.up1._ops(tape, x5, x4, out_planes=cp)
+                y = yield from self.up1._gen(tape, x5, x4, out_planes=cp)
                 yield
-                y = self.up2._ops(tape, y, x3, out_planes=cp)
+                y = yield from self.up2._gen(tape, y, x3, out_planes=cp)
                 yield
-                y = self.up3._ops(tape, y, x2, out_planes=cp)
+                y = yield from self.up3._gen(tape, y, x2, out_planes=cp)
                 yield
-                y = self.up4._ops(tape, y, x1, head_next=True)          # (bf16 mode: the head reads its input as bf16 planes)
+                y = yield from self.up4._gen(tape, y, x1, head_next=True)          # (bf16 mode: the head reads its input as bf16 planes)
                 return self.outc._ops(tape, y)
             logits = run_staged(prog, [x], _stage_params(self), self.fused_tape, input_planes=E.input_planes_for(self), name="unet")
         else:
@@ -248,32 +251,46 @@ class CubeNET(torch.nn.Module):
             self.upconv4 = DoubleConv(64 + first_depth, 64)
         self.outc = OutConv(64, self.n_classes)
 
-    def _stem_ops(self, tape, x, need_dx, room=0):
+    def _stem_gen(self, tape, x, need_dx, room=0):
         prec = getattr(self, "hpri_precision", None)
         h = E.conv_bn_relu(tape, x, self.first_conv.weight, self.first_conv.bias, E.BNRef(self.inc[1]),
                            self.training, 3, need_dx=need_dx, precision=prec, next_cout=self.inc2[0].weight.shape[0])
+        yield
         return E.conv_bn_relu(tape, h, self.inc2[0].weight, self.inc2[0].bias, E.BNRef(self.inc2[1]),
                               self.training, 3, precision=prec, room=room)
+
+    def _stem_ops(self, *args, **kw):
+        return _drain(self._stem_gen(*args, **kw))
 
     def _stem(self, x):
         params = list(self.inc.parameters()) + list(self.inc2.parameters())
         return run(lambda tape, a, need: self._stem_ops(tape, a[0], need[0]), [x], params, name="cubenet_stem")
 
-    def _up4_ops(self, tape, y, x1, need_dx1=True, head_next=False):
+    def _up4_gen(self, tape, y, x1, need_dx1=True, head_next=False):
         """Last decoder stage: ``up4`` (first_depth 64) or the inline upsample4 -> pad -> cat -> upconv4 (models.py:229-240)."""
         if self.first_depth == 64:
-            return self.up4._ops(tape, y, x1, need_dx1, head_next=head_next)
+            return self.up4._gen(tape, y, x1, need_dx1, head_next=head_next)
         w4 = None if self.bilinear else self.upsample4.weight
         b4 = None if self.bilinear else self.upsample4.bias
         cat = E.up_concat(tape, y, x1, w4, b4, need_dx1=need_dx1, precision=getattr(self, "hpri_precision", None))
-        return self.upconv4._ops(tape, cat, head_next=head_next)
+        return self.upconv4._gen(tape, cat, head_next=head_next)
+
+    def _up4_ops(self, *args, **kw):
+        return _drain(self._up4_gen(*args, **kw))
 
     fused_tape = True       # see UNet.fused_tape
 
     def _stages(self):
-        last = [self.up4] if self.first_depth == 64 else [self.upsample4, self.upconv4]
-        return [[self.inc, self.inc2], [self.down1], [self.down2], [self.down3], [self.down4], [self.up1], [self.up2], [self.up3],
-                last + [self.outc]]
+        st = [[self.inc], [self.inc2]]
+        for m in (self.down1, self.down2, self.down3, self.down4, self.up1, self.up2, self.up3):
+            st += m._stages()
+        if self.first_depth == 64:
+            st += self.up4._stages()
+        else:
+            first, second = self.upconv4._stages()
+            st += [[self.upsample4] + first, second]
+        st[-1] = st[-1] + [self.outc]
+        return st
 
     def forward(self, x):
         if x.dim() != 5 or x.shape[2] != self.depth:
@@ -282,24 +299,24 @@ class CubeNET(torch.nn.Module):
         if self.fused_tape and not has_hooks(self):
             def prog(tape, a, need):
                 up4 = self.up4 if self.first_depth == 64 else self.upsample4
-                x1 = self._stem_ops(tape, a[0], need[0], room=skip_room(up4))
+                x1 = yield from self._stem_gen(tape, a[0], need[0], room=skip_room(up4))
                 yield
-                x2 = self.down1._ops(tape, x1, room=skip_room(self.up3))
+                x2 = yield from self.down1._gen(tape, x1, room=skip_room(self.up3))
                 yield
-                x3 = self.down2._ops(tape, x2, room=skip_room(self.up2))
+                x3 = yield from self.down2._gen(tape, x2, room=skip_room(self.up2))
                 yield
-                x4 = self.down3._ops(tape, x3, room=skip_room(self.up1))
+                x4 = yield from self.down3._gen(tape, x3, room=skip_room(self.up1))
                 yield
                 cp = E.convt_planes_mode(self) and not self.bilinear and not self.use_attention     # see UNet.forward
-                x5 = self.down4._ops(tape, x4, out_planes=cp)
+                x5 = yield from self.down4._gen(tape, x4, out_planes=cp)
                 yield
-                y = self.up1._ops(tape, x5, x4, out_planes=cp)
+                y = yield from self.up1._gen(tape, x5, x4, out_planes=cp)
                 yield
-                y = self.up2._ops(tape, y, x3, out_planes=cp)
+                y = yield from self.up2._gen(tape, y, x3, out_planes=cp)
                 yield
-                y = self.up3._ops(tape, y, x2, out_planes=cp)
+                y = yield from self.up3._gen(tape, y, x2, out_planes=cp)
                 yield
-                y = self._up4_ops(tape, y, x1, head_next=True)
+                y = yield from self._up4_gen(tape, y, x1, head_next=True)
                 return self.outc._ops(tape, y)
             logits = run_staged(prog, [x], _stage_params(self), self.fused_tape, input_planes=E.input_planes_for(self), name="cubenet")
         else:

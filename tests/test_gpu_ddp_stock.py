@@ -61,10 +61,11 @@ def test_one_rank_rccl_full_size_buckets_leave_during_backward(tmp_path):
     """CubeNET-64 on two 608x968x238 cubes, DDP over RCCL (world 1), default 25 MiB buckets."""
     z = _launch(tmp_path, 1, "nccl", "full")[0]
     frac_bytes = _check_hand_over(z, "full_rccl")
-    assert list(z["plan"]) == [3, 1, 1, 1, 3]
-    # SURVEY.md 8e: most of the gradient bytes are with the reducer while a good part of the backward is still to run.  Stock DDP's
-    # 25 MiB buckets put the cuts at 1 / 37.7 / 46 / 28 MB and leave down3's first convolution + down2 + down1 + stem (9.8 MB) for
-    # the last one; the HIP-event clock says how much of the backward's GPU time was still ahead at each hand-over.
+    assert list(z["plan"]) == [3, 4, 1, 1, 1, 1, 1, 6]             # stages are single convolutions; cuts every >= 8 MB from the end
+    # SURVEY.md 8e: most of the gradient bytes are with the reducer while a good part of the backward is still to run.  Stock DDP
+    # re-buckets in arrival order with its 25 MiB cap: what is left for the last bucket is whatever arrives after the last cap
+    # was reached (down3's first convolution + down2 + down1 + stem, 9.4 MB); the HIP-event clock says how much of the
+    # backward's GPU time was still ahead at each hand-over.
     ms, total = z["bucket_ms"], float(z["backward_ms"])
     cum = np.cumsum(z["bucket_bytes"]) / float(z["bucket_bytes"].sum())
     left = 1.0 - ms / total

@@ -107,6 +107,32 @@ def test_chain_equals_one_node_and_hands_gradients_over_early(cpu_bridge, monkey
     assert log2[-1] == "grad w0"
 
 
+def test_a_node_runs_one_stage_ahead_before_it_waits_for_the_weight_gradient_stream(cpu_bridge, monkeypatch):
+    """With weight gradients on a second stream a node must make the main stream wait for that stream before its gradients
+    leave; it first enqueues the stage in front of its slice, so the wait is covered (autograd._HipFn._backward)."""
+    x = _cl(2, 8, 3, 5, 1)
+    out1, g1, gx1, _ = _run(True, 0.0, monkeypatch, x)
+    events = []
+    monkeypatch.setattr(A, "_side_mark", lambda dev: events.append("mark") or len(events))
+    monkeypatch.setattr(A, "_wait_mark", lambda dev, mark: events.append("wait"))
+    monkeypatch.setattr(A, "SEGMENT_MB", 0.0)
+    torch.manual_seed(0)
+    ws = [torch.nn.Parameter(torch.rand(1) + 0.5) for _ in range(4)]
+    for i, w in enumerate(ws):
+        w.register_post_accumulate_grad_hook(lambda p, i=i: events.append(f"grad w{i}"))
+    inner = _staged_net(ws, events)
+
+    def prog(tape, a, need):
+        tape.used_side = True               # (as if the stages had issued weight gradients on the second stream)
+        return (yield from inner(tape, a, need))
+    xin = x.clone().requires_grad_(True)
+    out = A.run_staged(prog, [xin], [[w] for w in ws], "segmented")
+    out.backward(_cl(*out.shape, 9))
+    assert events == ["s3", "mark", "s2", "wait", "grad w3", "mark", "s1", "wait", "grad w2", "mark", "s0", "wait", "grad w1", "grad w0"]
+    assert torch.equal(out.detach(), out1) and torch.equal(xin.grad, gx1)
+    assert all(torch.equal(w.grad, g) for w, g in zip(ws, g1))
+
+
 def test_a_gradient_added_after_its_segment_left_is_an_internal_error(cpu_bridge, monkeypatch):
     """A parameter listed under a stage behind its last tape node would leave with unfinished contents: refused."""
     monkeypatch.setattr(A, "SEGMENT_MB", 0.0)
@@ -163,4 +189,4 @@ def test_networks_list_every_parameter_under_one_stage():
                 H.SpectralUNET(10, 1, 4, bnorm=False)):
         st = _stage_params(net)
         ids = [id(p) for ps in st for p in ps]
-        assert len(ids) == len(set(ids)) == len(list(net.parameters())) and len(st) == 9
+        assert len(ids) == len(set(ids)) == len(list(net.parameters())) and len(st) in (9, 18)
