@@ -94,6 +94,36 @@ extern "C" int hpri_stream_destroy(void* stream) {
 
 #endif   // HPRI_DIAG_KERNELS
 
+// ---- item queues of the persistent kernels (common.h) ------------------------------------------------------------------------------
+// stream -> caller-owned counter buffer.  A small table under a mutex: launchers look their stream up on every persistent launch
+// (a handful of entries; the engine registers one buffer per stream it launches on and never unregisters while it may launch).
+static std::mutex g_q_mutex;
+static struct { hipStream_t stream; void* q; bool used; } g_q[32];
+
+void* hpri_item_queue(hipStream_t stream) {
+  std::lock_guard<std::mutex> lock(g_q_mutex);
+  for (auto& e : g_q)
+    if (e.used && e.stream == stream) return e.q;
+  return nullptr;
+}
+
+extern "C" int hpri_item_queue_bytes(void) { return HPRI_Q_WORDS * 4; }
+
+extern "C" int hpri_set_item_queue(void* queue, size_t bytes, hipStream_t stream) {
+  HPRI_REQUIRE(queue == nullptr || (bytes >= (size_t)HPRI_Q_WORDS * 4 && ((uintptr_t)queue & 3) == 0),
+               "set_item_queue: the queue must hold hpri_item_queue_bytes() zeroed bytes, 4-byte aligned");
+  std::lock_guard<std::mutex> lock(g_q_mutex);
+  for (auto& e : g_q)
+    if (e.used && e.stream == stream) {
+      if (queue == nullptr) e.used = false; else e.q = queue;
+      return HPRI_OK;
+    }
+  if (queue == nullptr) return HPRI_OK;
+  for (auto& e : g_q)
+    if (!e.used) { e.stream = stream; e.q = queue; e.used = true; return HPRI_OK; }
+  return hpri_set_error(HPRI_ERR_ARG, "set_item_queue: more than 32 streams hold a queue");
+}
+
 extern "C" int hpri_get_option(const char* name) {
   for (int i = 0; i < 5; ++i)
     if (name && strcmp(name, g_opt_name[i]) == 0) return hpri_option(i);

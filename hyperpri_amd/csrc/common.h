@@ -69,6 +69,44 @@ typedef int hpri_rsrc_t;
 #define HPRI_LDS_DMA16(rs_, lds_, voff_, soff_) ((void)(rs_))
 #endif
 
+// ---- item queues of the persistent kernels (conv_bf16v3, gemm_bf16v3, gemm_f32v2) ----------------------------------------------
+// These kernels start 2 x CUs workgroups (two per CU, all of a SIMD's vector registers and ~75 KB of LDS each).  With FIXED item
+// lists a workgroup that cannot become resident at once -- a collective's kernel holds part of its CU (RCCL beside the backward of
+// a DDP step) -- starts when another one retires and then walks its whole list alone: a second wave, up to 2 x the launch.  With a
+// queue (hpri_set_item_queue: HPRI_Q_WORDS zeroed 32-bit counters owned by the caller, one buffer per stream) every workgroup
+// DRAWS its items: counter x of K slice z hands out the items of XCD x's band in the same order the fixed lists walked them, a
+// workgroup whose own band is exhausted helps the other XCDs out, and a late workgroup finds the queues empty and leaves.  Which
+// workgroup computes an item changes, nothing else: results are bit-identical.  The last workgroup to leave re-arms the counters.
+#define HPRI_Q_SLICES 8
+#define HPRI_Q_WORDS (8 * HPRI_Q_SLICES + 1)
+void* hpri_item_queue(hipStream_t stream);     // the queue registered for this stream, or nullptr (api.cpp)
+#ifdef __HIPCC__
+__device__ __forceinline__ unsigned hpri_q_draw(unsigned* q, int xcd) {
+  return __hip_atomic_fetch_add(q + xcd, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// (one thread) draw from queue *qx; when that band is exhausted try the other XCDs' in turn.  nvalid(x) = items of band x.
+// Returns the item's index inside the band and leaves the band in *qx, or -1: nothing left anywhere.
+template <typename NV>
+__device__ __forceinline__ int hpri_q_steal(unsigned* q, int* qx, unsigned first, NV nvalid) {
+  unsigned v = first;
+  int x = *qx;
+  for (int j = 0;; ++j) {
+    if (v < (unsigned)nvalid(x)) { *qx = x; return (int)v; }
+    if (j == 7) return -1;
+    x = (x + 1) & 7;
+    v = hpri_q_draw(q, x);
+  }
+}
+// (one thread, once per workgroup, after its last draw has returned) count the workgroup out
+__device__ __forceinline__ void hpri_q_leave(unsigned* qbase, unsigned total_workgroups, int nslices) {
+  unsigned* done = qbase + 8 * HPRI_Q_SLICES;
+  if (__hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == total_workgroups) {
+    for (int i = 0; i < 8 * nslices; ++i) __hip_atomic_store(qbase + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+#endif
+
 // host: fill a PlaneOut from C-ABI arguments (planes == nullptr: no plane output)
 static inline int hpri_plane_out(PlaneOut* po, void* planes, long long plane_stride, int pl_cs, int pl_coff, int pl_cw, int npl, int C) {
   po->p = reinterpret_cast<__bf16*>(planes); po->plane = plane_stride; po->cs = pl_cs; po->coff = pl_coff; po->cw = pl_cw; po->npl = npl;

@@ -43,8 +43,23 @@ def _rup(x: int, m: int) -> int:
     return (x + m - 1) // m * m
 
 
+# Item queues of the persistent MFMA kernels (include/hyperpri_hip.h: hpri_set_item_queue): one zeroed counter buffer per stream the
+# engine launches on, registered the first time the stream is seen.  With a queue a workgroup that becomes resident late (an RCCL
+# kernel holds part of its CU during a DDP backward) finds the items gone instead of walking a fixed list alone; results do not
+# change.  HPRI_ITEM_QUEUE=0: fixed lists (the round-4 behaviour; tools/cu_share_probe.py measures both).
+ITEM_QUEUE = os.environ.get("HPRI_ITEM_QUEUE", "1") != "0"
+_item_queues: Dict[Tuple[int, int], torch.Tensor] = {}
+
+
 def _stream() -> ctypes.c_void_p:
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    st = torch.cuda.current_stream()
+    h = st.cuda_stream
+    if ITEM_QUEUE and (st.device_index, h) not in _item_queues:
+        lib = _lib.load()
+        q = torch.zeros(lib.hpri_item_queue_bytes() // 4, dtype=torch.int32, device=torch.device("cuda", st.device_index))
+        _item_queues[(st.device_index, h)] = q           # (kept for the life of the process: the library holds the raw pointer)
+        _lib.call("hpri_set_item_queue", _p(q), q.numel() * 4, ctypes.c_void_p(h))
+    return ctypes.c_void_p(h)
 
 
 def _p(t: Optional[torch.Tensor]) -> ctypes.c_void_p:

@@ -52,6 +52,18 @@ int hpri_set_option(const char* name, int value);
 int hpri_get_option(const char* name);
 const char* hpri_last_error(void);
 
+/* ---- item queues of the persistent MFMA kernels (hpri_conv_bf16v3*, hpri_gemm_bf16v3 / hpri_convt_*_bf16*, hpri_gemm_f32v2 /
+ * hpri_convt_*_f32v2) ----------------------------------------------------------------------------------------------------------
+ * These launches start 2 x CUs workgroups, two per CU.  Without a queue every workgroup walks a fixed list of work items; a
+ * workgroup that cannot become resident at once (another kernel -- an RCCL collective beside the backward of a DDP step,
+ * PLTrainer.py:434-442 -- holds part of its CU) then runs its whole list late.  hpri_set_item_queue(queue, bytes, stream) gives
+ * every later persistent launch ON THAT STREAM `queue` -- hpri_item_queue_bytes() bytes of device memory, zeroed once by the
+ * caller, owned by the caller and alive while it may launch -- as its item counters: workgroups draw items (same items, same
+ * per-XCD order, results bit-identical), a late workgroup finds nothing left, the kernel leaves the counters zeroed.  One queue
+ * per stream (launches of one stream run one after the other); queue == NULL unregisters the stream. */
+int hpri_item_queue_bytes(void);
+int hpri_set_item_queue(void* queue, size_t bytes, hipStream_t stream);
+
 /* ---- weight packing: nn.Parameter layouts -> [chunk][tap][32][Ncols_pad] LDS panels ---------------
  * mode 0 conv fwd   (replaces cuDNN's filter transform for nn.Conv2d, model_parts.py:22,25,96; nn.Conv3d
  *                    models.py:169; nn.Linear models.py:108,103)

@@ -29,6 +29,7 @@ if not os.path.exists(HOG) or os.path.getmtime(HOG) < os.path.getmtime(os.path.j
                            os.path.join(ROOT, "tools", "cu_hog.hip")])
 hog = ctypes.CDLL(HOG)
 hog.cu_hog_launch.argtypes = [ctypes.c_int, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p]
+hog.cu_hog_launch_lds.argtypes = [ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
 dev = torch.device("cuda", 0)
 hog_stream = torch.cuda.Stream(device=dev)
 sink = torch.zeros(1024, dtype=torch.int32, device=dev)
@@ -58,13 +59,13 @@ def make(kind, prec):
     return step
 
 
-def timed(step, n, hog_wg, hog_ms):
+def timed(step, n, hog_wg, hog_ms, lds=65536):
     """ms per step over n back-to-back steps; with hog_wg > 0 a hog of that many workgroups is resident for hog_ms from just
     before the first step (the steps must end inside that window: checked by the caller against the returned time)."""
     torch.cuda.synchronize()
     if hog_wg:
         with torch.cuda.stream(hog_stream):
-            assert hog.cu_hog_launch(hog_wg, float(hog_ms), sink.data_ptr(), hog_stream.cuda_stream) == 0
+            assert hog.cu_hog_launch_lds(hog_wg, float(hog_ms), lds, sink.data_ptr(), hog_stream.cuda_stream) == 0
         time.sleep(0.002)                   # the hog is on the chip before the first kernel of the step is enqueued
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -94,6 +95,13 @@ def main():
                                        "excess_over_cu_share": round(t / base - 1.0 - w / res["cus"], 4),
                                        "steps_ended_inside_hog_window": bool(t * nsteps < window)}
             print(name, "W", w, leg["with_hog"][str(w)], flush=True)
+        # controls: ONE hog workgroup, and W = 8 workgroups that hold 2 KB of LDS (both workgroups of a persistent kernel still
+        # fit beside one): what a second busy queue costs by itself, apart from the compute units it holds
+        window = base * nsteps * 2.6 + 20.0
+        for key, w, lds in (("one_workgroup_64KB", 1, 65536), ("8_workgroups_2KB", 8, 2048), ("64_workgroups_2KB", 64, 2048)):
+            t = sorted(timed(step, nsteps, w, window, lds) for _ in range(3))[1]
+            leg.setdefault("controls", {})[key] = {"ms_per_step": round(t, 3), "slowdown": round(t / base, 4)}
+            print(name, key, leg["controls"][key], flush=True)
         res["legs"][name] = leg
         del step
         torch.cuda.empty_cache()
