@@ -42,7 +42,7 @@ def _as4d(t: torch.Tensor) -> torch.Tensor:
 # backward runs its slice of the shared tape and returns the gradients of ITS parameters.  The kernels, their order and the buffers
 # (skip gradients accumulate inside the tape's own gradient table as before -- autograd never adds two activation gradients) are
 # those of the one-node tape, so logits and gradients are bit-identical; between the nodes autograd carries a one-element token.
-SEGMENT_MB = float(os.environ.get("HPRI_SEGMENT_MB", "8"))
+SEGMENT_MB = 8.0
 _TOKEN = object()
 _token_grads: dict = {}
 
@@ -139,7 +139,7 @@ def segmentation_wanted(mode) -> bool:
     return engine._GRAD_SINK is None and dist.is_available() and dist.is_initialized()
 
 
-SEGMENT_AUTO = os.environ.get("HPRI_SEGMENT_TAPE", "1") != "0"
+SEGMENT_AUTO = True                # False: a process group alone does not select the chain (``fused_tape = "segmented"`` still does)
 RUN_AHEAD = True                   # see _HipFn._backward (False: every node joins the weight-gradient stream at the end of its slice)
 
 

@@ -95,32 +95,35 @@ extern "C" int hpri_stream_destroy(void* stream) {
 #endif   // HPRI_DIAG_KERNELS
 
 // ---- item queues of the persistent kernels (common.h) ------------------------------------------------------------------------------
-// stream -> caller-owned counter buffer.  A small table under a mutex: launchers look their stream up on every persistent launch
-// (a handful of entries; the engine registers one buffer per stream it launches on and never unregisters while it may launch).
+// stream -> caller-owned counter buffer + the parity of the next launch.  A small table under a mutex: launchers take their half
+// right before the launch (a handful of entries; the engine registers one buffer per stream it launches on).
 static std::mutex g_q_mutex;
-static struct { hipStream_t stream; void* q; bool used; } g_q[32];
+static struct { hipStream_t stream; unsigned* q; unsigned seq; bool used; } g_q[32];
 
-void* hpri_item_queue(hipStream_t stream) {
+HpriQueueHalves hpri_item_queue_take(hipStream_t stream) {
   std::lock_guard<std::mutex> lock(g_q_mutex);
   for (auto& e : g_q)
-    if (e.used && e.stream == stream) return e.q;
-  return nullptr;
+    if (e.used && e.stream == stream) {
+      const unsigned h = e.seq++ & 1u;
+      return HpriQueueHalves{e.q + h * HPRI_Q_HALF, e.q + (h ^ 1u) * HPRI_Q_HALF};
+    }
+  return HpriQueueHalves{nullptr, nullptr};
 }
 
 extern "C" int hpri_item_queue_bytes(void) { return HPRI_Q_WORDS * 4; }
 
 extern "C" int hpri_set_item_queue(void* queue, size_t bytes, hipStream_t stream) {
-  HPRI_REQUIRE(queue == nullptr || (bytes >= (size_t)HPRI_Q_WORDS * 4 && ((uintptr_t)queue & 3) == 0),
-               "set_item_queue: the queue must hold hpri_item_queue_bytes() zeroed bytes, 4-byte aligned");
+  HPRI_REQUIRE(queue == nullptr || (bytes >= (size_t)HPRI_Q_WORDS * 4 && ((uintptr_t)queue & 255) == 0),
+               "set_item_queue: the queue must hold hpri_item_queue_bytes() zeroed bytes, 256-byte aligned");
   std::lock_guard<std::mutex> lock(g_q_mutex);
   for (auto& e : g_q)
     if (e.used && e.stream == stream) {
-      if (queue == nullptr) e.used = false; else e.q = queue;
+      if (queue == nullptr) e.used = false; else { e.q = reinterpret_cast<unsigned*>(queue); e.seq = 0; }
       return HPRI_OK;
     }
   if (queue == nullptr) return HPRI_OK;
   for (auto& e : g_q)
-    if (!e.used) { e.stream = stream; e.q = queue; e.used = true; return HPRI_OK; }
+    if (!e.used) { e.stream = stream; e.q = reinterpret_cast<unsigned*>(queue); e.seq = 0; e.used = true; return HPRI_OK; }
   return hpri_set_error(HPRI_ERR_ARG, "set_item_queue: more than 32 streams hold a queue");
 }
 

@@ -72,38 +72,31 @@ typedef int hpri_rsrc_t;
 // ---- item queues of the persistent kernels (conv_bf16v3, gemm_bf16v3, gemm_f32v2) ----------------------------------------------
 // These kernels start 2 x CUs workgroups (two per CU, all of a SIMD's vector registers and ~75 KB of LDS each).  With FIXED item
 // lists a workgroup that cannot become resident at once -- a collective's kernel holds part of its CU (RCCL beside the backward of
-// a DDP step) -- starts when another one retires and then walks its whole list alone: a second wave, up to 2 x the launch.  With a
-// queue (hpri_set_item_queue: HPRI_Q_WORDS zeroed 32-bit counters owned by the caller, one buffer per stream) every workgroup
-// DRAWS its items: counter x of K slice z hands out the items of XCD x's band in the same order the fixed lists walked them, a
-// workgroup whose own band is exhausted helps the other XCDs out, and a late workgroup finds the queues empty and leaves.  Which
-// workgroup computes an item changes, nothing else: results are bit-identical.  The last workgroup to leave re-arms the counters.
+// a DDP step) -- starts when another one retires and then walks its whole list alone: ONE such workgroup costs a bf16 step 6-15 %
+// (tools/cu_share_probe.py, profiles/r05_cu_share_before.json).  With a queue (hpri_set_item_queue: caller-owned counters, one
+// buffer per stream) the workgroups DRAW their items: counter x of K slice z hands out the items of band x (the items the
+// workgroups with id mod 8 == x used to walk, in the same order); a workgroup that becomes resident late finds the band
+// exhausted and leaves.  Which workgroup computes an item changes, nothing else: results are bit-identical.
+//   * Device-scope atomics are executed on the memory side of the fabric (~2 us, and they queue per address): a first version
+//     with one synchronous draw per workgroup at kernel start, stealing from the other bands and an exit count cost every launch
+//     ~30 us (profiles/r05_queue_ab_v1.jsonl).  So: the FIRST occupant of every CU (workgroup ids below the CU count) takes its
+//     first item statically, as in the fixed lists, and draws from its second item on; the second occupants draw their first item
+//     while they sit out their start-up stagger; every later ticket is drawn one item ahead, during the previous item's epilogue,
+//     and parked in LDS -- no workgroup ever waits for an atomic inside the item loop, and none is issued at the end.
+//   * The buffer holds two halves of HPRI_Q_HALF counters; launches on a stream alternate (the launcher keeps the parity), and
+//     every launch zeroes the half the NEXT one will use: no exit protocol, no memset node between launches.
 #define HPRI_Q_SLICES 8
-#define HPRI_Q_WORDS (8 * HPRI_Q_SLICES + 1)
-void* hpri_item_queue(hipStream_t stream);     // the queue registered for this stream, or nullptr (api.cpp)
+#define HPRI_Q_HALF (8 * HPRI_Q_SLICES)
+#define HPRI_Q_WORDS (2 * HPRI_Q_HALF)
+struct HpriQueueHalves { unsigned *use, *clear; };
+HpriQueueHalves hpri_item_queue_take(hipStream_t stream);     // this launch's half and the one it must zero ({nullptr, nullptr}: no queue); api.cpp
 #ifdef __HIPCC__
-__device__ __forceinline__ unsigned hpri_q_draw(unsigned* q, int xcd) {
-  return __hip_atomic_fetch_add(q + xcd, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+__device__ __forceinline__ unsigned hpri_q_draw(unsigned* q, int band, unsigned n) {
+  return __hip_atomic_fetch_add(q + band, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// (one thread) draw from queue *qx; when that band is exhausted try the other XCDs' in turn.  nvalid(x) = items of band x.
-// Returns the item's index inside the band and leaves the band in *qx, or -1: nothing left anywhere.
-template <typename NV>
-__device__ __forceinline__ int hpri_q_steal(unsigned* q, int* qx, unsigned first, NV nvalid) {
-  unsigned v = first;
-  int x = *qx;
-  for (int j = 0;; ++j) {
-    if (v < (unsigned)nvalid(x)) { *qx = x; return (int)v; }
-    if (j == 7) return -1;
-    x = (x + 1) & 7;
-    v = hpri_q_draw(q, x);
-  }
-}
-// (one thread, once per workgroup, after its last draw has returned) count the workgroup out
-__device__ __forceinline__ void hpri_q_leave(unsigned* qbase, unsigned total_workgroups, int nslices) {
-  unsigned* done = qbase + 8 * HPRI_Q_SLICES;
-  if (__hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == total_workgroups) {
-    for (int i = 0; i < 8 * nslices; ++i) __hip_atomic_store(qbase + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
+// (the first 64 threads of one workgroup) zero the half the next launch on this stream will draw from
+__device__ __forceinline__ void hpri_q_clear(unsigned* other, int tid) {
+  if (other != nullptr && tid < HPRI_Q_HALF) __hip_atomic_store(other + tid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 #endif
 

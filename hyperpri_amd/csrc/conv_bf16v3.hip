@@ -46,7 +46,7 @@ struct ConvV3Args {
   int nseg, tiles_img, ntiles, nb_count, per_xcd, nb_major;
   int seg_twl[V3_MAXSEG], seg_xbeg[V3_MAXSEG], seg_ntx[V3_MAXSEG], seg_first[V3_MAXSEG];
   int ncu, stagger_cycles;                   // compute units of the device; one-off delay of each CU's second occupant
-  unsigned* queue;                           // item counters (common.h: hpri_set_item_queue), or nullptr = fixed item lists
+  unsigned *queue, *queue_clear;             // item counters of this launch and the half it zeroes for the next one (common.h), or nullptr = fixed item lists
   // conv_bf16v3_kernel<true> (a data-gradient launch that writes the ONLY contribution to dL/dx, x = ReLU(BN(bn_x))): the epilogue
   // also reads the pre-BN tensor bn_x (bf16, elements per pixel bn_x_cs, first channel bn_x_coff, bn_cw readable channels) at its
   // output positions and leaves per-tile partial sums of that BatchNorm's backward, bn_part[stat tile][2][bn_cpart] =
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16v3_kernel(ConvV3Args a) {
   unsigned char* b_lds = smem + 2 * V3_A_BYTES;
   float* bias_lds = reinterpret_cast<float*>(smem + 2 * V3_A_BYTES + 2 * V3_B_BYTES);   // [2 slots][64]: a block's biases (0 beyond Cout)
   unsigned* arrive_lds = reinterpret_cast<unsigned*>(smem + 2 * V3_A_BYTES + 2 * V3_B_BYTES + 512);   // waves that have left their statistics record
-  int* next_lds = reinterpret_cast<int*>(smem + 2 * V3_A_BYTES + 2 * V3_B_BYTES + 512 + 16);           // [2 slots][item index in its band, band]: item queue
+  int* next_lds = reinterpret_cast<int*>(smem + 2 * V3_A_BYTES + 2 * V3_B_BYTES + 512 + 16);           // [2 slots]: the next item's index in the band (item queue)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, lq = lane >> 4;
@@ -110,12 +110,8 @@ __global__ __launch_bounds__(256, 2) void conv_bf16v3_kernel(ConvV3Args a) {
   //      columns / rows they share meet in that XCD's L2.  Every workgroup runs a fixed list: the grid drains by itself. ----
   const int xcd = blockIdx.x & 7, nloc = (int)(gridDim.x >> 3);
   const int items_all = a.ntiles * a.nb_count;
-  // items of XCD x's band (what its counter may hand out)
-  auto band_items = [&](int x) -> int {
-    return a.nb_major ? min(a.per_xcd, a.ntiles * (a.nb_count >> 3)) : max(0, min(a.per_xcd, items_all - x * a.per_xcd));
-  };
-  auto tile_of = [&](int k, int xcd, V3Tile& t) -> bool {
-    if (k < 0 || k >= a.per_xcd) return false;
+  auto tile_of = [&](int k, V3Tile& t) -> bool {
+    if (k >= a.per_xcd) return false;
     if (a.nb_major) {
       // wide layers (Cout_pad >= 512): XCD x owns the channel blocks nb = x (mod 8) of EVERY pixel tile, so the one or two packed
       // weight slices it needs (Cin_pad x 1152 B each) stay in its L2 and the small input is what gets re-read; banded (below)
@@ -147,13 +143,9 @@ __global__ __launch_bounds__(256, 2) void conv_bf16v3_kernel(ConvV3Args a) {
   const int cps = (nchunks_all + a.ksplit - 1) / a.ksplit;
   const int chunk0 = blockIdx.z * cps;
   const int nchunks = min(nchunks_all, chunk0 + cps);
-  unsigned* const qbase = a.queue;
-  unsigned* const q = qbase != nullptr ? qbase + blockIdx.z * 8 : nullptr;       // this K slice's eight band counters
-  const unsigned q_total = gridDim.x * gridDim.z;
-  if (chunk0 >= nchunks) {
-    if (qbase != nullptr && tid == 0) hpri_q_leave(qbase, q_total, (int)gridDim.z);
-    return;
-  }
+  unsigned* const q = a.queue != nullptr ? a.queue + blockIdx.z * 8 : nullptr;   // this K slice's eight band counters
+  if (blockIdx.x == 0 && blockIdx.z == 0) hpri_q_clear(a.queue_clear, tid);      // (for the next launch on this stream)
+  if (chunk0 >= nchunks) return;
   const int S0 = chunk0 * 3, S = nchunks * 3;
 
   // ---- DMA source offsets of the item being LOADED (32-bit per-lane byte offsets against wave-uniform buffer descriptors;
@@ -242,26 +234,29 @@ __global__ __launch_bounds__(256, 2) void conv_bf16v3_kernel(ConvV3Args a) {
   const int bofs = li * 64 + ((lq ^ (((li >> 2) & 1) << 1)) << 4);
 
   V3Tile cur, nxt;
-  int k = (int)(blockIdx.x >> 3), qx = xcd;    // item index inside band qx (fixed lists: always the workgroup's own XCD's band)
-  unsigned pend = 0u;                          // (thread 0) the draw in flight: the ticket of the item AFTER the next one
-  if (q != nullptr) {
-    // the first item is drawn and waited for; the second one's ticket is on its way while this item is set up
-    if (tid == 0) {
-      int bx_ = xcd;
-      next_lds[0] = hpri_q_steal(q, &bx_, hpri_q_draw(q, xcd), band_items);
-      next_lds[1] = bx_;
-      pend = hpri_q_draw(q, bx_);
-    }
+  // ---- first item.  Fixed lists: item k = id / 8 of the band, then k + nloc, ...  Item queue (common.h): the first occupants of
+  //      the CUs (ids below the CU count) start on the same item and draw from their second item on (ticket t = item nstatic + t);
+  //      the second occupants draw their first two items now, and the answer arrives while they sit out their stagger ----
+  int k = (int)(blockIdx.x >> 3);
+  const int nstatic = min(nloc, a.ncu >> 3);
+  const bool late_start = (unsigned)(blockIdx.x - a.ncu) < (unsigned)a.ncu;
+  unsigned pend = 0u;                          // (thread 0) the ticket of the NEXT item, drawn one item ahead
+  if (q != nullptr && tid == 0) pend = hpri_q_draw(q, xcd, k < nstatic ? 1u : 2u);
+  // Two workgroups share a CU and every workgroup of a launch runs the same program on items of the same size: the second
+  // occupants (workgroups [ncu, 2 ncu) in dispatch order) start late once, so that from then on one workgroup's epilogue runs
+  // under the other's main loop.  Placement is not promised by HIP: another dispatch order costs the overlap, never correctness.
+  if (late_start && a.stagger_cycles > 0) {
+    const long long t0 = (long long)__builtin_amdgcn_s_memtime();
+    while ((long long)__builtin_amdgcn_s_memtime() - t0 < (long long)a.stagger_cycles) __builtin_amdgcn_s_sleep(32);
+  }
+  if (q != nullptr && k >= nstatic) {
+    if (tid == 0) { next_lds[0] = nstatic + (int)pend; pend += 1u; }
     __syncthreads();
     k = __builtin_amdgcn_readfirstlane(next_lds[0]);
-    qx = __builtin_amdgcn_readfirstlane(next_lds[1]);
     __syncthreads();                           // (slot 0 is written again at the top of the first item)
   }
-  bool have = tile_of(k, qx, cur);
-  if (!have) {
-    if (qbase != nullptr && tid == 0) hpri_q_leave(qbase, q_total, (int)gridDim.z);
-    return;
-  }
+  bool have = tile_of(k, cur);
+  if (!have) return;
   setup_dma(cur);
   build_aofs(cur.twl);
   // the channel block's biases go through LDS (16 scalar loads per lane in the epilogue were 16 serialized round trips: hipcc
@@ -273,13 +268,6 @@ __global__ __launch_bounds__(256, 2) void conv_bf16v3_kernel(ConvV3Args a) {
     bias_next = (a.bias != nullptr && a.ksplit == 1 && n < a.Cout) ? a.bias[n] : 0.f;
   }
 
-  // Two workgroups share a CU and every workgroup of a launch runs the same program on items of the same size: the second
-  // occupants (workgroups [ncu, 2 ncu) in dispatch order) start late once, so that from then on one workgroup's epilogue runs
-  // under the other's main loop.  Placement is not promised by HIP: another dispatch order costs the overlap, never correctness.
-  if ((unsigned)(blockIdx.x - a.ncu) < (unsigned)a.ncu && a.stagger_cycles > 0) {
-    const long long t0 = (long long)__builtin_amdgcn_s_memtime();
-    while ((long long)__builtin_amdgcn_s_memtime() - t0 < (long long)a.stagger_cycles) __builtin_amdgcn_s_sleep(32);
-  }
 #ifdef HPRI_STAMPS
   if (a.stamps != nullptr && threadIdx.x == 0) a.stamps[((size_t)blockIdx.z * gridDim.x + blockIdx.x) * 16 + 7] = __builtin_amdgcn_s_memrealtime();
   long long wait_cycles = 0;                   // cycles wave 0 spent between the top of a stage and the end of its barrier
@@ -365,7 +353,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16v3_kernel(ConvV3Args a) {
     if (tid < 64) bias_lds[slot * 64 + tid] = bias_next;      // visible to everyone behind the first stage's barrier
     // the NEXT item's ticket (drawn during the previous item's epilogue) is parked in LDS: it does not live in a register across
     // the main loop.  (The first stage waits for vmcnt(0) anyway: this wait is that one, a few instructions early.)
-    if (q != nullptr && tid == 0) next_lds[slot * 2] = (int)pend;
+    if (q != nullptr && tid == 0) next_lds[slot] = nstatic + (int)pend;
 
     f32x4 acc[4][4];                           // [pixel tile mt][channel tile nt]: channels nt*16 + 4*lq + r, pixel mt*16 + li
 #pragma unroll
@@ -396,22 +384,10 @@ __global__ __launch_bounds__(256, 2) void conv_bf16v3_kernel(ConvV3Args a) {
     // ---- the next item's first halo and weight stage start to load now and land while this item's results are written out:
     //      every wave has left the main loop (barrier), so halo buffer 0 and weight buffer 0 are free whatever the chunk parity;
     //      the statistics scratch below lives in halo buffer 1 ----
-    if (q != nullptr && tid == 0) {
-      // is the parked ticket an item of the band?  If not the band is exhausted: help the other XCDs out (end of the launch only)
-      int bx_ = qx;
-      const int kn = hpri_q_steal(q, &bx_, (unsigned)next_lds[slot * 2], band_items);
-      next_lds[slot * 2] = kn;
-      next_lds[slot * 2 + 1] = bx_;
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    }
     V3_BARRIER();
-    if (q != nullptr) {
-      k = __builtin_amdgcn_readfirstlane(next_lds[slot * 2]);
-      qx = __builtin_amdgcn_readfirstlane(next_lds[slot * 2 + 1]);
-    } else {
-      k += nloc;
-    }
-    have = tile_of(k, qx, nxt);
+    if (q != nullptr) k = __builtin_amdgcn_readfirstlane(next_lds[slot]);      // (beyond the band: the workgroup is done)
+    else k += nloc;
+    have = tile_of(k, nxt);
     if (have) {
       setup_dma(nxt);
       V3_PROLOGUE_LOADS()
@@ -419,7 +395,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16v3_kernel(ConvV3Args a) {
         const int n = nxt.nb * 64 + tid;
         bias_next = (a.bias != nullptr && a.ksplit == 1 && n < a.Cout) ? a.bias[n] : 0.f;
       }
-      if (q != nullptr && tid == 0) pend = hpri_q_draw(q, qx);       // the ticket of the item after that one
+      if (q != nullptr && tid == 0) pend = hpri_q_draw(q, xcd, 1u);      // the ticket of the item after that one
     }
 
 #ifdef HPRI_STAMPS
@@ -799,7 +775,6 @@ __global__ __launch_bounds__(256, 2) void conv_bf16v3_kernel(ConvV3Args a) {
     cur = nxt;
     slot ^= 1;
   }
-  if (qbase != nullptr && tid == 0) hpri_q_leave(qbase, q_total, (int)gridDim.z);      // (its last draw came back long ago)
 #ifdef HPRI_STAMPS
   if (a.stamps != nullptr && threadIdx.x == 0) {
     unsigned long long* sp = a.stamps + ((size_t)blockIdx.z * gridDim.x + blockIdx.x) * 16;
@@ -954,7 +929,7 @@ static int v3_launch(const void* xp, long long x_plane, int x_cs, int x_coff, co
   a.nb_major = (a.nb_count % 8 == 0) ? 1 : 0;
   a.per_xcd = a.nb_major ? a.ntiles * (a.nb_count / 8) : (int)((items + 7) / 8);
   a.ncu = hpri_cu_count(); a.stagger_cycles = stagger_cycles;
-  a.queue = a.ksplit <= HPRI_Q_SLICES ? reinterpret_cast<unsigned*>(hpri_item_queue(stream)) : nullptr;
+  a.queue = a.queue_clear = nullptr;      // (taken right before the launch: the stream's parity advances with every real launch)
 #ifdef HPRI_STAMPS
   a.stamps = stamps;
 #else
@@ -987,11 +962,13 @@ static int v3_launch(const void* xp, long long x_plane, int x_cs, int x_coff, co
     a.bn_mean = bn->mean; a.bn_invstd = bn->invstd; a.bn_scale = bn->scale; a.bn_shift = bn->shift;
     a.bn_relu = bn->relu; a.bn_part = bn->part; a.bn_cpart = bn->cpart;
 #ifdef HPRI_DIAG_KERNELS
+    if (a.ksplit <= HPRI_Q_SLICES) { const HpriQueueHalves qh = hpri_item_queue_take(stream); a.queue = qh.use; a.queue_clear = qh.clear; }
     hipLaunchKernelGGL(conv_bf16v3_kernel<true>, grid, dim3(256), 0, stream, a);
 #else
     return hpri_set_error(HPRI_ERR_UNSUPPORTED, "conv_bf16v3_bnred: diagnostics build only (HPRI_DIAG=1 python -m hyperpri_amd.build)");
 #endif
   } else {
+    if (a.ksplit <= HPRI_Q_SLICES) { const HpriQueueHalves qh = hpri_item_queue_take(stream); a.queue = qh.use; a.queue_clear = qh.clear; }
     hipLaunchKernelGGL(conv_bf16v3_kernel<false>, grid, dim3(256), 0, stream, a);
   }
   HPRI_CHECK_LAUNCH();

@@ -44,7 +44,7 @@ struct GemmV3Args {
   int accumulate, relu;
   int tiles_img, ntiles, nb_count, per_xcd;
   int ncu, stagger_cycles;
-  unsigned* queue;                           // item counters (common.h: hpri_set_item_queue), or nullptr = fixed item lists
+  unsigned *queue, *queue_clear;             // item counters of this launch and the half it zeroes for the next one (common.h), or nullptr = fixed item lists
 };
 
 __device__ __forceinline__ float g3_row_sum(float v) {
@@ -66,15 +66,14 @@ template <int MODE>
 __global__ __launch_bounds__(256, 2) void gemm_bf16v3_kernel(GemmV3Args a) {
   __shared__ __attribute__((aligned(1024))) unsigned char smem[3 * G3_STAGE_BYTES + 2 * G3_BN * 4 + 16];
   float* bias_lds = reinterpret_cast<float*>(smem + 3 * G3_STAGE_BYTES);     // [2 slots][G3_BN]
-  int* next_lds = reinterpret_cast<int*>(smem + 3 * G3_STAGE_BYTES + 2 * G3_BN * 4);      // [2 slots][item index in its band, band]: item queue
+  int* next_lds = reinterpret_cast<int*>(smem + 3 * G3_STAGE_BYTES + 2 * G3_BN * 4);      // [2 slots]: the next item's index in the band (item queue)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, lq = lane >> 4;
   const int xcd = blockIdx.x & 7, nloc = (int)(gridDim.x >> 3);
   const int items_all = a.ntiles * a.nb_count;
-  auto band_items = [&](int x) -> int { return max(0, min(a.per_xcd, items_all - x * a.per_xcd)); };     // items of XCD x's band
-  auto tile_of = [&](int k, int xcd, G3Tile& t) -> bool {
-    if (k < 0 || k >= a.per_xcd) return false;
+  auto tile_of = [&](int k, G3Tile& t) -> bool {
+    if (k >= a.per_xcd) return false;
     const int item = xcd * a.per_xcd + k;
     if (item >= items_all) return false;
     t.bx = item / a.nb_count; t.nb = item - t.bx * a.nb_count;
@@ -146,26 +145,26 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16v3_kernel(GemmV3Args a) {
   const int S = a.nchunks;
 
   G3Tile cur, nxt;
-  int k = (int)(blockIdx.x >> 3), qx = xcd;    // item index inside band qx (fixed lists: always the workgroup's own XCD's band)
-  unsigned* const q = a.queue;                 // see conv_bf16v3.hip: the same item queue
-  unsigned pend = 0u;                          // (thread 0) the draw in flight: the ticket of the item AFTER the next one
-  if (q != nullptr) {
-    if (tid == 0) {
-      int bx_ = xcd;
-      next_lds[0] = hpri_q_steal(q, &bx_, hpri_q_draw(q, xcd), band_items);
-      next_lds[1] = bx_;
-      pend = hpri_q_draw(q, bx_);
-    }
+  // first item: see conv_bf16v3.hip (fixed lists, or the item queue of common.h)
+  int k = (int)(blockIdx.x >> 3);
+  unsigned* const q = a.queue;
+  if (blockIdx.x == 0) hpri_q_clear(a.queue_clear, tid);
+  const int nstatic = min(nloc, a.ncu >> 3);
+  const bool late_start = (unsigned)(blockIdx.x - a.ncu) < (unsigned)a.ncu;
+  unsigned pend = 0u;                          // (thread 0) the ticket of the NEXT item, drawn one item ahead
+  if (q != nullptr && tid == 0) pend = hpri_q_draw(q, xcd, k < nstatic ? 1u : 2u);
+  if (late_start && a.stagger_cycles > 0) {      // see conv_wino4.hip: the CU's second occupant starts late once
+    const long long t0 = (long long)__builtin_amdgcn_s_memtime();
+    while ((long long)__builtin_amdgcn_s_memtime() - t0 < (long long)a.stagger_cycles) __builtin_amdgcn_s_sleep(32);
+  }
+  if (q != nullptr && k >= nstatic) {
+    if (tid == 0) { next_lds[0] = nstatic + (int)pend; pend += 1u; }
     __syncthreads();
     k = __builtin_amdgcn_readfirstlane(next_lds[0]);
-    qx = __builtin_amdgcn_readfirstlane(next_lds[1]);
     __syncthreads();
   }
-  bool have = tile_of(k, qx, cur);
-  if (!have) {
-    if (q != nullptr && tid == 0) hpri_q_leave(q, gridDim.x, 1);
-    return;
-  }
+  bool have = tile_of(k, cur);
+  if (!have) return;
   setup_dma(cur);
   float bias_next[1] = {0.f};
   auto load_bias = [&](const G3Tile& t) {
@@ -176,17 +175,13 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16v3_kernel(GemmV3Args a) {
     }
   };
   load_bias(cur);
-  if ((unsigned)(blockIdx.x - a.ncu) < (unsigned)a.ncu && a.stagger_cycles > 0) {
-    const long long t0 = (long long)__builtin_amdgcn_s_memtime();
-    while ((long long)__builtin_amdgcn_s_memtime() - t0 < (long long)a.stagger_cycles) __builtin_amdgcn_s_sleep(32);
-  }
   G3_ISSUE(0, 0)
   if (S > 1) G3_ISSUE(1, 1)
   int slot = 0;
 
   while (have) {
     if (tid < G3_BN) bias_lds[slot * G3_BN + tid] = bias_next[0];      // visible behind the first stage's barrier
-    if (q != nullptr && tid == 0) next_lds[slot * 2] = (int)pend;      // the next item's ticket, parked (conv_bf16v3.hip)
+    if (q != nullptr && tid == 0) next_lds[slot] = nstatic + (int)pend;      // the next item's ticket, parked (conv_bf16v3.hip)
 
     f32x4 acc[4][G3_NT];
 #pragma unroll
@@ -226,27 +221,16 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16v3_kernel(GemmV3Args a) {
       __builtin_amdgcn_s_setprio(0);
       bo = bo == 2 * G3_STAGE_BYTES ? 0 : bo + G3_STAGE_BYTES;
     }
-    if (q != nullptr && tid == 0) {
-      int bx_ = qx;
-      const int kn = hpri_q_steal(q, &bx_, (unsigned)next_lds[slot * 2], band_items);
-      next_lds[slot * 2] = kn;
-      next_lds[slot * 2 + 1] = bx_;
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    }
     G3_BARRIER();                                // every wave has left the main loop: all three buffers are free
-    if (q != nullptr) {
-      k = __builtin_amdgcn_readfirstlane(next_lds[slot * 2]);
-      qx = __builtin_amdgcn_readfirstlane(next_lds[slot * 2 + 1]);
-    } else {
-      k += nloc;
-    }
-    have = tile_of(k, qx, nxt);
+    if (q != nullptr) k = __builtin_amdgcn_readfirstlane(next_lds[slot]);
+    else k += nloc;
+    have = tile_of(k, nxt);
     if (have) {
       setup_dma(nxt);
       G3_ISSUE(0, 0)
       if (S > 1) G3_ISSUE(1, 1)
       load_bias(nxt);
-      if (q != nullptr && tid == 0) pend = hpri_q_draw(q, qx);       // the ticket of the item after that one
+      if (q != nullptr && tid == 0) pend = hpri_q_draw(q, xcd, 1u);      // the ticket of the item after that one
     }
 
     // ------------------------------- epilogue -------------------------------
@@ -414,7 +398,6 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16v3_kernel(GemmV3Args a) {
     cur = nxt;
     slot ^= 1;
   }
-  if (q != nullptr && tid == 0) hpri_q_leave(q, gridDim.x, 1);
 #undef G3_ISSUE
 #undef G3_DMA_A
 #undef G3_DMA_B
@@ -490,11 +473,12 @@ static int g3_launch(int mode, const void* xp, int x_cs, int x_coff, const void*
   HPRI_REQUIRE(items < (1ll << 28), "gemm_bf16v3: too many work items");
   a.per_xcd = (int)((items + 7) / 8);
   a.ncu = hpri_cu_count(); a.stagger_cycles = G3_STAGGER_CYCLES;
-  a.queue = reinterpret_cast<unsigned*>(hpri_item_queue(stream));
+  a.queue = a.queue_clear = nullptr;
   int nloc = (2 * a.ncu) / 8;
   if (nloc < 1) nloc = 1;
   if (nloc > a.per_xcd) nloc = a.per_xcd;
   dim3 grid((unsigned)(nloc * 8));
+  { const HpriQueueHalves qh = hpri_item_queue_take(stream); a.queue = qh.use; a.queue_clear = qh.clear; }
   if (mode == 0) hipLaunchKernelGGL(gemm_bf16v3_kernel<0>, grid, dim3(256), 0, stream, a);
   else if (mode == 1) hipLaunchKernelGGL(gemm_bf16v3_kernel<1>, grid, dim3(256), 0, stream, a);
   else hipLaunchKernelGGL(gemm_bf16v3_kernel<2>, grid, dim3(256), 0, stream, a);

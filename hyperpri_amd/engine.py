@@ -46,8 +46,8 @@ def _rup(x: int, m: int) -> int:
 # Item queues of the persistent MFMA kernels (include/hyperpri_hip.h: hpri_set_item_queue): one zeroed counter buffer per stream the
 # engine launches on, registered the first time the stream is seen.  With a queue a workgroup that becomes resident late (an RCCL
 # kernel holds part of its CU during a DDP backward) finds the items gone instead of walking a fixed list alone; results do not
-# change.  HPRI_ITEM_QUEUE=0: fixed lists (the round-4 behaviour; tools/cu_share_probe.py measures both).
-ITEM_QUEUE = os.environ.get("HPRI_ITEM_QUEUE", "1") != "0"
+# change.  engine.ITEM_QUEUE = False before the first launch: fixed lists (the round-4 behaviour; tools/cu_share_probe.py measures both).
+ITEM_QUEUE = True
 _item_queues: Dict[Tuple[int, int], torch.Tensor] = {}
 
 

@@ -119,3 +119,67 @@ def test_full_size_c2_batch2_vs_reference_fixture():
             np.testing.assert_allclose(b.detach().cpu().numpy().astype(np.float64), z["buf/" + k].astype(np.float64),
                                        rtol=1e-4, atol=1e-5, err_msg=k)
     check_deep(z, net, "deep/c2_batch2_full", mult=4.0, floor_rel=2e-3, zero_floor=1e-4)
+
+
+# ---- the reduced-precision modes against the same fp64 samples -------------------------------------------
+# In the bf16 mode every activation, pre-BN tensor and single-reader activation gradient is STORED as bf16: the
+# norm-only gates of the full-size bf16 tests would pass a permuted or mis-routed gradient of the right norm.  Here every gradient
+# tensor of the benched step is compared element-wise (256 sampled positions per tensor) with the reference's fp64 gradient:
+# relative L2 of the difference and cosine, per tensor, recorded (gpurun_out/bf16_grad_parity.json -> profiles/) and gated at
+# the measured level + 50 %.  A mis-routed gradient has cosine ~0 and relative L2 ~1.4.
+#        mode      max rel L2 (weights)  min cosine  max rel L2 (BatchNorm weight / bias: sums of products of rounded values)
+LOWP = {"bf16": (0.12, 0.993, 0.12), "bf16x3": (8e-3, 0.9999, 8e-3)}
+
+
+@pytest.mark.parametrize("precision", ["bf16", "bf16x3"])
+def test_full_size_c2_batch2_reduced_precision_gradients_vs_fp64_samples(precision):
+    import json
+    import hyperpri_amd as H
+    z = np.load(os.path.join(G, "grads_cubenet64_full_b2.npz"))
+    Hh, Ww = 608, 968
+    net = H.CubeNET(238, 1, first_depth=64, bilinear=False)
+    shapes = OrderedDict((k, tuple(v.shape)) for k, v in net.state_dict().items())
+    net.load_state_dict(O.synth_state_dict(shapes))
+    net = H.set_precision(net.to(DEV), precision).train()
+    x = torch.cat([_u(1234 + n, (1, 1, 238, Hh, Ww)) for n in range(2)], 0)
+    mask = torch.cat([(_u(4321 + n, (1, 1, Hh, Ww)) > 0.9).float() for n in range(2)], 0)
+    logits = net(x.to(DEV))
+    loss = torch.nn.BCEWithLogitsLoss()(logits, mask.to(DEV))
+    loss.backward()
+    torch.cuda.synchronize()
+    tol_w, tol_cos, tol_bn = LOWP[precision]
+    assert abs(float(loss.detach()) - float(z["loss64"])) < (2e-3 if precision == "bf16" else 1e-5)
+    ns = int(z["ns"])
+    rows, worst_w, worst_bn, worst_cos = {}, 0.0, 0.0, 1.0
+    for k, (nm, p) in enumerate(net.named_parameters()):
+        g = p.grad.detach().reshape(-1)
+        assert torch.isfinite(g).all(), nm
+        idx = torch.from_numpy(sample_index(k, g.numel(), ns)).to(g.device)
+        cnt = int(z["grad_sample_count"][k])
+        hip = g[idx].double().cpu().numpy()
+        g64 = z["grad_sample64"][k, :cnt]
+        ref = float(np.linalg.norm(g64))
+        if float(z["grad_l2_64"][k]) < 1e-6:             # a convolution bias in front of a training-mode BatchNorm: exactly zero here
+            assert float(np.abs(hip).max()) <= 1e-4, nm
+            continue
+        rel = float(np.linalg.norm(hip - g64)) / ref
+        cos = float(np.dot(hip, g64) / (np.linalg.norm(hip) * ref + 1e-300))
+        l2 = float(g.double().norm()) / float(z["grad_l2_64"][k])
+        rows[nm] = {"rel_l2": rel, "cosine": cos, "norm_over_fp64_norm": l2, "samples": cnt}
+        if p.dim() >= 2:
+            worst_w = max(worst_w, rel)
+        else:
+            worst_bn = max(worst_bn, rel)
+        if cnt >= 16:
+            worst_cos = min(worst_cos, cos)
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, f"{precision}_grad_parity_c2_batch2.json"), "w") as f:
+        json.dump({"what": f"CubeNET-64, two 238x608x968 cubes, precision {precision}: every gradient tensor at the fixture's sampled positions "
+                           "against the reference's fp64 gradient (tests/golden/grads_cubenet64_full_b2.npz)", "loss": float(loss.detach()),
+                   "loss_fp64": float(z["loss64"]), "worst_rel_l2_weights": worst_w, "worst_rel_l2_1d": worst_bn, "worst_cosine": worst_cos,
+                   "tensors": rows}, f, indent=1)
+    record_margin(f"deep/c2_batch2_{precision}/grad_rel_l2_weights", worst_w, tol_w)
+    record_margin(f"deep/c2_batch2_{precision}/grad_rel_l2_1d", worst_bn, tol_bn)
+    record_margin(f"deep/c2_batch2_{precision}/one_minus_cosine", 1.0 - worst_cos, 1.0 - tol_cos)
+    assert worst_w <= tol_w and worst_bn <= tol_bn and worst_cos >= tol_cos, (worst_w, worst_bn, worst_cos)

@@ -306,6 +306,34 @@ def test_full_size_cubenet128_bf16_vs_reference_fixture():
         g = float(grads[k].detach().double().norm())
         ref = float(z["grad_l2"][i])
         assert abs(g - ref) <= 0.1 * ref + 1e-6, (k, g, ref)
+    check_heads_lowp(z, net, "full/c5_bf16", HEAD_BAND_BF16)
+
+
+# Element-wise gate of the reduced-precision gradients at full size: the fixture's first 16 values of every
+# weight tensor against the HIP gradient, as a fraction of the tensor's RMS gradient.  Norms alone would pass a permuted or mis-routed
+# gradient (those are off by >= 1 RMS on almost every element); bf16 operands and bf16-stored activation gradients put single
+# elements up to the band below from the fp32 reference (measured: gpurun_out/parity_margins.json, keys full/*/grad_head_over_rms).
+HEAD_BAND_BF16 = 0.6
+
+
+def check_heads_lowp(z, net, tag, band):
+    grads = OrderedDict((k, p.grad) for k, p in net.named_parameters())
+    worst, cos_min = 0.0, 1.0
+    for i, k in enumerate(list(z["grad_names"])):
+        g = grads[k].detach().double().flatten().cpu()
+        ref = float(z["grad_l2"][i])
+        if g.numel() < 16 or ref < 1e-6:
+            continue
+        head = torch.from_numpy(z["grad_head"][i][:16].astype(np.float64))
+        rms = ref / math.sqrt(g.numel())
+        d = float((g[:16] - head).abs().max()) / rms
+        worst = max(worst, d)
+        assert d <= band, (k, d, g[:16].tolist(), head.tolist())
+        if float(head.norm()) > 0.25 * rms * 4.0:        # (a head that is not itself far below the tensor's level)
+            cos_min = min(cos_min, float(torch.dot(g[:16], head) / (g[:16].norm() * head.norm() + 1e-300)))
+    record_margin(f"{tag}/grad_head_over_rms", worst, band)
+    record_margin(f"{tag}/grad_head_one_minus_cosine", 1.0 - cos_min, 0.1)
+    assert cos_min >= 0.9, cos_min
 
 
 def test_full_size_spectral1650_bf16_vs_reference_fixture():
@@ -346,6 +374,7 @@ def test_full_size_spectral1650_bf16_vs_reference_fixture():
         worst = max(worst, abs(g - ref) / (ref + 1e-12))
         assert abs(g - ref) <= 0.1 * ref + 1e-6, (k, g, ref)
     record_margin("full/c3_bf16/grad_norms", worst, 0.1)
+    check_heads_lowp(z, net, "full/c3_bf16", HEAD_BAND_BF16)
 
 
 X3_CASES = [c for c in CASES if c[0] in ("net_unet3_tiny", "net_cubenet64_tiny", "net_cubenet128_tiny", "net_spectral_f50")]
