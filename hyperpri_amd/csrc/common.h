@@ -85,18 +85,24 @@ typedef int hpri_rsrc_t;
 //     and parked in LDS -- no workgroup ever waits for an atomic inside the item loop, and none is issued at the end.
 //   * The buffer holds two halves of HPRI_Q_HALF counters; launches on a stream alternate (the launcher keeps the parity), and
 //     every launch zeroes the half the NEXT one will use: no exit protocol, no memset node between launches.
+//   * Every counter has a 4 KB stretch of the buffer to itself: with the eight band counters side by side in one 64-byte line all
+//     512 workgroups of a launch queued at ONE memory channel (+20-40 us on a 100 us launch: profiles/r05_queue_ab_v2.jsonl).
+//     Launches whose workgroups get one item each (band items <= workgroups per band) keep their fixed lists: nothing to draw.
 #define HPRI_Q_SLICES 8
-#define HPRI_Q_HALF (8 * HPRI_Q_SLICES)
+#define HPRI_Q_STRIDE 1024                       // 32-bit words between two counters
+#define HPRI_Q_COUNTERS (8 * HPRI_Q_SLICES)      // per half: [K slice][band]
+#define HPRI_Q_HALF (HPRI_Q_COUNTERS * HPRI_Q_STRIDE)
 #define HPRI_Q_WORDS (2 * HPRI_Q_HALF)
 struct HpriQueueHalves { unsigned *use, *clear; };
 HpriQueueHalves hpri_item_queue_take(hipStream_t stream);     // this launch's half and the one it must zero ({nullptr, nullptr}: no queue); api.cpp
 #ifdef __HIPCC__
+// q: the counters of one K slice (half + slice * 8 * HPRI_Q_STRIDE)
 __device__ __forceinline__ unsigned hpri_q_draw(unsigned* q, int band, unsigned n) {
-  return __hip_atomic_fetch_add(q + band, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return __hip_atomic_fetch_add(q + band * HPRI_Q_STRIDE, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // (the first 64 threads of one workgroup) zero the half the next launch on this stream will draw from
 __device__ __forceinline__ void hpri_q_clear(unsigned* other, int tid) {
-  if (other != nullptr && tid < HPRI_Q_HALF) __hip_atomic_store(other + tid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (other != nullptr && tid < HPRI_Q_COUNTERS) __hip_atomic_store(other + tid * HPRI_Q_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 #endif
 

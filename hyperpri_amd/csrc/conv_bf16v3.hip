@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16v3_kernel(ConvV3Args a) {
   const int cps = (nchunks_all + a.ksplit - 1) / a.ksplit;
   const int chunk0 = blockIdx.z * cps;
   const int nchunks = min(nchunks_all, chunk0 + cps);
-  unsigned* const q = a.queue != nullptr ? a.queue + blockIdx.z * 8 : nullptr;   // this K slice's eight band counters
+  unsigned* const q = a.queue != nullptr ? a.queue + blockIdx.z * (8 * HPRI_Q_STRIDE) : nullptr;   // this K slice's eight band counters
   if (blockIdx.x == 0 && blockIdx.z == 0) hpri_q_clear(a.queue_clear, tid);      // (for the next launch on this stream)
   if (chunk0 >= nchunks) return;
   const int S0 = chunk0 * 3, S = nchunks * 3;
@@ -962,13 +962,13 @@ static int v3_launch(const void* xp, long long x_plane, int x_cs, int x_coff, co
     a.bn_mean = bn->mean; a.bn_invstd = bn->invstd; a.bn_scale = bn->scale; a.bn_shift = bn->shift;
     a.bn_relu = bn->relu; a.bn_part = bn->part; a.bn_cpart = bn->cpart;
 #ifdef HPRI_DIAG_KERNELS
-    if (a.ksplit <= HPRI_Q_SLICES) { const HpriQueueHalves qh = hpri_item_queue_take(stream); a.queue = qh.use; a.queue_clear = qh.clear; }
+    if (a.ksplit <= HPRI_Q_SLICES && a.per_xcd > nloc) { const HpriQueueHalves qh = hpri_item_queue_take(stream); a.queue = qh.use; a.queue_clear = qh.clear; }
     hipLaunchKernelGGL(conv_bf16v3_kernel<true>, grid, dim3(256), 0, stream, a);
 #else
     return hpri_set_error(HPRI_ERR_UNSUPPORTED, "conv_bf16v3_bnred: diagnostics build only (HPRI_DIAG=1 python -m hyperpri_amd.build)");
 #endif
   } else {
-    if (a.ksplit <= HPRI_Q_SLICES) { const HpriQueueHalves qh = hpri_item_queue_take(stream); a.queue = qh.use; a.queue_clear = qh.clear; }
+    if (a.ksplit <= HPRI_Q_SLICES && a.per_xcd > nloc) { const HpriQueueHalves qh = hpri_item_queue_take(stream); a.queue = qh.use; a.queue_clear = qh.clear; }
     hipLaunchKernelGGL(conv_bf16v3_kernel<false>, grid, dim3(256), 0, stream, a);
   }
   HPRI_CHECK_LAUNCH();

@@ -44,8 +44,11 @@ class _Queue:
         assert self.lib.hpri_set_item_queue(P(self.buf), self.buf.numel() * 4, self.h) == 0, self.lib.hpri_last_error()
         self.launches = 0                   # (registration resets the parity: the first launch draws from half 0)
 
-    def next_half_is_zero(self):
-        """After a launch: the half the NEXT launch will draw from has been zeroed, the one just used holds its tickets."""
+    def next_half_is_zero(self, taken=True):
+        """After a launch: the half the NEXT launch will draw from has been zeroed, the one just used holds its tickets.
+        ``taken=False``: a launch whose workgroups have one item each keeps its fixed lists and leaves the queue alone."""
+        if not taken:
+            return int(self.buf.abs().sum()) == 0
         self.launches += 1
         h = self.buf.numel() // 2
         nxt = self.buf[:h] if self.launches % 2 == 0 else self.buf[h:]
@@ -111,7 +114,7 @@ def test_conv_bf16v3_queue_equals_fixed_lists(lib, queue, shape):
         assert torch.equal(y0, y1), (shape, rep)
         if pr["ksplit"] == 1:
             assert torch.equal(s0, s1), (shape, rep)
-        assert queue.next_half_is_zero(), (shape, rep, queue.buf.tolist())
+        assert queue.next_half_is_zero(taken=shape[1] > 19), (shape, rep)
 
 
 @pytest.fixture(scope="module")
