@@ -87,7 +87,9 @@ typedef int hpri_rsrc_t;
 //     every launch zeroes the half the NEXT one will use: no exit protocol, no memset node between launches.
 //   * Every counter has a 4 KB stretch of the buffer to itself: with the eight band counters side by side in one 64-byte line all
 //     512 workgroups of a launch queued at ONE memory channel (+20-40 us on a 100 us launch: profiles/r05_queue_ab_v2.jsonl).
-//     Launches whose workgroups get one item each (band items <= workgroups per band) keep their fixed lists: nothing to draw.
+//     Launches with fewer than two items per workgroup keep their fixed lists: there a ticket's latency (same-address atomics take
+//     turns at the memory side, a few hundred ns each) sits on the critical path of the second occupants and nothing absorbs it
+//     (+23 % on the 72-items-per-band layers at 76x121), and a late workgroup costs one or two items at most anyway.
 #define HPRI_Q_SLICES 8
 #define HPRI_Q_STRIDE 1024                       // 32-bit words between two counters
 #define HPRI_Q_COUNTERS (8 * HPRI_Q_SLICES)      // per half: [K slice][band]

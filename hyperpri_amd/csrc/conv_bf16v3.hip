@@ -962,13 +962,13 @@ static int v3_launch(const void* xp, long long x_plane, int x_cs, int x_coff, co
     a.bn_mean = bn->mean; a.bn_invstd = bn->invstd; a.bn_scale = bn->scale; a.bn_shift = bn->shift;
     a.bn_relu = bn->relu; a.bn_part = bn->part; a.bn_cpart = bn->cpart;
 #ifdef HPRI_DIAG_KERNELS
-    if (a.ksplit <= HPRI_Q_SLICES && a.per_xcd > nloc) { const HpriQueueHalves qh = hpri_item_queue_take(stream); a.queue = qh.use; a.queue_clear = qh.clear; }
+    if (a.ksplit <= HPRI_Q_SLICES && a.per_xcd >= 2 * nloc) { const HpriQueueHalves qh = hpri_item_queue_take(stream); a.queue = qh.use; a.queue_clear = qh.clear; }
     hipLaunchKernelGGL(conv_bf16v3_kernel<true>, grid, dim3(256), 0, stream, a);
 #else
     return hpri_set_error(HPRI_ERR_UNSUPPORTED, "conv_bf16v3_bnred: diagnostics build only (HPRI_DIAG=1 python -m hyperpri_amd.build)");
 #endif
   } else {
-    if (a.ksplit <= HPRI_Q_SLICES && a.per_xcd > nloc) { const HpriQueueHalves qh = hpri_item_queue_take(stream); a.queue = qh.use; a.queue_clear = qh.clear; }
+    if (a.ksplit <= HPRI_Q_SLICES && a.per_xcd >= 2 * nloc) { const HpriQueueHalves qh = hpri_item_queue_take(stream); a.queue = qh.use; a.queue_clear = qh.clear; }
     hipLaunchKernelGGL(conv_bf16v3_kernel<false>, grid, dim3(256), 0, stream, a);
   }
   HPRI_CHECK_LAUNCH();

@@ -478,7 +478,7 @@ static int g3_launch(int mode, const void* xp, int x_cs, int x_coff, const void*
   if (nloc < 1) nloc = 1;
   if (nloc > a.per_xcd) nloc = a.per_xcd;
   dim3 grid((unsigned)(nloc * 8));
-  if (a.per_xcd > nloc) { const HpriQueueHalves qh = hpri_item_queue_take(stream); a.queue = qh.use; a.queue_clear = qh.clear; }
+  if (a.per_xcd >= 2 * nloc) { const HpriQueueHalves qh = hpri_item_queue_take(stream); a.queue = qh.use; a.queue_clear = qh.clear; }
   if (mode == 0) hipLaunchKernelGGL(gemm_bf16v3_kernel<0>, grid, dim3(256), 0, stream, a);
   else if (mode == 1) hipLaunchKernelGGL(gemm_bf16v3_kernel<1>, grid, dim3(256), 0, stream, a);
   else hipLaunchKernelGGL(gemm_bf16v3_kernel<2>, grid, dim3(256), 0, stream, a);

@@ -377,7 +377,7 @@ static int f2_launch(int mode, const float* x, int x_cs, int x_coff, const float
   if (nloc < 1) nloc = 1;
   if (nloc > a.per_xcd) nloc = a.per_xcd;
   dim3 grid((unsigned)(nloc * 8));
-  if (a.per_xcd > nloc) { const HpriQueueHalves qh = hpri_item_queue_take(stream); a.queue = qh.use; a.queue_clear = qh.clear; }
+  if (a.per_xcd >= 2 * nloc) { const HpriQueueHalves qh = hpri_item_queue_take(stream); a.queue = qh.use; a.queue_clear = qh.clear; }
   if (mode == 0) hipLaunchKernelGGL(gemm_f32v2_kernel<0>, grid, dim3(256), 0, stream, a);
   else if (mode == 1) hipLaunchKernelGGL(gemm_f32v2_kernel<1>, grid, dim3(256), 0, stream, a);
   else hipLaunchKernelGGL(gemm_f32v2_kernel<2>, grid, dim3(256), 0, stream, a);
