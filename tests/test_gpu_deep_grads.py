@@ -127,30 +127,38 @@ def test_full_size_c2_batch2_vs_reference_fixture():
 # tensor of the benched step is compared element-wise (256 sampled positions per tensor) with the reference's fp64 gradient:
 # relative L2 of the difference and cosine, per tensor, recorded (gpurun_out/bf16_grad_parity.json -> profiles/) and gated at
 # the measured level + 50 %.  A mis-routed gradient has cosine ~0 and relative L2 ~1.4.
-#        mode      max rel L2 (weights)  min cosine  max rel L2 (BatchNorm weight / bias: sums of products of rounded values)
-LOWP = {"bf16": (0.12, 0.993, 0.12), "bf16x3": (8e-3, 0.9999, 8e-3)}
+# What the numbers mean (profiles/r05_bf16_grad_parity_*.json): on this workload -- white-noise cubes, default-bound random weights,
+# every gradient a small residual of BatchNorm's projections -- the backward pass amplifies rounding by ~1e5: the REFERENCE's own fp32
+# gradients sit 7e-3 from its fp64 ones, operands rounded to 16 mantissa bits (bf16x3: activations still stored in fp32) give 2.1e-2, and
+# the bf16 mode (8-bit operands, bf16-stored activations and gradients) 0.02 % at the head, 2-5 % one decoder stage down, 21-58 % in
+# the deepest layers (cosine >= 0.82) with every tensor's NORM within 1.2 % -- the same ladder, layer by layer, as bf16x3's at 1/25.
+#        mode      max rel L2 (weights)  min cosine  max rel L2 (1-D: BatchNorm weight / bias)          [measured + 50 %]
+LOWP = {("c2", "bf16"): (0.88, 0.735, 0.85), ("c2", "bf16x3"): (0.032, 0.9996, 0.035),
+        ("c5", "bf16"): (0.95, 0.70, 0.95)}
+FULL_LOWP = {"c2": ("grads_cubenet64_full_b2", 238, 64, 2), "c5": ("grads_cubenet128_300_full_b1", 300, 128, 1)}
 
 
-@pytest.mark.parametrize("precision", ["bf16", "bf16x3"])
-def test_full_size_c2_batch2_reduced_precision_gradients_vs_fp64_samples(precision):
+@pytest.mark.parametrize("cfg,precision", [("c2", "bf16"), ("c2", "bf16x3"), ("c5", "bf16")])
+def test_full_size_reduced_precision_gradients_vs_fp64_samples(cfg, precision):
     import json
     import hyperpri_amd as H
-    z = np.load(os.path.join(G, "grads_cubenet64_full_b2.npz"))
+    fixture, bands, depth, batch = FULL_LOWP[cfg]
+    z = np.load(os.path.join(G, fixture + ".npz"))
     Hh, Ww = 608, 968
-    net = H.CubeNET(238, 1, first_depth=64, bilinear=False)
+    net = H.CubeNET(bands, 1, first_depth=depth, bilinear=False)
     shapes = OrderedDict((k, tuple(v.shape)) for k, v in net.state_dict().items())
     net.load_state_dict(O.synth_state_dict(shapes))
     net = H.set_precision(net.to(DEV), precision).train()
-    x = torch.cat([_u(1234 + n, (1, 1, 238, Hh, Ww)) for n in range(2)], 0)
-    mask = torch.cat([(_u(4321 + n, (1, 1, Hh, Ww)) > 0.9).float() for n in range(2)], 0)
+    x = torch.cat([_u(1234 + n, (1, 1, bands, Hh, Ww)) for n in range(batch)], 0)
+    mask = torch.cat([(_u(4321 + n, (1, 1, Hh, Ww)) > 0.9).float() for n in range(batch)], 0)
     logits = net(x.to(DEV))
     loss = torch.nn.BCEWithLogitsLoss()(logits, mask.to(DEV))
     loss.backward()
     torch.cuda.synchronize()
-    tol_w, tol_cos, tol_bn = LOWP[precision]
+    tol_w, tol_cos, tol_bn = LOWP[(cfg, precision)]
     assert abs(float(loss.detach()) - float(z["loss64"])) < (2e-3 if precision == "bf16" else 1e-5)
     ns = int(z["ns"])
-    rows, worst_w, worst_bn, worst_cos = {}, 0.0, 0.0, 1.0
+    rows, worst_w, worst_bn, worst_cos, worst_norm = {}, 0.0, 0.0, 1.0, 0.0
     for k, (nm, p) in enumerate(net.named_parameters()):
         g = p.grad.detach().reshape(-1)
         assert torch.isfinite(g).all(), nm
@@ -168,18 +176,20 @@ def test_full_size_c2_batch2_reduced_precision_gradients_vs_fp64_samples(precisi
         rows[nm] = {"rel_l2": rel, "cosine": cos, "norm_over_fp64_norm": l2, "samples": cnt}
         if p.dim() >= 2:
             worst_w = max(worst_w, rel)
+            worst_norm = max(worst_norm, abs(l2 - 1.0))
         else:
             worst_bn = max(worst_bn, rel)
         if cnt >= 16:
             worst_cos = min(worst_cos, cos)
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     os.makedirs(out, exist_ok=True)
-    with open(os.path.join(out, f"{precision}_grad_parity_c2_batch2.json"), "w") as f:
-        json.dump({"what": f"CubeNET-64, two 238x608x968 cubes, precision {precision}: every gradient tensor at the fixture's sampled positions "
-                           "against the reference's fp64 gradient (tests/golden/grads_cubenet64_full_b2.npz)", "loss": float(loss.detach()),
+    with open(os.path.join(out, f"{precision}_grad_parity_{cfg}.json"), "w") as f:
+        json.dump({"what": f"CubeNET-{depth}, {batch} x {bands}x608x968, precision {precision}: every gradient tensor at the fixture's sampled positions "
+                           f"against the reference's fp64 gradient (tests/golden/{fixture}.npz)", "loss": float(loss.detach()),
                    "loss_fp64": float(z["loss64"]), "worst_rel_l2_weights": worst_w, "worst_rel_l2_1d": worst_bn, "worst_cosine": worst_cos,
-                   "tensors": rows}, f, indent=1)
-    record_margin(f"deep/c2_batch2_{precision}/grad_rel_l2_weights", worst_w, tol_w)
-    record_margin(f"deep/c2_batch2_{precision}/grad_rel_l2_1d", worst_bn, tol_bn)
-    record_margin(f"deep/c2_batch2_{precision}/one_minus_cosine", 1.0 - worst_cos, 1.0 - tol_cos)
-    assert worst_w <= tol_w and worst_bn <= tol_bn and worst_cos >= tol_cos, (worst_w, worst_bn, worst_cos)
+                   "worst_weight_norm_error": worst_norm, "tensors": rows}, f, indent=1)
+    record_margin(f"deep/{cfg}_{precision}/grad_rel_l2_weights", worst_w, tol_w)
+    record_margin(f"deep/{cfg}_{precision}/grad_rel_l2_1d", worst_bn, tol_bn)
+    record_margin(f"deep/{cfg}_{precision}/one_minus_cosine", 1.0 - worst_cos, 1.0 - tol_cos)
+    record_margin(f"deep/{cfg}_{precision}/weight_norm_error", worst_norm, 0.05)
+    assert worst_w <= tol_w and worst_bn <= tol_bn and worst_cos >= tol_cos and worst_norm <= 0.05, (worst_w, worst_bn, worst_cos, worst_norm)

@@ -53,6 +53,9 @@ def main():
     ksteps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
     tag = sys.argv[3] if len(sys.argv) > 3 else "r01"
     precision = sys.argv[4] if len(sys.argv) > 4 else "fp32"
+    if "--grads-fp32" in sys.argv:          # A/B: the activation gradients of the bf16 mode stored as fp32 again (round 3's storage)
+        for a in ("SKIP_GRAD_BF16", "GRAD_BF16_SINGLE", "GRAD_BF16_INNER", "GRAD_BF16_GEMM"):
+            setattr(engine, a, False)
     dev = torch.device("cuda", 0)
     torch.set_num_threads(bench.host_cores())
     val = list(range(45, 45 + nval))
