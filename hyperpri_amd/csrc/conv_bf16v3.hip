@@ -27,9 +27,6 @@
 #include "common.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-typedef unsigned v3_u32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned v3_u32x2 __attribute__((ext_vector_type(2)));
 
 #define V3_MAXSEG 4
 #define V3_A_PIECES 24                       // 1-KB DMA pieces per halo buffer: 384 pixel slots (largest halo: 10 x 34 = 340)
@@ -95,12 +92,7 @@ __device__ __forceinline__ float v3_row_sum(float v) {
 // Geometry of one work item (256-pixel tile x 64-channel block); wave-uniform.
 struct V3Tile { int img, y0, x0, xlim, twl, nb, bx; };
 
-// KTAIL: K per tap ends in a HALF chunk (Cin_pad = 32 m + 16: 238 -> 240, 300 -> 304, 3 -> 16 input channels -- the first layers).
-// The half chunk is staged like any other (its upper 16 channels are structural zeros in the planes and in the packed weights) and
-// multiplied by 16-deep MFMAs behind the chunk loop: half the matrix cycles for that chunk; the dropped products are exact zeros.
-// A separate instantiation: the chunk loop of the plain kernel has no register to spare, and a second MFMA sequence under an
-// if / else inside it makes hipcc keep two copies of the accumulators (gemm_bf16v3.hip has the same story).
-template <bool BNRED, bool KTAIL>
+template <bool BNRED>
 __global__ __launch_bounds__(256, 2) void conv_bf16v3_kernel(ConvV3Args a) {
   __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * V3_A_BYTES + 2 * V3_B_BYTES + 512 + 16 + 16];
   unsigned char* a_lds = smem;
@@ -147,7 +139,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16v3_kernel(ConvV3Args a) {
     return true;
   };
 
-  const int nchunks_all = (a.Cin_pad + 31) >> 5;      // (KTAIL: the last one is the half chunk; the launcher sends such problems here only unsplit)
+  const int nchunks_all = a.Cin_pad >> 5;
   const int cps = (nchunks_all + a.ksplit - 1) / a.ksplit;
   const int chunk0 = blockIdx.z * cps;
   const int nchunks = min(nchunks_all, chunk0 + cps);
@@ -369,7 +361,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16v3_kernel(ConvV3Args a) {
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    for (int c = chunk0; c < nchunks - (KTAIL ? 1 : 0); ++c) {
+    for (int c = chunk0; c < nchunks; ++c) {
       {
         const bool more_c = c + 1 < nchunks;
         V3_STAGE(0, 0)
@@ -383,45 +375,6 @@ __global__ __launch_bounds__(256, 2) void conv_bf16v3_kernel(ConvV3Args a) {
         V3_STAGE(1, 0)
         V3_STAGE(1, 1)
         V3_STAGE(1, 2)
-      }
-    }
-    if constexpr (KTAIL) {
-      // ---- the half chunk (its halo and its first weight stage were loaded by the last full chunk's stages, or by the prologue).
-      //      A fragment register quad holds k-slot lq of its row (8 channels); slots 2, 3 -- lanes 32..63 -- are the zero channels.
-      //      v_permlane32_swap moves registers 2, 3 of lanes 0..31 into registers 0, 1 of lanes 32..63: registers 0, 1 then hold four
-      //      valid channels in EVERY lane (lane groups 0..3: channels 0-3, 8-11, 4-7, 12-15, the same in both operands) -- the
-      //      operand of v_mfma_f32_16x16x16.  Buffer parities are run-time values here (one copy of this code) ----
-      const int c = nchunks - 1;
-      const int par = (c - chunk0) & 1;
-      const unsigned char* abase = a_lds + par * V3_A_BYTES;
-#pragma unroll
-      for (int dy = 0; dy < 3; ++dy) {
-        const int s_ = c * 3 + dy, bbi = (par * 3 + dy) & 1;
-        V3_WAIT_VM(0);
-        V3_BARRIER();
-        if (dy < 2) {
-#pragma unroll
-          for (int q_ = 0; q_ < 3; ++q_) V3_DMA_B_(bbi ^ 1, s_ + 1, q_);
-        }
-        const unsigned char* bbase = b_lds + bbi * V3_B_BYTES + bofs;
-        V3_SETPRIO(1);
-#pragma unroll
-        for (int dx = 0; dx < 3; ++dx) {
-          s16x4 ta[4], tb[4];
-#pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            v3_u32x4 w = *reinterpret_cast<const v3_u32x4*>(i < 4 ? abase + aofs[i][dy * 3 + dx] : bbase + dx * 4096 + (i - 4) * 1024);
-            asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %2\n\tv_permlane32_swap_b32 %1, %3" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]));
-            const s16x4 h = __builtin_bit_cast(s16x4, v3_u32x2{w[0], w[1]});
-            if (i < 4) ta[i] = h; else tb[i - 4] = h;
-          }
-#pragma unroll
-          for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
-              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(tb[nt], ta[mt], acc[mt][nt], 0, 0, 0);
-        }
-        V3_SETPRIO(0);
       }
     }
 #ifdef HPRI_STAMPS
@@ -892,10 +845,9 @@ static V3Segs v3_segments(int H, int W) {
 // Split-K (host only), priced as in conv_bf16v2.hip: a slice costs 2 k output sizes of fp32 slab traffic against the partial
 // round of workgroup slots (two per CU) it fills; only problems below half a round are cut.
 static int v3_ksplit(int N, int H, int W, int Cin_pad, int Cout_pad) {
-  Cin_pad = (Cin_pad + 31) & ~31;               // (a trailing half chunk does not change the plan)
   const int ncu = hpri_cu_count();
   const long long blocks = (long long)N * v3_segments(H, W).tiles_img * (Cout_pad / 64);
-  const int nchunks = (Cin_pad + 31) / 32;
+  const int nchunks = Cin_pad / 32;
   if (blocks >= ncu) return 1;
   const double t_compute = 2.0 * N * H * W * (double)Cin_pad * Cout_pad * 9.0 / 900e12;
   const double out_bytes = 4.0 * N * H * W * (double)Cout_pad;
@@ -938,12 +890,12 @@ static int v3_launch(const void* xp, long long x_plane, int x_cs, int x_coff, co
                      const V3Out2* o2 = nullptr) {
   HPRI_REQUIRE(xp && wp && y, "conv_bf16v3: null pointer");
   HPRI_REQUIRE(N > 0 && H > 0 && W > 0, "conv_bf16v3: empty image");
-  HPRI_REQUIRE(Cin_pad > 0 && Cin_pad % 16 == 0, "conv_bf16v3: Cin_pad must be a positive multiple of 16");
+  HPRI_REQUIRE(Cin_pad > 0 && Cin_pad % 32 == 0, "conv_bf16v3: Cin_pad must be a positive multiple of 32");
   HPRI_REQUIRE(Cout_pad % 64 == 0 && Cout <= Cout_pad && Cout > 0, "conv_bf16v3: Cout_pad must be a multiple of 64 >= Cout");
-  HPRI_REQUIRE(x_cs % 8 == 0 && x_coff % 8 == 0 && x_coff + ((Cin_pad + 31) & ~31) <= x_cs, "conv_bf16v3: plane channel stride/offset must be multiples of 8 and hold Cin_pad channels rounded up to 32");
+  HPRI_REQUIRE(x_cs % 8 == 0 && x_coff % 8 == 0 && x_coff + Cin_pad <= x_cs, "conv_bf16v3: plane channel stride/offset must be multiples of 8 and hold Cin_pad channels");
   HPRI_REQUIRE(((uintptr_t)xp & 15) == 0 && ((uintptr_t)wp & 15) == 0, "conv_bf16v3: pointers must be 16-byte aligned");
   HPRI_REQUIRE((long long)H * W * x_cs * 2 < 0x7FFFFF00ll, "conv_bf16v3: one image of the input planes exceeds 2 GiB (32-bit DMA offsets)");
-  HPRI_REQUIRE((long long)((Cin_pad + 31) / 32) * 9 * Cout_pad * 64 < 0x7FFFFF00ll, "conv_bf16v3: packed weights exceed 2 GiB");
+  HPRI_REQUIRE((long long)(Cin_pad / 32) * 9 * Cout_pad * 64 < 0x7FFFFF00ll, "conv_bf16v3: packed weights exceed 2 GiB");
   HPRI_REQUIRE(split == 0, "conv_bf16v3: only plain bf16 planes (split 0) are built");
   (void)x_plane;
   ConvV3Args a;
@@ -1011,24 +963,13 @@ static int v3_launch(const void* xp, long long x_plane, int x_cs, int x_coff, co
     a.bn_relu = bn->relu; a.bn_part = bn->part; a.bn_cpart = bn->cpart;
 #ifdef HPRI_DIAG_KERNELS
     if (a.ksplit <= HPRI_Q_SLICES && a.per_xcd >= 2 * nloc) { const HpriQueueHalves qh = hpri_item_queue_take(stream); a.queue = qh.use; a.queue_clear = qh.clear; }
-    HPRI_REQUIRE(Cin_pad % 32 == 0, "conv_bf16v3_bnred: Cin_pad must be a multiple of 32");
-    hipLaunchKernelGGL((conv_bf16v3_kernel<true, false>), grid, dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(conv_bf16v3_kernel<true>, grid, dim3(256), 0, stream, a);
 #else
     return hpri_set_error(HPRI_ERR_UNSUPPORTED, "conv_bf16v3_bnred: diagnostics build only (HPRI_DIAG=1 python -m hyperpri_amd.build)");
 #endif
   } else {
     if (a.ksplit <= HPRI_Q_SLICES && a.per_xcd >= 2 * nloc) { const HpriQueueHalves qh = hpri_item_queue_take(stream); a.queue = qh.use; a.queue_clear = qh.clear; }
-    if (Cin_pad % 32 != 0) {
-      // a half chunk at the end of K: the 16-deep form
-      if (a.ksplit == 1) {
-        hipLaunchKernelGGL((conv_bf16v3_kernel<false, true>), grid, dim3(256), 0, stream, a);
-      } else {                                  // a split problem multiplies the half chunk's zero channels at full depth
-        a.Cin_pad = (Cin_pad + 31) & ~31;
-        hipLaunchKernelGGL((conv_bf16v3_kernel<false, false>), grid, dim3(256), 0, stream, a);
-      }
-    } else {
-      hipLaunchKernelGGL((conv_bf16v3_kernel<false, false>), grid, dim3(256), 0, stream, a);
-    }
+    hipLaunchKernelGGL(conv_bf16v3_kernel<false>, grid, dim3(256), 0, stream, a);
   }
   HPRI_CHECK_LAUNCH();
   if (a.ksplit == 1) return HPRI_OK;

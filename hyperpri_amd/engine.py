@@ -306,21 +306,11 @@ def planes_of(x: Act, npl: int = 1) -> Planes:
     return x.pl
 
 
-# K of the plane convolution: channels per tap rounded up to 16, not 32 -- a trailing HALF chunk (238 -> 240, 300 -> 304, 3 -> 16
-# input channels: the first layers) runs 16-deep MFMAs on its 16 channels instead of multiplying 16 structural zeros at full
-# depth (conv_bf16v3.hip; the dropped products are exact zeros: results bit-identical).  False: the round-4 rounding.
-K_TAIL = True
-
-
-def _v3_kpad(k: int) -> int:
-    return _rup(k, 16) if K_TAIL else _rup(k, 32)
-
-
 def _conv_launch_v2(x: Act, wp: torch.Tensor, bias: Optional[torch.Tensor], y: Act, stats: Optional[torch.Tensor],
                     cin: int, cout: int, cout_pad: int, y_cw: int, accumulate: int = 0) -> None:
     """3x3 convolution on bf16 planes (forward, or data gradient with the mode-1 pack)."""
     pl = planes_of(x, 1)
-    cin_pad = _v3_kpad(cin)
+    cin_pad = _rup(cin, 32)
     ksplit = ctypes.c_int(); tiles = ctypes.c_int(); wsf = ctypes.c_size_t()
     _lib.call("hpri_conv_bf16v3_plan", x.N, x.H, x.W, cin_pad, cout_pad, ctypes.byref(ksplit), ctypes.byref(tiles), ctypes.byref(wsf))
     ws = _ws(wsf.value, x.buf.device) if wsf.value else None
@@ -922,7 +912,7 @@ def _conv_pick_kernels(c, cat_room: int, cat_into: Optional[Act], planes_only: b
 def _v3_plan(x: Act, k: int, ncols: int) -> Tuple[int, int]:
     """(ksplit, statistics tiles) of the bf16 plane convolution for a K = ``k``, ``ncols``-column problem over x's pixels."""
     ksp = ctypes.c_int(); tl = ctypes.c_int(); wsf = ctypes.c_size_t()
-    _lib.call("hpri_conv_bf16v3_plan", x.N, x.H, x.W, _v3_kpad(k), _rup(ncols, 64), ctypes.byref(ksp), ctypes.byref(tl), ctypes.byref(wsf))
+    _lib.call("hpri_conv_bf16v3_plan", x.N, x.H, x.W, _rup(k, 32), _rup(ncols, 64), ctypes.byref(ksp), ctypes.byref(tl), ctypes.byref(wsf))
     return ksp.value, tl.value
 
 
@@ -947,7 +937,7 @@ def _conv_forward(c) -> None:
         if c.wino:
             _lib.call("hpri_conv_wino4_plan", x.N, x.H, x.W, ctypes.byref(tl))
         elif c.v2:
-            _lib.call("hpri_conv_bf16v3_plan", x.N, x.H, x.W, _v3_kpad(c.cin), cout_pad, ctypes.byref(ksp), ctypes.byref(tl), ctypes.byref(wsf))
+            _lib.call("hpri_conv_bf16v3_plan", x.N, x.H, x.W, _rup(c.cin, 32), cout_pad, ctypes.byref(ksp), ctypes.byref(tl), ctypes.byref(wsf))
         elif c.g3:
             _lib.call("hpri_gemm_bf16v3_plan", x.N, x.H * x.W, ctypes.byref(tl))
         elif c.lowp:

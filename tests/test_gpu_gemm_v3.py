@@ -334,54 +334,3 @@ def test_bf16_plane_conv_v3_second_output(lib, shape, only):
         # ... which must reach Cout from below the range
         assert lib.hpri_conv_bf16v3_y2(P(planes), cs16, 0, P(wpd), P(None), P(g16), c0 + 8, 0, P(st3), N, H, W, cs16, Cols, cols_pad, c0 - 4,
                                        P(y2b), y2cs, 4, c0, cw2, 3, _st()) != 0
-
-
-@pytest.mark.parametrize("shape", [(2, 76, 121, 238, 64), (1, 40, 70, 3, 64), (2, 33, 50, 40, 128), (1, 19, 30, 300, 128), (2, 38, 60, 208, 1024)])
-@pytest.mark.parametrize("out16", [0, 1])
-def test_bf16_plane_conv_v3_half_chunk_of_k(lib, shape, out16):
-    """Cin_pad = 32 m + 16 (238 -> 240, 3 -> 16, 40 -> 48, 300 -> 304 input channels: the first layers of the networks, models.py:169,
-    model_parts.py:22): the trailing half chunk of K runs 16-deep MFMAs instead of multiplying 16 structural-zero channels at full
-    depth.  The dropped products are exact zeros: outputs and statistics are bit-identical to the launch with K rounded up to 32 (the
-    last shape is a split-K plan, which rounds up by itself), and the result is the convolution (fp64 reference)."""
-    N, H, W, K, Cols = shape
-    torch.manual_seed(23)
-    cs16, cols_pad, cw = rup(K, 32), rup(Cols, 64), rup(Cols, 8)
-    npx = N * H * W
-    x = torch.randn(npx, K, device=DEV)
-    planes = torch.zeros(npx, cs16, dtype=torch.bfloat16, device=DEV)
-    planes[:, :K] = x.to(torch.bfloat16)
-    w = torch.randn(Cols, K, 3, 3, device=DEV) * 0.05
-    b = torch.randn(Cols, device=DEV)
-    wp = torch.empty((cs16 // 32) * 9 * cols_pad * 32, dtype=torch.bfloat16, device=DEV)
-    assert lib.hpri_pack_weight_bf16(P(w), P(wp), 0, K, Cols, cols_pad, 9, K, 0, 0, _st()) == 0, lib.hpri_last_error()
-    k16, k32 = rup(K, 16), rup(K, 32)
-    assert k16 % 32 == 16
-    plans = []
-    for kp in (k16, k32):
-        k, tl, wsf = ctypes.c_int(), ctypes.c_int(), ctypes.c_size_t()
-        assert lib.hpri_conv_bf16v3_plan(N, H, W, kp, cols_pad, ctypes.byref(k), ctypes.byref(tl), ctypes.byref(wsf)) == 0
-        plans.append((k.value, tl.value, wsf.value))
-    assert plans[0] == plans[1]                                  # the half chunk does not change the plan
-    ksplit, tiles, wsf = plans[0]
-    use16 = out16 and ksplit == 1
-    outs = []
-    for kp in (k16, k32):
-        y = torch.full((npx, cw), 7.0, dtype=torch.bfloat16 if use16 else torch.float32, device=DEV)
-        stats = torch.full((tiles * cols_pad * 4,), float("nan"), device=DEV)
-        ws = torch.empty(max(wsf, 4), device=DEV)
-        rc = lib.hpri_conv_bf16v3(P(planes), 0, cs16, 0, P(wp), P(b), P(y), cw, 0, P(stats), N, H, W, kp, Cols, cols_pad, cw, 4 if use16 else 0, 0,
-                                  P(ws), ws.numel(), _st())
-        assert rc == 0, lib.hpri_last_error()
-        torch.cuda.synchronize()
-        outs.append((y, stats))
-    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
-    xr = planes[:, :K].double().cpu().reshape(N, H, W, K).permute(0, 3, 1, 2)
-    ref = torch.nn.functional.conv2d(xr, w.to(torch.bfloat16).double().cpu(), b.double().cpu(), padding=1).permute(0, 2, 3, 1).reshape(-1, Cols)
-    sc = max(1.0, float(ref.abs().max()))
-    err = float((outs[0][0].double().cpu()[:, :Cols] - ref).abs().max())
-    tol = (1e-2 if use16 else 2e-5) * sc
-    record_margin(f"bf16v3/half_chunk/{N}x{H}x{W}x{K}x{Cols}/out16_{int(use16)}", err, tol)
-    assert err < tol, (shape, err)
-    # the planes must hold the rounded-up K
-    assert lib.hpri_conv_bf16v3(P(planes), 0, cs16, 16, P(wp), P(b), P(outs[0][0]), cw, 0, P(None), N, H, W, k16, Cols, cols_pad, cw, 4 if use16 else 0, 0,
-                                P(None), 0, _st()) != 0

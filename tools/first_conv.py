@@ -83,15 +83,11 @@ def measure(reps=20, modes=("bf16_planes", "fp32"), settle_s=1.0):
             wp = torch.empty((cs16 // 32) * 9 * cout_pad * 32, dtype=torch.bfloat16, device=dev)
             assert lib.hpri_pack_weight_bf16(P(w), P(wp), 0, CIN, COUT, cout_pad, 9, CIN, 0, 0, st) == 0
             kern = "hpri_conv_bf16v3"        # the kernel the bf16 mode runs
-            # K as the engine passes it (engine._v3_kpad): 238 -> 240 = seven 32-channel chunks + a half chunk multiplied 16 deep;
-            # FIRST_CONV_K32=1: rounded up to 256 as in round 4 (eight full chunks, 7 % of the MFMAs on zero channels)
-            kpad = cs16 if os.environ.get("FIRST_CONV_K32") == "1" else (CIN + 15) // 16 * 16
-            out["k_per_tap"] = kpad
-            getattr(lib, kern + "_plan")(N, H, W, kpad, cout_pad, ctypes.byref(k), ctypes.byref(tl), ctypes.byref(wsf))
+            getattr(lib, kern + "_plan")(N, H, W, cs16, cout_pad, ctypes.byref(k), ctypes.byref(tl), ctypes.byref(wsf))
             stats = torch.empty(tl.value * cout_pad * 4, device=dev)
             ws = torch.empty(max(wsf.value, 4), device=dev)
             conv = getattr(lib, kern)
-            call = lambda: conv(P(planes), 0, cs16, 0, P(wp), P(b), P(y), COUT, 0, P(stats), N, H, W, kpad, COUT,
+            call = lambda: conv(P(planes), 0, cs16, 0, P(wp), P(b), P(y), COUT, 0, P(stats), N, H, W, cs16, COUT,
                                 cout_pad, COUT, 0, 0, P(ws), ws.numel(), st)
             out["bf16_kernel"] = kern
             alg_bytes = N * H * W * (cs16 * 2 + COUT * 4) + wp.numel() * 2
@@ -99,7 +95,7 @@ def measure(reps=20, modes=("bf16_planes", "fp32"), settle_s=1.0):
                 # the form the bf16 STEP runs (engine.YR_BF16): the pre-BN tensor leaves as bf16 straight from the accumulators
                 # (statistics from the fp32 sums) -- SURVEY.md 7.3-2's fp16-in / fp16-out variant of the roofline claim
                 y16 = torch.empty(N * H * W * COUT, dtype=torch.bfloat16, device=dev)
-                call16 = lambda: conv(P(planes), 0, cs16, 0, P(wp), P(b), P(y16), COUT, 0, P(stats), N, H, W, kpad, COUT,
+                call16 = lambda: conv(P(planes), 0, cs16, 0, P(wp), P(b), P(y16), COUT, 0, P(stats), N, H, W, cs16, COUT,
                                       cout_pad, COUT, 4, 0, P(ws), ws.numel(), st)
                 alg16 = N * H * W * (cs16 * 2 + COUT * 2) + wp.numel() * 2
         else:
