@@ -17,9 +17,13 @@ LIB_PATH = os.path.join(_HERE, "lib", "libhyperpri_hip_diag.so" if DIAG else "li
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "hyperpri_hip.h")
 DIAG_HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "hyperpri_hip_diag.h")
 
+LIB_F16_PATH = os.path.join(_HERE, "lib", "libhyperpri_hip_f16.so")      # the same sources with IEEE half as the 16-bit type (precision "f16")
+
 _lock = threading.Lock()
 _lib = None
+_lib_f16 = None
 _decls = None
+_tls = threading.local()        # .kind: which library the calls of this thread go to ("f16" inside an f16-mode tape, see ``using``)
 
 
 def _ctype(decl: str):
@@ -82,9 +86,54 @@ def load():
     return _lib
 
 
+def load_f16():
+    """The half-precision build of the same library (hyperpri_amd/build.py: LIB_F16); raises if it has not been built."""
+    global _lib_f16
+    if _lib_f16 is not None:
+        return _lib_f16
+    load()
+    with _lock:
+        if _lib_f16 is not None:
+            return _lib_f16
+        if not os.path.exists(LIB_F16_PATH):
+            raise RuntimeError(f"hyperpri_amd: precision 'f16' needs {LIB_F16_PATH} (python -m hyperpri_amd.build)")
+        lib = ctypes.CDLL(LIB_F16_PATH)
+        for name, (restype, argtypes) in parse_header().items():
+            fn = getattr(lib, name)
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _lib_f16 = lib
+    return _lib_f16
+
+
+def current():
+    """The library the calling thread's launches go to."""
+    return load_f16() if getattr(_tls, "kind", None) == "f16" else load()
+
+
+def kind() -> str:
+    return "f16" if getattr(_tls, "kind", None) == "f16" else "bf16"
+
+
+class using:
+    """``with using("f16"):`` -- the launches of this thread go to the half-precision library (an f16-mode tape, forward and backward)."""
+
+    def __init__(self, kind):
+        self.kind = "f16" if kind == "f16" else None
+
+    def __enter__(self):
+        self.prev = getattr(_tls, "kind", None)
+        _tls.kind = self.kind
+        return self
+
+    def __exit__(self, *exc):
+        _tls.kind = self.prev
+        return False
+
+
 def call(name: str, *args) -> None:
     """Call an int-returning launcher; raise RuntimeError with the library's message on failure."""
-    lib = load()
+    lib = current()
     rc = getattr(lib, name)(*args)
     if rc != 0:
         msg = lib.hpri_last_error()

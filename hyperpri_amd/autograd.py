@@ -12,11 +12,12 @@ from __future__ import annotations
 import itertools
 import os
 import threading
-from typing import Callable, List, Sequence
+from typing import Callable, List, Optional, Sequence
 
 import torch
 
-from .engine import Act, Tape, _require_cuda, join_side
+from . import _lib
+from .engine import Act, Tape, _require_cuda, join_side, scale_tensors_
 
 
 def _as4d(t: torch.Tensor) -> torch.Tensor:
@@ -156,22 +157,22 @@ LAST_PLAN: List[int] = []          # stage counts of the most recent segmented f
 
 
 def run_staged(gen_fn: Callable, inputs: Sequence[torch.Tensor], stages: Sequence[Sequence[torch.Tensor]], mode=True,
-               input_planes: int = 0, name: str = "run_program") -> torch.Tensor:
+               input_planes: int = 0, name: str = "run_program", lib_kind: Optional[str] = None) -> torch.Tensor:
     """Run a staged tape program (a generator yielding after each of its ``len(stages)`` stages but the last; ``stages[i]`` = the
     parameters stage i reads) -- as one autograd node, or, when ``segmentation_wanted(mode)``, as a chain of nodes."""
     params = [p for st in stages for p in st]
     if not (torch.is_grad_enabled() and segmentation_wanted(mode) and all(p.requires_grad for p in params)):
-        return run(drain(gen_fn), inputs, params, input_planes, name)
+        return run(drain(gen_fn), inputs, params, input_planes, name, lib_kind)
     counts = plan_segments(stages, int(SEGMENT_MB * (1 << 20)))
     LAST_PLAN[:] = counts
     if len(counts) < 2:
-        return run(drain(gen_fn), inputs, params, input_planes, name)
+        return run(drain(gen_fn), inputs, params, input_planes, name, lib_kind)
     shared = _SharedTape(gen_fn)
     out, s0 = None, 0
     for k, n in enumerate(counts):
         seg = _Segment(shared, n, s0, last=(k == len(counts) - 1))
         seg_params = [p for st in stages[s0:s0 + n] for p in st]
-        out = run(seg, list(inputs) if k == 0 else [out], seg_params, input_planes if k == 0 else 0, "segment")
+        out = run(seg, list(inputs) if k == 0 else [out], seg_params, input_planes if k == 0 else 0, "segment", lib_kind)
         s0 += n
     return out
 
@@ -184,7 +185,13 @@ class _HipFn(torch.autograd.Function):
 
     @staticmethod
     def _forward(ctx, program: Callable, n_in: int, params: Sequence[torch.Tensor], grad_on, *tensors: torch.Tensor):
-        grad_on, input_planes = grad_on          # (caller's grad mode, bf16 planes wanted for the inputs)
+        ctx.kind = grad_on[2] if len(grad_on) > 2 else None       # which library the tape's launches go to (_lib.using)
+        with _lib.using(ctx.kind):
+            return _HipFn._forward_impl(ctx, program, n_in, params, grad_on, *tensors)
+
+    @staticmethod
+    def _forward_impl(ctx, program: Callable, n_in: int, params: Sequence[torch.Tensor], grad_on, *tensors: torch.Tensor):
+        grad_on, input_planes = grad_on[0], grad_on[1]          # (caller's grad mode, bf16 planes wanted for the inputs)
         inputs = tensors[:n_in]
         need = list(ctx.needs_input_grad[4:])
         # needs_input_grad is True for trainable parameters even under torch.no_grad() / inference_mode(), and
@@ -229,6 +236,11 @@ class _HipFn(torch.autograd.Function):
 
     @staticmethod
     def _backward(ctx, gout: torch.Tensor):
+        with _lib.using(getattr(ctx, "kind", None)):
+            return _HipFn._backward_impl(ctx, gout)
+
+    @staticmethod
+    def _backward_impl(ctx, gout: torch.Tensor):
         tape: Tape = ctx.tape
         if tape is None:
             raise RuntimeError("hyperpri_amd: backward called twice (retain_graph is not supported)")
@@ -282,12 +294,22 @@ class _HipFn(torch.autograd.Function):
                 sunk = id(p) in tape.sunk
                 res.append(tape.param_grads.pop(id(p), None) if (need[ctx.n_in + j] and not sunk) else None)
                 tape.delivered.add(id(p))
+            if tape.gscale != 1.0:                 # half-precision mode: the loss scale leaves the parameter gradients here
+                scale_tensors_([g for g in res[1:] if g is not None], 1.0 / tape.gscale)
             ctx.acts = ctx.params = ctx.out_act = ctx.holder = None
             return (None, None, None, None, *res)
+        n_act = len(res)
         for j, p in enumerate(ctx.params):
             # gradients the engine wrote into a GradSync bucket are handed over by GradSync.finish(), not by autograd
             sunk = id(p) in tape.sunk
             res.append(tape.param_grads.get(id(p)) if (need[ctx.n_in + j] and not sunk) else None)
+        if tape.gscale != 1.0:
+            # half-precision mode: the loss scale leaves the parameter gradients here (gradients in a GradSync bucket lost it before
+            # their hand-over: engine.Tape.backward); an input gradient carries it too
+            scale_tensors_([g for g in res[n_act:] if g is not None] + [g.contiguous() for g in res[:n_act] if g is not None and g.is_contiguous()],
+                           1.0 / tape.gscale)
+            if any(g is not None and not g.is_contiguous() for g in res[:n_act]):
+                raise RuntimeError("hyperpri_amd: precision 'f16' cannot return a channels-last input gradient (whole networks only)")
         tape.sunk.clear()
         tape.grads.clear()
         tape.param_grads.clear()
@@ -316,11 +338,12 @@ class _Ctx:      # what _HipFn keeps on its ctx, for the operator path
 
 
 def _op_forward(inputs: List[torch.Tensor], params: List[torch.Tensor], program: int, grad_mode: bool, input_planes: int) -> torch.Tensor:
-    prog = _PROGRAMS[program]
+    prog, kind = _PROGRAMS[program]
     st = _Ctx()
+    st.handle = program
     st.needs_input_grad = (False, False, False, False, *[t.requires_grad for t in inputs], *[p.requires_grad for p in params])
     with torch.cuda.device(inputs[0].device):
-        res = _HipFn._forward(st, prog, len(inputs), tuple(params), (grad_mode, int(input_planes)), *inputs, *params)
+        res = _HipFn._forward(st, prog, len(inputs), tuple(params), (grad_mode, int(input_planes), kind), *inputs, *params)
     # picked up by _op_setup_context, which the autograd kernel calls right after this forward (nothing to keep when nothing was recorded)
     _TLS.last = st if getattr(st, "tape", None) is not None else None
     return res
@@ -329,6 +352,9 @@ def _op_forward(inputs: List[torch.Tensor], params: List[torch.Tensor], program:
 def _op_setup_context(ctx, inputs, output):
     ctx.st = getattr(_TLS, "last", None)
     _TLS.last = None
+    if ctx.st is not None and ctx.st.handle != inputs[2]:       # (the state left by ANOTHER call of the operator: never attach it)
+        ctx.st = None
+        raise RuntimeError("hyperpri_amd: internal error: the tape handed to setup_context belongs to another operator call")
 
 
 def _op_backward(ctx, gout):
@@ -361,7 +387,7 @@ OPS = _register_ops()
 
 
 def run(program: Callable, inputs: Sequence[torch.Tensor], params: Sequence[torch.Tensor], input_planes: int = 0,
-        name: str = "run_program") -> torch.Tensor:
+        name: str = "run_program", lib_kind: Optional[str] = None) -> torch.Tensor:
     """Run ``program`` as one autograd node.  ``params`` are the nn.Parameters the program reads (the
     program closes over the owning module; they are listed here so autograd routes their gradients).
     ``input_planes`` > 0: the layout pass of an NCHW input also writes that many bf16 planes (bf16 plane mode).
@@ -377,9 +403,9 @@ def run(program: Callable, inputs: Sequence[torch.Tensor], params: Sequence[torc
         _require_cuda(t, "input tensor")
     if USE_DISPATCHER:
         h = next(_HANDLES)
-        _PROGRAMS[h] = program
+        _PROGRAMS[h] = (program, lib_kind)
         try:
             return getattr(torch.ops.hyperpri, name)(list(inputs), list(params), h, torch.is_grad_enabled(), int(input_planes))
         finally:
             _PROGRAMS.pop(h, None)
-    return _HipFn.apply(program, len(inputs), tuple(params), (torch.is_grad_enabled(), int(input_planes)), *inputs, *params)
+    return _HipFn.apply(program, len(inputs), tuple(params), (torch.is_grad_enabled(), int(input_planes), lib_kind), *inputs, *params)

@@ -18,6 +18,9 @@ LIBDIR = os.path.join(HERE, "lib")
 # family per precision mode and form.
 DIAG = os.environ.get("HPRI_DIAG", "0") == "1"
 LIB = os.path.join(LIBDIR, "libhyperpri_hip_diag.so" if DIAG else "libhyperpri_hip.so")
+# The product is TWO libraries built from the same sources: libhyperpri_hip.so (16-bit type of the plane paths = bf16: precision modes
+# fp32 / bf16 / bf16x3 / bf16x6) and libhyperpri_hip_f16.so (-DHPRI_H16_F16: IEEE half, precision mode "f16"; csrc/common.h).
+LIB_F16 = os.path.join(LIBDIR, "libhyperpri_hip_f16.so")
 SOURCES = ["api.cpp", "conv_fwd.hip", *(["conv_bf16v2.hip"] if DIAG else []), "conv_bf16v3.hip", "gemm_bf16v3.hip", "gemm_f32v2.hip", "wgrad_bf16v3.hip", "conv_wino.hip", "conv_wino4.hip", "conv_wgrad.hip", "conv_wgrad_bf16v2.hip", "pack.hip", "bn.hip", "elementwise.hip", "step.hip", "ingest.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", *(["-DHPRI_DIAG_KERNELS"] if DIAG else [])]
 
@@ -29,28 +32,36 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found")
 
 
-def _stamp() -> str:
+def _stamp(flags=None) -> str:
     h = hashlib.sha256()
     for f in sorted(os.listdir(CSRC)):
         if not os.path.isfile(os.path.join(CSRC, f)):
             continue
         with open(os.path.join(CSRC, f), "rb") as fh:
             h.update(f.encode()); h.update(fh.read())
-    h.update(" ".join(FLAGS).encode())
+    h.update(" ".join(FLAGS if flags is None else flags).encode())
     return h.hexdigest()
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
+    """Build the library (both product libraries unless HPRI_DIAG=1); returns the path of libhyperpri_hip.so."""
+    lib = _build_one(LIB, FLAGS, "_diag.o" if DIAG else ".o", force, verbose)
+    if not DIAG:
+        _build_one(LIB_F16, FLAGS + ["-DHPRI_H16_F16"], "_f16.o", force, verbose)
+    return lib
+
+
+def _build_one(LIB: str, FLAGS, osuffix: str, force: bool, verbose: bool) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
     stamp_file = LIB + ".stamp"
-    stamp = _stamp()
+    stamp = _stamp(FLAGS)
     if not force and os.path.exists(LIB) and os.path.exists(stamp_file) and open(stamp_file).read() == stamp:
         return LIB
     hipcc = _hipcc()
     objs = []
     procs = []
     for s in SOURCES:
-        o = os.path.join(LIBDIR, s.rsplit(".", 1)[0] + ("_diag.o" if DIAG else ".o"))
+        o = os.path.join(LIBDIR, s.rsplit(".", 1)[0] + osuffix)
         objs.append(o)
         cmd = [hipcc, *FLAGS, "-x", "hip", "-c", os.path.join(CSRC, s), "-o", o, "-I", CSRC]
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

@@ -127,6 +127,17 @@ extern "C" int hpri_set_item_queue(void* queue, size_t bytes, hipStream_t stream
   return hpri_set_error(HPRI_ERR_ARG, "set_item_queue: more than 32 streams hold a queue");
 }
 
+// ---- loss scale of the half-precision library (common.h: h16_t) ------------------------------------------------------------------
+// The gradient that the fused head forms from the logits (hpri_outconv_bwd_bce / _x16) is multiplied by this factor -- set by the
+// calling thread right before the launch (thread-local: backward runs on autograd's worker threads).  1 unless set.
+static thread_local float g_loss_scale = 1.f;
+float hpri_loss_scale() { return g_loss_scale; }
+extern "C" int hpri_set_loss_scale(float scale) {
+  HPRI_REQUIRE(scale > 0.f, "set_loss_scale: the scale must be positive");
+  g_loss_scale = scale;
+  return HPRI_OK;
+}
+
 extern "C" int hpri_get_option(const char* name) {
   for (int i = 0; i < 5; ++i)
     if (name && strcmp(name, g_opt_name[i]) == 0) return hpri_option(i);

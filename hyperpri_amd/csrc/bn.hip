@@ -185,7 +185,7 @@ __global__ void bn_fold_kernel(const float* __restrict__ rm, const float* __rest
 template <bool XB>
 __device__ __forceinline__ float4 bn_load_x4(const float* __restrict__ x, size_t idx) {
   if (XB) {
-    const bf16x4_t v = *reinterpret_cast<const bf16x4_t*>(reinterpret_cast<const __bf16*>(x) + idx);
+    const bf16x4_t v = *reinterpret_cast<const bf16x4_t*>(reinterpret_cast<const h16_t*>(x) + idx);
     return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
   }
   return *reinterpret_cast<const float4*>(x + idx);

@@ -9,6 +9,34 @@
 #define HPRI_ERR_WORKSPACE (-3)
 #define HPRI_ERR_LAUNCH (-4)   // hipGetLastError() after a launch was not hipSuccess
 
+// The 16-bit storage / MFMA operand type of the "plane" paths.  The product library is built twice from the same sources
+// (hyperpri_amd/build.py): libhyperpri_hip.so with h16_t = bf16 (precision modes "bf16", "bf16x3", "bf16x6"; fp32 kernels), and
+// libhyperpri_hip_f16.so (-DHPRI_H16_F16) with h16_t = IEEE half for precision mode "f16": the same kernels, activations / pre-BN
+// tensors / activation gradients stored as fp16, v_mfma_*_f16 -- 11 mantissa bits where bf16 has 8 (max |dlogit|
+// 3.5e-3 against 2.3e-2), 5 exponent bits: the engine scales the gradient that enters the head by a power of two (loss scale) and
+// takes it out of the parameter gradients again.  Entry points keep their names in both libraries ("bf16" = "the 16-bit type").
+#ifdef HPRI_H16_F16
+typedef _Float16 h16_t;
+#define HPRI_MFMA_16X16X32 __builtin_amdgcn_mfma_f32_16x16x32_f16
+#define HPRI_MFMA_32X32X16 __builtin_amdgcn_mfma_f32_32x32x16_f16
+#define HPRI_DS_READ_TR16_B64 __builtin_amdgcn_ds_read_tr16_b64_v4f16
+#define HPRI_H16_IS_F16 1
+#else
+typedef __bf16 h16_t;
+#define HPRI_MFMA_16X16X32 __builtin_amdgcn_mfma_f32_16x16x32_bf16
+#define HPRI_MFMA_32X32X16 __builtin_amdgcn_mfma_f32_32x32x16_bf16
+#define HPRI_DS_READ_TR16_B64 __builtin_amdgcn_ds_read_tr16_b64_v4bf16
+#define HPRI_H16_IS_F16 0
+#endif
+
+// (the transposed-read builtin of the half type wants __fp16 vectors)
+#ifdef HPRI_H16_F16
+typedef __fp16 hpri_tr4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
+#else
+typedef __bf16 hpri_tr4_t __attribute__((ext_vector_type(4)));
+#endif
+typedef hpri_tr4_t __attribute__((address_space(3))) * hpri_lds_tr4_ptr;
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -26,6 +54,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 int hpri_set_error(int code, const char* msg);
 int hpri_option(int idx);   // 0 conv_nbx_min, 1 wgrad_xcd_min_tiles, 2 wgrad_xcd_min_strips, 3 bf16v3_tile_width, 4 bn_wide_cq (api.cpp; thread-safe)
 int hpri_cu_count();        // compute units of the current device (api.cpp; cached)
+float hpri_loss_scale();    // the calling thread's loss scale (hpri_set_loss_scale; 1 unless set)
 
 static inline int hpri_cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t hpri_cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
@@ -37,8 +66,8 @@ enum { HPRI_E_DIRECT = 0, HPRI_E_D2S = 1 };   // D2S: scatter 2x2 stride-2 patch
 // Optional second output of the element-wise producers: the same values as bf16 NHWC planes (hi | hi,lo | hi,mid,lo:
 // plane k = bf16 of what the previous planes left), which the bf16-mode convolutions stage by LDS-DMA
 // (conv_bf16v2.hip).  Channels [C, cw) of the planes are zero-filled by the producer.
-typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
-struct PlaneOut { __bf16* p; long long plane; int cs, coff, cw, npl; };
+typedef h16_t bf16x4_t __attribute__((ext_vector_type(4)));
+struct PlaneOut { h16_t* p; long long plane; int cs, coff, cw, npl; };
 
 #ifdef __HIPCC__
 __device__ __forceinline__ void plane_store4(const PlaneOut& pl, size_t pix, int c, float o0, float o1, float o2, float o3) {
@@ -46,7 +75,7 @@ __device__ __forceinline__ void plane_store4(const PlaneOut& pl, size_t pix, int
   for (int k = 0; k < pl.npl; ++k) {
     bf16x4_t h;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { const __bf16 t = (__bf16)v[j]; h[j] = t; v[j] -= (float)t; }
+    for (int j = 0; j < 4; ++j) { const h16_t t = (h16_t)v[j]; h[j] = t; v[j] -= (float)t; }
     *reinterpret_cast<bf16x4_t*>(pl.p + (size_t)k * pl.plane + pix * pl.cs + pl.coff + c) = h;
   }
 }
@@ -110,7 +139,7 @@ __device__ __forceinline__ void hpri_q_clear(unsigned* other, int tid) {
 
 // host: fill a PlaneOut from C-ABI arguments (planes == nullptr: no plane output)
 static inline int hpri_plane_out(PlaneOut* po, void* planes, long long plane_stride, int pl_cs, int pl_coff, int pl_cw, int npl, int C) {
-  po->p = reinterpret_cast<__bf16*>(planes); po->plane = plane_stride; po->cs = pl_cs; po->coff = pl_coff; po->cw = pl_cw; po->npl = npl;
+  po->p = reinterpret_cast<h16_t*>(planes); po->plane = plane_stride; po->cs = pl_cs; po->coff = pl_coff; po->cw = pl_cw; po->npl = npl;
   if (planes == nullptr) { po->cw = 0; po->npl = 0; return HPRI_OK; }
   HPRI_REQUIRE(npl >= 1 && npl <= 3 && pl_cw >= C && pl_cw % 4 == 0 && pl_coff % 4 == 0 && pl_cs % 4 == 0 && pl_coff + pl_cw <= pl_cs &&
                    plane_stride % 4 == 0 && ((uintptr_t)planes & 7) == 0, "bad plane geometry");

@@ -26,7 +26,7 @@
 // Epilogue contract (bias, ReLU, accumulate, split-K raw slabs, statistics records) as conv_bf16v2.hip.
 #include "common.h"
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef h16_t bf16x8 __attribute__((ext_vector_type(8)));
 
 #define V3_MAXSEG 4
 #define V3_A_PIECES 24                       // 1-KB DMA pieces per halo buffer: 384 pixel slots (largest halo: 10 x 34 = 340)
@@ -34,13 +34,13 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define V3_B_BYTES (12 * 1024)               // 3 taps x 64 channels x 32 k x 2 B
 
 struct ConvV3Args {
-  const __bf16* xp; int x_cs, x_coff;        // activation plane: elements per pixel (multiple of 32), first channel (multiple of 8)
-  const __bf16* wp;                          // packed weights [chunk][tap][Cout_pad][32] (hpri_pack_weight_bf16)
+  const h16_t* xp; int x_cs, x_coff;        // activation plane: elements per pixel (multiple of 32), first channel (multiple of 8)
+  const h16_t* wp;                          // packed weights [chunk][tap][Cout_pad][32] (hpri_pack_weight_bf16)
   const float* bias;
   float* y; int y_cs, y_coff;
   float4* stats;
   int N, H, W, Cin_pad, Cout, Cout_pad, y_cw, accumulate, relu;
-  int y16;                                   // the output view is bf16 (y points at __bf16, y_cs / y_coff in elements): the pre-BN tensor of
+  int y16;                                   // the output view is bf16 (y points at h16_t, y_cs / y_coff in elements): the pre-BN tensor of
                                              // the bf16 mode at 2 bytes per element (statistics still from the fp32 sums)
   int ksplit; float* ws;
   int nseg, tiles_img, ntiles, nb_count, per_xcd, nb_major;
@@ -54,8 +54,8 @@ struct ConvV3Args {
   // second output: channels [y2_c0, y2_c0 + y2_cw) (whole 64-channel blocks) of the result ALSO (y2_only: ONLY) as bf16 rows of
   // y2_cs elements from y2_coff on -- the gradient of the upsampled half of a decoder concat, which its readers (the transposed
   // convolution's data and weight gradient: gemm_bf16v3.hip, wgrad_bf16v3.hip) stage as planes
-  __bf16* y2; int y2_cs, y2_coff, y2_c0, y2_cw, y2_only;
-  const __bf16* bn_x; int bn_x_cs, bn_x_coff, bn_cw, bn_relu, bn_cpart;
+  h16_t* y2; int y2_cs, y2_coff, y2_c0, y2_cw, y2_only;
+  const h16_t* bn_x; int bn_x_cs, bn_x_coff, bn_cw, bn_relu, bn_cpart;
   const float *bn_mean, *bn_invstd, *bn_scale, *bn_shift;
   float* bn_part;
 #ifdef HPRI_STAMPS
@@ -295,7 +295,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16v3_kernel(ConvV3Args a) {
 #define V3_MFMA_TAP(fa_, fb_, dma0_, dma1_)                                                                           \
   _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) {                                                                  \
     _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                                  \
-        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb_[nt], fa_[mt], acc[mt][nt], 0, 0, 0);                \
+        acc[mt][nt] = HPRI_MFMA_16X16X32(fb_[nt], fa_[mt], acc[mt][nt], 0, 0, 0);                \
     if (mt == 0) { dma0_ }                                                                                            \
     if (mt == 2) { dma1_ }                                                                                            \
   }
@@ -447,7 +447,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16v3_kernel(ConvV3Args a) {
       for (int mt = 0; mt < 4; ++mt) {
         const int p = (wave * 4 + mt) * 16 + li;
         const int iy = min(cur.y0 + (p >> twl), a.H - 1), ix = min(cur.x0 + (p & (TW - 1)), a.W - 1);
-        const __bf16* xr = a.bn_x + ((size_t)(cur.img * a.H + iy) * a.W + ix) * a.bn_x_cs + a.bn_x_coff;
+        const h16_t* xr = a.bn_x + ((size_t)(cur.img * a.H + iy) * a.W + ix) * a.bn_x_cs + a.bn_x_coff;
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)      // channels beyond the readable width: any in-bounds quad (their g is an exact zero)
           xq[mt][nt] = *reinterpret_cast<const bf16x4_t*>(xr + min(nlane + nt * 16, a.bn_cw - 4));
@@ -516,7 +516,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16v3_kernel(ConvV3Args a) {
           poff[mt][kk] = (unsigned)((min(iy, a.H - 1) * a.W + min(ix, a.W - 1)) * dcs);
         }
       if (a.y16) {
-        __bf16* d16 = reinterpret_cast<__bf16*>(a.y) + (ybase - dst);
+        h16_t* d16 = reinterpret_cast<h16_t*>(a.y) + (ybase - dst);
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
@@ -524,7 +524,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16v3_kernel(ConvV3Args a) {
             if ((vm >> (4 * mt + kk)) & 1u) {
               bf16x4_t h;
 #pragma unroll
-              for (int r = 0; r < 4; ++r) h[r] = (__bf16)acc[mt][kk][r];
+              for (int r = 0; r < 4; ++r) h[r] = (h16_t)acc[mt][kk][r];
               *reinterpret_cast<bf16x4_t*>(d16 + poff[mt][kk]) = h;
             }
       } else {
@@ -637,12 +637,12 @@ __global__ __launch_bounds__(256, 2) void conv_bf16v3_kernel(ConvV3Args a) {
         if ((vmask >> mt) & 1u) {
           const int p = (wave * 4 + mt) * 16 + li;
           const int iy = cur.y0 + (p >> twl), ix = cur.x0 + (p & (TW - 1));
-          __bf16* q = a.y2 + ((size_t)(cur.img * a.H + iy) * a.W + ix) * a.y2_cs + a.y2_coff + (cur.nb * 64 - a.y2_c0) + 4 * lq;
+          h16_t* q = a.y2 + ((size_t)(cur.img * a.H + iy) * a.W + ix) * a.y2_cs + a.y2_coff + (cur.nb * 64 - a.y2_c0) + 4 * lq;
 #pragma unroll
           for (int nt = 0; nt < 4; ++nt) {
             bf16x4_t h;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) h[r] = (__bf16)acc[mt][nt][r];
+            for (int r = 0; r < 4; ++r) h[r] = (h16_t)acc[mt][nt][r];
             *reinterpret_cast<bf16x4_t*>(q + nt * 16) = h;
           }
         }
@@ -654,17 +654,17 @@ __global__ __launch_bounds__(256, 2) void conv_bf16v3_kernel(ConvV3Args a) {
       // (this block of the result exists as bf16 rows only)
     } else if (!BNRED && !raw && a.y16) {
       // bf16 output: a lane's four channels are one 8-byte store (round-to-nearest-even, v_cvt_pk_bf16_f32)
-      __bf16* d16 = reinterpret_cast<__bf16*>(a.y);
+      h16_t* d16 = reinterpret_cast<h16_t*>(a.y);
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) {
         if ((vmask >> mt) & 1u) {
-          __bf16* q = d16 + (prow[mt] - dst);
+          h16_t* q = d16 + (prow[mt] - dst);
 #pragma unroll
           for (int nt = 0; nt < 4; ++nt)
             if (full || nlane + nt * 16 < dcw) {
               bf16x4_t h;
 #pragma unroll
-              for (int r = 0; r < 4; ++r) h[r] = (__bf16)acc[mt][nt][r];
+              for (int r = 0; r < 4; ++r) h[r] = (h16_t)acc[mt][nt][r];
               *reinterpret_cast<bf16x4_t*>(q + nt * 16) = h;
             }
         }
@@ -899,8 +899,8 @@ static int v3_launch(const void* xp, long long x_plane, int x_cs, int x_coff, co
   HPRI_REQUIRE(split == 0, "conv_bf16v3: only plain bf16 planes (split 0) are built");
   (void)x_plane;
   ConvV3Args a;
-  a.xp = reinterpret_cast<const __bf16*>(xp); a.x_cs = x_cs; a.x_coff = x_coff;
-  a.wp = reinterpret_cast<const __bf16*>(wp); a.bias = bias; a.y = y; a.y_cs = y_cs; a.y_coff = y_coff;
+  a.xp = reinterpret_cast<const h16_t*>(xp); a.x_cs = x_cs; a.x_coff = x_coff;
+  a.wp = reinterpret_cast<const h16_t*>(wp); a.bias = bias; a.y = y; a.y_cs = y_cs; a.y_coff = y_coff;
   a.stats = reinterpret_cast<float4*>(stats);
   a.N = N; a.H = H; a.W = W; a.Cin_pad = Cin_pad; a.Cout = Cout; a.Cout_pad = Cout_pad;
   a.y_cw = y_cw < Cout ? Cout : y_cw; a.accumulate = accumulate & 1; a.relu = (accumulate >> 1) & 1; a.y16 = (accumulate >> 2) & 1;
@@ -947,7 +947,7 @@ static int v3_launch(const void* xp, long long x_plane, int x_cs, int x_coff, co
     HPRI_REQUIRE(o2->c0 % 64 == 0 && o2->cw % 64 == 0 && o2->cw > 0 && o2->c0 + o2->cw <= Cout_pad, "conv_bf16v3_y2: the channel range must be whole 64-channel blocks");
     HPRI_REQUIRE(o2->cs % 4 == 0 && o2->coff % 4 == 0 && o2->coff + o2->cw <= o2->cs && ((uintptr_t)o2->y2 & 7) == 0,
                  "conv_bf16v3_y2: the bf16 view must be 8-byte aligned and hold the channel range");
-    a.y2 = reinterpret_cast<__bf16*>(o2->y2); a.y2_cs = o2->cs; a.y2_coff = o2->coff; a.y2_c0 = o2->c0; a.y2_cw = o2->cw; a.y2_only = o2->only;
+    a.y2 = reinterpret_cast<h16_t*>(o2->y2); a.y2_cs = o2->cs; a.y2_coff = o2->coff; a.y2_c0 = o2->c0; a.y2_cw = o2->cw; a.y2_only = o2->only;
   }
   a.bn_part = nullptr;
   if (bn != nullptr) {
@@ -957,7 +957,7 @@ static int v3_launch(const void* xp, long long x_plane, int x_cs, int x_coff, co
     HPRI_REQUIRE(bn->x_cs % 4 == 0 && bn->x_coff % 4 == 0 && ((uintptr_t)bn->x16 & 7) == 0 && bn->x_cs - bn->x_coff >= 4,
                  "conv_bf16v3_bnred: the pre-BN view must be 8-byte aligned (stride and offset multiples of 4)");
     HPRI_REQUIRE(bn->x_cs - bn->x_coff >= ((Cout + 3) & ~3) && bn->cpart >= Cout, "conv_bf16v3_bnred: pre-BN view / partial rows narrower than the channels");
-    a.bn_x = reinterpret_cast<const __bf16*>(bn->x16); a.bn_x_cs = bn->x_cs; a.bn_x_coff = bn->x_coff;
+    a.bn_x = reinterpret_cast<const h16_t*>(bn->x16); a.bn_x_cs = bn->x_cs; a.bn_x_coff = bn->x_coff;
     a.bn_cw = (bn->x_cs - bn->x_coff) & ~3;
     a.bn_mean = bn->mean; a.bn_invstd = bn->invstd; a.bn_scale = bn->scale; a.bn_shift = bn->shift;
     a.bn_relu = bn->relu; a.bn_part = bn->part; a.bn_cpart = bn->cpart;

@@ -38,7 +38,7 @@ struct ConvFwdArgs {
   int H2, W2, py0, px0, Cup;  // S2D / D2S geometry: hi-res image dims, pad offsets, channels per tap
   int ksplit;            // >1: blockIdx.z takes a slice of the K chunks and stores raw partial sums to ws
   float* ws;             // [ksplit][N*H*W][Cout_pad] partial sums (split-K only)
-  __bf16* plp; int pl_cs, pl_coff;   // D2S only: the scattered result ALSO (y != nullptr) or ONLY (y == nullptr) as one bf16 plane
+  h16_t* plp; int pl_cs, pl_coff;   // D2S only: the scattered result ALSO (y != nullptr) or ONLY (y == nullptr) as one bf16 plane
   // Tile segments: the image width is cut into column bands of tile width 32, 16, 8 or 4 (tile height grows as the
   // width shrinks, pixels per tile stay constant) so that W = 484 / 242 / 121 does not round up to 512 / 256 / 128.
   int nseg, tiles_img;
@@ -256,8 +256,8 @@ __global__ __launch_bounds__(256, (WM == 2) ? 3 : 2) void conv_fwd_kernel(ConvFw
 //     bf16 MFMA retires 16x the flops of the fp32 one in half the cycles
 //   * workgroup shapes and buffer counts are chosen for residency (three workgroups per CU where LDS allows)
 // All forms of the fp32 kernel (3x3 / 1x1 forward and data gradient, ConvTranspose2d scatter / gather).
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef h16_t bf16x8 __attribute__((ext_vector_type(8)));
+typedef h16_t bf16x4 __attribute__((ext_vector_type(4)));
 
 // SPLIT = 1 is precision mode "bf16x3": every operand is carried as hi = bf16(x) and lo = bf16(x - hi) (16 mantissa
 // bits) and each k16-step issues three MFMAs, hi*hi + hi*lo + lo*hi, into the same fp32 accumulator -- ~4e-5 on the
@@ -290,9 +290,9 @@ __global__ __launch_bounds__(256, (SPLIT == 2) ? 2 : (NTW == 1) ? 4 : ((WM == 4 
   // workgroup hides more than prefetching the next stage inside the workgroup did (measured +5..16 %; a three-buffer
   // ring with two stages in flight measured 0 %).
   constexpr int NBUF = ((SPLIT && WM == 2) || NTW == 1) ? 1 : 2;
-  __shared__ __attribute__((aligned(16))) __bf16 smem_h[NPL * MAXHP * CS + NBUF * SR * BN * BS];
-  __bf16* a_lds = smem_h;
-  __bf16* b_lds = smem_h + NPL * MAXHP * CS;
+  __shared__ __attribute__((aligned(16))) h16_t smem_h[NPL * MAXHP * CS + NBUF * SR * BN * BS];
+  h16_t* a_lds = smem_h;
+  h16_t* b_lds = smem_h + NPL * MAXHP * CS;
   float* smem = reinterpret_cast<float*>(smem_h);  // the statistics epilogue reuses the staging area as floats
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -336,7 +336,7 @@ __global__ __launch_bounds__(256, (SPLIT == 2) ? 2 : (NTW == 1) ? 4 : ((WM == 4 
   // XOR-swizzled with (row>>2)&3 to keep the ds_read_b128 of 32 consecutive rows conflict-free (ds_read_b128 is served
   // in the lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, ...: (row>>1)&3 left them 2-way conflicted); the DMA cannot permute,
   // but every lane chooses WHICH global segment it fetches, which is the same thing.
-  const __bf16* wpk = reinterpret_cast<const __bf16*>(a.wp);
+  const h16_t* wpk = reinterpret_cast<const h16_t*>(a.wp);
   int goff[NLD_B];
 #pragma unroll
   for (int p = 0; p < NLD_B; ++p) {
@@ -347,8 +347,8 @@ __global__ __launch_bounds__(256, (SPLIT == 2) ? 2 : (NTW == 1) ? 4 : ((WM == 4 
   }
 #define LOAD_STAGE(s_)                                                                               \
   {                                                                                                  \
-    const __bf16* pb_ = wpk + (size_t)(s_) * SR * a.Cout_pad * 32;                                   \
-    __bf16* lb_ = b_lds + ((s_) % NBUF) * SR * BN * BS;                                              \
+    const h16_t* pb_ = wpk + (size_t)(s_) * SR * a.Cout_pad * 32;                                   \
+    h16_t* lb_ = b_lds + ((s_) % NBUF) * SR * BN * BS;                                              \
     _Pragma("unroll") for (int p = 0; p < NLD_B; ++p)                                                \
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pb_ + goff[p]),           \
                                          (__attribute__((address_space(3))) void*)(lb_ + (p * 4 + wave) * 512), 16, 0, 0); \
@@ -433,9 +433,9 @@ __global__ __launch_bounds__(256, (SPLIT == 2) ? 2 : (NTW == 1) ? 4 : ((WM == 4 
       if (st == NST - 1 && chunk + 1 < nchunks) { LOAD_A((chunk + 1) * 32) }
     }
 
-    const __bf16* bp = b_lds + (s % NBUF) * SR * BN * BS + b_base;
+    const h16_t* bp = b_lds + (s % NBUF) * SR * BN * BS + b_base;
     if (!SPLIT) {
-      const __bf16* ap = a_lds + a_base + st * HW * CS;
+      const h16_t* ap = a_lds + a_base + st * HW * CS;
 #pragma unroll
       for (int dx = 0; dx < KS; ++dx) {
 #pragma unroll
@@ -449,12 +449,12 @@ __global__ __launch_bounds__(256, (SPLIT == 2) ? 2 : (NTW == 1) ? 4 : ((WM == 4 
           for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NTW; ++nt)
-              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mt], bf[nt], acc[mt][nt], 0, 0, 0);
+              acc[mt][nt] = HPRI_MFMA_32X32X16(af[mt], bf[nt], acc[mt][nt], 0, 0, 0);
         }
       }
     } else {
       const int dy = st / KS, dx = st - dy * KS;
-      const __bf16* ap = a_lds + a_base + (dy * HW + dx) * CS;
+      const h16_t* ap = a_lds + a_base + (dy * HW + dx) * CS;
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
         bf16x8 afr[NPL][2], bfr[NPL][NTW];
@@ -473,7 +473,7 @@ __global__ __launch_bounds__(256, (SPLIT == 2) ? 2 : (NTW == 1) ? 4 : ((WM == 4 
           for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
             for (int t = 6 - NTERM; t < 6; ++t)
-              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[TA[t]][mt], bfr[TB[t]][nt], acc[mt][nt], 0, 0, 0);
+              acc[mt][nt] = HPRI_MFMA_32X32X16(afr[TA[t]][mt], bfr[TB[t]][nt], acc[mt][nt], 0, 0, 0);
       }
     }
   }
@@ -718,7 +718,7 @@ static int conv_fwd_bf16_impl(const float* x, int x_cs, int x_coff, const void* 
   a.N = N; a.H = H; a.W = W; a.Cin_pad = Cin_pad; a.Cout = Cout; a.Cout_pad = Cout_pad;
   a.y_cw = y_cw < Cout ? Cout : y_cw; a.accumulate = accumulate & 1; a.relu = (accumulate >> 1) & 1;
   a.H2 = H2; a.W2 = W2; a.py0 = py0; a.px0 = px0; a.Cup = Cup;
-  a.plp = reinterpret_cast<__bf16*>(planes); a.pl_cs = pl_cs; a.pl_coff = pl_coff;
+  a.plp = reinterpret_cast<h16_t*>(planes); a.pl_cs = pl_cs; a.pl_coff = pl_coff;
   if (epi == HPRI_E_DIRECT) HPRI_REQUIRE(a.y_cw + y_coff <= y_cs, "conv_fwd_bf16: output channels exceed the channel stride");
   if (amode == HPRI_A_S2D || epi == HPRI_E_D2S) {
     HPRI_REQUIRE(KS == 1, "conv_fwd_bf16: S2D/D2S need KS == 1");

@@ -185,14 +185,14 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
 // (192 / 320-byte pitch); the MFMA operands need 8 consecutive PIXELS per lane, i.e. the transpose of that image,
 // which gfx950's ds_read_b64_tr_b16 delivers for free (4 pixels x 16 channels per 16-lane group, column-major).
 // v_mfma_f32_32x32x16_bf16, fp32 accumulate; same slab layout and fixed-order reduce as the fp32 kernel.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef h16_t bf16x8 __attribute__((ext_vector_type(8)));
+typedef h16_t bf16x4 __attribute__((ext_vector_type(4)));
 typedef bf16x4 __attribute__((address_space(3))) * lds_bf16x4_ptr;
 
-__device__ __forceinline__ bf16x8 tr_frag(const __bf16* p, int pitch4) {
+__device__ __forceinline__ bf16x8 tr_frag(const h16_t* p, int pitch4) {
   // p: this lane's address for pixel row (8h + q); rows +4 further down supply k-slots 4..7
-  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(p));
-  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(p + pitch4));
+  const bf16x4 lo = __builtin_bit_cast(bf16x4, HPRI_DS_READ_TR16_B64((hpri_lds_tr4_ptr)(p)));
+  const bf16x4 hi = __builtin_bit_cast(bf16x4, HPRI_DS_READ_TR16_B64((hpri_lds_tr4_ptr)(p + pitch4)));
   return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
@@ -218,9 +218,9 @@ __global__ __launch_bounds__(256, (KS == 3 && KR == 1 && SPLIT < 2) ? 3 : 2) voi
                                                   // = 16 (mod 32): the 4 pixel rows of a transposed read hit disjoint banks
   constexpr int NLD_X = (HP * (BC / 4) + 255) / 256;
   constexpr int NLD_Y = (NPIX * (BNW / 4)) / 256;
-  __shared__ __attribute__((aligned(16))) __bf16 smem[NPL * (HP * PX + NPIX * PY)];
-  __bf16* x_lds = smem;
-  __bf16* y_lds = smem + NPL * HP * PX;
+  __shared__ __attribute__((aligned(16))) h16_t smem[NPL * (HP * PX + NPIX * PY)];
+  h16_t* x_lds = smem;
+  h16_t* y_lds = smem + NPL * HP * PX;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wc = wave >> 1, wn = wave & 1;
@@ -250,8 +250,8 @@ __global__ __launch_bounds__(256, (KS == 3 && KR == 1 && SPLIT < 2) ? 3 : 2) voi
   const int units_per_split = (total_units + a.splits - 1) / a.splits;
   const int u_begin = split_id * units_per_split;
   const int u_end = min(total_units, u_begin + units_per_split);
-  const __bf16* xb = x_lds + (lh * 8 + lq) * PX + wc * (CT * 32) + lg * 16 + lp * 4;
-  const __bf16* yb = y_lds + (lh * 8 + lq) * PY + wn * (NT * 32) + lg * 16 + lp * 4;
+  const h16_t* xb = x_lds + (lh * 8 + lq) * PX + wc * (CT * 32) + lg * 16 + lp * 4;
+  const h16_t* yb = y_lds + (lh * 8 + lq) * PY + wn * (NT * 32) + lg * 16 + lp * 4;
 
   // The unit's global loads are converted to bf16 at once (half the staging registers).  KS == 1 (64 accumulators) and
   // the one-kernel-row 3x3 form (48) fetch the NEXT unit while the current one is multiplied; with all nine taps in one
@@ -351,7 +351,7 @@ _Pragma("unroll")                                                               
           for (int j = 0; j < NT; ++j)
 #pragma unroll
             for (int q = 6 - NTERM; q < 6; ++q)
-              acc[t][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[TA[q]][j], bfr[TB[q]][i], acc[t][i][j], 0, 0, 0);
+              acc[t][i][j] = HPRI_MFMA_32X32X16(af[TA[q]][j], bfr[TB[q]][i], acc[t][i][j], 0, 0, 0);
       }
     }
   }

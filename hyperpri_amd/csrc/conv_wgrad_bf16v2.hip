@@ -26,13 +26,13 @@
 //              hpri_wgrad_reduce_ex sums the slabs in fixed order into OIHW
 #include "common.h"
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef h16_t bf16x8 __attribute__((ext_vector_type(8)));
+typedef h16_t bf16x4 __attribute__((ext_vector_type(4)));
 typedef bf16x4 __attribute__((address_space(3))) * lds_bf16x4_ptr;
 
 struct WgV2Args {
-  const __bf16* xp; int x_cs, x_coff, x_cvalid;       // plane 0 of the convolution input; channels >= x_cvalid read as zero
-  const __bf16* dyp; int dy_cs, dy_coff, dy_cvalid;   // plane 0 of the gradient w.r.t. the convolution output
+  const h16_t* xp; int x_cs, x_coff, x_cvalid;       // plane 0 of the convolution input; channels >= x_cvalid read as zero
+  const h16_t* dyp; int dy_cs, dy_coff, dy_cvalid;   // plane 0 of the gradient w.r.t. the convolution output
   float* ws;                                          // [splits][9][Nr][Cr]
   int N, H, W, Cr, Nr;
   int splits, tiles_c, tiles, units_x, units_y, total_units, units_per_split;
@@ -48,8 +48,8 @@ struct WgV2Args {
 
 #ifdef WG_BUILTIN_TR      /* the form of rounds 2-3 (A/B): hipcc puts "s_waitcnt vmcnt(0)" in front of every group of these reads */
 __device__ __forceinline__ bf16x8 wg_tr_frag(const unsigned char* p) {
-  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(p));
-  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(p + 512));     // pixel rows +4
+  const bf16x4 lo = __builtin_bit_cast(bf16x4, HPRI_DS_READ_TR16_B64((hpri_lds_tr4_ptr)(p)));
+  const bf16x4 hi = __builtin_bit_cast(bf16x4, HPRI_DS_READ_TR16_B64((hpri_lds_tr4_ptr)(p + 512)));     // pixel rows +4
   return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 #endif
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_bf16v2_kernel(WgV2Args a) {
         const int odd = T0 & 1, tbit = ((T0 - odd) >> 1) & 1;
         const int base = (odd ? xO : xE) ^ (tbit << 6);
         const bf16x8 bfr = wg_tr_frag(sb + base + kg * (2 * WG_HW * 128) + T0 * 128);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[t], 0, 0, 0);
+        acc[t] = HPRI_MFMA_32X32X16(af, bfr, acc[t], 0, 0, 0);
         if (more) {
           const int m = k4 * 9 + t;
           if (m == 2) ISSUE_X(0)
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_bf16v2_kernel(WgV2Args a) {
       const bf16x8 a8 = wg_frag(af[k4 & 1]);
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, wg_frag(ba[t]), acc[t], 0, 0, 0);
+        acc[t] = HPRI_MFMA_32X32X16(a8, wg_frag(ba[t]), acc[t], 0, 0, 0);
         if (more) {
           const int m = k4 * 9 + t;
           if (m == 2) ISSUE_X(0)
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_bf16v2_kernel(WgV2Args a) {
       }
 #pragma unroll
       for (int t = 4; t < 9; ++t) {
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, wg_frag(bb[t - 4]), acc[t], 0, 0, 0);
+        acc[t] = HPRI_MFMA_32X32X16(a8, wg_frag(bb[t - 4]), acc[t], 0, 0, 0);
         if (more) {
           const int m = k4 * 9 + t;
           if (m == 8) ISSUE_X(1)
@@ -341,8 +341,8 @@ extern "C" int hpri_conv_wgrad_bf16v2(const void* x_planes, int x_cs, int x_coff
   WgV2Args a;
   wgv2_geometry(N, H, W, Cin_pad, Cout_pad, &a);
   if ((size_t)a.splits * 9 * a.Cr * a.Nr > ws_floats) return hpri_set_error(HPRI_ERR_WORKSPACE, "conv_wgrad_bf16v2: workspace too small");
-  a.xp = reinterpret_cast<const __bf16*>(x_planes); a.x_cs = x_cs; a.x_coff = x_coff; a.x_cvalid = x_cvalid;
-  a.dyp = reinterpret_cast<const __bf16*>(dy_planes); a.dy_cs = dy_cs; a.dy_coff = dy_coff; a.dy_cvalid = dy_cvalid;
+  a.xp = reinterpret_cast<const h16_t*>(x_planes); a.x_cs = x_cs; a.x_coff = x_coff; a.x_cvalid = x_cvalid;
+  a.dyp = reinterpret_cast<const h16_t*>(dy_planes); a.dy_cs = dy_cs; a.dy_coff = dy_coff; a.dy_cvalid = dy_cvalid;
   a.ws = ws; a.N = N; a.H = H; a.W = W;
   const int items = a.splits * a.tiles;
   dim3 grid((unsigned)(hpri_cdiv(items, 8) * 8), 1u, 1u);

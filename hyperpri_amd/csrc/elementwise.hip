@@ -110,7 +110,7 @@ template <bool B16>
 __device__ __forceinline__ void ew_store4(float* __restrict__ p, float4 v) {
   if (B16) {
     bf16x4_t h;
-    h[0] = (__bf16)v.x; h[1] = (__bf16)v.y; h[2] = (__bf16)v.z; h[3] = (__bf16)v.w;
+    h[0] = (h16_t)v.x; h[1] = (h16_t)v.y; h[2] = (h16_t)v.z; h[3] = (h16_t)v.w;
     *reinterpret_cast<bf16x4_t*>(p) = h;
   } else {
     *reinterpret_cast<float4*>(p) = v;
@@ -119,11 +119,11 @@ __device__ __forceinline__ void ew_store4(float* __restrict__ p, float4 v) {
 // element pointer into a tensor of either storage type (the float* carries bf16 elements when B16)
 template <bool B16>
 __device__ __forceinline__ const float* ew_at(const float* base, long long idx) {
-  return B16 ? reinterpret_cast<const float*>(reinterpret_cast<const __bf16*>(base) + idx) : base + idx;
+  return B16 ? reinterpret_cast<const float*>(reinterpret_cast<const h16_t*>(base) + idx) : base + idx;
 }
 template <bool B16>
 __device__ __forceinline__ float* ew_at(float* base, long long idx) {
-  return B16 ? reinterpret_cast<float*>(reinterpret_cast<__bf16*>(base) + idx) : base + idx;
+  return B16 ? reinterpret_cast<float*>(reinterpret_cast<h16_t*>(base) + idx) : base + idx;
 }
 
 template <bool XB>
@@ -276,7 +276,7 @@ __global__ void fill_kernel(float* __restrict__ d, long long n, float v) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) d[i] = v;
 }
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef h16_t bf16x8 __attribute__((ext_vector_type(8)));
 // ---------------------------------- 1x1 output conv ---------------------------------------------
 // logits[n][k][p] = sum_c x[n][p][c] * w[k][c] + b[k]   (NHWC in, NCHW out).  One 16-lane group per pixel.
 // BCE-with-logits pieces for the fused head (the loss inside the last layer's kernels; the stand-alone forms
@@ -294,7 +294,7 @@ __device__ __forceinline__ float oc_bce_grad(float xi, float yi) {           // 
 template <bool XB>
 __device__ __forceinline__ float4 oc_load4(const float* __restrict__ x, size_t idx) {
   if (XB) {
-    const bf16x4_t v = *reinterpret_cast<const bf16x4_t*>(reinterpret_cast<const __bf16*>(x) + idx);
+    const bf16x4_t v = *reinterpret_cast<const bf16x4_t*>(reinterpret_cast<const h16_t*>(x) + idx);
     return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
   }
   return *reinterpret_cast<const float4*>(x + idx);
@@ -419,7 +419,7 @@ __global__ __launch_bounds__(256) void outconv_fwd_wide_kernel(const float* __re
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         if (XB) {
-          const bf16x8 t = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(x) + base[u] + c);
+          const bf16x8 t = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const h16_t*>(x) + base[u] + c);
           v[u][0] = make_float4((float)t[0], (float)t[1], (float)t[2], (float)t[3]);
           v[u][VEC / 4 - 1] = make_float4((float)t[4], (float)t[5], (float)t[6], (float)t[7]);
         } else {
@@ -466,8 +466,9 @@ __global__ __launch_bounds__(256) void outconv_fwd_wide_kernel(const float* __re
 template <bool BCE, bool DXB = false>
 __global__ void outconv_bwd_data_kernel(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx,
                                         int dx_cs, int dx_coff, int N, long long P, int C, int Cw, int K, int accumulate,
-                                        const float* __restrict__ target, const float* __restrict__ gscale, int CQ) {
-  const float gs = BCE ? (gscale ? gscale[0] : 1.f) / (float)((double)N * K * P) : 1.f;
+                                        const float* __restrict__ target, const float* __restrict__ gscale, int CQ, float lscale) {
+  // (lscale: the loss scale of the half-precision mode, hpri_set_loss_scale -- 1 otherwise; a power of two: exact)
+  const float gs = BCE ? (gscale ? gscale[0] : 1.f) / (float)((double)N * K * P) * lscale : 1.f;
   const int C4 = Cw >> 2;
   const long long total = (long long)N * P * C4;
   if (K == 1) {
@@ -540,8 +541,8 @@ __global__ void outconv_bwd_data_kernel(const float* __restrict__ dy, const floa
 template <bool BCE, bool XB>
 __global__ void outconv_bwd_weight_kernel(const float* __restrict__ dy, const float* __restrict__ x, int x_cs, int x_coff,
                                           int N, long long P, int C, int K, int CQ, float* __restrict__ part, int Cpart,
-                                          const float* __restrict__ target, const float* __restrict__ gscale) {
-  const float gs = BCE ? (gscale ? gscale[0] : 1.f) / (float)((double)N * K * P) : 1.f;
+                                          const float* __restrict__ target, const float* __restrict__ gscale, float lscale) {
+  const float gs = BCE ? (gscale ? gscale[0] : 1.f) / (float)((double)N * K * P) * lscale : 1.f;
   __shared__ float4 red[256];
   __shared__ float redb[256];
   const int rows = 256 / CQ;
@@ -894,16 +895,16 @@ static int outconv_bwd_impl(const float* dy, const float* target, const float* g
     HPRI_REQUIRE(!dx_bf16 || K == 1, "outconv_bwd: a bf16 input gradient is built for one class");
     if (dx_bf16 && bce)
       hipLaunchKernelGGL((outconv_bwd_data_kernel<true, true>), grid, dim3(256), 0, stream, dy, w,
-                         dx, dx_cs, dx_coff, N, P, C, dx_cw, K, dx_accumulate, target, gscale, dq);
+                         dx, dx_cs, dx_coff, N, P, C, dx_cw, K, dx_accumulate, target, gscale, dq, hpri_loss_scale());
     else if (dx_bf16)
       hipLaunchKernelGGL((outconv_bwd_data_kernel<false, true>), grid, dim3(256), 0, stream, dy, w,
-                         dx, dx_cs, dx_coff, N, P, C, dx_cw, K, dx_accumulate, (const float*)nullptr, (const float*)nullptr, dq);
+                         dx, dx_cs, dx_coff, N, P, C, dx_cw, K, dx_accumulate, (const float*)nullptr, (const float*)nullptr, dq, hpri_loss_scale());
     else if (bce)
       hipLaunchKernelGGL(outconv_bwd_data_kernel<true>, grid, dim3(256), 0, stream, dy, w,
-                         dx, dx_cs, dx_coff, N, P, C, dx_cw, K, dx_accumulate, target, gscale, dq);
+                         dx, dx_cs, dx_coff, N, P, C, dx_cw, K, dx_accumulate, target, gscale, dq, hpri_loss_scale());
     else
       hipLaunchKernelGGL(outconv_bwd_data_kernel<false>, grid, dim3(256), 0, stream, dy, w,
-                         dx, dx_cs, dx_coff, N, P, C, dx_cw, K, dx_accumulate, (const float*)nullptr, (const float*)nullptr, dq);
+                         dx, dx_cs, dx_coff, N, P, C, dx_cw, K, dx_accumulate, (const float*)nullptr, (const float*)nullptr, dq, hpri_loss_scale());
     HPRI_CHECK_LAUNCH();
   }
   int nblk, Cpart;
@@ -912,10 +913,10 @@ static int outconv_bwd_impl(const float* dy, const float* target, const float* g
   const int c4 = hpri_cdiv(C, 4), cq = pick_cq(c4);
   if (bce)
     hipLaunchKernelGGL((outconv_bwd_weight_kernel<true, XB>), dim3(nblk, hpri_cdiv(c4, cq), K), dim3(256), 0, stream, dy, x, x_cs, x_coff,
-                       N, P, C, K, cq, workspace, Cpart, target, gscale);
+                       N, P, C, K, cq, workspace, Cpart, target, gscale, hpri_loss_scale());
   else
     hipLaunchKernelGGL((outconv_bwd_weight_kernel<false, XB>), dim3(nblk, hpri_cdiv(c4, cq), K), dim3(256), 0, stream, dy, x, x_cs, x_coff,
-                       N, P, C, K, cq, workspace, Cpart, (const float*)nullptr, (const float*)nullptr);
+                       N, P, C, K, cq, workspace, Cpart, (const float*)nullptr, (const float*)nullptr, hpri_loss_scale());
   HPRI_CHECK_LAUNCH();
   hipLaunchKernelGGL(outconv_bwd_weight_finalize_kernel, dim3(K * (C + 1)), dim3(256), 0, stream, workspace,
                      nblk, K, Cpart, C, dw, db, accumulate_param_grads);
@@ -1160,7 +1161,7 @@ extern "C" int hpri_copy_slice_any(const float* src, int s_cs, int s_coff, float
 
 // ---- fp32 NHWC view -> bf16 planes (generic producer; fused producers write planes themselves) ---------------------------
 // planes[p][pixel][cs16]: plane 0 = bf16(x), plane 1 = bf16(x - hi), plane 2 = bf16(x - hi - mid); channels [C, cw16) = 0
-__global__ void to_planes_kernel(const float* __restrict__ x, int cs, int coff, __bf16* __restrict__ pl, long long plane,
+__global__ void to_planes_kernel(const float* __restrict__ x, int cs, int coff, h16_t* __restrict__ pl, long long plane,
                                  int cs16, int coff16, long long P, int C, int cw16, int npl) {
   const int q8 = cw16 >> 3;
   const long long total = P * q8;
@@ -1182,7 +1183,7 @@ __global__ void to_planes_kernel(const float* __restrict__ x, int cs, int coff, 
     for (int k = 0; k < npl; ++k) {
       bf16x8 o;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) { const __bf16 hv = (__bf16)v[e]; o[e] = hv; v[e] -= (float)hv; }
+      for (int e = 0; e < 8; ++e) { const h16_t hv = (h16_t)v[e]; o[e] = hv; v[e] -= (float)hv; }
       *reinterpret_cast<bf16x8*>(pl + (size_t)k * plane + p * cs16 + coff16 + c) = o;
     }
   }
@@ -1198,7 +1199,7 @@ extern "C" int hpri_to_planes(const float* x, int cs, int coff, void* planes, lo
   long long blocks = (total + 255) / 256;
   if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(to_planes_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, cs, coff,
-                     reinterpret_cast<__bf16*>(planes), plane_stride, cs16, coff16, P, C, cw16, npl);
+                     reinterpret_cast<h16_t*>(planes), plane_stride, cs16, coff16, P, C, cw16, npl);
   HPRI_CHECK_LAUNCH();
   return HPRI_OK;
 }

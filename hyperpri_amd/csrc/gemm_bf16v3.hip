@@ -19,7 +19,7 @@
 //              depth-to-space scatter of the transposed convolution (mode 1).
 #include "common.h"
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef h16_t bf16x8 __attribute__((ext_vector_type(8)));
 
 #ifndef G3_NT
 #define G3_NT 8                                 // column tiles of 16 per wave
@@ -31,11 +31,11 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define G3_STAGE_BYTES (G3_A_BYTES + G3_B_BYTES)
 
 struct GemmV3Args {
-  const __bf16* xp; int x_cs, x_coff;        // A planes: elements per pixel row (multiple of 8), first channel (multiple of 8)
-  const __bf16* wp;                          // packed [chunk][Ncols_pad][32] (hpri_pack_weight_bf16, T = 1)
+  const h16_t* xp; int x_cs, x_coff;        // A planes: elements per pixel row (multiple of 8), first channel (multiple of 8)
+  const h16_t* wp;                          // packed [chunk][Ncols_pad][32] (hpri_pack_weight_bf16, T = 1)
   const float* bias;                         // per output channel (mode 1: per Cup channel), or nullptr
   float* y; int y_cs, y_coff, y_cw;          // fp32 output view (nullptr: none)
-  __bf16* y16; int y16_cs, y16_coff;         // bf16 output view (nullptr: none)
+  h16_t* y16; int y16_cs, y16_coff;         // bf16 output view (nullptr: none)
   int acc16;                                 // mode 0: add the bf16 view's old contents (accumulate flag with no fp32 view)
   float4* stats; int stat_cp;                // mode 0: [tile][stat_cp] (mean, M2, count) records, or nullptr
   int N, HW;                                 // images, GEMM rows per image (mode 1 / 2: H * W of the low-resolution grid)
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16v3_kernel(GemmV3Args a) {
       for (int nt = 0; nt < G3_NT; ++nt) {
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb_[nt], fa_[mt], acc[mt][nt], 0, 0, 0);
+          acc[mt][nt] = HPRI_MFMA_16X16X32(fb_[nt], fa_[mt], acc[mt][nt], 0, 0, 0);
           if (more_ && nt == 0 && mt < G3_BQ) { G3_DMA_B_AT(bo2, s + 2, mt); }
           if (more_ && nt == 1) { G3_DMA_A_AT(bo2, s + 2, mt); }
         }
@@ -319,7 +319,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16v3_kernel(GemmV3Args a) {
           for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-              const bf16x4_t z = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+              const bf16x4_t z = {(h16_t)0.f, (h16_t)0.f, (h16_t)0.f, (h16_t)0.f};
               o16[mt][q] = (((vmask >> mt) & 1u) && cok[q]) ? *reinterpret_cast<const bf16x4_t*>(a.y16 + orow[mt] * a.y16_cs + a.y16_coff + coff[q]) : z;
             }
 #pragma unroll
@@ -339,7 +339,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16v3_kernel(GemmV3Args a) {
               if (cok[q]) {
                 bf16x4_t hv;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) hv[r] = (__bf16)acc[mt][h * 4 + q][r];
+                for (int r = 0; r < 4; ++r) hv[r] = (h16_t)acc[mt][h * 4 + q][r];
                 *reinterpret_cast<bf16x4_t*>(a.y16 + rr * a.y16_cs + a.y16_coff + cc) = hv;
               }
             }
@@ -427,10 +427,10 @@ static int g3_launch(int mode, const void* xp, int x_cs, int x_coff, const void*
   HPRI_REQUIRE(((uintptr_t)xp & 15) == 0 && ((uintptr_t)wp & 15) == 0, "gemm_bf16v3: pointers must be 16-byte aligned");
   HPRI_REQUIRE((long long)(K_pad / 32) * Ncols_pad * 64 < 0x7FFFFF00ll, "gemm_bf16v3: packed weights exceed 2 GiB");
   GemmV3Args a;
-  a.xp = reinterpret_cast<const __bf16*>(xp); a.x_cs = x_cs; a.x_coff = x_coff;
-  a.wp = reinterpret_cast<const __bf16*>(wp); a.bias = bias;
+  a.xp = reinterpret_cast<const h16_t*>(xp); a.x_cs = x_cs; a.x_coff = x_coff;
+  a.wp = reinterpret_cast<const h16_t*>(wp); a.bias = bias;
   a.y = y; a.y_cs = y_cs; a.y_coff = y_coff; a.y_cw = y_cw;
-  a.y16 = reinterpret_cast<__bf16*>(y16); a.y16_cs = y16_cs; a.y16_coff = y16_coff;
+  a.y16 = reinterpret_cast<h16_t*>(y16); a.y16_cs = y16_cs; a.y16_coff = y16_coff;
   a.stats = reinterpret_cast<float4*>(stats); a.stat_cp = stat_cp;
   a.N = N; a.HW = (int)HW; a.W = W; a.H2 = H2; a.W2 = W2; a.py0 = py0; a.px0 = px0; a.cup = cup;
   a.nchunks = K_pad / 32; a.Ncols = Ncols; a.Ncols_pad = Ncols_pad;

@@ -74,7 +74,7 @@ extern "C" int hpri_pack_weight_scaled(const float* w, float* wp, const float* c
 // gap_len > 0 (modes 0 and 1): the INPUT-channel axis of the layer carries gap_len structural-zero channels from gap_at on (the
 // padded concat of the bf16 plane mode: [a | zeros to the next multiple of 32 | b]); K (mode 0) resp. Ncols (mode 1) count the
 // padded axis, the weight tensor has the reference's unpadded width.
-__global__ void pack_weight_bf16_kernel(const float* __restrict__ w, __bf16* __restrict__ wp, int mode, int K, int Ncols,
+__global__ void pack_weight_bf16_kernel(const float* __restrict__ w, h16_t* __restrict__ wp, int mode, int K, int Ncols,
                                         int Ncols_pad, int T, int chunks, int src_d1, int Cup, int split,
                                         const float* __restrict__ colscale, int gap_at = 0, int gap_len = 0) {
   const size_t total = (size_t)chunks * T * Ncols_pad * 32;
@@ -101,14 +101,14 @@ __global__ void pack_weight_bf16_kernel(const float* __restrict__ w, __bf16* __r
       if (colscale != nullptr) v *= colscale[col];     // eval-mode BN folded into the conv (scaled in fp32, then split)
     }
     if (!split) {
-      wp[idx] = (__bf16)v;
+      wp[idx] = (h16_t)v;
     } else {               // split + 1 planes per tap: hi, (mid,) lo -- each the bf16 rounding of what the previous ones left
       const int npl = split + 1;
       const size_t plane = (size_t)Ncols_pad * 32;
       const size_t o = ((size_t)(chunk * T + t) * npl) * plane + (size_t)col * 32 + kk;
       float rest = v;
       for (int pl = 0; pl < npl; ++pl) {
-        const __bf16 h = (__bf16)rest;
+        const h16_t h = (h16_t)rest;
         wp[o + pl * plane] = h;
         rest -= (float)h;
       }
@@ -126,7 +126,7 @@ extern "C" int hpri_pack_weight_bf16(const float* w, void* wp, int mode, int K, 
   const size_t total = (size_t)chunks * T * Ncols_pad * 32;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(pack_weight_bf16_kernel, dim3(blocks), dim3(256), 0, stream, w, reinterpret_cast<__bf16*>(wp), mode, K,
+  hipLaunchKernelGGL(pack_weight_bf16_kernel, dim3(blocks), dim3(256), 0, stream, w, reinterpret_cast<h16_t*>(wp), mode, K,
                      Ncols, Ncols_pad, T, chunks, src_d1, Cup, split, (const float*)nullptr);
   HPRI_CHECK_LAUNCH();
   return HPRI_OK;
@@ -144,7 +144,7 @@ extern "C" int hpri_pack_weight_bf16_gap(const float* w, void* wp, int mode, int
   const size_t total = (size_t)chunks * T * Ncols_pad * 32;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(pack_weight_bf16_kernel, dim3(blocks), dim3(256), 0, stream, w, reinterpret_cast<__bf16*>(wp), mode, K, Ncols, Ncols_pad,
+  hipLaunchKernelGGL(pack_weight_bf16_kernel, dim3(blocks), dim3(256), 0, stream, w, reinterpret_cast<h16_t*>(wp), mode, K, Ncols, Ncols_pad,
                      T, chunks, src_d1, 0, 0, (const float*)nullptr, gap_at, gap_len);
   HPRI_CHECK_LAUNCH();
   return HPRI_OK;
@@ -161,7 +161,7 @@ extern "C" int hpri_pack_weight_bf16_scaled(const float* w, void* wp, const floa
   const size_t total = (size_t)chunks * T * Ncols_pad * 32;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(pack_weight_bf16_kernel, dim3(blocks), dim3(256), 0, stream, w, reinterpret_cast<__bf16*>(wp), 0, K,
+  hipLaunchKernelGGL(pack_weight_bf16_kernel, dim3(blocks), dim3(256), 0, stream, w, reinterpret_cast<h16_t*>(wp), 0, K,
                      Ncols, Ncols_pad, T, chunks, src_d1, 0, split, colscale);
   HPRI_CHECK_LAUNCH();
   return HPRI_OK;

@@ -310,6 +310,33 @@ extern "C" int hpri_adam_step(float* const* params, const float* const* grads, f
   });
 }
 
+__global__ __launch_bounds__(STEP_THREADS) void scale_kernel(OptTensors t, float scale) {
+  int k = 0;
+  while (k < t.count - 1 && (int)blockIdx.x >= t.blk_end[k]) ++k;
+  const int b0 = k ? t.blk_end[k - 1] : 0;
+  const long long base = (long long)(blockIdx.x - b0) * OPT_ELEMS_PER_BLOCK;
+  float* __restrict__ p = t.p[k];
+  const long long n = t.n[k];
+#pragma unroll 4
+  for (int j = 0; j < 16; ++j) {
+    const long long i = base + j * STEP_THREADS + threadIdx.x;
+    if (i < n) p[i] *= scale;
+  }
+}
+
+// tensors[k][0 .. numel[k]) *= scale, all tensors in one launch per 48 (the half-precision mode takes its loss scale out of the
+// parameter gradients with this: hyperpri_amd/engine.py)
+extern "C" int hpri_scale_tensors(float* const* tensors, const long long* numel, int ntensors, float scale, hipStream_t stream) {
+  HPRI_REQUIRE(tensors && numel && ntensors > 0, "scale_tensors: bad arguments");
+  for (int k = 0; k < ntensors; ++k) HPRI_REQUIRE(numel[k] >= 0 && (numel[k] == 0 || tensors[k]), "scale_tensors: null tensor pointer");
+  return opt_for_chunks(tensors, reinterpret_cast<const float* const*>(tensors), nullptr, nullptr, numel, ntensors,
+                        [&](const OptTensors& t, int blocks) {
+    hipLaunchKernelGGL(scale_kernel, dim3(blocks), dim3(STEP_THREADS), 0, stream, t, scale);
+    HPRI_CHECK_LAUNCH();
+    return HPRI_OK;
+  });
+}
+
 extern "C" int hpri_sgd_step(float* const* params, const float* const* grads, float* const* momentum_buf,
                              const long long* numel, int ntensors, float lr, float momentum, float weight_decay,
                              int first_step, const float* grad_scale, hipStream_t stream) {

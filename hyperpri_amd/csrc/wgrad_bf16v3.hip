@@ -18,16 +18,16 @@
 //   output     deterministic split-K: slab ws[split][n][c] per workgroup, summed in fixed order by hpri_wgrad_reduce_ex
 #include "common.h"
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef h16_t bf16x8 __attribute__((ext_vector_type(8)));
+typedef h16_t bf16x4 __attribute__((ext_vector_type(4)));
 typedef bf16x4 __attribute__((address_space(3))) * w1_lds_bf16x4_ptr;
 
 #define W1_STAGE_BYTES (24 * 1024)       // dY: 4 arrays of [32 px][64 ch] (16 KB), X: 2 arrays (8 KB)
 #define W1_XB (16 * 1024)
 
 struct Wg1Args {
-  const __bf16* xp; int x_cs, x_coff, x_cvalid;       // plane 0 of the layer input; channels >= x_cvalid read as zero
-  const __bf16* dyp; int dy_cs, dy_coff, dy_cvalid;   // plane 0 of the gradient w.r.t. the layer output
+  const h16_t* xp; int x_cs, x_coff, x_cvalid;       // plane 0 of the layer input; channels >= x_cvalid read as zero
+  const h16_t* dyp; int dy_cs, dy_coff, dy_cvalid;   // plane 0 of the gradient w.r.t. the layer output
   float* ws;                                          // [splits][Nr][Cr]
   long long P;                                        // pixels (all images)
   int Cr, Nr, splits, tiles_c, tiles, stages_per_split, total_stages;
@@ -84,8 +84,8 @@ __global__ __launch_bounds__(256, 2) void wgrad1x1_bf16v3_kernel(Wg1Args a) {
                                  : (unsigned)((isx ? r * a.x_cs : r * a.dy_cs) + ch) * 2u;
     okbits |= ok ? (1u << q) : 0u;                   // channels beyond the valid width: zero-filled (out-of-range offset)
   }
-  const __bf16* xbase = a.xp + a.x_coff + c_blk;
-  const __bf16* ybase = MODE == 1 ? a.dyp + a.dy_coff : a.dyp + a.dy_coff + n_blk;
+  const h16_t* xbase = a.xp + a.x_coff + c_blk;
+  const h16_t* ybase = MODE == 1 ? a.dyp + a.dy_coff : a.dyp + a.dy_coff + n_blk;
   // MODE 1: the four dY arrays of a workgroup are 64-channel runs of (possibly different) taps; a wave's four dY pieces (q = 0..3)
   // are the SAME 8 pixel rows of the four arrays, so the gather position is computed once per stage and lane
   int tapoff[4] = {0, 0, 0, 0};                      // elements to add to the gathered row's offset for array q
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256, 2) void wgrad1x1_bf16v3_kernel(Wg1Args a) {
 #define W1_MFMAS(a_, b_, M0_)                                                                                         \
   _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                       \
       _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                                 \
-    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_[i], b_[j], acc[i][j], 0, 0, 0);                            \
+    acc[i][j] = HPRI_MFMA_32X32X16(a_[i], b_[j], acc[i][j], 0, 0, 0);                            \
     if (more) {                                                                                                       \
       const int m = (M0_) + i * 2 + j;                                                                                \
       if (m == 1) W1_ISSUE(0, bo2)                                                                                    \
@@ -252,8 +252,8 @@ extern "C" int hpri_wgrad1x1_bf16v3(const void* x_planes, int x_cs, int x_coff, 
   Wg1Args a;
   wg1_geometry(P, Cin_pad, Cout_pad, &a);
   if ((size_t)a.splits * a.Cr * a.Nr > ws_floats) return hpri_set_error(HPRI_ERR_WORKSPACE, "wgrad1x1_bf16v3: workspace too small");
-  a.xp = reinterpret_cast<const __bf16*>(x_planes); a.x_cs = x_cs; a.x_coff = x_coff; a.x_cvalid = x_cvalid;
-  a.dyp = reinterpret_cast<const __bf16*>(dy_planes); a.dy_cs = dy_cs; a.dy_coff = dy_coff; a.dy_cvalid = dy_cvalid;
+  a.xp = reinterpret_cast<const h16_t*>(x_planes); a.x_cs = x_cs; a.x_coff = x_coff; a.x_cvalid = x_cvalid;
+  a.dyp = reinterpret_cast<const h16_t*>(dy_planes); a.dy_cs = dy_cs; a.dy_coff = dy_coff; a.dy_cvalid = dy_cvalid;
   a.ws = ws; a.P = P;
   a.HW = a.W = a.H2 = a.W2 = a.py0 = a.px0 = a.cup = 0;
   const long long items = (long long)a.splits * a.tiles;
@@ -282,8 +282,8 @@ extern "C" int hpri_wgrad_convt_bf16v3(const void* x_planes, int x_cs, int x_cof
   const long long P = (long long)N * H * W;
   wg1_geometry(P, Cin_pad, 4 * Cup, &a);
   if ((size_t)a.splits * a.Cr * a.Nr > ws_floats) return hpri_set_error(HPRI_ERR_WORKSPACE, "wgrad_convt_bf16v3: workspace too small");
-  a.xp = reinterpret_cast<const __bf16*>(x_planes); a.x_cs = x_cs; a.x_coff = x_coff; a.x_cvalid = x_cvalid;
-  a.dyp = reinterpret_cast<const __bf16*>(dy_planes); a.dy_cs = dy_cs; a.dy_coff = dy_coff; a.dy_cvalid = 4 * Cup;
+  a.xp = reinterpret_cast<const h16_t*>(x_planes); a.x_cs = x_cs; a.x_coff = x_coff; a.x_cvalid = x_cvalid;
+  a.dyp = reinterpret_cast<const h16_t*>(dy_planes); a.dy_cs = dy_cs; a.dy_coff = dy_coff; a.dy_cvalid = 4 * Cup;
   a.ws = ws; a.P = P;
   a.HW = H * W; a.W = W; a.H2 = H2; a.W2 = W2; a.py0 = py0; a.px0 = px0; a.cup = Cup;
   const long long items = (long long)a.splits * a.tiles;

@@ -48,18 +48,32 @@ def _rup(x: int, m: int) -> int:
 # kernel holds part of its CU during a DDP backward) finds the items gone instead of walking a fixed list alone; results do not
 # change.  engine.ITEM_QUEUE = False before the first launch: fixed lists (the round-4 behaviour; tools/cu_share_probe.py measures both).
 ITEM_QUEUE = True
-_item_queues: Dict[Tuple[int, int], torch.Tensor] = {}
+_item_queues: Dict[tuple, torch.Tensor] = {}
 
 
 def _stream() -> ctypes.c_void_p:
     st = torch.cuda.current_stream()
     h = st.cuda_stream
-    if ITEM_QUEUE and (st.device_index, h) not in _item_queues:
-        lib = _lib.load()
+    key = (st.device_index, h) if _lib.kind() == "bf16" else (st.device_index, h, _lib.kind())      # (each library keeps its own registry)
+    if ITEM_QUEUE and key not in _item_queues:
+        lib = _lib.current()
         q = torch.zeros(lib.hpri_item_queue_bytes() // 4, dtype=torch.int32, device=torch.device("cuda", st.device_index))
-        _item_queues[(st.device_index, h)] = q           # (kept for the life of the process: the library holds the raw pointer)
+        _item_queues[key] = q           # (kept for the life of the process: the library holds the raw pointer)
         _lib.call("hpri_set_item_queue", _p(q), q.numel() * 4, ctypes.c_void_p(h))
     return ctypes.c_void_p(h)
+
+
+def scale_tensors_(tensors: List[torch.Tensor], scale: float) -> None:
+    """t *= scale for every (contiguous fp32) tensor of the list, one launch per 48 tensors (hpri_scale_tensors)."""
+    ts = [t for t in tensors if t is not None and t.numel() > 0]
+    if not ts or scale == 1.0:
+        return
+    for t in ts:
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            raise RuntimeError("hyperpri_amd: internal error: scale_tensors_ wants contiguous fp32 tensors")
+    ptrs = (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+    n = (ctypes.c_longlong * len(ts))(*[t.numel() for t in ts])
+    _lib.call("hpri_scale_tensors", ptrs, n, len(ts), float(scale), _stream())
 
 
 def _p(t: Optional[torch.Tensor]) -> ctypes.c_void_p:
@@ -359,6 +373,7 @@ class Tape:
         self._touched: List[int] = []               # parameters the running node asked a gradient slot for
         self.delivered: set = set()                 # segmented tape: parameters whose gradient has left with an earlier slice
         self.done_to: Optional[int] = None          # segmented tape: the backward has run down to this node index (a slice's node runs one stage ahead)
+        self.gscale = 1.0                           # half-precision mode: the power of two the head multiplies into the gradient (out_conv)
 
     def note_params(self, *params: Optional[torch.Tensor]) -> None:
         """Called by an op while it records its backward node: it will contribute to these parameters' gradients.  A
@@ -433,6 +448,8 @@ class Tape:
                     continue                                # not in a bucket, or another node still adds to this gradient
                 # a bucket's all-reduce orders itself behind the CURRENT stream: before the hand-over that completes a
                 # bucket, the main stream waits for the weight gradients still running on the second one
+                if self.gscale != 1.0:              # half-precision mode: the loss scale leaves the gradient before its bucket does
+                    scale_tensors_([self.param_grads[pid]], 1.0 / self.gscale)
                 if self.used_side and getattr(sink, "completes_bucket", lambda q: True)(p):
                     # neither compute stream is held up: a third stream waits for both and hands the bucket over
                     dev = p.device
@@ -724,6 +741,7 @@ def _cached_pack(w: torch.Tensor, key: tuple, build, extra=None, also=()):
     except RuntimeError:        # inference tensors carry no version counter: never cache them
         return build()
     stamp = (w.data_ptr(), ver, _PARAM_EPOCH)
+    key = key + (_lib.kind(),)           # (the 16-bit packs of the two libraries differ: bf16 / IEEE half)
     if ent is None or ent["stamp"] != stamp:
         if ent is None:
             import weakref
@@ -1926,6 +1944,11 @@ def out_conv(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.Tens
     xa = (_p(x.pl.buf), x.pl.cs, x.pl.coff) if x16 else (x.ptr, x.cs, x.coff)
     y = torch.empty((x.N, K, x.H, x.W), dtype=torch.float32, device=dev)
     holder: Dict[str, torch.Tensor] = {}
+    if tape.record and _lib.kind() == "f16":
+        # half-precision mode: activation gradients are stored as IEEE half (5 exponent bits).  The gradient of a MEAN-reduced loss
+        # w.r.t. a logit is at most 1 / (number of logits): the head multiplies what arrives by the next power of two above that
+        # number, and the parameter gradients lose the factor again when they leave the tape (autograd._HipFn._backward)
+        tape.gscale = float(2 ** max(0, (y.numel() - 1).bit_length()))
     slot = getattr(_PENDING, "bce", None)
     if fuse_loss and slot is not None and not slot.used and tape.record and slot.target.numel() == y.numel() and slot.target.device == dev:
         # forward_loss(): the loss of PLTrainer.py:86 computed while the logits are produced
@@ -1967,6 +1990,12 @@ def out_conv(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.Tens
                 _lib.call("hpri_bce_logits_bwd", _p(logits), _p(tgt), logits.numel(), _p(gs), _p(g2), _stream())
                 gy = gy + g2
             gy = logits if fused else gy.contiguous()
+            if tp.gscale != 1.0:
+                if fused:
+                    _lib.call("hpri_set_loss_scale", tp.gscale)       # (the fused heads multiply it into the gradient they form)
+                else:
+                    gy = gy.clone()                                   # (autograd's tensor is not ours to scale in place)
+                    scale_tensors_([gy], tp.gscale)
             dw, acc_w = tp.param_slot(weight)
             db = None
             if bias is not None:
@@ -2000,6 +2029,8 @@ def out_conv(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.Tens
             else:
                 _lib.call("hpri_outconv_bwd", _p(gy), x.ptr, x.cs, x.coff, _p(weight), gxp, gcs, gco, gcw, int(acc),
                           _p(dw), _p(db), acc_w, _p(ws), ws.numel(), x.N, x.H * x.W, C, K, _stream())
+            if tp.gscale != 1.0 and fused:
+                _lib.call("hpri_set_loss_scale", 1.0)
             if k_gap:
                 g0, gl = k_gap
                 _lib.call("hpri_copy_slice_any", _p(dwk), C, 0, _p(dw), Cw, 0, K, g0, 0, acc_w, _stream())

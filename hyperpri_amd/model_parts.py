@@ -62,12 +62,16 @@ def has_hooks(module):
 
 
 def set_precision(module, precision):
-    """Select the contraction arithmetic ("fp32" exact, default | "bf16" MFMA) for ``module`` and all its children.
-    Not part of the reference API; the default keeps the reference's fp32 semantics."""
-    if precision not in E.PRECISIONS:
-        raise ValueError(f"precision must be one of {E.PRECISIONS}")
+    """Select the contraction arithmetic for ``module`` and all its children: "fp32" (exact, the default: the reference's semantics),
+    "bf16" / "f16" (16-bit MFMA operands and 16-bit stored activations: bf16, or IEEE half -- 11 mantissa bits instead of 8, the
+    kernels of libhyperpri_hip_f16.so, activation gradients under a power-of-two loss scale chosen from the number of logits of a
+    mean-reduced loss), "bf16x3" / "bf16x6" (fp32 operands split into 2 / 3 bf16 planes).  Not part of the reference API.
+    "f16" is a mode of whole networks (UNet / CubeNET / SpectralUNET): the loss scale enters at their output layer."""
+    if precision not in E.PRECISIONS + ("f16",):
+        raise ValueError(f"precision must be one of {E.PRECISIONS + ('f16',)}")
     for m in module.modules():
-        m.hpri_precision = precision
+        m.hpri_precision = "bf16" if precision == "f16" else precision      # (the engine's plane paths; the 16-bit TYPE is the library's)
+        m.hpri_h16 = "f16" if precision == "f16" else None
     return module
 
 
@@ -95,7 +99,8 @@ class DoubleConv(nn.Module):
         return [[seq[0], seq[1]], [seq[3], seq[4]]]
 
     def forward(self, x):
-        return run(lambda tape, a, need: self._ops(tape, a[0], need[0]), [x], list(self.parameters()), name="double_conv")
+        return run(lambda tape, a, need: self._ops(tape, a[0], need[0]), [x], list(self.parameters()), name="double_conv",
+                   lib_kind=getattr(self, "hpri_h16", None))
 
 
 class Down(nn.Module):
@@ -115,7 +120,7 @@ class Down(nn.Module):
         return self.maxpool_conv[1]._stages()
 
     def forward(self, x):
-        return run(lambda tape, a, need: self._ops(tape, a[0]), [x], list(self.parameters()), name="down")
+        return run(lambda tape, a, need: self._ops(tape, a[0]), [x], list(self.parameters()), name="down", lib_kind=getattr(self, "hpri_h16", None))
 
 
 class Up(nn.Module):
@@ -152,7 +157,8 @@ class Up(nn.Module):
         return [[self.up] + first, second]            # (nn.Upsample has no parameters)
 
     def forward(self, x1, x2):
-        return run(lambda tape, a, need: self._ops(tape, a[0], a[1], need[0]), [x1, x2], list(self.parameters()), name="up")
+        return run(lambda tape, a, need: self._ops(tape, a[0], a[1], need[0]), [x1, x2], list(self.parameters()), name="up",
+                   lib_kind=getattr(self, "hpri_h16", None))
 
 
 class OutConv(nn.Module):
@@ -166,4 +172,5 @@ class OutConv(nn.Module):
         return E.out_conv(tape, x, self.conv.weight, self.conv.bias, need_dx)
 
     def forward(self, x):
-        return run(lambda tape, a, need: self._ops(tape, a[0], need[0]), [x], list(self.parameters()), name="out_conv")
+        return run(lambda tape, a, need: self._ops(tape, a[0], need[0]), [x], list(self.parameters()), name="out_conv",
+                   lib_kind=getattr(self, "hpri_h16", None))

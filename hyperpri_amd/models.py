@@ -99,7 +99,8 @@ class UNet(nn.Module):
                 yield
                 y = yield from self.up4._gen(tape, y, x1, head_next=True)          # (bf16 mode: the head reads its input as bf16 planes)
                 return self.outc._ops(tape, y)
-            logits = run_staged(prog, [x], _stage_params(self), self.fused_tape, input_planes=E.input_planes_for(self), name="unet")
+            logits = run_staged(prog, [x], _stage_params(self), self.fused_tape, input_planes=E.input_planes_for(self), name="unet",
+                                lib_kind=getattr(self, "hpri_h16", None))
         else:
             x1 = self.inc(x)
             x2 = self.down1(x1)
@@ -209,7 +210,7 @@ class SpectralUNET(torch.nn.Module):
             yield
             t = L(tape, E.concat_channels(tape, x1, t), self.up4)
             return E.out_conv(tape, E.concat_channels(tape, x0, t), self.outc.weight, self.outc.bias, fuse_loss=self.n_classes == 1)
-        out = run_staged(prog, [x], _stage_params(self), self.fused_tape, name="spectral_unet")
+        out = run_staged(prog, [x], _stage_params(self), self.fused_tape, name="spectral_unet", lib_kind=getattr(self, "hpri_h16", None))
         if self.n_classes != 1:
             # models.py:144 stores each image's (R*C, n_classes) result with .reshape(n_classes, R, C): the FLAT order is
             # pixel-major, class-minor.  `out` holds true class planes (N, K, R, C); re-order to the reference's element order
@@ -264,7 +265,7 @@ class CubeNET(torch.nn.Module):
 
     def _stem(self, x):
         params = list(self.inc.parameters()) + list(self.inc2.parameters())
-        return run(lambda tape, a, need: self._stem_ops(tape, a[0], need[0]), [x], params, name="cubenet_stem")
+        return run(lambda tape, a, need: self._stem_ops(tape, a[0], need[0]), [x], params, name="cubenet_stem", lib_kind=getattr(self, "hpri_h16", None))
 
     def _up4_gen(self, tape, y, x1, need_dx1=True, head_next=False):
         """Last decoder stage: ``up4`` (first_depth 64) or the inline upsample4 -> pad -> cat -> upconv4 (models.py:229-240)."""
@@ -318,7 +319,8 @@ class CubeNET(torch.nn.Module):
                 yield
                 y = yield from self._up4_gen(tape, y, x1, head_next=True)
                 return self.outc._ops(tape, y)
-            logits = run_staged(prog, [x], _stage_params(self), self.fused_tape, input_planes=E.input_planes_for(self), name="cubenet")
+            logits = run_staged(prog, [x], _stage_params(self), self.fused_tape, input_planes=E.input_planes_for(self), name="cubenet",
+                                lib_kind=getattr(self, "hpri_h16", None))
         else:
             x1 = self._stem(x)
             x2 = self.down1(x1)
@@ -332,7 +334,8 @@ class CubeNET(torch.nn.Module):
                 y = self.up4(y, x1)
             else:
                 params4 = list(self.upsample4.parameters()) + list(self.upconv4.parameters())
-                y = run(lambda tape, a, need: self._up4_ops(tape, a[0], a[1], need[0]), [y, x1], params4, name="cubenet_up4")
+                y = run(lambda tape, a, need: self._up4_ops(tape, a[0], a[1], need[0]), [y, x1], params4, name="cubenet_up4",
+                        lib_kind=getattr(self, "hpri_h16", None))
             logits = self.outc(y)
         if self.analyze:
             return (logits, logits, torch.sigmoid(logits))

@@ -64,6 +64,14 @@ const char* hpri_last_error(void);
  * next one will use (the library keeps the parity per registered stream).  One queue per stream (launches of one stream run one
  * after the other; the null stream of one device per process); queue == NULL unregisters the stream. */
 int hpri_item_queue_bytes(void);
+/* ---- the half-precision build (libhyperpri_hip_f16.so: the same entry points with IEEE half as the 16-bit type of every "bf16" plane,
+ * row and packed-weight argument; precision mode "f16" of hyperpri_amd) needs a loss scale: hpri_set_loss_scale(s) makes the fused
+ * heads of the CALLING THREAD (hpri_outconv_bwd_bce, hpri_outconv_bwd_x16 with a target) form s times the loss gradient -- s a power
+ * of two chosen by the caller from the number of logits, so that activation gradients sit in half's range -- and
+ * hpri_scale_tensors(tensors, numel, n, 1 / s) takes it out of the parameter gradients afterwards.  In libhyperpri_hip.so (bf16:
+ * eight exponent bits) both exist and the scale stays 1. */
+int hpri_set_loss_scale(float scale);
+int hpri_scale_tensors(float* const* tensors, const long long* numel, int ntensors, float scale, hipStream_t stream);
 int hpri_set_item_queue(void* queue, size_t bytes, hipStream_t stream);
 
 /* ---- weight packing: nn.Parameter layouts -> [chunk][tap][32][Ncols_pad] LDS panels ---------------

@@ -142,8 +142,11 @@ def cubenet_forward(sd: SD, x: Tensor, first_depth: int = 64, train: bool = True
 
 
 def _basic(sd: SD, p: str, x: Tensor, train: bool) -> Tensor:
-    """SpectralUNET._basic_module, models.py:105-115: Linear -> BatchNorm1d -> ReLU."""
+    """SpectralUNET._basic_module, models.py:105-115: Linear -> BatchNorm1d -> ReLU; with ``bnorm=False`` (:106-110) the module is
+    Linear -> ReLU and its state dict has no ``<name>.1.*`` entries."""
     x = F.linear(x, sd[p + ".0.weight"], sd[p + ".0.bias"])
+    if (p + ".1.weight") not in sd:
+        return F.relu(x)
     return F.relu(_bn(sd, p + ".1", x, train))
 
 
@@ -246,14 +249,15 @@ def cubenet_shapes(depth: int, n_classes: int, first_depth: int = 64, bilinear: 
     return sd
 
 
-def spectral_shapes(depth: int, n_classes: int, f: int) -> "OrderedDict[str, tuple]":
-    """state_dict keys/shapes of SpectralUNET(depth, n_classes, bn_feats=f), models.py:72-103."""
+def spectral_shapes(depth: int, n_classes: int, f: int, bnorm: bool = True) -> "OrderedDict[str, tuple]":
+    """state_dict keys/shapes of SpectralUNET(depth, n_classes, bn_feats=f, bnorm=bnorm), models.py:72-103."""
     sd = OrderedDict()
     for name, cin in [("tail", depth), ("down1", f), ("down2", f), ("down3", f), ("down4", f),
                       ("up1", f), ("up2", 2 * f), ("up3", 2 * f), ("up4", 2 * f)]:
         sd[name + ".0.weight"] = (f, cin)
         sd[name + ".0.bias"] = (f,)
-        _bn_keys(sd, name + ".1", f)
+        if bnorm:
+            _bn_keys(sd, name + ".1", f)
     sd["outc.weight"] = (n_classes, 2 * f)
     sd["outc.bias"] = (n_classes,)
     return sd

@@ -134,7 +134,7 @@ def test_full_size_c2_batch2_vs_reference_fixture():
 # the deepest layers (cosine >= 0.82) with every tensor's NORM within 1.2 % -- the same ladder, layer by layer, as bf16x3's at 1/25.
 #        mode      max rel L2 (weights)  min cosine  max rel L2 (1-D: BatchNorm weight / bias)          [measured + 50 %]
 LOWP = {("c2", "bf16"): (0.88, 0.735, 0.85), ("c2", "bf16x3"): (0.032, 0.9996, 0.035),
-        ("c5", "bf16"): (0.95, 0.70, 0.95)}
+        ("c5", "bf16"): (0.75, 0.765, 0.84)}
 FULL_LOWP = {"c2": ("grads_cubenet64_full_b2", 238, 64, 2), "c5": ("grads_cubenet128_300_full_b1", 300, 128, 1)}
 
 

@@ -61,6 +61,8 @@ def _mk(name):
         "net_spectral_f48": lambda: H.SpectralUNET(22, 1, 48),
         "net_spectral_f50": lambda: H.SpectralUNET(22, 1, 50),
         "net_spectral_3class": lambda: H.SpectralUNET(10, 3, 4),
+        "net_spectral_nobn_tiny": lambda: H.SpectralUNET(10, 1, 4, bnorm=False),
+        "net_spectral_nobn_f50": lambda: H.SpectralUNET(22, 1, 50, bnorm=False),
         "net_spectral1650_small": lambda: H.SpectralUNET(238, 1, 1650),
         "net_cubenet128_300_small": lambda: H.CubeNET(300, 1, first_depth=128, bilinear=False),
     }[name]()
@@ -72,6 +74,8 @@ CASES = [("net_unet3_tiny", 1234, (2, 3, 36, 50), 4321, 0.9), ("net_cubenet64_ti
          ("net_cubenet64_bilinear_tiny", 1241, (2, 1, 6, 36, 50), 4321, 0.9), ("net_spectral_tiny", 1237, (3, 10, 7, 9), 4322, 0.7),
          ("net_spectral_3class", 1252, (2, 10, 7, 9), 4332, 0.7),
          ("net_spectral_f48", 1238, (2, 22, 12, 20), 4323, 0.7), ("net_spectral_f50", 1242, (2, 22, 9, 14), 4324, 0.7),
+         # SpectralUNET(bnorm=False): models.py:72,105-110 (fixtures: tests/golden/make_golden_nobn.py)
+         ("net_spectral_nobn_tiny", 1237, (3, 10, 7, 9), 4322, 0.7), ("net_spectral_nobn_f50", 1242, (2, 22, 9, 14), 4324, 0.7),
          # BASELINE configs C3 / C5 at their exact channel widths, reduced spatial size
          ("net_spectral1650_small", 1250, (2, 238, 16, 24), 4330, 0.8),
          ("net_cubenet128_300_small", 1251, (2, 1, 300, 32, 48), 4331, 0.9)]

@@ -108,6 +108,9 @@ NETS = [
     ("net_spectral_f48", lambda: O.spectral_shapes(22, 1, 48), O.spectral_forward, {}, 1238, (2, 22, 12, 20), 4323),
     ("net_spectral_3class", lambda: O.spectral_shapes(10, 3, 4), O.spectral_forward, {}, 1252, (2, 10, 7, 9), 4332),
     ("net_spectral_f50", lambda: O.spectral_shapes(22, 1, 50), O.spectral_forward, {}, 1242, (2, 22, 9, 14), 4324),
+    # SpectralUNET(bnorm=False) (models.py:72,105-110): Linear -> ReLU stages, no BatchNorm entries in the state dict
+    ("net_spectral_nobn_tiny", lambda: O.spectral_shapes(10, 1, 4, bnorm=False), O.spectral_forward, {}, 1237, (3, 10, 7, 9), 4322),
+    ("net_spectral_nobn_f50", lambda: O.spectral_shapes(22, 1, 50, bnorm=False), O.spectral_forward, {}, 1242, (2, 22, 9, 14), 4324),
     # the BASELINE configs' exact channel widths at reduced spatial size (tests/golden/make_golden_widths.py)
     ("net_spectral1650_small", lambda: O.spectral_shapes(238, 1, 1650), O.spectral_forward, {}, 1250, (2, 238, 16, 24), 4330),
     ("net_cubenet128_300_small", lambda: O.cubenet_shapes(300, 1, 128), O.cubenet_forward, dict(first_depth=128), 1251,
