@@ -182,9 +182,11 @@ OTHER_CONFIGS = {
 }
 
 
-def run_other_configs(dev, modes_for, steps=3, warmup=3):
-    """One GPU, forward + BCE loss + backward (the metric's step), ``warmup`` untimed + ``steps`` timed steps per (config, mode):
-    ms/step, units/s, model TFLOP/s (SURVEY.md 8d's algorithmic flops), peak memory, device allocations inside the timed steps."""
+def run_other_configs(dev, modes_for, steps=10, settle_s=1.0):
+    """One GPU, forward + BCE loss + backward (the metric's step) per (config, mode), timed as the 238->64 leg is: back-to-back steps
+    for ``settle_s`` seconds (at least 3: the allocator meets the shapes, the chip reaches the clock it holds under this load), then
+    ``steps`` timed steps -- ms/step, units/s, model TFLOP/s (SURVEY.md 8d's algorithmic flops), peak memory, device allocations inside
+    the timed steps -- and one more step under the per-kernel HIP-event log for the mode's dominant MFMA kernel (``roofline``)."""
     import gc
     import hyperpri_amd as HP
     from hyperpri_amd import engine
@@ -208,8 +210,12 @@ def run_other_configs(dev, modes_for, steps=3, warmup=3):
                 loss.backward()
                 return loss
             torch.cuda.reset_peak_memory_stats(dev)
-            for _ in range(warmup):
+            t0, nwarm = time.perf_counter(), 0
+            while nwarm < 3 or time.perf_counter() - t0 < settle_s:
                 step()
+                nwarm += 1
+                if nwarm % 2 == 0:
+                    torch.cuda.synchronize()
             torch.cuda.synchronize()
             m0 = torch.cuda.memory_stats(dev).get("num_device_alloc", 0)
             t0 = time.perf_counter()
@@ -219,13 +225,48 @@ def run_other_configs(dev, modes_for, steps=3, warmup=3):
             dt = (time.perf_counter() - t0) / steps
             row[mode] = {"ms_per_step": round(dt * 1e3, 2), "units_per_s": round(batch / dt, 3),
                          "model_tflops": round(batch * gflop / dt / 1e3, 1), "loss": round(float(loss.detach()), 6),
+                         "settle_steps": nwarm, "timed_steps": steps,
                          "peak_mem_gib": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1),
                          "device_mallocs_in_timed_steps": int(torch.cuda.memory_stats(dev).get("num_device_alloc", 0) - m0)}
+            # the mode's dominant MFMA kernel against its roofline (HIP events on the launching stream, one extra step)
+            engine.enable_event_log(True)
+            step()
+            torch.cuda.synchronize()
+            summ = engine.event_log_summary()
+            engine.enable_event_log(False)
+            if summ:
+                tag, v = max(summ.items(), key=lambda kv: kv[1]["total_ms"])
+                peak = PEAK_F32_MFMA_TFLOPS if mode == "fp32" else 2500.0
+                row[mode]["roofline"] = {"bound": "mfma", "kernel": tag, "achieved": round(v["executed_tflops"], 1), "peak": peak, "unit": "TFLOP/s",
+                                         "frac": round(v["executed_tflops"] / peak, 4), "avg_launch_ms": round(v["avg_ms"], 4),
+                                         "launches_per_step": v["launches"], "ms_per_step": round(v["total_ms"], 3),
+                                         "algorithmic_gflop_per_launch": round(v["flops_per_launch"] / 1e9, 2),
+                                         "traffic": config_traffic(name, mode, tag)}
             del net, x, mask, step, loss
             gc.collect()
             torch.cuda.empty_cache()
         out[name] = row
     return out
+
+
+def config_traffic(name, mode, tag):
+    """HBM bytes per launch of a side config's dominant kernel, REPLAYED from profiles/rNN_<config>_<mode>_pmc_traffic.json (rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE passes of tools/run_config.py on the same build: tools/pmc_c3.sh + tools/pmc_traffic.py), or None."""
+    import glob
+    key = {"C3_spectralunet_1650": "c3"}.get(name)
+    if key is None:
+        return None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_{key}_{mode}_pmc_traffic.json")))
+    if not files:
+        return None
+    kern, why = _replayable(files[-1])
+    if kern is None:
+        return None
+    want = "gemm_bf16v3_kernel<0>" if "gemm" in tag or "linear" in tag.lower() else None
+    for k, v in kern.items():
+        if want and want in k:
+            return round(v["hbm_bytes_per_launch"])
+    return None
 
 
 def _free_port():
@@ -552,7 +593,7 @@ def main():
                           "note": "4 reads + 3 writes of fp32 per element; not part of `value`"}
 
     # ---- secondary lines: the same workload in the other precision modes (never the headline) ----
-    ms_step_hint = {"bf16": 0.010, "bf16x3": 0.024, "bf16x6": 0.039}      # seconds per step, for sizing the warm-up (~0.25 s) only
+    ms_step_hint = {"bf16": 0.010, "f16": 0.010, "bf16x3": 0.024, "bf16x6": 0.039}      # seconds per step, for sizing the warm-up (~0.25 s) only
     def timed_mode(mode):
         time.sleep(2.0)            # let the clocks recover from the previous mode (DVFS give-back), outside any timed region
         HP.set_precision(net, mode)
@@ -577,7 +618,7 @@ def main():
                 "ms_per_step": round(dtb / args.bf16_steps * 1e3, 3), "loss": round(float(lossb.detach()), 6),
                 "device_mallocs_in_timed_steps": torch.cuda.memory_stats(dev).get("num_device_alloc", 0) - m0}
 
-    bf16_mode = bf16x3_mode = bf16x6_mode = None
+    bf16_mode = bf16x3_mode = bf16x6_mode = f16_mode = None
     trace("precision-mode legs")
     if args.bf16_steps > 0:
         bf16x6_mode = timed_mode("bf16x6")
@@ -594,6 +635,15 @@ def main():
             "parity": "meets the fp32 contract on every fixture: full-size logits within 1e-3 of the reference, Dice/IoU equal "
                       "to 4 dp on all 42 held-out comparisons, max |dlogit| 7.8e-5 (profiles/r01_bf16x3_dice_parity.json); "
                       "reported separately because BASELINE config C2 names fp32"})
+        f16_mode = timed_mode("f16")
+        f16_mode.update({
+            "dtype": "IEEE half operands / f32 accumulate (v_mfma_f32_16x16x32_f16 forward + data gradient, 32x32x16 weight gradient): the bf16 "
+                     "mode's kernels with half as the 16-bit type (libhyperpri_hip_f16.so); activations, pre-BN tensors and activation gradients "
+                     "stored as half, activation gradients under a power-of-two loss scale (2^21 for 2 x 608 x 968 logits)",
+            "parity": "at identical weights on the benched shape: max |dlogit| 4.7e-3 against the reference fixture (bf16: 5.0e-2), 0.08 % sign "
+                      "flips, loss within 3e-7, Dice / IoU within 1e-4; gradients against the reference's fp64 samples: worst tensor 0.21 "
+                      "relative L2 / cosine 0.976 (bf16: 0.58 / 0.82) -- tests/test_gpu_f16.py, profiles/r05_f16_grad_parity_c2.json; "
+                      "NOT the headline value"})
         bf16_mode = timed_mode("bf16")
         bf16_mode.update({
             "dtype": "bf16 operands / f32 accumulate (v_mfma_f32_16x16x32_bf16 forward + data gradient, 32x32x16 weight gradient); BN statistics, pooling, gradients f32",
@@ -669,6 +719,14 @@ def main():
                       "energy_floor": "profiles/r04_energy_floor.jsonl: a bare loop with this kernel's MFMA / ds_read / LDS-DMA mix per stage and "
                                       "no epilogue sustains 1297-1300 TF = 0.52 of 2.5 PF at 1.54-1.55 GHz in-kernel on random operands",
                       "fp32_kernel_same_layer": r["fp32"], "fp32_winograd_same_layer": r.get("fp32_winograd")}
+        # the same launch in the f16 mode's library (IEEE half planes / weights / pre-BN output, v_mfma_f32_16x16x32_f16): the dtype
+        # north_star names for the roofline claim
+        rh = FC.measure(reps=10, settle_s=1.0, modes=("bf16_planes",), kind="f16")
+        th = rh.get("bf16_planes_bf16_out") or rh["bf16_planes"]
+        first_conv["f16"] = {"mode": "fp16 operand planes in, fp16 pre-BN output, hpri_conv_bf16v3 of libhyperpri_hip_f16.so (the launch of the f16 step)",
+                             "ms": th["ms"], "TF": th["tflops"], "frac_of_2.5PF": th["frac_of_2.5PF"], "ms_burst_from_idle": th["ms_burst_from_idle"],
+                             "f32_out": {"ms": rh["bf16_planes"]["ms"], "TF": rh["bf16_planes"]["tflops"],
+                                         "frac_of_2.5PF": rh["bf16_planes"]["frac_of_2.5PF"]}}
 
     # ---- BASELINE.json's other configurations on this GPU (N = 1 only: they are per-GPU figures; never part of `value`) ----
     configs = None
@@ -678,8 +736,9 @@ def main():
         import gc
         gc.collect()
         torch.cuda.empty_cache()
-        configs = run_other_configs(dev, lambda name: ("fp32", "bf16x3", "bf16") if name.startswith("C3") else ("fp32", "bf16"))
-        configs["note"] = ("per-GPU step = forward + BCEWithLogits + backward on synthetic inputs, 3 warm-up + 3 timed steps; fp32 = exact "
+        configs = run_other_configs(dev, lambda name: ("fp32", "bf16x3", "bf16") if name.startswith("C3") else ("fp32", "bf16", "f16"))
+        configs["note"] = ("per-GPU step = forward + BCEWithLogits + backward on synthetic inputs; per leg >= 1 s of back-to-back steps, then 10 timed "
+                           "steps, then one step under the per-kernel event log (roofline of the leg's dominant MFMA kernel); fp32 = exact "
                            "fp32 MFMA (Winograd for 3x3), bf16x3 = 2 bf16 planes per operand (meets the fp32 contract: logits within 1e-3, "
                            "Dice/IoU to 4 dp on the reference fixture), bf16 = Dice-level parity; model_tflops = SURVEY.md 8d flops / time")
 
@@ -713,7 +772,7 @@ def main():
             "model_tflops_note": "value x 2910.17 GFLOP/cube (direct-convolution flops of the reference graph, SURVEY.md 8d) per GPU; "
                                  "the fp32 path executes fewer multiplies than that (Winograd), so this can exceed the fp32 MFMA peak",
             "value_training_shaped": training_shaped,
-            "roofline": roofline, "roofline_238to64": first_conv, "cpu_baseline": cpu, "optimizer_step": optimizer_step, "configs": configs, "bf16x6_mode": bf16x6_mode, "bf16x3_mode": bf16x3_mode, "bf16_mode": bf16_mode,
+            "roofline": roofline, "roofline_238to64": first_conv, "cpu_baseline": cpu, "optimizer_step": optimizer_step, "configs": configs, "bf16x6_mode": bf16x6_mode, "bf16x3_mode": bf16x3_mode, "bf16_mode": bf16_mode, "f16_mode": f16_mode,
         }
         print(json.dumps(out), flush=True)
     if use_pg:

@@ -54,8 +54,15 @@ def _time(call, reps, settle_s, check):
     return burst, e0.elapsed_time(e1) / n
 
 
-def measure(reps=20, modes=("bf16_planes", "fp32"), settle_s=1.0):
-    lib = _lib.load()
+def measure(reps=20, modes=("bf16_planes", "fp32"), settle_s=1.0, kind=None):
+    """``kind`` = "f16": the same launches on libhyperpri_hip_f16.so (IEEE half planes and weights, v_mfma_f32_16x16x32_f16: the
+    form the f16 mode runs; the result keys keep their "bf16" names = "the 16-bit type")."""
+    with _lib.using(kind):
+        return _measure(reps, modes, settle_s)
+
+
+def _measure(reps, modes, settle_s):
+    lib = _lib.current()
     dev = torch.device("cuda", 0)
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     P = lambda t: ctypes.c_void_p(t.data_ptr())
