@@ -10,3 +10,20 @@ from .trainer import (BCEWithLogitsLoss, forward_loss, FusedAdam, FusedSGD, PRCu
                       average_precision, load_checkpoint, network_state_dict)
 
 __version__ = "0.1.0"
+
+
+def _warn_removed_switches():
+    """Environment switches of earlier rounds that no longer exist (folded into HPRI_FUSIONS or dropped): setting one is a silent
+    no-op otherwise."""
+    import os
+    import sys
+    gone = ("HPRI_FUSE_BN_REDUCE", "HPRI_FUSE_BN_REDUCE_BF16", "HPRI_CONVT_PLANES", "HPRI_GRAD_BF16_INNER", "HPRI_PLANES_CAT1", "HPRI_YR_BF16",
+            "HPRI_WINO4", "HPRI_BUCKET_MB", "HPRI_TAIL_MB")
+    hit = [v for v in gone if v in os.environ]
+    if hit:
+        print("hyperpri_amd: " + ", ".join(hit) + " no longer exist" + ("s" if len(hit) == 1 else "") + ": the per-feature switches are module "
+              "attributes of hyperpri_amd.engine under the HPRI_FUSIONS master switch (INTEGRATION.md); GradSync takes bucket_mb / tail_mb "
+              "as arguments.", file=sys.stderr)
+
+
+_warn_removed_switches()

@@ -487,6 +487,25 @@ class Tape:
         self.delivered.clear()
 
 
+_IDENTITY_BN: Dict[tuple, "BNRef"] = {}
+
+
+def _identity_bn(c: int, device) -> "BNRef":
+    """gamma = 1, beta = 0, mean = 0, var = 1, eps = 0: an eval-mode BatchNorm that changes nothing (cached per width and device)."""
+    key = (c, str(device))
+    ref = _IDENTITY_BN.get(key)
+    if ref is None:
+        ref = BNRef.__new__(BNRef)
+        ref.weight = torch.ones(c, dtype=torch.float32, device=device)
+        ref.bias = torch.zeros(c, dtype=torch.float32, device=device)
+        ref.running_mean = torch.zeros(c, dtype=torch.float32, device=device)
+        ref.running_var = torch.ones(c, dtype=torch.float32, device=device)
+        ref.num_batches_tracked = torch.zeros((), dtype=torch.long, device=device)
+        ref.eps, ref.momentum = 0.0, 0.0
+        _IDENTITY_BN[key] = ref
+    return ref
+
+
 class BNRef:
     """The tensors of one nn.BatchNorm{1,2,3}d (model_parts.py:23,26; models.py:113,172,178)."""
     __slots__ = ("weight", "bias", "running_mean", "running_var", "num_batches_tracked", "eps", "momentum")
@@ -879,9 +898,14 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
     prec = precision or DEFAULT_PRECISION
     if prec not in PRECISIONS:
         raise RuntimeError(f"hyperpri_amd: unknown precision {prec!r}; choose from {PRECISIONS}")
+    if bn is None and relu:
+        # Linear / Conv -> ReLU without a BatchNorm (SpectralUNET(bnorm=False), models.py:105-110): the ReLU and its backward are the
+        # BatchNorm stage's own, run with an identity "BatchNorm" in eval mode (scale 1, shift 0: y = relu(1 * x + 0) exactly; its
+        # two parameter gradients land in scratch).  Until round 5 this branch returned the convolution WITHOUT the ReLU.
+        bn, train = _identity_bn(cout, x.buf.device), False
     if bn is not None and not train and not tape.record and FOLD_EVAL_BN:
         return _conv_folded_eval(x, weight, bias, bn, ks, cin, cout, relu, prec, room,
-                                 inner=(next_cout > 0 or (head_next and HEAD_PLANES)) and groups == 1)
+                                 inner=(max(next_cout, 1 if (head_next and HEAD_PLANES) else 0) if groups == 1 else 0))
     c = types.SimpleNamespace(x=x, weight=weight, bias=bias, bn=bn, ks=ks, T=T, groups=groups, relu=relu, need_dx=need_dx, prec=prec,
                               cin=cin, cout=cout, cin_pad=x.cw, k_gap=k_gap, dev=x.buf.device, lowp=prec in LOWP,
                               split=_SPLIT.get(prec, 0), use_batch=bn is not None and train)
@@ -1259,7 +1283,7 @@ def _conv_bwd_data_planes(tp: Tape, c, dyr: Act, gx: Optional[Act], acc: bool, g
 # fp32 mode: the BatchNorm-backward reduction of a conv -> BN -> ReLU stage whose output has a single consumer (the inner tensor of a
 # DoubleConv, CubeNET's first layer) is taken in the epilogue of that consumer's Winograd data-gradient launch
 # (hpri_conv_wino4_bnred + hpri_bn_relu_bwd_fused) instead of two sweeps over the gradient and the pre-BN tensor.
-# HPRI_FUSE_BN_REDUCE: 1 (default) / 0.
+# engine.FUSE_BN_REDUCE (a module attribute under the HPRI_FUSIONS master switch; the per-feature HPRI_* variables of rounds 2-3 are gone).
 FUSE_BN_REDUCE = FUSIONS
 # the ConvTranspose2d bias gradient from the epilogue records of the data-gradient kernel that wrote the concat's gradient
 # (hpri_colsum_from_stats) instead of a pass over that tensor (hpri_col_sum).  (HPRI_FUSIONS.)
@@ -1269,10 +1293,11 @@ FOLD_LAUNCHES = 0     # folded conv+BN+ReLU stages executed (tests assert that t
 
 
 def _conv_folded_eval(x: Act, weight: torch.Tensor, bias: Optional[torch.Tensor], bn: BNRef, ks: int, cin: int, cout: int,
-                      relu: bool, prec: str = "fp32", room: int = 0, inner: bool = False) -> Act:
+                      relu: bool, prec: str = "fp32", room: int = 0, inner: int = 0) -> Act:
     """Eval-mode Conv -> BatchNorm -> ReLU (running statistics) without the normalise pass: w' = w*gamma/sqrt(var+eps),
     b' = (b-mean)*gamma/sqrt(var+eps)+beta, ReLU in the conv epilogue.  Used when nothing is recorded for backward
-    (torch.no_grad / inference_mode: PLTrainer.py:530,626).  ``inner``: the result is the inner tensor of a DoubleConv, or the head's input; in the bf16
+    (torch.no_grad / inference_mode: PLTrainer.py:530,626).  ``inner`` > 0: the result is the inner tensor of a DoubleConv (``inner`` = the
+    channels of the convolution that reads it), or the head's input (1); in the bf16
     mode the plane kernel then writes it as bf16 rows, which ARE the next convolution's planes (no fp32 copy, no conversion pass)."""
     global FOLD_LAUNCHES
     FOLD_LAUNCHES += 1
@@ -1318,7 +1343,7 @@ def _conv_folded_eval(x: Act, weight: torch.Tensor, bias: Optional[torch.Tensor]
         _conv_launch_wino(x, wp, fbias, y, None, cin, cout, cout_pad, y.cw, accumulate=2 if relu else 0)
     elif lowp and PLANE_CONV and prec == "bf16" and ks == 3 and _planes_fit(x, max(cin, cout)):
         if (inner and room == 0 and cout % 32 == 0 and PLANES_ONLY_ACT and PLANE_PRODUCERS
-                and _v3_plan(x, cin, cout)[0] == 1 and _planes_fit(y, cout)):
+                and _v3_plan(x, cin, cout)[0] == 1 and _planes_fit(y, max(cout, inner))):     # (the reader must be able to take planes too)
             # (cout a multiple of 32: the rows have no pad channels to zero; split-K problems finish in fp32)
             rows = Act(torch.empty(y.P * cout, dtype=torch.bfloat16, device=dev), x.N, x.H, x.W, cout, cout, 0)
             rows.b16 = True

@@ -386,7 +386,7 @@ def test_training_step_uses_the_fused_loss():
 
 @pytest.mark.parametrize("kind", ["unet", "cube64", "cube128"])
 def test_bf16_mode_transposed_convolutions_on_planes(kind):
-    """HPRI_CONVT_PLANES (default on): ConvTranspose2d forward, data gradient and weight gradient on the plane-fed kernels, the gradient
+    """engine.CONVT_PLANES (default on; a module attribute under HPRI_FUSIONS): ConvTranspose2d forward, data gradient and weight gradient on the plane-fed kernels, the gradient
     of the upsampled half arriving as bf16 rows from hpri_conv_bf16v3_y2.  Same bf16 operand values as the round-1 kernels (which
     round fp32 while staging), another summation order: a few last-place flips of bf16 roundings downstream."""
     import hyperpri_amd as H
@@ -657,7 +657,7 @@ def test_bf16_mode_head_reads_planes(kind):
 
 @pytest.mark.parametrize("kind", ["unet", "cube64"])
 def test_bf16_mode_inner_gradient_stored_as_bf16(kind):
-    """HPRI_GRAD_BF16_INNER (default on): the gradient of the inner tensor of every DoubleConv is written as bf16 by the second
+    """engine.GRAD_BF16_INNER (default on; a module attribute under HPRI_FUSIONS): the gradient of the inner tensor of every DoubleConv is written as bf16 by the second
     convolution's data-gradient launch and read as bf16 by the first stage's BatchNorm backward (hpri_bn_relu_bwd_x16_dy16).  One
     more rounding to 8 mantissa bits of a tensor whose only reader rounds its own result the same way: gradients move like
     between any two correct bf16 paths on this tiny, ill-conditioned net; logits are untouched."""
