@@ -877,7 +877,7 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
                  train: bool, ks: int, groups: int = 1, relu: bool = True, need_dx: bool = True,
                  precision: Optional[str] = None, room: int = 0, next_cout: int = 0, cat_room: int = 0,
                  cat_into: Optional[Act] = None, k_gap: Optional[Tuple[int, int]] = None, planes_only: bool = False,
-                 out_planes: bool = False, head_next: bool = False) -> Act:
+                 out_planes: bool = False, head_next: bool = False, relu_without_bn: bool = False) -> Act:
     """Conv2d(k=ks, pad=ks//2) -> BatchNorm -> ReLU  (model_parts.py:22-27; models.py:169-180 with the
     Conv3d weight (F,1,D,3,3) read as (F,D,3,3); models.py:108-114 for Linear -> BatchNorm1d -> ReLU with
     ks = 1 and ``groups`` = images, each image being its own BN batch, models.py:132).
@@ -898,7 +898,8 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
     prec = precision or DEFAULT_PRECISION
     if prec not in PRECISIONS:
         raise RuntimeError(f"hyperpri_amd: unknown precision {prec!r}; choose from {PRECISIONS}")
-    if bn is None and relu:
+    if bn is None and relu and relu_without_bn:
+        # (``bn=None`` alone is the bare convolution / linear layer, as the kernel-level tests use it)
         # Linear / Conv -> ReLU without a BatchNorm (SpectralUNET(bnorm=False), models.py:105-110): the ReLU and its backward are the
         # BatchNorm stage's own, run with an identity "BatchNorm" in eval mode (scale 1, shift 0: y = relu(1 * x + 0) exactly; its
         # two parameter gradients land in scratch).  Until round 5 this branch returned the convolution WITHOUT the ReLU.

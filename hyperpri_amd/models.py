@@ -148,7 +148,7 @@ class SpectralUNET(torch.nn.Module):
     def _layer(self, tape, x, seq, need_dx=True, **kw):
         bn = E.BNRef(seq[1]) if self._bnorm else None
         return E.conv_bn_relu(tape, x, seq[0].weight, seq[0].bias, bn, self.training, 1, groups=x.N, need_dx=need_dx,
-                              precision=getattr(self, "hpri_precision", None), **kw)
+                              precision=getattr(self, "hpri_precision", None), relu_without_bn=not self._bnorm, **kw)
 
     fused_tape = True       # see UNet.fused_tape (no per-child route here: the reference's forward is one loop over images)
 
