@@ -357,6 +357,9 @@ def main():
                          "cubes/s, none slow: profiles/r03_no_settle_sequences.txt); see the comment at the loop")
     ap.add_argument("--force-sync", action="store_true",
                     help="rehearsal: run the RCCL GradSync path (process group, hooks, all-reduce) even with one rank")
+    ap.add_argument("--rccl-max-channels", type=int, default=0,
+                    help="N > 1: cap RCCL's channels (NCCL_MAX_NCHANNELS, set before the communicator is created): every channel is a workgroup "
+                         "that holds part of a compute unit while a bucket's all-reduce runs beside the backward (tools/cu_share_probe.py); 0 = RCCL's default")
     ap.add_argument("--dry-launch", action="store_true",
                     help="launcher rehearsal: the ranks run a gloo all-reduce on the CPU instead of the GPU workload")
     args = ap.parse_args()
@@ -383,6 +386,8 @@ def main():
     if use_pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
+        if args.rccl_max_channels > 0:
+            os.environ["NCCL_MAX_NCHANNELS"] = str(args.rccl_max_channels)
         # librccl prints a version banner to fd 1 when the communicator comes up: stdout must carry the ONE result line only
         sys.stdout.flush()
         saved_fd = os.dup(1)
@@ -524,6 +529,10 @@ def main():
                                        "gradients| / max|mean| (0.0 = bit-equal; null at N = 1)",
                      "ranks_hold_equal_gradients": equal, "grad_mb": round(sum(b.flat.numel() for b in sync.buckets) * 4 / 2 ** 20, 1),
                      "gradients_written_in_place": True, "overlap": ov, "buckets_issued_by": dict(sync.issued),
+                     # what bounds the compute units the collective's kernels hold beside the backward (RCCL reads these when the
+                     # communicator is created; unset = its own choice for the topology)
+                     "rccl_channel_env": {k: os.environ.get(k) for k in ("NCCL_MAX_NCHANNELS", "NCCL_MIN_NCHANNELS", "NCCL_NTHREADS", "RCCL_MSCCL_ENABLE")},
+                     "item_queues": bool(engine.ITEM_QUEUE),
                      "note": "buckets are issued from inside the backward tape as their last gradient lands; "
                              "issue_to_finish_ms[0] is the window in which communication ran beside the rest of backward"}
 

@@ -325,6 +325,10 @@ class _HipFn(torch.autograd.Function):
 # through ``register_autograd``.  ``program`` is a handle into the table of tape programs of the calling module (the op graph the
 # reference module stands for, closed over the module for its BatchNorm buffers, which a training-mode forward updates in place as
 # nn.BatchNorm does); the kernels behind it are reached through the C ABI (include/hyperpri_hip.h) exactly as from _HipFn.
+# The BatchNorm buffers a training-mode forward updates are NOT declared as mutated arguments: torch.library refuses an autograd formula
+# on a mutating operator ("Cannot register autograd formula for non-functional operator": tried in round 5), and the functional
+# alternative -- the operator returning new buffer values for Python to copy back -- would put 81 small copy kernels into every step.
+# The operators are therefore correct in eager mode (what the reference's callers run) and not meant for torch.compile / export.
 # HPRI_DISPATCHER=0 routes the modules through the plain autograd.Function instead (same tape, same kernels, same results).
 OP_NAMES = ("unet", "cubenet", "cubenet_stem", "cubenet_up4", "spectral_unet", "double_conv", "down", "up", "out_conv", "run_program", "segment")
 USE_DISPATCHER = os.environ.get("HPRI_DISPATCHER", "1") != "0"
