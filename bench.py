@@ -745,7 +745,7 @@ def main():
         import gc
         gc.collect()
         torch.cuda.empty_cache()
-        configs = run_other_configs(dev, lambda name: ("fp32", "bf16x3", "bf16") if name.startswith("C3") else ("fp32", "bf16", "f16"))
+        configs = run_other_configs(dev, lambda name: ("fp32", "bf16x3", "bf16", "f16") if name.startswith("C3") else ("fp32", "bf16", "f16"))
         configs["note"] = ("per-GPU step = forward + BCEWithLogits + backward on synthetic inputs; per leg >= 1 s of back-to-back steps, then 10 timed "
                            "steps, then one step under the per-kernel event log (roofline of the leg's dominant MFMA kernel); fp32 = exact "
                            "fp32 MFMA (Winograd for 3x3), bf16x3 = 2 bf16 planes per operand (meets the fp32 contract: logits within 1e-3, "

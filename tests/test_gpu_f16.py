@@ -142,3 +142,30 @@ def test_f16_step_is_deterministic_and_leaves_the_bf16_library_alone():
     for a, b in (("h0", "h1"), ("b0", "b1")):
         assert torch.equal(out[a][0], out[b][0]) and all(torch.equal(p, q) for p, q in zip(out[a][2], out[b][2])), (a, b)
     assert not torch.equal(out["h0"][0], out["b0"][0])
+
+
+def test_full_size_spectral1650_f16_vs_reference_fixture():
+    """BASELINE config C3 (SpectralUNET-1650 @608x700, batch 1) in the f16 mode against the reference fixture: the whole Linear stack
+    on the plane GEMM / weight-gradient kernels of the half-precision library.  Logits (bf16 mode: 1.7e-2), loss, sign agreement,
+    Dice / IoU, gradient norms and gradient heads."""
+    z = TN._load("net_spectral1650_full")
+    net, xd, mask, lg, loss = TN._full_size_step("c3", "f16")
+    stride = int(z["stride"])
+    sub = lg.reshape(-1)[::stride].numpy()
+    d = float(np.abs(sub - z["logits_sub"]).max())
+    record_margin("f16/c3/logits", d, 6e-3)
+    assert d < 6e-3 and abs(loss - float(z["loss"])) < 5e-5, (d, loss)
+    assert float(((sub > 0) != (z["logits_sub"] > 0)).mean()) < 2e-3
+    acc, dice, iou = O.seg_metrics(lg, mask)
+    assert abs(dice - float(z["dice"])) < 1e-4 and abs(iou - float(z["iou"])) < 1e-4
+    grads = OrderedDict((k, p.grad) for k, p in net.named_parameters())
+    worst = 0.0
+    for i, k in enumerate(list(z["grad_names"])):
+        if grads[k].dim() <= 1:
+            continue
+        assert torch.isfinite(grads[k]).all(), k
+        g, ref = float(grads[k].detach().double().norm()), float(z["grad_l2"][i])
+        worst = max(worst, abs(g - ref) / (ref + 1e-12))
+    record_margin("f16/c3/grad_norms", worst, 0.05)
+    assert worst <= 0.05, worst
+    TN.check_heads_lowp(z, net, "f16/c3", 0.3)

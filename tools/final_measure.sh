@@ -21,6 +21,9 @@ else
   timeout -k 10 300 python tools/determinism_check.py bf16 6 >> $G/${TAG}_determinism.txt 2>&1; echo "determinism rc $?"; grep -v amdgpu $G/${TAG}_determinism.txt | tail -2
   timeout -k 10 400 python tools/dice_parity.py 14 20 ${TAG} fp32 > $G/${TAG}_dice_fp32.log 2>&1; echo "dice fp32 rc $?"; tail -1 $G/${TAG}_dice_fp32.log | cut -c1-300
   timeout -k 10 400 python tools/dice_parity.py 14 20 ${TAG}_bf16 bf16 > $G/${TAG}_dice_bf16.log 2>&1; echo "dice bf16 rc $?"; tail -1 $G/${TAG}_dice_bf16.log | cut -c1-300
+  timeout -k 10 300 python tools/dice_parity.py 14 20 ${TAG}_f16 f16 > $G/${TAG}_dice_f16.log 2>&1; echo "dice f16 rc $?"; tail -1 $G/${TAG}_dice_f16.log | cut -c1-300
+  timeout -k 10 200 python tools/ddp_stock_bench.py > $G/${TAG}_ddp_stock_one_rank.json 2> $G/${TAG}_ddp_stock.err; echo "stock ddp rc $?"
   timeout -k 10 500 python bench.py > $G/${TAG}_bench_final.json 2> $G/${TAG}_bench_final.err; echo "bench rc $?"
   bash tools/prof_c3.sh bf16 ${TAG}_c3_bf16_final > /dev/null 2>&1; echo "c3 profile rc $?"
+  bash tools/pmc_c3.sh bf16 ${TAG}_c3_bf16 > /dev/null 2>&1; echo "c3 pmc rc $?"      # then: python tools/pmc_traffic.py gpurun_out/${TAG}_c3_bf16 ${TAG}_c3_bf16
 fi
