@@ -21,6 +21,11 @@ extern "C" int hpri_version(void) { return 100; }  // 0.1.0
 //   bf16v3_tile_width     conv_bf16v3 tile shape: 0 = by padding cost (32 x 8 first), 16 = 16 x 16 tiles only    (HPRI_V3_TILE_WIDTH, 0)
 //   bn_wide_cq            BatchNorm / reduction kernels: 1 = tensors wider than 1024 channels take whole 1024-channel runs of one
 //                         pixel per workgroup, 0 = 256-channel columns of four pixels                         (HPRI_BN_WIDE_CQ, 1)
+//   wgrad_cu_reserve      compute units the fp32 Winograd weight gradient leaves free: its workgroups hold a whole CU each (104 KB of
+//                         LDS) and its pixel splits are planned so that the grid is an exact multiple of the CUs -- with ONE CU held
+//                         by another kernel (a collective's channel) the last workgroup starts when the first retires: 2 x the
+//                         launch (profiles/r05_hog_kernels_fp32.json).  n > 0 plans for 256 - n CUs (a different split = another,
+//                         equally deterministic summation order); 0 = all of them                          (HPRI_WGRAD_CU_RESERVE, 0)
 #include <stdlib.h>
 #include <atomic>
 #include <mutex>
@@ -28,14 +33,14 @@ extern "C" int hpri_version(void) { return 100; }  // 0.1.0
 // autograd's worker threads): the options are atomics initialised exactly once, from the environment, under std::call_once;
 // hpri_set_option stores with release order and the launchers' reads are relaxed loads of an int (a plan option changes
 // block order only, never results).
-static std::atomic<int> g_opt[5];
+static std::atomic<int> g_opt[6];
 static std::once_flag g_opt_once;
-static const char* const g_opt_name[5] = {"conv_nbx_min", "wgrad_xcd_min_tiles", "wgrad_xcd_min_strips", "bf16v3_tile_width", "bn_wide_cq"};
-static const char* const g_opt_env[5] = {"HPRI_NBX_MIN", "HPRI_WGRAD_XCD_MIN", "HPRI_WGRAD_XCD_STRIPS", "HPRI_V3_TILE_WIDTH", "HPRI_BN_WIDE_CQ"};
-static const int g_opt_default[5] = {9, 128, 2048, 0, 1};
+static const char* const g_opt_name[6] = {"conv_nbx_min", "wgrad_xcd_min_tiles", "wgrad_xcd_min_strips", "bf16v3_tile_width", "bn_wide_cq", "wgrad_cu_reserve"};
+static const char* const g_opt_env[6] = {"HPRI_NBX_MIN", "HPRI_WGRAD_XCD_MIN", "HPRI_WGRAD_XCD_STRIPS", "HPRI_V3_TILE_WIDTH", "HPRI_BN_WIDE_CQ", "HPRI_WGRAD_CU_RESERVE"};
+static const int g_opt_default[6] = {9, 128, 2048, 0, 1, 0};
 
 static void opt_init() {
-  for (int i = 0; i < 5; ++i) {
+  for (int i = 0; i < 6; ++i) {
     const char* e = getenv(g_opt_env[i]);
     int v = e ? atoi(e) : g_opt_default[i];
     if (v < 0) v = g_opt_default[i];
@@ -50,7 +55,7 @@ int hpri_option(int idx) {
 
 extern "C" int hpri_set_option(const char* name, int value) {
   std::call_once(g_opt_once, opt_init);
-  for (int i = 0; i < 5; ++i)
+  for (int i = 0; i < 6; ++i)
     if (name && strcmp(name, g_opt_name[i]) == 0) {
       if (value < 0) return hpri_set_error(HPRI_ERR_ARG, "set_option: value must be >= 0");
       g_opt[i].store(value, std::memory_order_release);
@@ -139,7 +144,7 @@ extern "C" int hpri_set_loss_scale(float scale) {
 }
 
 extern "C" int hpri_get_option(const char* name) {
-  for (int i = 0; i < 5; ++i)
+  for (int i = 0; i < 6; ++i)
     if (name && strcmp(name, g_opt_name[i]) == 0) return hpri_option(i);
   return hpri_set_error(HPRI_ERR_ARG, "get_option: unknown option");
 }

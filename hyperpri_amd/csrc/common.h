@@ -52,7 +52,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
   } while (0)
 
 int hpri_set_error(int code, const char* msg);
-int hpri_option(int idx);   // 0 conv_nbx_min, 1 wgrad_xcd_min_tiles, 2 wgrad_xcd_min_strips, 3 bf16v3_tile_width, 4 bn_wide_cq (api.cpp; thread-safe)
+int hpri_option(int idx);   // 0 conv_nbx_min, 1 wgrad_xcd_min_tiles, 2 wgrad_xcd_min_strips, 3 bf16v3_tile_width, 4 bn_wide_cq, 5 wgrad_cu_reserve (api.cpp; thread-safe)
 int hpri_cu_count();        // compute units of the current device (api.cpp; cached)
 float hpri_loss_scale();    // the calling thread's loss scale (hpri_set_loss_scale; 1 unless set)
 

@@ -718,14 +718,23 @@ extern "C" int hpri_wino_wgrad_plan(int N, int H, int W, int Cin_pad, int Cout_p
   *Cr = cblk * 64; *Nr = nblk * 64;
   const int tiles = cblk * nblk;
   // one workgroup per CU: splits such that tiles * splits is close to a multiple of 256, with >= 8 strips per split
-  int best = 1; double best_eff = 0.0;
-  for (int k = 1; k <= 512; ++k) {
-    if (k > 1 && total / k < 8) break;
-    const double per_cu = (double)tiles * k / 256.0;
-    double eff = per_cu / (double)((long long)(per_cu + 0.999999));
-    if (per_cu < 1.0) eff = per_cu;
-    if (eff > best_eff + 1e-9) { best_eff = eff; best = k; }
-  }
+  auto plan = [&](int cus, int kmax, double tol) {
+    int best = 1; double best_eff = 0.0;
+    for (int k = 1; k <= kmax; ++k) {
+      if (k > 1 && total / k < 8) break;
+      const double per_cu = (double)tiles * k / (double)cus;
+      double eff = per_cu / (double)((long long)(per_cu + 0.999999));
+      if (per_cu < 1.0) eff = per_cu;
+      if (eff > best_eff + tol + 1e-9) { best_eff = eff; best = k; }
+    }
+    return best;
+  };
+  int best = plan(256, 512, 0.0);
+  // option wgrad_cu_reserve (api.cpp): plan for that many fewer CUs, so that a few CUs held by another kernel do not push the last
+  // workgroups into a second wave -- with at most twice the slabs of the plain plan, and a smaller split preferred unless a larger
+  // one fills the CUs at least 5 % better
+  const int reserve = hpri_option(5);
+  if (reserve > 0) best = plan(256 - (reserve < 192 ? reserve : 192), 2 * best, 0.05);
   *splits = best;
   return HPRI_OK;
 }

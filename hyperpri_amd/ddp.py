@@ -52,7 +52,7 @@ class _Bucket:
 
 class GradSync:
     def __init__(self, module: torch.nn.Module, bucket_mb: Optional[float] = None, process_group=None,
-                 broadcast_buffers: bool = False, force: bool = False, tail_mb: Optional[float] = None):
+                 broadcast_buffers: bool = False, force: bool = False, tail_mb: Optional[float] = None, reserve_cus: int = 0):
         if bucket_mb is None:
             bucket_mb = 24.0           # few large messages: xGMI is point-to-point (7 links x ~153 GB/s), a ring is per-link bound
         if tail_mb is None:
@@ -114,6 +114,13 @@ class GradSync:
             print("hyperpri_amd.GradSync: GPU_MAX_HW_QUEUES could not be raised to 8 any more (the HIP runtime was initialised "
                   "before hyperpri_amd was imported); weight gradients stay on the main stream under the gradient sink "
                   "(~3 % slower backward).  Export GPU_MAX_HW_QUEUES=8 before the process starts.", file=sys.stderr, flush=True)
+        # reserve_cus > 0: the fp32 Winograd weight gradient (one 104 KB workgroup per CU, grids of exact multiples of the CU count)
+        # plans its pixel splits for that many fewer CUs, so that a collective's channels holding a few CUs do not push its last
+        # workgroup into a second wave (2 x the launch: profiles/r05_hog_kernels_fp32.json).  Off by default: it changes the split,
+        # i.e. the (still deterministic) summation order of those weight gradients, against a run without it.
+        self.reserve_cus = int(reserve_cus)
+        if self.reserve_cus > 0:
+            engine.set_plan_option("wgrad_cu_reserve", self.reserve_cus)
         self._accumulating = False      # inside no_sync(): gradients add up locally, no collective
         self._micro = 0                 # backward passes since the last finish()
         self._direct: set = set()       # ids of parameters whose gradient the engine wrote into the bucket this step
@@ -280,3 +287,5 @@ class GradSync:
             self._buf_hook = None
         if engine._GRAD_SINK is self:
             engine.set_grad_sink(None)
+        if self.reserve_cus > 0:
+            engine.set_plan_option("wgrad_cu_reserve", 0)

@@ -63,6 +63,11 @@ def _stream() -> ctypes.c_void_p:
     return ctypes.c_void_p(h)
 
 
+def set_plan_option(name: str, value: int) -> None:
+    """A launch-plan option of the HIP library (include/hyperpri_hip.h: hpri_set_option), e.g. "wgrad_cu_reserve"."""
+    _lib.call("hpri_set_option", name.encode(), int(value))
+
+
 def scale_tensors_(tensors: List[torch.Tensor], scale: float) -> None:
     """t *= scale for every (contiguous fp32) tensor of the list, one launch per 48 tensors (hpri_scale_tensors)."""
     ts = [t for t in tensors if t is not None and t.numel() > 0]

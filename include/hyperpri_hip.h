@@ -16,7 +16,7 @@
  *   - Return value: 0 = ok, <0 = error (HPRI_ERR_*); hpri_last_error() returns the thread's message.
  *     Nothing throws across the ABI.
  *   - Launchers are re-entrant (autograd calls them from worker threads).  The only process-wide state is immutable after
- *     its first use or atomic: the three launch-plan options (read once from the environment under std::call_once, then
+ *     its first use or atomic: the launch-plan options (read once from the environment under std::call_once, then
  *     atomics; hpri_set_option) and a per-device cache of the compute-unit count; the error message is thread-local.  Stamp
  *     buffers exist in the diagnostic builds (-DHPRI_STAMPS) only.
  */
@@ -43,7 +43,9 @@ extern "C" {
 
 int hpri_version(void);
 /* Launch-plan options (process-wide): "conv_nbx_min", "wgrad_xcd_min_tiles", "wgrad_xcd_min_strips", "bf16v3_tile_width", "bn_wide_cq" -- the problem sizes
- * from which the conv / weight-gradient kernels switch to their XCD-aware 1-D grids.  Results do not depend
+ * from which the conv / weight-gradient kernels switch to their XCD-aware 1-D grids -- and "wgrad_cu_reserve": compute
+ * units the fp32 Winograd weight gradient (one workgroup per CU, grids planned as exact multiples of the CU count) leaves to other
+ * kernels, e.g. the channels of a collective that runs beside the backward (0 = none).  Results do not depend
  * on them, only block order and (for weight gradients) the number of partial slabs, i.e. the summation order. */
 int hpri_set_option(const char* name, int value);
 /* A non-blocking stream of the lowest priority the current device offers (*priority receives it); the caller owns it. */

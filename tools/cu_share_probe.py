@@ -6,7 +6,7 @@ alone (a second wave: up to 2x the launch); with the per-XCD item counters every
 one finds the queue empty.  Here a hog (tools/cu_hog.hip: W workgroups x 512 threads x 64 KB LDS, asleep until a deadline) holds W
 CUs on a second stream for the length of several steps; the step time with and without it is recorded for the fp32 step, the bf16
 step and a C3-shaped bf16 step.
-usage: cu_share_probe.py [--fixed-lists] [out.json] [label]"""
+usage: cu_share_probe.py [--fixed-lists] [--reserve=N] [out.json] [label]"""
 import ctypes
 import json
 import os
@@ -77,13 +77,16 @@ def timed(step, n, hog_wg, hog_ms, lds=65536):
 
 
 def main():
-    args = [a for a in sys.argv[1:] if a != "--fixed-lists"]
+    args = [a for a in sys.argv[1:] if a != "--fixed-lists" and not a.startswith("--reserve=")]
     if "--fixed-lists" in sys.argv[1:]:
         engine.ITEM_QUEUE = False           # the round-4 behaviour: no item queues are registered, workgroups walk fixed lists
+    reserve = [int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("--reserve=")]
+    if reserve:
+        engine.set_plan_option("wgrad_cu_reserve", reserve[0])      # the fp32 Winograd weight gradient plans for that many fewer CUs
     out_path = args[0] if len(args) > 0 else None
     label = args[1] if len(args) > 1 else "current build"
     res = {"label": label, "library_stamp": bench._lib_stamp(), "hog": "W workgroups x 512 threads x 64 KB LDS, asleep (tools/cu_hog.hip)",
-           "cus": torch.cuda.get_device_properties(0).multi_processor_count, "legs": {}}
+           "cus": torch.cuda.get_device_properties(0).multi_processor_count, "wgrad_cu_reserve": (reserve[0] if reserve else 0), "legs": {}}
     for name, kind, prec, nsteps in (("fp32_c2", "c2", "fp32", 4), ("bf16_c2", "c2", "bf16", 10), ("bf16_c3_quarter", "c3", "bf16", 4)):
         step = make(kind, prec)
         for _ in range(4):
