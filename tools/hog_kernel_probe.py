@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Which kernels of the fp32 step lose time beside ONE resident hog workgroup (tools/cu_hog.hip, 64 KB of LDS)?  The step's
-per-kernel HIP-event table (engine.enable_event_log) with and without the hog.  usage: hog_kernel_probe.py [precision]"""
+per-kernel HIP-event table (engine.enable_event_log) with and without the hog.  usage: hog_kernel_probe.py [precision] [wgrad_cu_reserve]"""
 import ctypes
 import json
 import os
@@ -16,6 +16,8 @@ import hyperpri_amd as HP  # noqa: E402
 from hyperpri_amd import engine  # noqa: E402
 
 prec = sys.argv[1] if len(sys.argv) > 1 else "fp32"
+if len(sys.argv) > 2:
+    engine.set_plan_option("wgrad_cu_reserve", int(sys.argv[2]))       # the fp32 Winograd weight gradient plans for that many fewer CUs
 hog = ctypes.CDLL(os.path.join(ROOT, "tools", "bin", "libcuhog.so"))
 hog.cu_hog_launch_lds.argtypes = [ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
 dev = torch.device("cuda", 0)
