@@ -94,8 +94,9 @@ def test_one_rank_rccl_full_size_buckets_leave_during_backward(tmp_path):
             assert np.array_equal(z[k], z["plain/" + k[2:]]), k
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("prec", ["fp32", "bf16", "f16"])
 def test_two_ranks_gloo_stock_ddp_equals_mean_of_plain_gradients(tmp_path, prec):
+    """(f16: every node of the chain takes the loss scale out of its own parameters' gradients before it hands them over.)"""
     z = _launch(tmp_path, 2, "gloo", "tiny", prec)
     for r in range(2):
         _check_hand_over(z[r], f"tiny_gloo_{prec}")
