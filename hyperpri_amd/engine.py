@@ -379,6 +379,7 @@ class Tape:
         self.delivered: set = set()                 # segmented tape: parameters whose gradient has left with an earlier slice
         self.done_to: Optional[int] = None          # segmented tape: the backward has run down to this node index (a slice's node runs one stage ahead)
         self.gscale = 1.0                           # half-precision mode: the power of two the head multiplies into the gradient (out_conv)
+        self._unscale: List[torch.Tensor] = []      # ... and the sunk gradients that still carry it (unscaled where their bucket is handed over)
 
     def note_params(self, *params: Optional[torch.Tensor]) -> None:
         """Called by an op while it records its backward node: it will contribute to these parameters' gradients.  A
@@ -433,6 +434,11 @@ class Tape:
         self.param_grads[id(p)] = g
         return g, 0
 
+    def _flush_unscale(self) -> None:
+        if self._unscale:
+            scale_tensors_(self._unscale, 1.0 / self.gscale)
+            self._unscale.clear()
+
     def backward(self, lo: int = 0, hi: Optional[int] = None) -> None:
         """Run the recorded nodes ``[lo, hi)`` in reverse.  The whole tape by default; a segmented network (autograd.run_segmented:
         several chained autograd nodes sharing this tape) runs one slice per node, last slice first, and the bookkeeping is
@@ -453,8 +459,10 @@ class Tape:
                     continue                                # not in a bucket, or another node still adds to this gradient
                 # a bucket's all-reduce orders itself behind the CURRENT stream: before the hand-over that completes a
                 # bucket, the main stream waits for the weight gradients still running on the second one
-                if self.gscale != 1.0:              # half-precision mode: the loss scale leaves the gradient before its bucket does
-                    scale_tensors_([self.param_grads[pid]], 1.0 / self.gscale)
+                # half-precision mode: the loss scale leaves the gradient before its bucket does.  The gradient may still be in flight
+                # on the second stream, so the unscale runs where the hand-over runs: on the stream that has waited for both.
+                if self.gscale != 1.0:
+                    self._unscale.append(self.param_grads[pid])
                 if self.used_side and getattr(sink, "completes_bucket", lambda q: True)(p):
                     # neither compute stream is held up: a third stream waits for both and hands the bucket over
                     dev = p.device
@@ -462,8 +470,11 @@ class Tape:
                     iss.wait_stream(torch.cuda.current_stream(dev))
                     iss.wait_stream(_side(dev))
                     with torch.cuda.stream(iss):
+                        self._flush_unscale()
                         sink.ready(p)
                 else:
+                    if not self.used_side:
+                        self._flush_unscale()
                     sink.ready(p)
         if lo > 0:
             return
@@ -474,15 +485,27 @@ class Tape:
             for pid, left in self.uses.items():
                 p = self.sunk.get(pid)
                 if p is not None and left > 0 and pid in self.param_grads:
+                    if self.gscale != 1.0:
+                        self._unscale.append(self.param_grads[pid])
                     if self.used_side:
                         dev = p.device
                         iss = _issue_stream(dev)
                         iss.wait_stream(torch.cuda.current_stream(dev))
                         iss.wait_stream(_side(dev))
                         with torch.cuda.stream(iss):
+                            self._flush_unscale()
                             sink.ready(p)
                     else:
+                        self._flush_unscale()
                         sink.ready(p)
+        if self._unscale:                           # (a bucket that never completes: finish() zeroes what did not land, the rest is unscaled here)
+            dev = self._unscale[0].device
+            iss = _issue_stream(dev)
+            iss.wait_stream(torch.cuda.current_stream(dev))
+            iss.wait_stream(_side(dev))
+            with torch.cuda.stream(iss):
+                self._flush_unscale()
+            torch.cuda.current_stream(dev).wait_stream(iss)
         self.nodes.clear()
         self.keep.clear()
         self.uses.clear()

@@ -1,5 +1,5 @@
 """Child process of tests/test_gpu_ddp_sink.py::test_bucket_hand_over_is_ordered_behind_both_compute_streams (not collected by
-pytest).    python tests/_ddp_order_rank.py <port>
+pytest).    python tests/_ddp_order_rank.py <port> [precision]
 
 One rank, GradSync(force=True): the collective is replaced by ``flat.mul_(2)`` on a stream of its own that is ordered only behind
 the stream current at the call (ProcessGroupNCCL's contract).  Gradients must be exactly twice the plain-loop gradients."""
@@ -32,6 +32,8 @@ def main():
     shapes = OrderedDict((k, tuple(v.shape)) for k, v in net.state_dict().items())
     net.load_state_dict(O.synth_state_dict(shapes))
     net = net.to(dev).train()
+    if len(sys.argv) > 2 and sys.argv[2] != "fp32":
+        H.set_precision(net, sys.argv[2])       # (f16: the loss scale leaves each gradient on the stream that hands its bucket over)
     x = u(1235, (2, 1, 6, 144, 200)).to(dev)
     m = (u(4321, (2, 1, 144, 200)) > 0.9).float().to(dev)
     torch.nn.BCEWithLogitsLoss()(net(x), m).backward()

@@ -35,7 +35,7 @@ def _oracle_grads(rank):
     return loss, grads
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("prec", ["fp32", "bf16", "f16"])
 def test_two_ranks_engine_sink_equals_mean_of_oracle_gradients(tmp_path, prec):
     """(bf16: BASELINE config 4's arithmetic under DDP -- the plane kernels write the weight gradients into the buckets from the
     second stream; the same control flow and the same bit-equality between ranks, values in the bf16 band around the oracle mean.)"""
@@ -66,7 +66,7 @@ def test_two_ranks_engine_sink_equals_mean_of_oracle_gradients(tmp_path, prec):
         assert len(z[r]["issue_to_finish_ms"]) == nb          # overlap_ms(): one issue event per bucket
     # ---- values: identical on both ranks, and the mean of the per-rank oracle gradients ----
     ora = [_oracle_grads(r) for r in range(world)]
-    tol_loss, tol_g = (1e-5, 2e-2) if prec == "fp32" else (5e-3, 0.7)
+    tol_loss, tol_g = {"fp32": (1e-5, 2e-2), "bf16": (5e-3, 0.7), "f16": (1e-3, 0.7)}[prec]
     for r in range(world):
         assert abs(float(z[r]["loss0"]) - ora[r][0]) < tol_loss
     # ---- the gate: every reduced gradient equals the mean of the two ranks' PLAIN-loop HIP gradients,
@@ -101,14 +101,16 @@ def test_two_ranks_engine_sink_equals_mean_of_oracle_gradients(tmp_path, prec):
 
 
 
-def test_bucket_hand_over_is_ordered_behind_both_compute_streams():
+@pytest.mark.parametrize("prec", ["fp32", "bf16", "f16"])
+def test_bucket_hand_over_is_ordered_behind_both_compute_streams(prec):
     """an ordering test that is sensitive with ONE rank (tests/_ddp_order_rank.py, a fresh child process so
     that GPU_MAX_HW_QUEUES=8 holds and the weight-gradient stream is live under the sink).  The collective is replaced by an
     in-place ``mul_(2)`` launched on a stream of its own that waits only for what a c10d collective waits for -- the stream that is
     current when ``GradSync._issue`` calls it.  Every gradient must come out exactly 2x the plain-loop gradient: a weight-gradient
-    kernel still running on the second stream when its bucket is handed over (a missing join) lands after the doubling."""
+    kernel still running on the second stream when its bucket is handed over (a missing join) lands after the doubling.  (f16: the
+    head's loss scale is taken out of each gradient on the hand-over stream, behind the same join.)"""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4", GPU_MAX_HW_QUEUES="8")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_ddp_order_rank.py"), str(_free_port())], env=env,
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_ddp_order_rank.py"), str(_free_port()), prec], env=env,
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=420)
     assert r.returncode == 0, r.stdout[-3000:]
     assert "ORDER-OK" in r.stdout, r.stdout[-2000:]
