@@ -17,6 +17,7 @@ from typing import Callable, List, Optional, Sequence
 import torch
 
 from . import _lib
+from . import engine as _E
 from .engine import Act, Tape, _require_cuda, join_side, scale_tensors_
 
 
@@ -208,9 +209,13 @@ class _HipFn(torch.autograd.Function):
         else:
             tape = Tape(record)
         acts: List[Act] = []
+        raw_ok = input_planes == _E.INPUT_RAW_OK       # the program's first operation may read the caller's NCHW tensor itself
+        if raw_ok:
+            input_planes = -1
         for t in inputs:
             _require_cuda(t, "input tensor")
-            acts.append(Act.from_tensor(_as4d(t), input_planes))
+            lazy = Act.raw_nchw(_as4d(t), input_planes) if (raw_ok and not record and seg is None) else None
+            acts.append(lazy if lazy is not None else Act.from_tensor(_as4d(t), input_planes))
         lo = len(tape.nodes)
         out = program(tape, acts, need[:n_in])
         ctx.slice = (lo, len(tape.nodes), seg.ahead()) if seg is not None else None

@@ -21,7 +21,7 @@ LIB = os.path.join(LIBDIR, "libhyperpri_hip_diag.so" if DIAG else "libhyperpri_h
 # The product is TWO libraries built from the same sources: libhyperpri_hip.so (16-bit type of the plane paths = bf16: precision modes
 # fp32 / bf16 / bf16x3 / bf16x6) and libhyperpri_hip_f16.so (-DHPRI_H16_F16: IEEE half, precision mode "f16"; csrc/common.h).
 LIB_F16 = os.path.join(LIBDIR, "libhyperpri_hip_f16.so")
-SOURCES = ["api.cpp", "conv_fwd.hip", *(["conv_bf16v2.hip"] if DIAG else []), "conv_bf16v3.hip", "gemm_bf16v3.hip", "gemm_f32v2.hip", "wgrad_bf16v3.hip", "conv_wino.hip", "conv_wino4.hip", "conv_wgrad.hip", "conv_wgrad_bf16v2.hip", "pack.hip", "bn.hip", "elementwise.hip", "step.hip", "ingest.hip"]
+SOURCES = ["api.cpp", "conv_fwd.hip", *(["conv_bf16v2.hip"] if DIAG else []), "conv_bf16v3.hip", "gemm_bf16v3.hip", "gemm_f32v2.hip", "wgrad_bf16v3.hip", "conv_wino.hip", "conv_wino4.hip", "conv_wgrad.hip", "conv_wgrad_bf16v2.hip", "pack.hip", "bn.hip", "elementwise.hip", "step.hip", "ingest.hip", "conv_ingest.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", *(["-DHPRI_DIAG_KERNELS"] if DIAG else [])]
 
 

@@ -92,10 +92,12 @@ typedef __amdgpu_buffer_rsrc_t hpri_rsrc_t;
 #define HPRI_MAKE_RSRC(ptr_, bytes_) __builtin_amdgcn_make_buffer_rsrc((void*)(ptr_), 0, (int)(bytes_), 0x00020000)
 #define HPRI_LDS_DMA16(rs_, lds_, voff_, soff_) \
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_, (__attribute__((address_space(3))) void*)(lds_), 16, voff_, soff_, 0, 0)
+#define HPRI_BUFFER_LOAD_F32(rs_, voff_, soff_) __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_, voff_, soff_, 0))
 #else
 typedef int hpri_rsrc_t;
 #define HPRI_MAKE_RSRC(ptr_, bytes_) 0
 #define HPRI_LDS_DMA16(rs_, lds_, voff_, soff_) ((void)(rs_))
+#define HPRI_BUFFER_LOAD_F32(rs_, voff_, soff_) 0.f
 #endif
 
 // ---- item queues of the persistent kernels (conv_bf16v3, gemm_bf16v3, gemm_f32v2) ----------------------------------------------

@@ -99,7 +99,7 @@ class Act:
 
     Invariant: channels [C, cw) (cw = C rounded up to 8) exist inside the stride and hold zeros, so
     consumers may run their K loop over ``cw`` channels."""
-    __slots__ = ("buf", "N", "H", "W", "C", "cs", "coff", "pl", "parent", "f32_valid", "want_pl", "pl_part", "colsum_req", "b16", "bn_src", "cat_pl", "up_slice", "yr16", "skip_g16")
+    __slots__ = ("buf", "N", "H", "W", "C", "cs", "coff", "pl", "parent", "f32_valid", "want_pl", "pl_part", "colsum_req", "b16", "bn_src", "cat_pl", "up_slice", "yr16", "skip_g16", "raw")
 
     def __init__(self, buf: torch.Tensor, N: int, H: int, W: int, C: int, cs: int, coff: int = 0):
         self.buf, self.N, self.H, self.W, self.C, self.cs, self.coff = buf, N, H, W, C, cs, coff
@@ -115,6 +115,7 @@ class Act:
         self.bn_src = None                      # (pre-BN Act, statistics, relu): this tensor is BN(+ReLU) of that one and has ONE consumer
         self.yr16 = False                       # the pre-BN tensor behind this one is stored as bf16 (its BatchNorm backward can read a bf16 gradient)
         self.skip_g16 = False                   # a decoder concat whose skip half's gradient is stored as bf16 rows (SKIP_GRAD_BF16)
+        self.raw = None                         # (caller's NCHW tensor, planes for the layout pass): not laid out yet (Act.raw_nchw)
 
     @property
     def cw(self) -> int:
@@ -190,6 +191,23 @@ class Act:
         else:
             _lib.call("hpri_nchw_to_nhwc", _p(t), a.ptr, N, C, H * W, a.cs, 0, a.cw, _stream())
         return a
+
+    @staticmethod
+    def raw_nchw(t: torch.Tensor, npl: int) -> Optional["Act"]:
+        """The caller's contiguous (N,C,H,W) fp32 tensor as an Act that has NOT been laid out: the predict path's first 3x3 layer
+        reads it as it is (``_conv_ingest_eval``, csrc/conv_ingest.hip); any other reader calls ``materialize()`` = the layout pass
+        ``from_tensor`` would have run.  None: not eligible (not contiguous NCHW, too few channels to matter, or > 2 GiB per image)."""
+        if not (INGEST_FUSED and t.dim() == 4 and t.dtype == torch.float32 and t.is_contiguous() and t.data_ptr() % 4 == 0):
+            return None
+        N, C, H, W = t.shape
+        if C < 32 or H * W * C * 4 >= 0x7FFFFF00 or min(N, H, W) < 1:
+            return None
+        a = Act(t, N, H, W, C, _rup(C, 8), 0)
+        a.raw, a.f32_valid = (t, npl), False
+        return a
+
+    def materialize(self) -> "Act":
+        return Act.from_tensor(*self.raw) if self.raw is not None else self
 
     def to_nchw(self) -> torch.Tensor:
         out = torch.empty((self.N, self.C, self.H, self.W), dtype=torch.float32, device=self.buf.device)
@@ -303,12 +321,23 @@ def _pl_args(pl: Optional[Planes]):
     return _p(pl.buf), pl.plane, pl.cs, pl.coff, pl.cw, pl.npl
 
 
-def input_planes_for(module) -> int:
-    """Planes the input layout pass should write for a network whose first layer is a 3x3 convolution."""
+# Predict path of the 16-bit modes: the first 3x3 layer reads the caller's NCHW cube itself (csrc/conv_ingest.hip) instead of planes
+# written by a layout pass.  ``INPUT_RAW_OK`` as a program's ``input_planes``: as -1 (one plane, no fp32 copy), and the program's first
+# operation is a ``conv_bn_relu`` that may be handed the raw tensor when nothing is recorded (autograd._forward_impl).
+INGEST_FUSED = True
+INGEST_LAUNCHES = 0
+INPUT_RAW_OK = -3
+
+
+def input_planes_for(module, raw_ok: bool = False) -> int:
+    """Planes the input layout pass should write for a network whose first layer is a 3x3 convolution (``raw_ok``: that layer is the
+    program's first operation, a ``conv_bn_relu`` with one reader: see INPUT_RAW_OK)."""
     prec = getattr(module, "hpri_precision", None) or DEFAULT_PRECISION
     if not (PLANE_CONV and PLANE_PRODUCERS and prec == "bf16"):
         return 0
-    return -1 if (PLANES_ONLY_ACT and PLANE_WGRAD) else 1      # -1: one plane and NO fp32 copy (Act.from_tensor)
+    if not (PLANES_ONLY_ACT and PLANE_WGRAD):
+        return 1
+    return INPUT_RAW_OK if (raw_ok and INGEST_FUSED) else -1      # -1: one plane and NO fp32 copy (Act.from_tensor)
 
 
 def planes_of(x: Act, npl: int = 1) -> Planes:
@@ -926,6 +955,13 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
     prec = precision or DEFAULT_PRECISION
     if prec not in PRECISIONS:
         raise RuntimeError(f"hyperpri_amd: unknown precision {prec!r}; choose from {PRECISIONS}")
+    if x.raw is not None:
+        inner = max(next_cout, 1 if (head_next and HEAD_PLANES) else 0)
+        if (bn is not None and not train and not tape.record and FOLD_EVAL_BN and prec == "bf16" and ks == 3 and groups == 1 and room == 0
+                and inner > 0 and cout % 32 == 0 and PLANE_CONV and PLANES_ONLY_ACT and PLANE_PRODUCERS and not cat_room
+                and cat_into is None and k_gap is None and x.H * x.W * _rup(max(cout, inner), 32) * 2 < 0x7FFFFF00):
+            return _conv_ingest_eval(x, weight, bias, bn, cin, cout, relu)
+        x = x.materialize()
     if bn is None and relu and relu_without_bn:
         # (``bn=None`` alone is the bare convolution / linear layer, as the kernel-level tests use it)
         # Linear / Conv -> ReLU without a BatchNorm (SpectralUNET(bnorm=False), models.py:105-110): the ReLU and its backward are the
@@ -1318,26 +1354,14 @@ FUSE_BN_REDUCE = FUSIONS
 # (hpri_colsum_from_stats) instead of a pass over that tensor (hpri_col_sum).  (HPRI_FUSIONS.)
 COLSUM_FROM_STATS = FUSIONS
 FOLD_EVAL_BN = True   # inference only (no tape): conv + eval-mode BN + ReLU as ONE kernel with BN folded into w and b
-FOLD_LAUNCHES = 0     # folded conv+BN+ReLU stages executed (tests assert that the predict path really takes them)
-
-
-def _conv_folded_eval(x: Act, weight: torch.Tensor, bias: Optional[torch.Tensor], bn: BNRef, ks: int, cin: int, cout: int,
-                      relu: bool, prec: str = "fp32", room: int = 0, inner: int = 0) -> Act:
-    """Eval-mode Conv -> BatchNorm -> ReLU (running statistics) without the normalise pass: w' = w*gamma/sqrt(var+eps),
-    b' = (b-mean)*gamma/sqrt(var+eps)+beta, ReLU in the conv epilogue.  Used when nothing is recorded for backward
-    (torch.no_grad / inference_mode: PLTrainer.py:530,626).  ``inner`` > 0: the result is the inner tensor of a DoubleConv (``inner`` = the
-    channels of the convolution that reads it), or the head's input (1); in the bf16
-    mode the plane kernel then writes it as bf16 rows, which ARE the next convolution's planes (no fp32 copy, no conversion pass)."""
-    global FOLD_LAUNCHES
-    FOLD_LAUNCHES += 1
-    dev = x.buf.device
+def _folded_pack(weight: torch.Tensor, bias: Optional[torch.Tensor], bn: BNRef, ks: int, cin: int, cout: int, prec: str, wino: bool):
+    """(packed weights with the eval-mode BatchNorm's scale folded in, [scale | bias'] vector) of a folded stage; cached per weight,
+    precision and BatchNorm state."""
+    dev = weight.device
     T = ks * ks
     cout_pad = _rup(cout, 64)
     lowp = prec in LOWP
     split = _SPLIT.get(prec, 0)
-    wino = prec == "fp32" and ks == 3 and _wino_ok(x, cout)
-    if not x.f32_valid and not (lowp and PLANE_CONV and prec == "bf16" and ks == 3 and x.pl is not None and _planes_fit(x, max(cin, cout))):
-        raise RuntimeError("hyperpri_amd: internal error: a planes-only activation reached a kernel that reads fp32")
 
     def build():
         global PACK_LAUNCHES
@@ -1364,8 +1388,56 @@ def _conv_folded_eval(x: Act, weight: torch.Tensor, bias: Optional[torch.Tensor]
             return (t.data_ptr(), -1)
     bn_state = (_BN_EPOCH, ver(bn.running_mean), ver(bn.running_var), ver(bn.weight), ver(bn.bias),
                 None if bias is None else ver(bias))
-    wp, fold = _cached_pack(weight, ("fold", prec, ks, "wino4" if wino else False), build, extra=bn_state,
-                            also=(bn.running_mean, bn.running_var, bn.weight, bn.bias, bias))
+    return _cached_pack(weight, ("fold", prec, ks, "wino4" if wino else False), build, extra=bn_state,
+                        also=(bn.running_mean, bn.running_var, bn.weight, bn.bias, bias))
+
+
+def _conv_ingest_eval(x: Act, weight: torch.Tensor, bias: Optional[torch.Tensor], bn: BNRef, cin: int, cout: int, relu: bool) -> Act:
+    """First-layer fused ingest of the predict path (16-bit modes; models.py:169,215-216): eval-mode Conv3x3 -> BatchNorm -> ReLU
+    straight from the caller's NC(D)HW fp32 cube (``x.raw``), result as 16-bit rows = the next convolution's planes.  The same folded
+    weights and the same accumulation order as ``_conv_folded_eval`` behind a layout pass: bit-identical output, without the pass."""
+    global FOLD_LAUNCHES, INGEST_LAUNCHES
+    FOLD_LAUNCHES += 1
+    INGEST_LAUNCHES += 1
+    t = x.raw[0]
+    dev = t.device
+    cout_pad = _rup(cout, 64)
+    wp, fold = _folded_pack(weight, bias, bn, 3, cin, cout, "bf16", False)
+    rows = torch.empty(x.P * cout, dtype=torch.bfloat16, device=dev)
+    tag = "conv_ingest_h16<3,256x64>"
+    if SHAPE_TAGS:
+        tag += f" N{x.N} {x.H}x{x.W} C{cin} N{cout}"
+    with _timed(tag, 2.0 * x.P * 9 * cin * cout):
+        _lib.call("hpri_conv3x3_ingest_h16", _p(t), _p(wp), _p(fold[cout:]), _p(rows), cout, 0, x.N, cin, x.H, x.W, cout, cout_pad,
+                  1 if relu else 0, _stream())
+    y = Act(torch.empty(8, dtype=torch.float32, device=dev), x.N, x.H, x.W, cout, _rup(cout, 8), 0)
+    y.f32_valid = False
+    y.pl = Planes(rows, x.P * cout, cout, 0, 1)
+    return y
+
+
+FOLD_LAUNCHES = 0     # folded conv+BN+ReLU stages executed (tests assert that the predict path really takes them)
+
+
+def _conv_folded_eval(x: Act, weight: torch.Tensor, bias: Optional[torch.Tensor], bn: BNRef, ks: int, cin: int, cout: int,
+                      relu: bool, prec: str = "fp32", room: int = 0, inner: int = 0) -> Act:
+    """Eval-mode Conv -> BatchNorm -> ReLU (running statistics) without the normalise pass: w' = w*gamma/sqrt(var+eps),
+    b' = (b-mean)*gamma/sqrt(var+eps)+beta, ReLU in the conv epilogue.  Used when nothing is recorded for backward
+    (torch.no_grad / inference_mode: PLTrainer.py:530,626).  ``inner`` > 0: the result is the inner tensor of a DoubleConv (``inner`` = the
+    channels of the convolution that reads it), or the head's input (1); in the bf16
+    mode the plane kernel then writes it as bf16 rows, which ARE the next convolution's planes (no fp32 copy, no conversion pass)."""
+    global FOLD_LAUNCHES
+    FOLD_LAUNCHES += 1
+    dev = x.buf.device
+    T = ks * ks
+    cout_pad = _rup(cout, 64)
+    lowp = prec in LOWP
+    split = _SPLIT.get(prec, 0)
+    wino = prec == "fp32" and ks == 3 and _wino_ok(x, cout)
+    if not x.f32_valid and not (lowp and PLANE_CONV and prec == "bf16" and ks == 3 and x.pl is not None and _planes_fit(x, max(cin, cout))):
+        raise RuntimeError("hyperpri_amd: internal error: a planes-only activation reached a kernel that reads fp32")
+
+    wp, fold = _folded_pack(weight, bias, bn, ks, cin, cout, prec, wino)
     fbias = fold[cout:]
     y = Act.new_with_room(x.N, x.H, x.W, cout, room, dev)
     if wino:

@@ -319,7 +319,7 @@ class CubeNET(torch.nn.Module):
                 yield
                 y = yield from self._up4_gen(tape, y, x1, head_next=True)
                 return self.outc._ops(tape, y)
-            logits = run_staged(prog, [x], _stage_params(self), self.fused_tape, input_planes=E.input_planes_for(self), name="cubenet",
+            logits = run_staged(prog, [x], _stage_params(self), self.fused_tape, input_planes=E.input_planes_for(self, raw_ok=True), name="cubenet",
                                 lib_kind=getattr(self, "hpri_h16", None))
         else:
             x1 = self._stem(x)

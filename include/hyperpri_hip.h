@@ -194,6 +194,16 @@ int hpri_to_planes(const float* x, int cs, int coff, void* planes, long long pla
 
 int hpri_splitk_finish(const float* ws, int ksplit, int Cout_pad, const float* bias, float* y, int y_cs, int y_coff,
                        float* stats, int N, int HW, int Cout, int y_cw, int accumulate, int relu, hipStream_t stream);
+/* First-layer fused ingest (conv_ingest.hip; predict path of the 16-bit modes).  Replaces, for nn.Conv3d(1, F, (D,3,3), padding=(0,1,1)) on
+ * the caller's (N,1,D,H,W) cube -- reference models.py:169 (first_conv) as called at models.py:215-216 -- the pair layout pass
+ * (hpri_nchw_to_nhwc_pl) + hpri_conv_bf16v3: the 3x3 pad-1 convolution reads the contiguous fp32 NC(D)HW tensor `x` itself (C = D
+ * channels) and rounds it to the library's 16-bit type while staging.  `wp`: weights packed by hpri_pack_weight_bf16(_scaled)
+ * ([chunk][tap][Cout_pad][32], channels beyond C zero; eval-mode BatchNorm folded in by the caller: hpri_bn_fold), `bias` (may be
+ * null), `relu`; result as 16-bit rows y + pixel * y_cs + y_coff + channel (Cout a multiple of 4, y 8-byte aligned, y_cs / y_coff
+ * multiples of 4) = the planes the next convolution stages.  One image of x must stay below 2 GiB.  Same accumulation order as
+ * hpri_conv_bf16v3: bit-identical to the pair it replaces. */
+int hpri_conv3x3_ingest_h16(const float* x, const void* wp, const float* bias, void* y, int y_cs, int y_coff, int N, int C, int H,
+                            int W, int Cout, int Cout_pad, int relu, hipStream_t stream);
 /* Third form of the plane convolution (conv_bf16v3.hip): 4-wave workgroups of 256 pixels x 64 channels, TWO per CU (one's
  * prologue / store + statistics epilogue runs under the other's MFMAs), v_mfma_f32_16x16x32_bf16 with the weights as the A
  * operand (a lane's accumulator registers are consecutive channels of one pixel: 16-byte stores without an LDS transpose).
