@@ -34,4 +34,5 @@ else
   for k in bf16 f16; do timeout -k 10 120 python tools/ingest_conv_bench.py $k 2>/dev/null; done > $G/${TAG}_ingest_conv.jsonl; echo "ingest conv rc $?"
   timeout -k 10 300 python bench.py --force-sync --stock-ddp --no-configs --no-cpu-baseline > $G/${TAG}_force_sync_stock.json 2> $G/${TAG}_force_sync_stock.err; echo "force-sync bench rc $?"
   bash tools/prof_c3.sh bf16 ${TAG}_c3_bf16_final > /dev/null 2>&1; echo "c3 profile rc $?"
+  bash tools/pmc_cmd.sh ${TAG}ig tools/ingest_conv_bench.py bf16 > $G/${TAG}_ig_pmc.log 2>&1; echo "ingest conv pmc rc $?"    # then: python tools/pmc_traffic.py gpurun_out/${TAG}ig ${TAG}_ingest_conv
 fi
