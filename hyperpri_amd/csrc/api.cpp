@@ -18,7 +18,8 @@ extern "C" int hpri_version(void) { return 100; }  // 0.1.0
 //   wgrad_xcd_min_tiles   (C, N) tiles from which the weight-gradient kernels use the XCD-aware grid;
 //                         0 = never                                                          (HPRI_WGRAD_XCD_MIN, 128)
 //   wgrad_xcd_min_strips  ... and only with at least this many 64-pixel strips                (HPRI_WGRAD_XCD_STRIPS, 2048)
-//   bf16v3_tile_width     conv_bf16v3 tile shape: 0 = by padding cost (32 x 8 first), 16 = 16 x 16 tiles only    (HPRI_V3_TILE_WIDTH, 0)
+//   bf16v3_tile_width     conv_bf16v3 tile shapes: 0 = by padding cost (8 x 32 tiles first, the columns left over in 16 x 16 tiles and at
+//                         most one column of 32 x 8 tiles), 1 = without the 32 x 8 column (round 4), 16 = 16 x 16 tiles only    (HPRI_V3_TILE_WIDTH, 0)
 //   bn_wide_cq            BatchNorm / reduction kernels: 1 = tensors wider than 1024 channels take whole 1024-channel runs of one
 //                         pixel per workgroup, 0 = 256-channel columns of four pixels                         (HPRI_BN_WIDE_CQ, 1)
 //   wgrad_cu_reserve      compute units the fp32 Winograd weight gradient leaves free: its workgroups hold a whole CU each (104 KB of

@@ -814,25 +814,32 @@ __global__ __launch_bounds__(256, 2) void conv_bf16v3_kernel(ConvV3Args a) {
 }
 
 // ---- host side -------------------------------------------------------------------------------------------------------
-// column bands of tile width 32 / 16 (tile height 8 / 16: 256 pixels either way), as conv_bf16v2.hip's; 16 is the narrowest
-// tile (the fragment swizzle is conflict-free for runs of 16 consecutive halo pixels)
+// column bands of tile width 32 / 16 / 8 (tile height 8 / 16 / 32: 256 pixels either way), chosen by padding cost.  The fragment
+// swizzle is conflict-free for runs of 16 consecutive halo pixels; an 8-wide tile reads two runs of 8 (possibly 2-way conflicted), so
+// at most ONE column of them is used, for a remainder of at most 8 columns -- round 5: W = 968 is 30 x 32 + 8, and with the last 8
+// columns in 16-wide tiles the benched layer had 4636 items = 9.05 rounds of the 512 resident workgroups (a tenth round for 28 items);
+// 32 x 8 tiles there make it 4598 = 8.98 rounds.  Plan option bf16v3_tile_width: 0 = this, 1 = no 8-wide column, 16 = 16 x 16 only.
 struct V3Segs { int nseg, tiles_img, twl[V3_MAXSEG], xbeg[V3_MAXSEG], ntx[V3_MAXSEG], first[V3_MAXSEG]; };
 static V3Segs v3_segments(int H, int W) {
   auto th = [&](int tw) { return 256 / tw; };
   auto slots = [&](int tw, int ntx) { return (long long)hpri_cdiv(H, th(tw)) * th(tw) * tw * ntx; };
   V3Segs best{};
   long long best_cost = -1;
-  // candidates: n32 columns of 32-wide tiles, the rest in 16-wide tiles
-  const int max32 = hpri_option(3) == 16 ? 0 : hpri_cdiv(W, 32);
+  const int opt = hpri_option(3);
+  const bool allow8 = opt != 1 && opt != 16;
+  // candidates: n32 columns of 32-wide tiles, the rest in 16-wide tiles (the last of them 8 wide when it holds at most 8 columns)
+  const int max32 = opt == 16 ? 0 : hpri_cdiv(W, 32);
   for (int n32 = 0; n32 <= max32; ++n32) {
     const int rem = W - n32 * 32;
-    const int n16 = rem > 0 ? hpri_cdiv(rem, 16) : 0;
+    int n16 = rem > 0 ? hpri_cdiv(rem, 16) : 0, n8 = 0;
     if (rem <= 0 && n32 * 32 - W >= 32) continue;
-    const long long cost = (n32 ? slots(32, n32) : 0) + (n16 ? slots(16, n16) : 0);
-    if (best_cost < 0 || cost < best_cost || (cost == best_cost && n16 == 0)) {
+    if (allow8 && n16 > 0 && rem - (n16 - 1) * 16 <= 8) { n16 -= 1; n8 = 1; }
+    const long long cost = (n32 ? slots(32, n32) : 0) + (n16 ? slots(16, n16) : 0) + (n8 ? slots(8, n8) : 0);
+    if (best_cost < 0 || cost < best_cost || (cost == best_cost && n16 + n8 == 0)) {
       V3Segs g{};
       if (n32) { g.twl[g.nseg] = 5; g.xbeg[g.nseg] = 0; g.ntx[g.nseg] = n32; g.nseg++; }
       if (n16) { g.twl[g.nseg] = 4; g.xbeg[g.nseg] = n32 * 32; g.ntx[g.nseg] = n16; g.nseg++; }
+      if (n8) { g.twl[g.nseg] = 3; g.xbeg[g.nseg] = n32 * 32 + n16 * 16; g.ntx[g.nseg] = 1; g.nseg++; }
       best = g; best_cost = cost;
     }
   }

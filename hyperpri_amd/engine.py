@@ -64,8 +64,13 @@ def _stream() -> ctypes.c_void_p:
 
 
 def set_plan_option(name: str, value: int) -> None:
-    """A launch-plan option of the HIP library (include/hyperpri_hip.h: hpri_set_option), e.g. "wgrad_cu_reserve"."""
-    _lib.call("hpri_set_option", name.encode(), int(value))
+    """A launch-plan option of the HIP library (include/hyperpri_hip.h: hpri_set_option), e.g. "wgrad_cu_reserve"; set in both builds
+    of the library (the f16 mode's launches go to the half-precision one, which keeps its own options)."""
+    for kind in (None, "f16"):
+        if kind == "f16" and not os.path.exists(_lib.LIB_F16_PATH):
+            continue
+        with _lib.using(kind):
+            _lib.call("hpri_set_option", name.encode(), int(value))
 
 
 def scale_tensors_(tensors: List[torch.Tensor], scale: float) -> None:
