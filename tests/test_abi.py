@@ -111,10 +111,12 @@ def test_plane_conv_v3_plan_matches_a_python_restatement_of_its_tiling():
             rem = W - n32 * 32
             if rem <= 0 and n32 * 32 - W >= 32:
                 continue
-            n16 = cdiv(rem, 16) if rem > 0 else 0
-            cost = cdiv(H, 8) * 8 * 32 * n32 + cdiv(H, 16) * 16 * 16 * n16
-            t = cdiv(H, 8) * n32 + cdiv(H, 16) * n16
-            if best is None or cost < best[0] or (cost == best[0] and n16 == 0):
+            n16, n8 = (cdiv(rem, 16) if rem > 0 else 0), 0
+            if n16 > 0 and rem - (n16 - 1) * 16 <= 8:        # (round 5: at most 8 columns left for the last tile column: 32 x 8 tiles)
+                n16, n8 = n16 - 1, 1
+            cost = cdiv(H, 8) * 8 * 32 * n32 + cdiv(H, 16) * 16 * 16 * n16 + cdiv(H, 32) * 32 * 8 * n8
+            t = cdiv(H, 8) * n32 + cdiv(H, 16) * n16 + cdiv(H, 32) * n8
+            if best is None or cost < best[0] or (cost == best[0] and n16 + n8 == 0):
                 best = (cost, t)
         return best[1]
     for (N, H, W, cin_pad, cout_pad) in [(2, 608, 968, 256, 64), (2, 304, 484, 128, 128), (2, 152, 242, 512, 256), (1, 76, 121, 1024, 512),
