@@ -149,6 +149,18 @@ def test_cubenet_predict_takes_the_fused_ingest_and_changes_nothing(prec):
     # training-mode and grad-mode forwards never see the raw cube
     net.train()
     n1 = E.INGEST_LAUNCHES
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    with torch.no_grad():                        # no tape, but BatchNorm in training mode: batch statistics, nothing to fold
+        lt = net(x)
+    net.load_state_dict(sd)
+    E.INGEST_FUSED = False
+    try:
+        with torch.no_grad():
+            lt0 = net(x)
+    finally:
+        E.INGEST_FUSED = True
+    assert E.INGEST_LAUNCHES == n1 and torch.equal(lt, lt0)
+    net.load_state_dict(sd)
     net(x).sum().backward()
     net.eval()
     net(x)                                       # eval, but gradients on: the tape records, so the layout pass runs
