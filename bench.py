@@ -16,6 +16,7 @@ import json
 import math
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -702,67 +703,6 @@ def main():
                                              "launches_per_step": v["launches"] // 2,
                                              "ms_per_step": round(v["total_ms"] / 2, 3)} for k, v in sorted(summ.items())}}
 
-    # ---- the reference's own N > 1 caller: the same step under STOCK torch DistributedDataParallel (Lightning strategy="ddp",
-    #      PLTrainer.py:434-442) instead of the GradSync sink -- the network runs as a chain of autograd nodes over one tape
-    #      (hyperpri_amd/autograd.py::run_staged) and the reducer's buckets leave during backward.  Reported beside `value`, never
-    #      as it.  Every rank takes part; the sink is removed first (one gradient consumer at a time).
-    stock_ddp = None
-    trace("stock DistributedDataParallel leg")
-    if use_pg and (world > 1 or args.stock_ddp) and not args.no_stock_ddp:
-        from torch.nn.parallel import DistributedDataParallel as DDP
-        from hyperpri_amd import autograd as HA
-        sync.remove()
-        sync = None
-        for p in net.parameters():
-            p.grad = None
-        ddp_net = DDP(net, device_ids=[dev_index], broadcast_buffers=False, gradient_as_bucket_view=True)
-
-        def ddp_step():
-            for p in net.parameters():
-                p.grad = None
-            lo = crit(ddp_net(x), mask)
-            lo.backward()
-            return lo
-        stock_ddp = {"wrapper": "torch.nn.parallel.DistributedDataParallel(net, device_ids=[rank's GPU], broadcast_buffers=False, "
-                                "gradient_as_bucket_view=True), 25 MiB buckets, backend " + ("gloo (REHEARSAL)" if one_gpu else "nccl (RCCL)"),
-                     "what": "forward + BCEWithLogits + backward under stock DDP; value = cubes of all ranks / max-over-ranks time"}
-        for mode in ("bf16", "fp32"):
-            HP.set_precision(net, mode)
-            for _ in range(1 if one_gpu else 6):          # (the reducer rebuilds its buckets in arrival order after the first step)
-                ddp_step()
-            fence()
-            nst = 1 if one_gpu else args.steps
-            tb = time.perf_counter()
-            for _ in range(nst):
-                lo = ddp_step()
-            fence()
-            dts = time.perf_counter() - tb
-            if world > 1:
-                t = torch.tensor([dts], dtype=torch.float64, device=dev)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                dts = float(t.item())
-            stock_ddp[mode] = {"value": round(world * BATCH * nst / dts, 4), "unit": "cubes/s", "steps": nst,
-                               "ms_per_step": round(dts / nst * 1e3, 3), "loss": round(float(lo.detach()), 6)}
-        stock_ddp["autograd_nodes_stages"] = list(HA.LAST_PLAN)
-        if plain_flat is not None:                       # fp32 ran last: its reduced gradients against the mean of the ranks' plain ones
-            ref = plain_flat.clone()
-            dist.all_reduce(ref, op=dist.ReduceOp.SUM)
-            ref.div_(world)
-            got = torch.cat([p.grad.detach().reshape(-1) for p in net.parameters()])
-            errs, off = [], 0
-            for p in net.parameters():
-                n = p.numel()
-                d = (got[off:off + n].double() - ref[off:off + n].double()).abs().max()
-                errs.append(d / ref[off:off + n].double().abs().max().clamp_min(1e-30))
-                off += n
-            mre = torch.stack(errs).max()
-            dist.all_reduce(mre, op=dist.ReduceOp.MAX)
-            stock_ddp["max_rel_err_vs_mean_of_plain_gradients"] = float(mre)
-            del ref, got
-        del ddp_net
-        for p in net.parameters():
-            p.grad = None
-
     # ---- north_star's named kernel: the 238->64 encoder conv (models.py:169) against the bf16 MFMA roofline ----
     first_conv = None
     if rank == 0 and not args.no_roofline:
@@ -819,9 +759,71 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline()
 
+    # ---- the reference's own N > 1 caller: the same step under STOCK torch DistributedDataParallel (Lightning strategy="ddp",
+    #      PLTrainer.py:434-442) instead of the GradSync sink -- the network runs as a chain of autograd nodes over one tape
+    #      (hyperpri_amd/autograd.py::run_staged) and the reducer's buckets leave during backward.  Reported beside `value`, never
+    #      as it.  Every rank takes part; the sink is removed first (one gradient consumer at a time).
+    def stock_ddp_leg():
+        nonlocal sync
+        from torch.nn.parallel import DistributedDataParallel as DDP
+        from hyperpri_amd import autograd as HA
+        sync.remove()
+        sync = None
+        for p in net.parameters():
+            p.grad = None
+        ddp_net = DDP(net, device_ids=[dev_index], broadcast_buffers=False, gradient_as_bucket_view=True)
+
+        def ddp_step():
+            for p in net.parameters():
+                p.grad = None
+            lo = crit(ddp_net(x), mask)
+            lo.backward()
+            return lo
+        stock_ddp = {"wrapper": "torch.nn.parallel.DistributedDataParallel(net, device_ids=[rank's GPU], broadcast_buffers=False, "
+                                "gradient_as_bucket_view=True), 25 MiB buckets, backend " + ("gloo (REHEARSAL)" if one_gpu else "nccl (RCCL)"),
+                     "what": "forward + BCEWithLogits + backward under stock DDP; value = cubes of all ranks / max-over-ranks time"}
+        for mode in ("bf16", "fp32"):
+            HP.set_precision(net, mode)
+            for _ in range(1 if one_gpu else 6):          # (the reducer rebuilds its buckets in arrival order after the first step)
+                ddp_step()
+            fence()
+            nst = 1 if one_gpu else args.steps
+            tb = time.perf_counter()
+            for _ in range(nst):
+                lo = ddp_step()
+            fence()
+            dts = time.perf_counter() - tb
+            if world > 1:
+                t = torch.tensor([dts], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dts = float(t.item())
+            stock_ddp[mode] = {"value": round(world * BATCH * nst / dts, 4), "unit": "cubes/s", "steps": nst,
+                               "ms_per_step": round(dts / nst * 1e3, 3), "loss": round(float(lo.detach()), 6)}
+        stock_ddp["autograd_nodes_stages"] = list(HA.LAST_PLAN)
+        if plain_flat is not None:                       # fp32 ran last: its reduced gradients against the mean of the ranks' plain ones
+            ref = plain_flat.clone()
+            dist.all_reduce(ref, op=dist.ReduceOp.SUM)
+            ref.div_(world)
+            got = torch.cat([p.grad.detach().reshape(-1) for p in net.parameters()])
+            errs, off = [], 0
+            for p in net.parameters():
+                n = p.numel()
+                d = (got[off:off + n].double() - ref[off:off + n].double()).abs().max()
+                errs.append(d / ref[off:off + n].double().abs().max().clamp_min(1e-30))
+                off += n
+            mre = torch.stack(errs).max()
+            dist.all_reduce(mre, op=dist.ReduceOp.MAX)
+            stock_ddp["max_rel_err_vs_mean_of_plain_gradients"] = float(mre)
+            del ref, got
+        del ddp_net
+        for p in net.parameters():
+            p.grad = None
+        return stock_ddp
+
     trace("rank-0 legs done; closing barrier")
     if use_pg:
         dist.barrier()
+    out = None
     if rank == 0:
         cubes = world * BATCH * args.steps
         value = cubes / dt
@@ -846,8 +848,30 @@ def main():
                                  "the fp32 path executes fewer multiplies than that (Winograd), so this can exceed the fp32 MFMA peak",
             "value_training_shaped": training_shaped,
             "roofline": roofline, "roofline_238to64": first_conv, "cpu_baseline": cpu, "optimizer_step": optimizer_step, "configs": configs, "bf16x6_mode": bf16x6_mode, "bf16x3_mode": bf16x3_mode, "bf16_mode": bf16_mode, "f16_mode": f16_mode,
-            "stock_ddp": stock_ddp,
+            "stock_ddp": None,
         }
+    # The stock-DDP leg runs LAST, when everything the contract asks for is measured and the line is assembled: it is the one part of an
+    # N > 1 run that no one-GPU box could rehearse over RCCL with more than one rank.  If it raises, or has not come back within two
+    # minutes (a rank that failed alone leaves its peers in a collective), rank 0 prints the line without it and every rank leaves.
+    if use_pg and (world > 1 or args.stock_ddp) and not args.no_stock_ddp and net is not None:
+        trace("stock DistributedDataParallel leg")
+
+        def give_up():
+            if rank == 0:
+                out["stock_ddp"] = {"error": "the leg did not finish within 120 s; the line above it is complete"}
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+        dog = threading.Timer(3600.0 if one_gpu else 120.0, give_up)
+        dog.daemon = True
+        dog.start()
+        try:
+            res = stock_ddp_leg()
+        except Exception as e:                   # noqa: BLE001 -- whatever it is, the measured line must still go out
+            res = {"error": repr(e)[:500]}
+        dog.cancel()
+        if rank == 0:
+            out["stock_ddp"] = res
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if use_pg:
         dist.destroy_process_group()

@@ -7,7 +7,7 @@ import ast
 import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-COLLECTIVE_NAMES = {"step", "fence", "timed_mode", "ddp_step"}                    # bare-name calls inside bench.main()
+COLLECTIVE_NAMES = {"step", "fence", "timed_mode", "ddp_step", "stock_ddp_leg"}                    # bare-name calls inside bench.main()
 COLLECTIVE_ATTRS = {("dist", "all_reduce"), ("dist", "barrier"), ("dist", "broadcast"), ("dist", "all_gather"), ("sync", "finish")}
 
 
