@@ -66,8 +66,15 @@ for prec in ("bf16", "f16", "fp32"):
         kern[arm] = {k: {"avg_ms": round(v["avg_ms"], 4), "tflops": round(v["tflops"], 1), "launches": v["launches"] // 3}
                      for k, v in summ.items() if "608x968" in k and ("C238" in k or "C256" in k)}
     engine.INGEST_FUSED = True
+    engine.enable_event_log(True)            # the whole forward, per kernel family (MFMA kernels only: the others carry no tag)
+    for _ in range(3):
+        fwd()
+    torch.cuda.synchronize()
+    whole = {k: {"ms_per_forward": round(v["total_ms"] / 3, 4), "launches": v["launches"] // 3, "tflops": round(v["tflops"], 1)}
+             for k, v in sorted(engine.event_log_summary().items(), key=lambda kv: -kv[1]["total_ms"])}
+    engine.enable_event_log(False)
     med = {k: sorted(v)[len(v) // 2] for k, v in times.items()}
     out["modes"][prec] = {"ms": {k: [round(t, 3) for t in v] for k, v in times.items()}, "median_ms": {k: round(v, 3) for k, v in med.items()},
                           "fused_over_pair": round(med["fused"] / med["pair"], 4), "logits_bit_identical": bool(torch.equal(logits["fused"], logits["pair"])),
-                          "ingest_launches_seen": engine.INGEST_LAUNCHES, "first_layer_kernels": kern}
+                          "ingest_launches_seen": engine.INGEST_LAUNCHES, "first_layer_kernels": kern, "mfma_kernels_of_the_fused_forward": whole}
 print(json.dumps(out, indent=1))
