@@ -975,7 +975,8 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
         bn, train = _identity_bn(cout, x.buf.device), False
     if bn is not None and not train and not tape.record and FOLD_EVAL_BN:
         return _conv_folded_eval(x, weight, bias, bn, ks, cin, cout, relu, prec, room,
-                                 inner=(max(next_cout, 1 if (head_next and HEAD_PLANES) else 0) if groups == 1 else 0))
+                                 inner=(max(next_cout, 1 if (head_next and HEAD_PLANES) else 0) if groups == 1 else 0),
+                                 out_planes=out_planes and groups == 1)
     c = types.SimpleNamespace(x=x, weight=weight, bias=bias, bn=bn, ks=ks, T=T, groups=groups, relu=relu, need_dx=need_dx, prec=prec,
                               cin=cin, cout=cout, cin_pad=x.cw, k_gap=k_gap, dev=x.buf.device, lowp=prec in LOWP,
                               split=_SPLIT.get(prec, 0), use_batch=bn is not None and train)
@@ -1424,8 +1425,11 @@ def _conv_ingest_eval(x: Act, weight: torch.Tensor, bias: Optional[torch.Tensor]
 FOLD_LAUNCHES = 0     # folded conv+BN+ReLU stages executed (tests assert that the predict path really takes them)
 
 
+PREDICT_SKIP_PLANES = True     # predict path, bf16 / f16: skips and decoder concats as 16-bit planes only, transposed convolutions on the plane GEMM
+
+
 def _conv_folded_eval(x: Act, weight: torch.Tensor, bias: Optional[torch.Tensor], bn: BNRef, ks: int, cin: int, cout: int,
-                      relu: bool, prec: str = "fp32", room: int = 0, inner: int = 0) -> Act:
+                      relu: bool, prec: str = "fp32", room: int = 0, inner: int = 0, out_planes: bool = False) -> Act:
     """Eval-mode Conv -> BatchNorm -> ReLU (running statistics) without the normalise pass: w' = w*gamma/sqrt(var+eps),
     b' = (b-mean)*gamma/sqrt(var+eps)+beta, ReLU in the conv epilogue.  Used when nothing is recorded for backward
     (torch.no_grad / inference_mode: PLTrainer.py:530,626).  ``inner`` > 0: the result is the inner tensor of a DoubleConv (``inner`` = the
@@ -1458,7 +1462,26 @@ def _conv_folded_eval(x: Act, weight: torch.Tensor, bias: Optional[torch.Tensor]
             y.f32_valid = False
             y.pl = Planes(rows.buf, y.P * cout, cout, 0, 1)
             return y
+        par = y.parent
+        if (PREDICT_SKIP_PLANES and room > 0 and par is not None and SKIP_PLANES_ONLY and PLANES_CONCAT and PLANES_ONLY_ACT and PLANE_PRODUCERS
+                and PLANE_WGRAD and cout % 32 == 0 and _v3_plan(x, cin, cout)[0] == 1 and _planes_fit(par, par.C)):
+            # a skip tensor (round 5: as the training forward has had it since round 4): written as 16-bit rows into channels
+            # [0, Cskip) of a plane buffer of the decoder concat's width and nowhere else -- max-pooling reads those rows
+            # (hpri_maxpool2_fwd_x16), the decoder's transposed convolution adds its half on the plane GEMM (up_concat), the
+            # convolution behind the concat stages the planes: no fp32 skip, no fp32 concat, no conversion pass
+            cs16 = _rup(par.C, 32)
+            cpl = Planes(torch.empty(par.P * cs16, dtype=torch.bfloat16, device=dev), par.P * cs16, cs16, 0, 1)
+            par.pl_part = (cpl, cout)
+            rows = Act(cpl.buf, x.N, x.H, x.W, cout, cs16, 0)
+            rows.b16 = True
+            _conv_launch_v2(x, wp, fbias, rows, None, cin, cout, cout_pad, cout, accumulate=(2 if relu else 0) | 4)
+            y.pl = Planes(cpl.buf, cpl.plane, cpl.cs, 0, 1, cw=cout)
+            y.f32_valid = False
+            y.want_pl = 1
+            return y
         _conv_launch_v2(x, wp, fbias, y, None, cin, cout, cout_pad, y.cw, accumulate=2 if relu else 0)
+        if PREDICT_SKIP_PLANES and out_planes and room == 0 and CONVT_PLANES and PLANE_PRODUCERS and _planes_fit(y, cout):
+            planes_of(y, 1)      # the next decoder stage's transposed convolution stages these (a small tensor: one conversion pass)
     elif lowp:
         _conv_launch_bf16(x, wp, fbias, y, None, x.N, x.H, x.W, x.cw, cout, cout_pad, y.cw, ks, accumulate=2 if relu else 0,
                           cin_true=cin, split=split)

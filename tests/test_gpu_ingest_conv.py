@@ -165,3 +165,56 @@ def test_cubenet_predict_takes_the_fused_ingest_and_changes_nothing(prec):
     net.eval()
     net(x)                                       # eval, but gradients on: the tape records, so the layout pass runs
     assert E.INGEST_LAUNCHES == n1
+
+
+@pytest.mark.parametrize("prec", ["bf16", "f16"])
+def test_predict_path_keeps_skips_and_concats_as_planes(prec):
+    """Predict path of the 16-bit modes (round 5): a skip tensor is written as 16-bit rows into the decoder concat's plane buffer and
+    nowhere else, max-pooling reads those rows, the transposed convolution runs on the plane GEMM and adds its half to the same planes
+    (as the training forward does).  Same values as the fp32-skip form up to the summation order of the transposed convolution;
+    eval-mode fixture of the reference within the mode's band."""
+    import hyperpri_amd as H
+    from hyperpri_amd import engine as E
+    z = np.load(os.path.join(G, "net_cubenet64_tiny.npz"))
+    net = H.CubeNET(6, 1, first_depth=64, bilinear=False)
+    shapes = OrderedDict((k, tuple(v.shape)) for k, v in net.state_dict().items())
+    net.load_state_dict(O.synth_state_dict(shapes))
+    net = net.to(DEV).train()
+    x = _u(1235, (2, 1, 6, 36, 50)).to(DEV)
+    net(x)                                       # one training forward: the fixture's running statistics
+    H.set_precision(net, prec).eval()
+    with torch.inference_mode():
+        le = net(x).cpu().numpy()
+    d = float(np.abs(le - z["logits_eval"]).max())
+    record_margin(f"predict_planes/{prec}/tiny_fixture", d, 0.15 if prec == "bf16" else 0.03)
+    assert d < (0.15 if prec == "bf16" else 0.03)
+    # a larger cube: the upper levels are wide enough for the plane kernels' single-pass form
+    net = H.CubeNET(40, 1, first_depth=64, bilinear=False)
+    shapes = OrderedDict((k, tuple(v.shape)) for k, v in net.state_dict().items())
+    net.load_state_dict(O.synth_state_dict(shapes))
+    net = H.set_precision(net.to(DEV), prec).train()
+    x = _u(1237, (2, 1, 40, 128, 192)).to(DEV)
+    with torch.no_grad():
+        net(x)
+    net.eval()
+    out, tags, conv = {}, {}, {}
+    for flag in (True, False):
+        E.PREDICT_SKIP_PLANES = flag
+        try:
+            c0 = E.PLANE_CONVERSIONS
+            E.enable_event_log(True)
+            with torch.inference_mode():
+                out[flag] = net(x)
+            torch.cuda.synchronize()
+            tags[flag] = set(E.event_log_summary())
+            E.enable_event_log(False)
+            conv[flag] = E.PLANE_CONVERSIONS - c0
+        finally:
+            E.PREDICT_SKIP_PLANES = True
+    assert any(t.startswith("gemm_planes_bf16<convT") for t in tags[True]), tags[True]
+    assert not any(t.startswith("gemm_planes_bf16<convT") for t in tags[False])
+    assert not any(t.startswith("conv_fwd_bf16<1,4x1,direct,d2s>") for t in tags[True]) or conv[True] <= conv[False]     # (deep, narrow levels may keep the split-K form)
+    dd = float((out[True] - out[False]).abs().max())
+    record_margin(f"predict_planes/{prec}/vs_fp32_skips", dd, 2e-2 if prec == "bf16" else 3e-3)
+    assert dd <= (2e-2 if prec == "bf16" else 3e-3), dd
+    assert torch.isfinite(out[True]).all()
