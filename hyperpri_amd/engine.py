@@ -976,7 +976,8 @@ def conv_bn_relu(tape: Tape, x: Act, weight: torch.Tensor, bias: Optional[torch.
     if bn is not None and not train and not tape.record and FOLD_EVAL_BN:
         return _conv_folded_eval(x, weight, bias, bn, ks, cin, cout, relu, prec, room,
                                  inner=(max(next_cout, 1 if (head_next and HEAD_PLANES) else 0) if groups == 1 else 0),
-                                 out_planes=out_planes and groups == 1)
+                                 out_planes=out_planes and groups == 1, cat_room=cat_room, cat_into=cat_into, k_gap=k_gap,
+                                 planes_only=planes_only)
     c = types.SimpleNamespace(x=x, weight=weight, bias=bias, bn=bn, ks=ks, T=T, groups=groups, relu=relu, need_dx=need_dx, prec=prec,
                               cin=cin, cout=cout, cin_pad=x.cw, k_gap=k_gap, dev=x.buf.device, lowp=prec in LOWP,
                               split=_SPLIT.get(prec, 0), use_batch=bn is not None and train)
@@ -1428,14 +1429,94 @@ FOLD_LAUNCHES = 0     # folded conv+BN+ReLU stages executed (tests assert that t
 PREDICT_SKIP_PLANES = True     # predict path, bf16 / f16: skips and decoder concats as 16-bit planes only, transposed convolutions on the plane GEMM
 
 
+PREDICT_GEMM_PLANES = True     # predict path, bf16 / f16: the 1x1 layers (SpectralUNET's Linear stack) on the plane GEMM, concats on planes
+
+
+def predict_gemm_planes_ok(prec: Optional[str]) -> bool:
+    return bool(PREDICT_GEMM_PLANES and FOLD_EVAL_BN and (prec or DEFAULT_PRECISION) == "bf16" and PLANE_GEMM and PLANE_PRODUCERS)
+
+
+def _gemm_folded_eval(x: Act, weight: torch.Tensor, bias: Optional[torch.Tensor], bn: BNRef, cin: int, cout: int, relu: bool,
+                      cat_room: int, cat_into: Optional[Act], k_gap: Optional[Tuple[int, int]], planes_only: bool) -> Act:
+    """Eval-mode Linear / Conv1x1 -> BatchNorm -> ReLU of the 16-bit modes on the plane GEMM (gemm_bf16v3.hip; models.py:105-115 under
+    PLTrainer.py:530-532): BatchNorm folded into the packed weights and the bias, ReLU in the epilogue, the result written as 16-bit
+    rows -- into its half of a padded plane concat (``cat_room`` / ``cat_into``, as the training forward does) or into planes of its
+    own; fp32 rows only when the caller has an fp32 reader (``planes_only`` False and no concat).  Until round 5 these layers ran on the
+    round-1 kernel that converts fp32 activations while staging (393 TF on SpectralUNET-1650 where the plane GEMM reaches 860-1000)."""
+    global FOLD_LAUNCHES, PACK_LAUNCHES
+    FOLD_LAUNCHES += 1
+    dev = x.buf.device
+    K = x.C                                   # (a padded concat: its structural-zero channels included)
+    cout_pad = _rup(cout, 64)
+
+    def build():
+        global PACK_LAUNCHES
+        PACK_LAUNCHES += 1
+        fold = torch.empty(2 * cout, dtype=torch.float32, device=dev)
+        _lib.call("hpri_bn_fold", _p(bn.running_mean), _p(bn.running_var), _p(bn.weight), _p(bn.bias), _p(bias), bn.eps, cout,
+                  _p(fold[:cout]), _p(fold[cout:]), _stream())
+        # (once per weight version, cached: the column scale in fp32, then the gapped / plain pack rounds to 16 bits)
+        wf = (weight.detach().reshape(cout, cin) * fold[:cout].unsqueeze(1)).contiguous()
+        wp = torch.empty(((K + 31) // 32) * cout_pad * 32, dtype=torch.bfloat16, device=dev)
+        if k_gap is not None:
+            _lib.call("hpri_pack_weight_bf16_gap", _p(wf), _p(wp), 0, K, cout, cout_pad, 1, cin, k_gap[0], k_gap[1], _stream())
+        else:
+            _lib.call("hpri_pack_weight_bf16", _p(wf), _p(wp), 0, K, cout, cout_pad, 1, cin, 0, 0, _stream())
+        return wp, fold
+
+    def ver(t):
+        try:
+            return (t.data_ptr(), t._version)
+        except RuntimeError:
+            return (t.data_ptr(), -1)
+    bn_state = (_BN_EPOCH, ver(bn.running_mean), ver(bn.running_var), ver(bn.weight), ver(bn.bias), None if bias is None else ver(bias))
+    wp, fold = _cached_pack(weight, ("fold_gemm", K, k_gap), build, extra=bn_state,
+                            also=(bn.running_mean, bn.running_var, bn.weight, bn.bias, bias))
+    fbias = fold[cout:]
+    acc = 2 if relu else 0
+    if cat_room == 0 and cat_into is None and not planes_only:
+        y = Act.new(x.N, x.H, x.W, cout, dev)                     # an fp32 reader behind it
+        _gemm_launch(x, wp, fbias, y, None, K, cout, cout_pad, y.cw, accumulate=acc)
+        return y
+    y = Act(torch.empty(8, dtype=torch.float32, device=dev), x.N, x.H, x.W, cout, _rup(cout, 8), 0)
+    y.f32_valid = False
+    if cat_room > 0:
+        ob = _rup(cout, 32)
+        ccs = _rup(ob + cat_room, 32)
+        cbuf = torch.empty(y.P * ccs, dtype=torch.bfloat16, device=dev)
+        ypl = Planes(cbuf, y.P * ccs, ccs, 0, 1, cw=ob)
+        y.cat_pl = (cbuf, ccs, ob, cat_room)
+    elif cat_into is not None:
+        cbuf, ccs, ob, c2 = cat_into.cat_pl
+        if c2 != cout or cat_into.P != y.P:
+            raise RuntimeError("hyperpri_amd: internal error: concat halves do not match")
+        ypl = Planes(cbuf, y.P * ccs, ccs, ob, 1, cw=ccs - ob)
+    else:
+        cs16 = _rup(cout, 32)
+        ypl = Planes(torch.empty(y.P * cs16, dtype=torch.bfloat16, device=dev), y.P * cs16, cs16, 0, 1)
+    if ypl.cw > cout_pad:
+        raise RuntimeError("hyperpri_amd: internal error: plane rows wider than the packed columns")
+    y.pl = ypl
+    y.want_pl = 1
+    rows = Act(ypl.buf, x.N, x.H, x.W, cout, ypl.cs, ypl.coff)
+    rows.b16, rows.f32_valid = True, False
+    _gemm_launch(x, wp, fbias, rows, None, K, cout, cout_pad, ypl.cw, accumulate=acc)      # (columns [cout, cw): exact zeros)
+    return y
+
+
 def _conv_folded_eval(x: Act, weight: torch.Tensor, bias: Optional[torch.Tensor], bn: BNRef, ks: int, cin: int, cout: int,
-                      relu: bool, prec: str = "fp32", room: int = 0, inner: int = 0, out_planes: bool = False) -> Act:
+                      relu: bool, prec: str = "fp32", room: int = 0, inner: int = 0, out_planes: bool = False, cat_room: int = 0,
+                      cat_into: Optional[Act] = None, k_gap: Optional[Tuple[int, int]] = None, planes_only: bool = False) -> Act:
     """Eval-mode Conv -> BatchNorm -> ReLU (running statistics) without the normalise pass: w' = w*gamma/sqrt(var+eps),
     b' = (b-mean)*gamma/sqrt(var+eps)+beta, ReLU in the conv epilogue.  Used when nothing is recorded for backward
     (torch.no_grad / inference_mode: PLTrainer.py:530,626).  ``inner`` > 0: the result is the inner tensor of a DoubleConv (``inner`` = the
     channels of the convolution that reads it), or the head's input (1); in the bf16
     mode the plane kernel then writes it as bf16 rows, which ARE the next convolution's planes (no fp32 copy, no conversion pass)."""
     global FOLD_LAUNCHES
+    if ks == 1 and predict_gemm_planes_ok(prec) and room == 0 and (x.f32_valid or x.pl is not None) and _rup(x.C, 32) <= 8192:
+        return _gemm_folded_eval(x, weight, bias, bn, cin, cout, relu, cat_room, cat_into, k_gap, planes_only)
+    if cat_room or cat_into is not None or k_gap or planes_only:
+        raise RuntimeError("hyperpri_amd: internal error: the plane form of a skip concat needs the plane GEMM path (see plane_gemm_mode)")
     FOLD_LAUNCHES += 1
     dev = x.buf.device
     T = ks * ks

@@ -160,7 +160,8 @@ class SpectralUNET(torch.nn.Module):
         E.throttle(x.device)
         def prog(tape, a, need):
             L = self._layer
-            if E.plane_gemm_mode(self, self._bnorm) and (tape.record or self.training or not E.FOLD_EVAL_BN):    # (the folded predict path keeps the copying form)
+            if E.plane_gemm_mode(self, self._bnorm) and (tape.record or self.training or not E.FOLD_EVAL_BN
+                                                          or E.predict_gemm_planes_ok(getattr(self, "hpri_precision", None))):
                 # bf16 mode: the three inner skips are concatenated on bf16 planes -- the producers of both halves write into one
                 # padded plane buffer ([skip | zeros to a multiple of 32 | up]), the consumer's weight packs carry the gap -- and the
                 # tensors between the layers exist as planes only (torch.cat of models.py:139-143 without a byte moved)

@@ -218,3 +218,48 @@ def test_predict_path_keeps_skips_and_concats_as_planes(prec):
     record_margin(f"predict_planes/{prec}/vs_fp32_skips", dd, 2e-2 if prec == "bf16" else 3e-3)
     assert dd <= (2e-2 if prec == "bf16" else 3e-3), dd
     assert torch.isfinite(out[True]).all()
+
+
+SPECTRAL = [("net_spectral_f50", 1242, (2, 22, 9, 14), lambda H: H.SpectralUNET(22, 1, 50)),
+            ("net_spectral1650_small", 1250, (2, 238, 16, 24), lambda H: H.SpectralUNET(238, 1, 1650)),
+            ("net_spectral_nobn_f50", 1242, (2, 22, 9, 14), lambda H: H.SpectralUNET(22, 1, 50, bnorm=False))]
+
+
+@pytest.mark.parametrize("prec", ["bf16", "f16"])
+@pytest.mark.parametrize("name,xseed,xshape,mk", SPECTRAL, ids=[c[0] for c in SPECTRAL])
+def test_spectral_predict_runs_on_the_plane_gemm(name, xseed, xshape, mk, prec):
+    """SpectralUNET's predict forward in the 16-bit modes (round 5): the folded Linear -> BatchNorm1d -> ReLU layers on the plane GEMM
+    with the skips concatenated on planes (models.py:105-115,139-143 under PLTrainer.py:530-532), not on the round-1 kernel.  Against
+    the reference's eval-mode fixture (the mode's band) and against the previous form (same arithmetic, another summation order)."""
+    import hyperpri_amd as H
+    from hyperpri_amd import engine as E
+    z = np.load(os.path.join(G, name + ".npz"))
+    net = mk(H)
+    shapes = OrderedDict((k, tuple(v.shape)) for k, v in net.state_dict().items())
+    net.load_state_dict(O.synth_state_dict(shapes))
+    net = net.to(DEV).train()
+    x = _u(xseed, xshape).to(DEV)
+    net(x)                                       # one training forward in fp32: the fixture's running statistics
+    H.set_precision(net, prec).eval()
+    out, tags = {}, {}
+    for flag in (True, False):
+        E.PREDICT_GEMM_PLANES = flag
+        try:
+            E.enable_event_log(True)
+            with torch.inference_mode():
+                out[flag] = net(x)
+            torch.cuda.synchronize()
+            tags[flag] = set(E.event_log_summary())
+            E.enable_event_log(False)
+        finally:
+            E.PREDICT_GEMM_PLANES = True
+    assert any(t.startswith("gemm_planes_bf16<1") for t in tags[True]) and not any(t.startswith("conv_fwd_bf16<1") for t in tags[True]), tags[True]
+    assert any(t.startswith("conv_fwd_bf16<1") for t in tags[False]), tags[False]
+    le = out[True].cpu().numpy()
+    band = 0.1 if prec == "bf16" else 0.02
+    d = float(np.abs(le - z["logits_eval"]).max())
+    record_margin(f"predict_gemm/{prec}/{name}/fixture", d, band)
+    assert d < band, d
+    dd = float((out[True] - out[False]).abs().max())
+    record_margin(f"predict_gemm/{prec}/{name}/vs_round1_kernel", dd, band)
+    assert dd < band, dd
