@@ -345,6 +345,7 @@ def main():
     ap.add_argument("--no-optimizer-leg", action="store_true",
                     help="skip the optimizer-step comparison (its torch.optim.Adam half is the only ATen work of a bench run; "
                          "profiling passes use this so that their kernel tables show the hot path alone)")
+    ap.add_argument("--no-predict-leg", action="store_true", help="skip the forward-only (eval, inference_mode) leg")
     ap.add_argument("--no-training-shaped", action="store_true",
                     help="skip the `value_training_shaped` leg (the same loop with FusedAdam.step() after every backward)")
     ap.add_argument("--no-configs", action="store_true",
@@ -665,6 +666,30 @@ def main():
                       "losses to 2e-3; |dDice| <= 1.6e-4 everywhere: profiles/r04_bf16_dice_parity.json, final round-4 build -- activations, "
                       "pre-BN tensors and single-reader / skip gradients stored as bf16); NOT the headline value"})
 
+    # ---- the predict path (PLTrainer.py:530-532: eval mode under inference_mode) on the same cubes: forward only, eval-mode BatchNorm
+    #      folded into the convolutions; N = 1 only (it holds no collective); never part of `value` ----
+    predict = None
+    if rank == 0 and world == 1 and not args.no_predict_leg:
+        trace("predict leg")
+        net.eval()
+        predict = {"what": "CubeNET-64 forward only, eval mode under torch.inference_mode(), the same two cubes; cubes/s per mode"}
+        for mode in ("fp32", "bf16", "f16"):
+            HP.set_precision(net, mode)
+            with torch.inference_mode():
+                for _ in range(5):
+                    net(x)
+                torch.cuda.synchronize()
+                npred = 20 if mode == "fp32" else 50
+                tp0 = time.perf_counter()
+                for _ in range(npred):
+                    net(x)
+                torch.cuda.synchronize()
+                dtp = time.perf_counter() - tp0
+            predict[mode] = {"value": round(BATCH * npred / dtp, 2), "unit": "cubes/s", "ms_per_forward": round(dtp / npred * 1e3, 3)}
+        HP.set_precision(net, "fp32")
+        net.train()
+        torch.cuda.synchronize()
+
     roofline = None
     trace("per-kernel event pass")
     if not args.no_roofline:
@@ -848,6 +873,7 @@ def main():
                                  "the fp32 path executes fewer multiplies than that (Winograd), so this can exceed the fp32 MFMA peak",
             "value_training_shaped": training_shaped,
             "roofline": roofline, "roofline_238to64": first_conv, "cpu_baseline": cpu, "optimizer_step": optimizer_step, "configs": configs, "bf16x6_mode": bf16x6_mode, "bf16x3_mode": bf16x3_mode, "bf16_mode": bf16_mode, "f16_mode": f16_mode,
+            "predict": predict,
             "stock_ddp": None,
         }
     # The stock-DDP leg runs LAST, when everything the contract asks for is measured and the line is assembled: it is the one part of an
