@@ -222,7 +222,10 @@ def test_predict_path_keeps_skips_and_concats_as_planes(prec):
 
 SPECTRAL = [("net_spectral_f50", 1242, (2, 22, 9, 14), lambda H: H.SpectralUNET(22, 1, 50)),
             ("net_spectral1650_small", 1250, (2, 238, 16, 24), lambda H: H.SpectralUNET(238, 1, 1650)),
-            ("net_spectral_nobn_f50", 1242, (2, 22, 9, 14), lambda H: H.SpectralUNET(22, 1, 50, bnorm=False))]
+            ("net_spectral_nobn_f50", 1242, (2, 22, 9, 14), lambda H: H.SpectralUNET(22, 1, 50, bnorm=False)),
+            ("net_spectral_3class", 1252, (2, 10, 7, 9), lambda H: H.SpectralUNET(10, 3, 4)),
+            ("net_spectral_f48", 1238, (2, 22, 12, 20), lambda H: H.SpectralUNET(22, 1, 48)),
+            ("net_spectral_tiny", 1237, (3, 10, 7, 9), lambda H: H.SpectralUNET(10, 1, 4))]
 
 
 @pytest.mark.parametrize("prec", ["bf16", "f16"])
