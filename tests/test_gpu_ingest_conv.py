@@ -1,9 +1,12 @@
-"""First-layer fused ingest of the predict path (csrc/conv_ingest.hip, ``hpri_conv3x3_ingest_h16``; reference models.py:169 as called
-at models.py:215-216): in the 16-bit modes the first 3x3 layer of CubeNET reads the caller's NC(D)HW fp32 cube itself instead of planes
-written by a layout pass.  Gates: (i) the kernel against the oracle's arithmetic (fp64 convolution of the rounded operands) and
-BIT-identical to the pair it replaces (layout pass + hpri_conv_bf16v3) on ragged shapes, channel counts off every multiple, 1..3
-images, 32 / 64 / 128 outputs; (ii) CubeNET's predict forward with and without it: identical logits, and the layout kernel gone from
-the launches; (iii) the reference's eval-mode fixture.  Needs a real MI355X: ``-m gpu``."""
+"""The predict path of the 16-bit modes (eval mode under inference_mode / no_grad: PLTrainer.py:530-532,626), round 5.
+(1) First-layer fused ingest (csrc/conv_ingest.hip, ``hpri_conv3x3_ingest_h16``; reference models.py:169 as called at models.py:215-216):
+CubeNET's first 3x3 layer reads the caller's NC(D)HW fp32 cube itself instead of planes written by a layout pass.  Gates: the kernel
+against the oracle's arithmetic (fp64 convolution of the rounded operands) and BIT-identical to the pair it replaces (layout pass +
+hpri_conv_bf16v3) on ragged shapes, channel counts off every multiple, 1..3 images, 32 / 64 / 96 / 128 outputs; CubeNET's predict forward
+with and without it: identical logits; the reference's eval-mode fixture.  (2) Skips and decoder concats as planes only, transposed
+convolutions on the plane GEMM (``engine.PREDICT_SKIP_PLANES``).  (3) SpectralUNET's folded Linear -> BatchNorm1d -> ReLU layers on the
+plane GEMM with plane concats (``engine.PREDICT_GEMM_PLANES``; models.py:105-115,139-143), against the reference's eval-mode fixtures.
+Needs a real MI355X: ``-m gpu``."""
 import os
 from collections import OrderedDict
 
