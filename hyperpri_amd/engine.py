@@ -1361,6 +1361,16 @@ FUSE_BN_REDUCE = FUSIONS
 # (hpri_colsum_from_stats) instead of a pass over that tensor (hpri_col_sum).  (HPRI_FUSIONS.)
 COLSUM_FROM_STATS = FUSIONS
 FOLD_EVAL_BN = True   # inference only (no tape): conv + eval-mode BN + ReLU as ONE kernel with BN folded into w and b
+def _bn_fold_state(bn: "BNRef", bias: Optional[torch.Tensor]):
+    """What a folded pack depends on besides its weight: the versions of the BatchNorm's buffers / parameters and of the bias."""
+    def ver(t):
+        try:
+            return (t.data_ptr(), t._version)
+        except RuntimeError:
+            return (t.data_ptr(), -1)
+    return (_BN_EPOCH, ver(bn.running_mean), ver(bn.running_var), ver(bn.weight), ver(bn.bias), None if bias is None else ver(bias))
+
+
 def _folded_pack(weight: torch.Tensor, bias: Optional[torch.Tensor], bn: BNRef, ks: int, cin: int, cout: int, prec: str, wino: bool):
     """(packed weights with the eval-mode BatchNorm's scale folded in, [scale | bias'] vector) of a folded stage; cached per weight,
     precision and BatchNorm state."""
@@ -1388,14 +1398,7 @@ def _folded_pack(weight: torch.Tensor, bias: Optional[torch.Tensor], bn: BNRef, 
             _lib.call("hpri_pack_weight_scaled", _p(weight), _p(wp), _p(fold[:cout]), cin, cout, cout_pad, T, cin, _stream())
         return wp, fold
 
-    def ver(t):
-        try:
-            return (t.data_ptr(), t._version)
-        except RuntimeError:
-            return (t.data_ptr(), -1)
-    bn_state = (_BN_EPOCH, ver(bn.running_mean), ver(bn.running_var), ver(bn.weight), ver(bn.bias),
-                None if bias is None else ver(bias))
-    return _cached_pack(weight, ("fold", prec, ks, "wino4" if wino else False), build, extra=bn_state,
+    return _cached_pack(weight, ("fold", prec, ks, "wino4" if wino else False), build, extra=_bn_fold_state(bn, bias),
                         also=(bn.running_mean, bn.running_var, bn.weight, bn.bias, bias))
 
 
@@ -1464,13 +1467,7 @@ def _gemm_folded_eval(x: Act, weight: torch.Tensor, bias: Optional[torch.Tensor]
             _lib.call("hpri_pack_weight_bf16", _p(wf), _p(wp), 0, K, cout, cout_pad, 1, cin, 0, 0, _stream())
         return wp, fold
 
-    def ver(t):
-        try:
-            return (t.data_ptr(), t._version)
-        except RuntimeError:
-            return (t.data_ptr(), -1)
-    bn_state = (_BN_EPOCH, ver(bn.running_mean), ver(bn.running_var), ver(bn.weight), ver(bn.bias), None if bias is None else ver(bias))
-    wp, fold = _cached_pack(weight, ("fold_gemm", K, k_gap), build, extra=bn_state,
+    wp, fold = _cached_pack(weight, ("fold_gemm", K, k_gap), build, extra=_bn_fold_state(bn, bias),
                             also=(bn.running_mean, bn.running_var, bn.weight, bn.bias, bias))
     fbias = fold[cout:]
     acc = 2 if relu else 0
